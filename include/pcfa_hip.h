@@ -1,0 +1,190 @@
+/*
+ * pcfa_hip.h -- C-ABI of libpcfa_hip.so, the MI355X (gfx950) kernels behind the
+ * PCFA perturbation-optimisation hot path.
+ *
+ * Everything here is `extern "C"`, takes raw DEVICE pointers + sizes + a
+ * hipStream_t (passed as void*), allocates nothing, never synchronises and is
+ * re-entrant per stream, so a caller may capture the calls into a hipGraph.
+ * All tensors are fp32, contiguous unless strides are passed explicitly.
+ * Return value: 0 = PCFA_OK, <0 = argument error (PCFA_ERR_*), >0 = hipError_t
+ * of the failed launch.
+ *
+ * Each entry point names the reference interface (cv-stuttgart/PCFA, paths
+ * relative to the reference root) that it replaces.
+ */
+#ifndef PCFA_HIP_H
+#define PCFA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCFA_OK 0
+#define PCFA_ERR_INVALID_ARG (-1)
+#define PCFA_ERR_UNSUPPORTED (-2)
+#define PCFA_ERR_WORKSPACE (-3)
+
+/* Exported from libpcfa_hip.so (the library is built with -fvisibility=hidden). */
+#if defined(__GNUC__)
+#define PCFA_API __attribute__((visibility("default")))
+#else
+#define PCFA_API
+#endif
+
+#define PCFA_MAX_LEVELS 8
+#define PCFA_ABI_VERSION 1
+
+/* f_type of the similarity term: helper_functions/losses.py:145-174 */
+#define PCFA_LOSS_AEE 0
+#define PCFA_LOSS_MSE 1
+#define PCFA_LOSS_COSIM 2
+
+/* box constraint: attack_PCFA.py:20-29, helper_functions/own_models.py:72-80 */
+#define PCFA_BOX_CLIPPING 0
+#define PCFA_BOX_CHANGE_OF_VARIABLES 1
+
+PCFA_API int pcfa_abi_version(void);
+/* Human-readable text for a return code (static storage). */
+PCFA_API const char* pcfa_status_string(int status);
+
+/* ------------------------------------------------------------------------- *
+ * RAFT / GMA all-pairs correlation pyramid.
+ * Replaces CorrBlock.__init__ + CorrBlock.corr  (models/raft/corr.py:12-27,52-60;
+ * identical models/gma/corr.py:15-30,55-63).
+ *
+ * HBM layout ("slab per query"): the 4D volume and its pooled levels are kept
+ * as ONE matrix  pyr[B*Q][slab]  (Q = H*W), row q holding level 0 (H*W
+ * floats), then level 1 ((H/2)*(W/2)), ... concatenated; `slab` is the sum
+ * rounded up to a multiple of 4 floats.  Level l of the reference's
+ * corr_pyramid[l] ([B*Q,1,H_l,W_l]) is  pyr[:, off_l : off_l + H_l*W_l].
+ * ------------------------------------------------------------------------- */
+
+/* floats per query row (multiple of 4) */
+PCFA_API long long pcfa_corr_slab_floats(int H, int W, int num_levels);
+/* offset (floats) of level l inside a row; *h_l,*w_l receive its extent */
+PCFA_API long long pcfa_corr_level_offset(int H, int W, int num_levels, int level, int* h_l, int* w_l);
+
+/* f2ext[B][D][slab] = fmap2 followed by its successively 2x2-average-pooled
+ * copies (floor semantics of F.avg_pool2d(.,2,stride=2)); pad columns are 0. */
+PCFA_API int pcfa_corr_f2ext_fwd(const float* fmap2, float* f2ext, int B, int D, int H, int W,
+                        int num_levels, void* stream);
+
+/* pyr[b*Q+q][n] = sum_d fmap1[b][d][q] * f2ext[b][d][n] / sqrt(D)
+ * (fp32-input MFMA, k-ordered fma chain).  fmap1: [B][D][Q]. */
+PCFA_API int pcfa_corr_pyramid_fwd(const float* fmap1, const float* f2ext, float* pyr, int B, int D,
+                          int H, int W, int num_levels, void* stream);
+
+/* Backward of the two calls above.  dpyr: [B*Q][slab] gradient w.r.t. pyr (as
+ * accumulated by pcfa_corr_lookup_bwd).  Writes dfmap1,dfmap2 [B][D][Q].
+ * workspace: device scratch of >= pcfa_corr_pyramid_bwd_workspace_bytes(). */
+PCFA_API size_t pcfa_corr_pyramid_bwd_workspace_bytes(int B, int D, int H, int W, int num_levels);
+PCFA_API int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, const float* f2ext,
+                          float* dfmap1, float* dfmap2, void* workspace, size_t workspace_bytes,
+                          int B, int D, int H, int W, int num_levels, void* stream);
+
+/* CorrBlock.__call__ (models/raft/corr.py:29-50) + bilinear_sampler
+ * (models/raft/utils/utils.py:57-71): coords [B][2][H][W] (x then y, pixel
+ * units of level 0), out [B][L*(2r+1)^2][H][W]; channel l*(2r+1)^2 + a*(2r+1) + b
+ * samples level l at (x = cx/2^l + a - r, y = cy/2^l + b - r), bilinear,
+ * zeros outside (the reference's x-major window order). */
+PCFA_API int pcfa_corr_lookup_fwd(const float* pyr, const float* coords, float* out, int B, int H, int W,
+                         int num_levels, int radius, void* stream);
+
+/* dpyr += d out / d pyr ^T * grad_out   (no gradient w.r.t. coords: the
+ * reference detaches them, models/raft/raft.py:122-123).  Deterministic: every
+ * (query, level) window is owned by one workgroup, no atomics.  dpyr must have
+ * been zeroed by the caller before the first accumulation of a backward pass. */
+PCFA_API int pcfa_corr_lookup_bwd(float* dpyr, const float* coords, const float* grad_out, int B, int H,
+                         int W, int num_levels, int radius, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * PWC-Net cost volume = spatial_correlation_sampler_backend.forward/backward
+ * (models/PWCNet/cpu_spatial_correlation_sampler-0.3.0/Correlation_Module/
+ *  correlation_sampler.cpp:58-81,83-112 ; CPU math correlation.cpp:9-37,39-73,
+ *  75-124,126-178).  Same 12 integers in the same order.
+ * in1,in2: [B][C][iH][iW];  out / grad_out: [B][patchH][patchW][oH][oW] with
+ * oH = (iH + 2*padH - ((kH-1)*dilH+1))/dH + 1 (same for W).
+ * The caller allocates out / grad_in1 / grad_in2 (the kernels fully overwrite
+ * them; no pre-zeroing needed).
+ * ------------------------------------------------------------------------- */
+PCFA_API int pcfa_spatial_corr_out_size(int iH, int iW, int kH, int kW, int padH, int padW, int dilH,
+                               int dilW, int dH, int dW, int* oH, int* oW);
+PCFA_API int pcfa_spatial_corr_fwd(const float* in1, const float* in2, float* out, int B, int C, int iH,
+                          int iW, int kH, int kW, int patchH, int patchW, int padH, int padW,
+                          int dilH, int dilW, int dil_patchH, int dil_patchW, int dH, int dW,
+                          void* stream);
+PCFA_API int pcfa_spatial_corr_bwd(const float* in1, const float* in2, const float* grad_out,
+                          float* grad_in1, float* grad_in2, int B, int C, int iH, int iW, int kH,
+                          int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
+                          int dil_patchH, int dil_patchW, int dH, int dW, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Attack math (fused elementwise + reductions).
+ * ------------------------------------------------------------------------- */
+
+/* ScaledInputModel.forward prologue (helper_functions/own_models.py:62-85):
+ *   x = image (+ delta broadcast over batch, delta may be NULL)
+ *   if cov:  x = 0.5/(1-eps) * (tanh(x) + (1-eps))
+ *   x = clamp(x, 0, 1);  x *= scale  (scale = 255 if make_unit_input else 1)
+ * image,out: [B][chw]; delta: [chw] or NULL.  `n_per_item` = C*H*W. */
+PCFA_API int pcfa_box_transform_fwd(const float* image, const float* delta, float* out, int B,
+                           long long n_per_item, int change_of_variables, double eps_box,
+                           float scale, void* stream);
+/* grad_image [B][chw] (may be NULL) and grad_delta [chw] (may be NULL; summed
+ * over the batch in a fixed order) from grad_out. */
+PCFA_API int pcfa_box_transform_bwd(const float* image, const float* delta, const float* grad_out,
+                           float* grad_image, float* grad_delta, int B, long long n_per_item,
+                           int change_of_variables, double eps_box, float scale, void* stream);
+
+/* extract_deltas (attack_PCFA.py:20-29): delta = box(nw_input) - image. */
+PCFA_API int pcfa_extract_deltas_fwd(const float* nw_input, const float* image, float* delta,
+                            long long n, int change_of_variables, double eps_box, void* stream);
+PCFA_API int pcfa_extract_deltas_bwd(const float* nw_input, const float* grad_delta, float* grad_nw_input,
+                            long long n, int change_of_variables, double eps_box, void* stream);
+
+/* extract_deltas_joint (attack_PCFA.py:32-37):
+ *   up = clamp(nw_delta + imax, 0, 1) - imax ; delta = clamp(up + imin, 0, 1) - imin */
+PCFA_API int pcfa_extract_deltas_joint_fwd(const float* nw_delta, const float* images_max,
+                                  const float* images_min, float* delta, long long n,
+                                  void* stream);
+PCFA_API int pcfa_extract_deltas_joint_bwd(const float* nw_delta, const float* images_max,
+                                  const float* images_min, const float* grad_delta,
+                                  float* grad_nw_delta, long long n, void* stream);
+
+/* loss_delta_constraint (helper_functions/losses.py:200-230) =
+ *   get_loss(f_type, pred, target) + mu * relu((|d1|^2+|d2|^2)/(n1+n2) - bound^2)
+ * pred/target: [B][2][H][W] views given by element strides (sb,sc,sh,sw) so the
+ * un-padded crop of the network output is read in place (no copy).
+ * out_scalars (8 floats): [0]=loss, [1]=similarity term, [2]=mean squared delta,
+ * [3..5] = cosim sums (p.t, p.p, t.t), [6] = mean squared delta - bound^2, [7] unused.
+ * workspace >= pcfa_flow_loss_workspace_bytes().
+ * delta2 may alias delta1 (joint perturbation; then both count, as in the reference). */
+PCFA_API size_t pcfa_flow_loss_workspace_bytes(void);
+PCFA_API int pcfa_flow_loss_fwd(const float* pred, const long long pred_strides[4], const float* target,
+                       const long long target_strides[4], int B, int H, int W,
+                       const float* delta1, long long n1, const float* delta2, long long n2,
+                       float delta_bound, float mu, int f_type, float* out_scalars,
+                       void* workspace, void* stream);
+/* grad_pred is written DENSE [B][2][H][W]; grad_delta1/2 [n1]/[n2] may be NULL.
+ * If delta2 aliases delta1 pass grad_delta2 = NULL and joint=1 (gradient doubled). */
+PCFA_API int pcfa_flow_loss_bwd(const float* pred, const long long pred_strides[4], const float* target,
+                       const long long target_strides[4], int B, int H, int W,
+                       const float* delta1, long long n1, const float* delta2, long long n2,
+                       float mu, int f_type, int joint, const float* fwd_scalars,
+                       const float* grad_loss, float* grad_pred, float* grad_delta1,
+                       float* grad_delta2, void* stream);
+
+/* Metric helpers (helper_functions/losses.py:3-30,129-142): out[0] = sum over
+ * pixels of sqrt(du^2+dv^2) / (B*H*W);  pcfa_sum_squares: out[0] = sum x^2. */
+PCFA_API int pcfa_avg_epe(const float* flow1, const long long strides1[4], const float* flow2,
+                 const long long strides2[4], int B, int H, int W, float* out, void* workspace,
+                 void* stream);
+PCFA_API int pcfa_sum_squares(const float* x, long long n, float* out, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCFA_HIP_H */

@@ -1,0 +1,282 @@
+"""ORACLE -- test infrastructure, not product code.
+
+CPU restatement (PyTorch fp32 / plain C) of the operators on the PCFA hot path,
+exposing the same interface as :mod:`pcfa_amd.hip_ops` so that tests can (a)
+compare the HIP kernels with it on identical inputs and (b) drive the host-side
+attack logic on machines without a GPU.  Pinned against golden vectors produced
+by the real reference (tests/golden/make_golden.py -> tests/golden/*.npz) and,
+for the cost volume, against the reference's own C++ build (oracle/_ref).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this package; nothing under pcfa_amd/ does.
+
+Every function cites the reference lines it follows (paths relative to the
+reference root).
+"""
+import ctypes
+import math
+import os
+
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------- #
+# RAFT / GMA correlation volume + lookup
+# --------------------------------------------------------------------------- #
+def corr_volume(fmap1, fmap2):
+    """models/raft/corr.py:52-60 -- all-pairs dot products scaled by 1/sqrt(dim)."""
+    b, d, h, w = fmap1.shape
+    a = fmap1.reshape(b, d, h * w).transpose(1, 2)
+    vol = torch.matmul(a, fmap2.reshape(b, d, h * w))
+    vol = vol.reshape(b, h, w, 1, h, w)
+    return vol / torch.sqrt(torch.tensor(d).float())
+
+
+def corr_pyramid(fmap1, fmap2, num_levels=4):
+    """models/raft/corr.py:13-27 -- level 0 + (num_levels-1) 2x2 average poolings."""
+    vol = corr_volume(fmap1, fmap2)
+    b, h1, w1, one, h2, w2 = vol.shape
+    level = vol.reshape(b * h1 * w1, one, h2, w2)
+    pyramid = [level]
+    for _ in range(num_levels - 1):
+        level = F.avg_pool2d(level, 2, stride=2)
+        pyramid.append(level)
+    return pyramid
+
+
+def _sample_pixels(img, xy):
+    """models/raft/utils/utils.py:57-71 (bilinear_sampler): pixel coords -> grid_sample."""
+    hh, ww = img.shape[-2:]
+    x, y = xy.split([1, 1], dim=-1)
+    x = 2 * x / (ww - 1) - 1
+    y = 2 * y / (hh - 1) - 1
+    return F.grid_sample(img, torch.cat([x, y], dim=-1), align_corners=True)
+
+
+def corr_lookup(pyramid, coords, radius=4):
+    """models/raft/corr.py:29-50 -- window lookup on every level.
+
+    Channel l*(2r+1)^2 + a*(2r+1) + b samples level l at
+    (x = cx/2^l + (a-r), y = cy/2^l + (b-r)): the reference stacks
+    meshgrid(dy, dx) onto (x, y), which makes the window x-major.
+    """
+    r = radius
+    n1 = 2 * r + 1
+    pts = coords.permute(0, 2, 3, 1)
+    b, h1, w1, _ = pts.shape
+    offs = torch.linspace(-r, r, n1)
+    first, second = torch.meshgrid(offs, offs, indexing="ij")
+    window = torch.stack([first, second], dim=-1).to(pts.device).view(1, n1, n1, 2)
+    outs = []
+    for lvl, vol in enumerate(pyramid):
+        centre = pts.reshape(b * h1 * w1, 1, 1, 2) / 2 ** lvl
+        taps = _sample_pixels(vol, centre + window)
+        outs.append(taps.view(b, h1, w1, -1))
+    return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+
+
+class CorrBlock:
+    """models/raft/corr.py:12-50."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels = num_levels
+        self.radius = radius
+        self.corr_pyramid = corr_pyramid(fmap1, fmap2, num_levels)
+
+    def __call__(self, coords):
+        return corr_lookup(self.corr_pyramid, coords, self.radius)
+
+
+def corr_lookup_loops(pyramid, coords, radius=4):
+    """First-principles double loop (numpy-speed: small cases only) of the same lookup,
+    written from the bilinear / zero-padding definition rather than grid_sample."""
+    import numpy as np
+    r, n1 = radius, 2 * radius + 1
+    c = coords.detach().numpy()
+    b, _, h1, w1 = c.shape
+    out = np.zeros((b, len(pyramid) * n1 * n1, h1, w1), dtype=np.float64)
+    for lvl, vol_t in enumerate(pyramid):
+        vol = vol_t.detach().numpy().astype(np.float64)
+        hh, ww = vol.shape[-2:]
+        for bi in range(b):
+            for y in range(h1):
+                for x in range(w1):
+                    q = (bi * h1 + y) * w1 + x
+                    cx, cy = c[bi, 0, y, x] / 2 ** lvl, c[bi, 1, y, x] / 2 ** lvl
+                    for a in range(n1):
+                        for bb in range(n1):
+                            sx, sy = cx + (a - r), cy + (bb - r)
+                            x0, y0 = math.floor(sx), math.floor(sy)
+                            fx, fy = sx - x0, sy - y0
+                            acc = 0.0
+                            for (yy, xx, wgt) in ((y0, x0, (1 - fx) * (1 - fy)), (y0, x0 + 1, fx * (1 - fy)),
+                                                  (y0 + 1, x0, (1 - fx) * fy), (y0 + 1, x0 + 1, fx * fy)):
+                                if 0 <= yy < hh and 0 <= xx < ww:
+                                    acc += wgt * vol[q, 0, yy, xx]
+                            out[bi, lvl * n1 * n1 + a * n1 + bb, y, x] = acc
+    return torch.from_numpy(out).float()
+
+
+# --------------------------------------------------------------------------- #
+# PWC-Net cost volume (plain-C restatement in spatial_corr.c)
+# --------------------------------------------------------------------------- #
+_clib = None
+
+
+def _c():
+    global _clib
+    if _clib is None:
+        path = os.path.join(_HERE, "_build", "liboracle.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _clib = ctypes.CDLL(path)
+    return _clib
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _fp(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class _SpatialCorr(torch.autograd.Function):
+    """spatial_correlation_sampler.py:45-91 on top of oracle/spatial_corr.c."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, kernel_size, patch_size, stride, padding, dilation, dilation_patch):
+        kH, kW = _pair(kernel_size)
+        pH, pW = _pair(patch_size)
+        padH, padW = _pair(padding)
+        dilH, dilW = _pair(dilation)
+        dpH, dpW = _pair(dilation_patch)
+        dH, dW = _pair(stride)
+        a, b = input1.contiguous().float(), input2.contiguous().float()
+        B, C, iH, iW = a.shape
+        oH, oW = ctypes.c_int(), ctypes.c_int()
+        _c().oracle_scorr_out_size(iH, iW, kH, kW, padH, padW, dilH, dilW, dH, dW, ctypes.byref(oH),
+                                   ctypes.byref(oW))
+        out = torch.empty((B, pH, pW, oH.value, oW.value), dtype=torch.float32)
+        ctx.params = (B, C, iH, iW, kH, kW, pH, pW, padH, padW, dilH, dilW, dpH, dpW, dH, dW)
+        _c().oracle_scorr_forward(_fp(a), _fp(b), _fp(out), *ctx.params)
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        a, b = ctx.saved_tensors
+        g = grad_output.contiguous().float()
+        g1, g2 = torch.empty_like(a), torch.empty_like(b)
+        _c().oracle_scorr_backward(_fp(a), _fp(b), _fp(g), _fp(g1), _fp(g2), *ctx.params)
+        return g1, g2, None, None, None, None, None, None
+
+
+def spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=1, stride=1, padding=0, dilation=1,
+                               dilation_patch=1):
+    """spatial_correlation_sampler.py:9-42."""
+    return _SpatialCorr.apply(input1, input2, kernel_size, patch_size, stride, padding, dilation, dilation_patch)
+
+
+def spatial_correlation_shift_sum(input1, input2, patch_size=9):
+    """Independent formulation of the k=1 / stride-1 cost volume (shift, multiply, sum over C)."""
+    B, C, H, W = input1.shape
+    r = (patch_size - 1) // 2
+    padded = F.pad(input2, (r, r, r, r))
+    out = torch.empty((B, patch_size, patch_size, H, W), dtype=input1.dtype)
+    for i in range(patch_size):
+        for j in range(patch_size):
+            out[:, i, j] = (input1 * padded[:, :, i:i + H, j:j + W]).sum(1)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# attack math
+# --------------------------------------------------------------------------- #
+def box_transform(image, delta=None, change_of_variables=False, eps_box=0., scale=1.):
+    """helper_functions/own_models.py:62-85 for one image tensor."""
+    x = image
+    if delta is not None:
+        x = x + delta.repeat([image.size()[0], 1, 1, 1])
+    if change_of_variables:
+        x = (1. / 2.) * 1. / (1. - eps_box) * (torch.tanh(x) + (1 - eps_box))
+    x = torch.clamp(x, 0., 1.)
+    if scale != 1.:
+        x = scale * x
+    return x
+
+
+def extract_deltas(nw_input1, nw_input2, image1, image2, boxconstraint, eps_box=0.):
+    """attack_PCFA.py:20-29."""
+    if boxconstraint in ['change_of_variables']:
+        k = (1. / 2.) * 1. / (1. - eps_box)
+        return (k * (torch.tanh(nw_input1) + (1. - eps_box)) - image1,
+                k * (torch.tanh(nw_input2) + (1. - eps_box)) - image2)
+    return torch.clamp(nw_input1, 0., 1.) - image1, torch.clamp(nw_input2, 0., 1.) - image2
+
+
+def extract_deltas_joint(nw_delta, images_max, images_min):
+    """attack_PCFA.py:32-37."""
+    upper = torch.clamp(nw_delta + images_max, 0., 1.) - images_max
+    delta = torch.clamp(upper + images_min, 0., 1.) - images_min
+    return delta, delta
+
+
+def avg_epe(flow1, flow2):
+    """helper_functions/losses.py:3-30."""
+    sq = (flow1 - flow2) ** 2
+    if sq.dim() == 3:
+        return torch.mean(torch.sum(sq, dim=0).sqrt())
+    if sq.dim() == 4:
+        return torch.mean(torch.sum(sq, dim=1).sqrt())
+    raise ValueError("The flow tensors do not have a valid number of dimensions "
+                     "(either [b,2,M,N] or [2,M,N]). Here: %s" % str(flow1.size()))
+
+
+def avg_mse(flow1, flow2):
+    """helper_functions/losses.py:32-44."""
+    return torch.mean((flow1 - flow2) ** 2)
+
+
+def f_cosim(pred, target):
+    """helper_functions/losses.py:76-88 (operator precedence kept: the quotient is MULTIPLIED by |t|)."""
+    return 1 - torch.sum(pred * target) / torch.sqrt(torch.sum(pred * pred)) * torch.sqrt(torch.sum(target * target))
+
+
+def two_norm_avg(x):
+    """helper_functions/losses.py:129-142."""
+    return torch.sqrt(torch.sum(torch.pow(torch.flatten(x), 2))) / (torch.numel(x) ** 0.5)
+
+
+def two_norm_avg_delta(delta1, delta2):
+    """helper_functions/losses.py:91-107."""
+    n = (torch.numel(delta1) + torch.numel(delta2)) ** 0.5
+    return torch.sqrt(torch.sum(torch.pow(torch.flatten(delta1), 2)) +
+                      torch.sum(torch.pow(torch.flatten(delta2), 2))) / n
+
+
+def two_norm_avg_delta_squared(delta1, delta2):
+    """helper_functions/losses.py:110-126."""
+    n = torch.numel(delta1) + torch.numel(delta2)
+    return (torch.sum(torch.pow(torch.flatten(delta1), 2)) + torch.sum(torch.pow(torch.flatten(delta2), 2))) / n
+
+
+def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound=0.001, mu=100., f_type="aee"):
+    """helper_functions/losses.py:145-230."""
+    if f_type == "aee":
+        sim = avg_epe(pred, target)
+    elif f_type == "cosim":
+        sim = f_cosim(pred, target)
+    elif f_type == "mse":
+        sim = avg_mse(pred, target)
+    else:
+        raise NotImplementedError(
+            "The requested loss type %s does not exist. Please choose one of 'aee', 'mse' or 'cosim'" % f_type)
+    excess = two_norm_avg_delta_squared(delta1, delta2) - torch.tensor(delta_bound ** 2).to(pred.device)
+    penalty = torch.max(torch.tensor(0.).to(pred.device), excess)
+    return sim + mu * penalty

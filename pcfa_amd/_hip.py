@@ -1,0 +1,94 @@
+"""ctypes binding of libpcfa_hip.so (C-ABI declared in include/pcfa_hip.h).
+
+There is no CPU fallback: if the shared library is missing or does not match
+the ABI version this module raises, and every op in :mod:`pcfa_amd.hip_ops`
+raises when handed a non-GPU tensor.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER
+
+ABI_VERSION = 1
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpcfa_hip.so")
+
+PCFA_LOSS = {"aee": 0, "mse": 1, "cosim": 2}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_P = c_void_p  # device pointer
+_S4 = POINTER(c_longlong)  # long long[4]
+
+# name -> (restype, argtypes); kept in lock-step with include/pcfa_hip.h
+SIGNATURES = {
+    "pcfa_abi_version": (c_int, []),
+    "pcfa_status_string": (c_char_p, [c_int]),
+    "pcfa_corr_slab_floats": (c_longlong, [c_int, c_int, c_int]),
+    "pcfa_corr_level_offset": (c_longlong, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "pcfa_corr_f2ext_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_corr_pyramid_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_corr_pyramid_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "pcfa_corr_pyramid_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_corr_lookup_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_corr_lookup_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_spatial_corr_out_size": (c_int, [c_int] * 10 + [POINTER(c_int), POINTER(c_int)]),
+    "pcfa_spatial_corr_fwd": (c_int, [_P, _P, _P] + [c_int] * 16 + [_P]),
+    "pcfa_spatial_corr_bwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 16 + [_P]),
+    "pcfa_box_transform_fwd": (c_int, [_P, _P, _P, c_int, c_longlong, c_int, c_double, c_float, _P]),
+    "pcfa_box_transform_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_longlong, c_int, c_double, c_float, _P]),
+    "pcfa_extract_deltas_fwd": (c_int, [_P, _P, _P, c_longlong, c_int, c_double, _P]),
+    "pcfa_extract_deltas_bwd": (c_int, [_P, _P, _P, c_longlong, c_int, c_double, _P]),
+    "pcfa_extract_deltas_joint_fwd": (c_int, [_P, _P, _P, _P, c_longlong, _P]),
+    "pcfa_extract_deltas_joint_bwd": (c_int, [_P, _P, _P, _P, _P, c_longlong, _P]),
+    "pcfa_flow_loss_workspace_bytes": (c_size_t, []),
+    "pcfa_flow_loss_fwd": (c_int, [_P, _S4, _P, _S4, c_int, c_int, c_int, _P, c_longlong, _P, c_longlong,
+                                   c_float, c_float, c_int, _P, _P, _P]),
+    "pcfa_flow_loss_bwd": (c_int, [_P, _S4, _P, _S4, c_int, c_int, c_int, _P, c_longlong, _P, c_longlong,
+                                   c_float, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "pcfa_avg_epe": (c_int, [_P, _S4, _P, _S4, c_int, c_int, c_int, _P, _P, _P]),
+    "pcfa_sum_squares": (c_int, [_P, c_longlong, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """Load (once) and return the ctypes handle; raises HipLibraryError if unavailable."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise HipLibraryError(
+            "libpcfa_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pcfa_amd/csrc`. pcfa_amd has no CPU fallback." % p)
+    try:
+        lib = ctypes.CDLL(p)
+    except OSError as e:  # e.g. missing libamdhip64
+        raise HipLibraryError("cannot load %s: %s" % (p, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HipLibraryError("%s does not export %s (stale build?)" % (p, name))
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.pcfa_abi_version()
+    if v != ABI_VERSION:
+        raise HipLibraryError("ABI version mismatch: library %d, binding %d" % (v, ABI_VERSION))
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().pcfa_status_string(status)
+        raise RuntimeError("%s failed: %s (status %d)" % (what, msg.decode() if msg else "?", status))
+
+
+def strides4(t):
+    """long long[4] element strides (b, c, h, w) of a 4-D tensor view."""
+    return (c_longlong * 4)(*t.stride())

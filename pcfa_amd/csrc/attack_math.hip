@@ -1,0 +1,477 @@
+// Fused attack math for gfx950: box-constraint transforms, perturbation
+// extraction, and the PCFA loss (similarity term + L2 penalty) with its gradient.
+//
+// Replaces (reference paths):
+//   ScaledInputModel.forward prologue   helper_functions/own_models.py:62-85
+//   extract_deltas / extract_deltas_joint   attack_PCFA.py:20-37
+//   avg_epe / avg_mse / f_cosim / relu_penalty / loss_delta_constraint
+//                                        helper_functions/losses.py:3-44,76-88,110-126,177-230
+//
+// All kernels are HBM-streaming: 16-B vector loads where the layout allows,
+// grid capped at 2048 workgroups with grid-stride loops.  Reductions are two
+// stage (per-workgroup partials in a fixed slot, then one workgroup sums them in
+// index order), so every scalar is bitwise reproducible run to run -- L-BFGS
+// amplifies summation-order noise.
+#include "common.hpp"
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;  // fixed: the partial count defines the summation order
+constexpr int RED_THREADS = 256;
+constexpr int NSUM = 8;           // partial sums per workgroup
+
+struct BoxConst {
+  float k;  // 0.5 / (1 - eps)   (evaluated in double like the Python scalar, then rounded)
+  float c;  // 1 - eps
+};
+inline BoxConst make_box(double eps) {
+  BoxConst b;
+  b.k = (float)((1. / 2.) * 1. / (1. - eps));
+  b.c = (float)(1. - eps);
+  return b;
+}
+
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+
+// ---------------------------------------------------------------- box transform
+__global__ void box_fwd_kernel(const float* __restrict__ image, const float* __restrict__ delta,
+                               float* __restrict__ out, int B, long long n, int cov, BoxConst bc,
+                               float scale) {
+  const long long total = (long long)B * n;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    float x = image[i];
+    if (delta) x = x + delta[i % n];
+    if (cov) x = bc.k * (tanhf(x) + bc.c);
+    x = clamp01(x);
+    if (scale != 1.f) x = scale * x;
+    out[i] = x;
+  }
+}
+
+// grad wrt (image+delta); grad_delta is the batch sum in index order.
+__global__ void box_bwd_kernel(const float* __restrict__ image, const float* __restrict__ delta,
+                               const float* __restrict__ gout, float* __restrict__ gimage,
+                               float* __restrict__ gdelta, int B, long long n, int cov,
+                               BoxConst bc, float scale) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    float gsum = 0.f;
+    const float d = delta ? delta[j] : 0.f;
+    for (int b = 0; b < B; ++b) {
+      const long long i = (long long)b * n + j;
+      float x = image[i];
+      if (delta) x = x + d;
+      float g = gout[i];
+      if (scale != 1.f) g = g * scale;
+      float y = x, t = 0.f;
+      if (cov) {
+        t = tanhf(x);
+        y = bc.k * (t + bc.c);
+      }
+      if (!(y >= 0.f && y <= 1.f)) g = 0.f;  // clamp backward: pass-through inside [0,1]
+      if (cov) g = (g * bc.k) * (1.f - t * t);
+      if (gimage) gimage[i] = g;
+      gsum += g;
+    }
+    if (gdelta) gdelta[j] = gsum;
+  }
+}
+
+// ---------------------------------------------------------------- extract_deltas
+__global__ void deltas_fwd_kernel(const float* __restrict__ w, const float* __restrict__ image,
+                                  float* __restrict__ delta, long long n, int cov, BoxConst bc) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float x = w[i];
+    const float y = cov ? bc.k * (tanhf(x) + bc.c) : clamp01(x);
+    delta[i] = y - image[i];
+  }
+}
+
+__global__ void deltas_bwd_kernel(const float* __restrict__ w, const float* __restrict__ gd,
+                                  float* __restrict__ gw, long long n, int cov, BoxConst bc) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float x = w[i];
+    float g = gd[i];
+    if (cov) {
+      const float t = tanhf(x);
+      g = (g * bc.k) * (1.f - t * t);
+    } else if (!(x >= 0.f && x <= 1.f)) {
+      g = 0.f;
+    }
+    gw[i] = g;
+  }
+}
+
+__global__ void deltas_joint_fwd_kernel(const float* __restrict__ nd,
+                                        const float* __restrict__ imax,
+                                        const float* __restrict__ imin, float* __restrict__ delta,
+                                        long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float up = clamp01(nd[i] + imax[i]) - imax[i];
+    delta[i] = clamp01(up + imin[i]) - imin[i];
+  }
+}
+
+__global__ void deltas_joint_bwd_kernel(const float* __restrict__ nd,
+                                        const float* __restrict__ imax,
+                                        const float* __restrict__ imin,
+                                        const float* __restrict__ gd, float* __restrict__ gnd,
+                                        long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float a = nd[i] + imax[i];
+    const float up = clamp01(a) - imax[i];
+    const float b = up + imin[i];
+    float g = gd[i];
+    if (!(b >= 0.f && b <= 1.f)) g = 0.f;
+    if (!(a >= 0.f && a <= 1.f)) g = 0.f;
+    gnd[i] = g;
+  }
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Sum NS values over the workgroup; result valid in thread 0.
+template <int NS>
+__device__ __forceinline__ void block_sum(float (&v)[NS], float* smem /*[NS][4]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const float s = wave_sum(v[k]);
+    if (lane == 0) smem[k * 4 + wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      v[k] = ((smem[k * 4 + 0] + smem[k * 4 + 1]) + smem[k * 4 + 2]) + smem[k * 4 + 3];
+  }
+}
+
+struct View4 {
+  long long sb, sc, sh, sw;
+};
+
+// partial[block][0]=sum epe, [1]=sum sq diff, [2]=p.t, [3]=p.p, [4]=t.t, [5]=sum d1^2, [6]=sum d2^2
+__global__ __launch_bounds__(RED_THREADS) void loss_partial_kernel(
+    const float* __restrict__ pred, View4 ps, const float* __restrict__ target, View4 ts, int B,
+    int H, int W, const float* __restrict__ d1, long long n1, const float* __restrict__ d2,
+    long long n2, float* __restrict__ partial) {
+  __shared__ float smem[NSUM * 4];
+  float v[NSUM];
+#pragma unroll
+  for (int k = 0; k < NSUM; ++k) v[k] = 0.f;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pred) {
+    const long long npix = (long long)B * H * W;
+    for (long long i = gid; i < npix; i += stride) {
+      const int x = i % W;
+      const long long t = i / W;
+      const int y = t % H;
+      const int b = (int)(t / H);
+      const long long po = b * ps.sb + y * ps.sh + x * ps.sw;
+      const long long to = b * ts.sb + y * ts.sh + x * ts.sw;
+      const float pu = pred[po], pv = pred[po + ps.sc];
+      const float tu = target[to], tv = target[to + ts.sc];
+      const float du = pu - tu, dv = pv - tv;
+      const float sq = du * du + dv * dv;
+      v[0] += sqrtf(sq);
+      v[1] += sq;
+      v[2] += pu * tu + pv * tv;
+      v[3] += pu * pu + pv * pv;
+      v[4] += tu * tu + tv * tv;
+    }
+  }
+  if (d1)
+    for (long long i = gid; i < n1; i += stride) v[5] += d1[i] * d1[i];
+  if (d2)
+    for (long long i = gid; i < n2; i += stride) v[6] += d2[i] * d2[i];
+  block_sum<NSUM>(v, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) partial[(size_t)blockIdx.x * NSUM + k] = v[k];
+  }
+}
+
+// mode 0: loss_delta_constraint scalars; mode 1: avg_epe only; mode 2: sum of squares (slot 5).
+__global__ __launch_bounds__(RED_THREADS) void loss_final_kernel(
+    const float* __restrict__ partial, int nblocks, float* __restrict__ out, int mode,
+    float npix, float nelem_flow, float ndelta, float bound_sq, float mu, int f_type) {
+  __shared__ float smem[NSUM * 4];
+  float v[NSUM];
+#pragma unroll
+  for (int k = 0; k < NSUM; ++k) v[k] = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) v[k] += partial[(size_t)i * NSUM + k];
+  }
+  block_sum<NSUM>(v, smem);
+  if (threadIdx.x != 0) return;
+  if (mode == 1) {
+    out[0] = v[0] / npix;
+    return;
+  }
+  if (mode == 2) {
+    out[0] = v[5];
+    return;
+  }
+  float sim;
+  if (f_type == PCFA_LOSS_AEE)
+    sim = v[0] / npix;
+  else if (f_type == PCFA_LOSS_MSE)
+    sim = v[1] / nelem_flow;
+  else  // bug-compatible with losses.py:88:  1 - (p.t / sqrt(p.p)) * sqrt(t.t)
+    sim = 1.f - v[2] / sqrtf(v[3]) * sqrtf(v[4]);
+  const float msq = (v[5] + v[6]) / ndelta;
+  const float pen = fmaxf(0.f, msq - bound_sq);
+  out[0] = sim + mu * pen;
+  out[1] = sim;
+  out[2] = msq;
+  out[3] = v[2];
+  out[4] = v[3];
+  out[5] = v[4];
+  out[6] = msq - bound_sq;
+}
+
+__global__ void loss_bwd_flow_kernel(const float* __restrict__ pred, View4 ps,
+                                     const float* __restrict__ target, View4 ts, int B, int H,
+                                     int W, int f_type, const float* __restrict__ fwd,
+                                     const float* __restrict__ gloss, float* __restrict__ gpred) {
+  const long long npix = (long long)B * H * W;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const float gl = gloss[0];
+  const float pt = fwd[3], pp = fwd[4], tt = fwd[5];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+    const int x = i % W;
+    const long long t = i / W;
+    const int y = t % H;
+    const int b = (int)(t / H);
+    const long long po = b * ps.sb + y * ps.sh + x * ps.sw;
+    const long long to = b * ts.sb + y * ts.sh + x * ts.sw;
+    const float pu = pred[po], pv = pred[po + ps.sc];
+    const float tu = target[to], tv = target[to + ts.sc];
+    float gu, gv;
+    if (f_type == PCFA_LOSS_AEE) {
+      // mean -> sqrt -> sum(dim=1) -> pow(2) -> sub, in autograd's order
+      const float du = pu - tu, dv = pv - tv;
+      const float g = gl / (float)npix;
+      const float gs = g / (2.f * sqrtf(du * du + dv * dv));
+      gu = gs * (2.f * du);
+      gv = gs * (2.f * dv);
+    } else if (f_type == PCFA_LOSS_MSE) {
+      const float g = gl / (float)(npix * 2);
+      gu = g * (2.f * (pu - tu));
+      gv = g * (2.f * (pv - tv));
+    } else {
+      const float spp = sqrtf(pp), stt = sqrtf(tt);
+      // L = 1 - pt * pp^-1/2 * tt^1/2
+      const float a = -gl * stt / spp;             // d/d(pt)
+      const float c = gl * stt * pt / (2.f * pp * spp);  // d/d(pp)
+      gu = a * tu + c * (2.f * pu);
+      gv = a * tv + c * (2.f * pv);
+    }
+    const long long o = ((long long)b * 2 * H + y) * W + x;
+    gpred[o] = gu;
+    gpred[o + (long long)H * W] = gv;
+  }
+}
+
+__global__ void loss_bwd_delta_kernel(const float* __restrict__ d, long long n, float ndelta,
+                                      float mu, float mult, const float* __restrict__ fwd,
+                                      const float* __restrict__ gloss, float* __restrict__ gd) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const float arg = fwd[6];  // msq - bound^2
+  // torch.max(0, x) backward: full gradient for x > 0, half at the tie, none below
+  const float sel = arg > 0.f ? 1.f : (arg == 0.f ? 0.5f : 0.f);
+  const float g = gloss[0] * mu * sel / ndelta;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    gd[i] = mult * (g * (2.f * d[i]));
+}
+
+inline int ew_blocks(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+inline View4 mkview(const long long s[4]) { return View4{s[0], s[1], s[2], s[3]}; }
+
+}  // namespace
+
+extern "C" int pcfa_abi_version(void) { return PCFA_ABI_VERSION; }
+
+extern "C" const char* pcfa_status_string(int status) {
+  switch (status) {
+    case PCFA_OK: return "ok";
+    case PCFA_ERR_INVALID_ARG: return "invalid argument";
+    case PCFA_ERR_UNSUPPORTED: return "unsupported parameter combination";
+    case PCFA_ERR_WORKSPACE: return "workspace too small";
+    default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown status";
+  }
+}
+
+extern "C" int pcfa_box_transform_fwd(const float* image, const float* delta, float* out, int B,
+                                      long long n, int cov, double eps_box, float scale,
+                                      void* stream) {
+  if (!image || !out || B < 1 || n < 1) return PCFA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(box_fwd_kernel, dim3(ew_blocks((long long)B * n)), dim3(256), 0,
+                     (hipStream_t)stream, image, delta, out, B, n, cov, make_box(eps_box), scale);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_box_transform_bwd(const float* image, const float* delta,
+                                      const float* grad_out, float* grad_image, float* grad_delta,
+                                      int B, long long n, int cov, double eps_box, float scale,
+                                      void* stream) {
+  if (!image || !grad_out || B < 1 || n < 1) return PCFA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(box_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, image,
+                     delta, grad_out, grad_image, grad_delta, B, n, cov, make_box(eps_box), scale);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_extract_deltas_fwd(const float* nw_input, const float* image, float* delta,
+                                       long long n, int cov, double eps_box, void* stream) {
+  if (!nw_input || !image || !delta || n < 1) return PCFA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(deltas_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream,
+                     nw_input, image, delta, n, cov, make_box(eps_box));
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_extract_deltas_bwd(const float* nw_input, const float* grad_delta,
+                                       float* grad_nw_input, long long n, int cov, double eps_box,
+                                       void* stream) {
+  if (!nw_input || !grad_delta || !grad_nw_input || n < 1) return PCFA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(deltas_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream,
+                     nw_input, grad_delta, grad_nw_input, n, cov, make_box(eps_box));
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_extract_deltas_joint_fwd(const float* nw_delta, const float* images_max,
+                                             const float* images_min, float* delta, long long n,
+                                             void* stream) {
+  if (!nw_delta || !images_max || !images_min || !delta || n < 1) return PCFA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(deltas_joint_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0,
+                     (hipStream_t)stream, nw_delta, images_max, images_min, delta, n);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_extract_deltas_joint_bwd(const float* nw_delta, const float* images_max,
+                                             const float* images_min, const float* grad_delta,
+                                             float* grad_nw_delta, long long n, void* stream) {
+  if (!nw_delta || !images_max || !images_min || !grad_delta || !grad_nw_delta || n < 1)
+    return PCFA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(deltas_joint_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0,
+                     (hipStream_t)stream, nw_delta, images_max, images_min, grad_delta,
+                     grad_nw_delta, n);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" size_t pcfa_flow_loss_workspace_bytes(void) {
+  return sizeof(float) * RED_BLOCKS * NSUM;
+}
+
+extern "C" int pcfa_flow_loss_fwd(const float* pred, const long long pred_strides[4],
+                                  const float* target, const long long target_strides[4], int B,
+                                  int H, int W, const float* delta1, long long n1,
+                                  const float* delta2, long long n2, float delta_bound, float mu,
+                                  int f_type, float* out_scalars, void* workspace, void* stream) {
+  if (!pred || !target || !pred_strides || !target_strides || !delta1 || !delta2 ||
+      !out_scalars || !workspace || B < 1 || H < 1 || W < 1 || n1 < 1 || n2 < 1 || f_type < 0 ||
+      f_type > 2)
+    return PCFA_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pred,
+                     mkview(pred_strides), target, mkview(target_strides), B, H, W, delta1, n1,
+                     delta2, n2, partial);
+  PCFA_LAUNCH_CHECK();
+  const float bound_sq = (float)((double)delta_bound * (double)delta_bound);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, RED_BLOCKS,
+                     out_scalars, 0, (float)((long long)B * H * W),
+                     (float)((long long)B * 2 * H * W), (float)(n1 + n2), bound_sq, mu, f_type);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_flow_loss_bwd(const float* pred, const long long pred_strides[4],
+                                  const float* target, const long long target_strides[4], int B,
+                                  int H, int W, const float* delta1, long long n1,
+                                  const float* delta2, long long n2, float mu, int f_type,
+                                  int joint, const float* fwd_scalars, const float* grad_loss,
+                                  float* grad_pred, float* grad_delta1, float* grad_delta2,
+                                  void* stream) {
+  if (!pred || !target || !pred_strides || !target_strides || !fwd_scalars || !grad_loss ||
+      B < 1 || H < 1 || W < 1 || f_type < 0 || f_type > 2)
+    return PCFA_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (grad_pred) {
+    hipLaunchKernelGGL(loss_bwd_flow_kernel, dim3(ew_blocks((long long)B * H * W)), dim3(256), 0,
+                       s, pred, mkview(pred_strides), target, mkview(target_strides), B, H, W,
+                       f_type, fwd_scalars, grad_loss, grad_pred);
+    PCFA_LAUNCH_CHECK();
+  }
+  const float ndelta = (float)(n1 + n2);
+  if (grad_delta1) {
+    if (!delta1) return PCFA_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(loss_bwd_delta_kernel, dim3(ew_blocks(n1)), dim3(256), 0, s, delta1, n1,
+                       ndelta, mu, joint ? 2.f : 1.f, fwd_scalars, grad_loss, grad_delta1);
+    PCFA_LAUNCH_CHECK();
+  }
+  if (grad_delta2) {
+    if (!delta2) return PCFA_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(loss_bwd_delta_kernel, dim3(ew_blocks(n2)), dim3(256), 0, s, delta2, n2,
+                       ndelta, mu, 1.f, fwd_scalars, grad_loss, grad_delta2);
+    PCFA_LAUNCH_CHECK();
+  }
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_avg_epe(const float* flow1, const long long strides1[4], const float* flow2,
+                            const long long strides2[4], int B, int H, int W, float* out,
+                            void* workspace, void* stream) {
+  if (!flow1 || !flow2 || !strides1 || !strides2 || !out || !workspace || B < 1 || H < 1 ||
+      W < 1)
+    return PCFA_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, flow1,
+                     mkview(strides1), flow2, mkview(strides2), B, H, W, (const float*)nullptr,
+                     0LL, (const float*)nullptr, 0LL, partial);
+  PCFA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, RED_BLOCKS,
+                     out, 1, (float)((long long)B * H * W), 0.f, 1.f, 0.f, 0.f, 0);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_sum_squares(const float* x, long long n, float* out, void* workspace,
+                                void* stream) {
+  if (!x || !out || !workspace || n < 1) return PCFA_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s,
+                     (const float*)nullptr, View4{0, 0, 0, 0}, (const float*)nullptr,
+                     View4{0, 0, 0, 0}, 1, 1, 1, x, n, (const float*)nullptr, 0LL, partial);
+  PCFA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, RED_BLOCKS,
+                     out, 2, 1.f, 1.f, 1.f, 0.f, 0.f, 0);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}

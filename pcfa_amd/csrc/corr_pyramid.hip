@@ -1,0 +1,375 @@
+// RAFT/GMA all-pairs correlation pyramid (build + backward) for gfx950.
+//
+// Replaces CorrBlock.corr + the avg_pool2d pyramid (reference
+// models/raft/corr.py:12-27,52-60) and their autograd backward.
+//
+// MI355X formulation: average pooling commutes with the inner product, so
+//   avg_pool_l(fmap1^T fmap2) == fmap1^T avg_pool_l(fmap2).
+// The whole pyramid is therefore ONE fp32-MFMA GEMM
+//   pyr[Q x slab] = fmap1^T [Q x D] . f2ext [D x slab] / sqrt(D)
+// against fmap2 extended by its pooled copies (f2ext), written straight into
+// the slab-per-query layout the lookup kernels read -- no pooling passes over
+// the 260 MB volume.  The backward is two split-K GEMMs against the same f2ext
+// followed by the (tiny) adjoint of the pooling on a [D x slab] matrix.
+//
+// GEMM core: 128x128x16 block tile, 4 waves (2x2), each wave 2x2 tiles of
+// v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain), LDS double buffer
+// fed by register prefetch.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDS_KM = 132;  // row stride (floats) when the operand arrives k-major (b128 writes)
+constexpr int LDS_MK = 130;  // row stride when transposing on the way in (conflict-free b32 writes)
+
+// Stage one 128(dim) x 16(k) operand tile: global -> registers.
+// KMAJ: stored [K][dim] (dim contiguous) ; else stored [dim][K] (k contiguous).
+template <bool KMAJ>
+__device__ __forceinline__ void tile_load(const float* __restrict__ X, long long ld, int dim,
+                                          int d0, int k0, int kend, bool vec, float4 (&r)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + 256 * i;
+    int k, d;
+    if (KMAJ) {
+      k = k0 + f / 32;
+      d = d0 + (f % 32) * 4;
+    } else {
+      d = d0 + f / 4;
+      k = k0 + (f % 4) * 4;
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KMAJ) {
+      if (k < kend) {
+        const float* p = X + (long long)k * ld + d;
+        if (vec && d + 3 < dim) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (d + 0 < dim) v.x = p[0];
+          if (d + 1 < dim) v.y = p[1];
+          if (d + 2 < dim) v.z = p[2];
+          if (d + 3 < dim) v.w = p[3];
+        }
+      }
+    } else {
+      if (d < dim) {
+        const float* p = X + (long long)d * ld + k;
+        if (vec && k + 3 < kend) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (k + 0 < kend) v.x = p[0];
+          if (k + 1 < kend) v.y = p[1];
+          if (k + 2 < kend) v.z = p[2];
+          if (k + 3 < kend) v.w = p[3];
+        }
+      }
+    }
+    r[i] = v;
+  }
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ void tile_store(float* __restrict__ s, const float4 (&r)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + 256 * i;
+    if (KMAJ) {
+      const int k = f / 32, d = (f % 32) * 4;
+      *reinterpret_cast<float4*>(s + k * LDS_KM + d) = r[i];
+    } else {
+      const int d = f / 4, k = (f % 4) * 4;
+      s[(k + 0) * LDS_MK + d] = r[i].x;
+      s[(k + 1) * LDS_MK + d] = r[i].y;
+      s[(k + 2) * LDS_MK + d] = r[i].z;
+      s[(k + 3) * LDS_MK + d] = r[i].w;
+    }
+  }
+}
+
+// C[m][n] = (sum_k A(m,k) B(k,n)) / div   over k in this block's split.
+// grid = (ceil(N/128), ceil(M/128), batch*splits).
+template <bool A_KM, bool B_KN>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
+    int N, int K, long long lda, long long ldb, long long ldc, long long bsA, long long bsB,
+    long long bsC, int splits, int kchunk, long long ssC, float div, int vecA, int vecB) {
+  constexpr int SA = A_KM ? LDS_KM : LDS_MK;
+  constexpr int SB = B_KN ? LDS_KM : LDS_MK;
+  __shared__ __attribute__((aligned(16))) float sA[2][BK * SA];
+  __shared__ __attribute__((aligned(16))) float sB[2][BK * SB];
+
+  const int batch = blockIdx.z / splits;
+  const int split = blockIdx.z - batch * splits;
+  A += batch * bsA;
+  B += batch * bsB;
+  C += batch * bsC + split * ssC;
+  const int kbeg = split * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2], rb[2];
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    tile_load<A_KM>(A, lda, M, m0, kbeg, kend, vecA, ra);
+    tile_load<B_KN>(B, ldb, N, n0, kbeg, kend, vecB, rb);
+    tile_store<A_KM>(sA[0], ra);
+    tile_store<B_KN>(sB[0], rb);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      tile_load<A_KM>(A, lda, M, m0, k0, kend, vecA, ra);
+      tile_load<B_KN>(B, ldb, N, n0, k0, kend, vecB, rb);
+    }
+    const float* a = sA[cur] + wr * 64 + l31;
+    const float* b = sB[cur] + wc * 64 + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = a[(kk + lh) * SA], a1 = a[(kk + lh) * SA + 32];
+      const float b0 = b[(kk + lh) * SB], b1 = b[(kk + lh) * SB + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+      tile_store<A_KM>(sA[cur ^ 1], ra);
+      tile_store<B_KN>(sB[cur ^ 1], rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // Epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + j * 32 + l31;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M) C[(long long)row * ldc + col] = acc[i][j][r] / div;
+      }
+    }
+}
+
+// out[i] = sum_s partial[s][i]  (fixed order -> deterministic).  No scaling:
+// the split GEMMs already divided every partial by sqrt(D).
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                     long long n, int splits, long long ss) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float s = part[i];
+    for (int k = 1; k < splits; ++k) s += part[(long long)k * ss + i];
+    out[i] = s;
+  }
+}
+
+// One workgroup per (b, d) plane: f2ext row = [fmap2 plane | pooled levels | 0 pad].
+__global__ __launch_bounds__(256) void f2ext_fwd_kernel(const float* __restrict__ fmap2,
+                                                        float* __restrict__ f2ext, int Q,
+                                                        PyrLayout P) {
+  extern __shared__ float s_lv[];  // levels >= 1, indexed by (off - Q)
+  const float* src = fmap2 + (size_t)blockIdx.x * Q;
+  float* dst = f2ext + (size_t)blockIdx.x * P.slab;
+  for (int i = threadIdx.x; i < Q; i += blockDim.x) dst[i] = src[i];
+  for (int l = 1; l < P.L; ++l) {
+    const int hl = P.h[l], wl = P.w[l], wp = P.w[l - 1];
+    const float* prev = (l == 1) ? src : (s_lv + P.off[l - 1] - Q);
+    float* cur = s_lv + P.off[l] - Q;
+    for (int i = threadIdx.x; i < hl * wl; i += blockDim.x) {
+      const int y = i / wl, x = i - y * wl;
+      const float* p = prev + (2 * y) * wp + 2 * x;
+      // F.avg_pool2d: sequential sum over the window, then one division
+      const float v = (((p[0] + p[1]) + p[wp]) + p[wp + 1]) / 4.0f;
+      cur[i] = v;
+      dst[P.off[l] + i] = v;
+    }
+    __syncthreads();
+  }
+  int used = P.off[P.L - 1] + P.h[P.L - 1] * P.w[P.L - 1];
+  for (int i = used + threadIdx.x; i < P.slab; i += blockDim.x) dst[i] = 0.f;
+}
+
+// Adjoint of the pooling chain: dfmap2 plane = g_0 + up(g_1)/4 + up(up(g_2)/4)/4 ...
+__global__ __launch_bounds__(256) void f2ext_bwd_kernel(const float* __restrict__ df2ext,
+                                                        float* __restrict__ dfmap2, int Q,
+                                                        PyrLayout P) {
+  extern __shared__ float s_lv[];
+  const float* src = df2ext + (size_t)blockIdx.x * P.slab;
+  float* dst = dfmap2 + (size_t)blockIdx.x * Q;
+  const int used = P.off[P.L - 1] + P.h[P.L - 1] * P.w[P.L - 1];
+  for (int i = Q + threadIdx.x; i < used; i += blockDim.x) s_lv[i - Q] = src[i];
+  __syncthreads();
+  for (int l = P.L - 1; l >= 2; --l) {
+    const int hl = P.h[l], wl = P.w[l], wp = P.w[l - 1];
+    const float* g = s_lv + P.off[l] - Q;
+    float* gp = s_lv + P.off[l - 1] - Q;
+    for (int i = threadIdx.x; i < 4 * hl * wl; i += blockDim.x) {
+      const int y = i / (2 * wl), x = i - y * (2 * wl);
+      gp[y * wp + x] += g[(y >> 1) * wl + (x >> 1)] / 4.0f;
+    }
+    __syncthreads();
+  }
+  const int W0 = P.w[0];
+  for (int i = threadIdx.x; i < Q; i += blockDim.x) {
+    float v = src[i];
+    if (P.L > 1) {
+      const int y = i / W0, x = i - y * W0;
+      if ((y >> 1) < P.h[1] && (x >> 1) < P.w[1])
+        v += s_lv[P.off[1] - Q + (y >> 1) * P.w[1] + (x >> 1)] / 4.0f;
+    }
+    dst[i] = v;
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr int BWD_SPLITS = 8;
+
+int choose_kchunk(int K, int splits) {
+  int per = (K + splits - 1) / splits;
+  return ((per + BK - 1) / BK) * BK;
+}
+
+}  // namespace
+
+extern "C" long long pcfa_corr_slab_floats(int H, int W, int num_levels) {
+  PyrLayout P;
+  if (!pcfa_make_layout(P, H, W, num_levels)) return -1;
+  return P.slab;
+}
+
+extern "C" long long pcfa_corr_level_offset(int H, int W, int num_levels, int level, int* h_l,
+                                            int* w_l) {
+  PyrLayout P;
+  if (!pcfa_make_layout(P, H, W, num_levels) || level < 0 || level >= num_levels) return -1;
+  if (h_l) *h_l = P.h[level];
+  if (w_l) *w_l = P.w[level];
+  return P.off[level];
+}
+
+extern "C" int pcfa_corr_f2ext_fwd(const float* fmap2, float* f2ext, int B, int D, int H, int W,
+                                   int num_levels, void* stream) {
+  PyrLayout P;
+  if (!fmap2 || !f2ext || B < 1 || D < 1 || !pcfa_make_layout(P, H, W, num_levels))
+    return PCFA_ERR_INVALID_ARG;
+  for (int l = 0; l < P.L; ++l)
+    if (P.h[l] < 1 || P.w[l] < 1) return PCFA_ERR_INVALID_ARG;
+  const int Q = H * W;
+  const size_t lds = (size_t)(P.slab - Q + 4) * sizeof(float);
+  if (lds > 64 * 1024) return PCFA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(f2ext_fwd_kernel, dim3(B * D), dim3(256), lds, (hipStream_t)stream, fmap2,
+                     f2ext, Q, P);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_corr_pyramid_fwd(const float* fmap1, const float* f2ext, float* pyr, int B,
+                                     int D, int H, int W, int num_levels, void* stream) {
+  PyrLayout P;
+  if (!fmap1 || !f2ext || !pyr || B < 1 || D < 1 || !pcfa_make_layout(P, H, W, num_levels))
+    return PCFA_ERR_INVALID_ARG;
+  const int Q = H * W, S = P.slab;
+  const int vecA = (Q % 4 == 0) && aligned16(fmap1);
+  const int vecB = aligned16(f2ext);  // slab % 4 == 0 by construction
+  dim3 grid(pcfa_cdiv(S, BN), pcfa_cdiv(Q, BM), B);
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0,
+                     (hipStream_t)stream, fmap1, f2ext, pyr, Q, S, D, (long long)Q,
+                     (long long)S, (long long)S, (long long)D * Q, (long long)D * S,
+                     (long long)Q * S, 1, ((D + BK - 1) / BK) * BK, 0LL, sqrtf((float)D), vecA,
+                     vecB);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" size_t pcfa_corr_pyramid_bwd_workspace_bytes(int B, int D, int H, int W,
+                                                        int num_levels) {
+  PyrLayout P;
+  if (B < 1 || D < 1 || !pcfa_make_layout(P, H, W, num_levels)) return 0;
+  const size_t Q = (size_t)H * W, S = P.slab;
+  // split-K partials of dfmap1 [splits][B][D][Q], of df2ext [splits][B][D][S], + df2ext [B][D][S]
+  return sizeof(float) * ((size_t)BWD_SPLITS * B * D * Q + (size_t)BWD_SPLITS * B * D * S +
+                          (size_t)B * D * S);
+}
+
+extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, const float* f2ext,
+                                     float* dfmap1, float* dfmap2, void* workspace,
+                                     size_t workspace_bytes, int B, int D, int H, int W,
+                                     int num_levels, void* stream) {
+  PyrLayout P;
+  if (!dpyr || !fmap1 || !f2ext || !dfmap1 || !dfmap2 || !workspace || B < 1 || D < 1 ||
+      !pcfa_make_layout(P, H, W, num_levels))
+    return PCFA_ERR_INVALID_ARG;
+  if (workspace_bytes < pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, num_levels))
+    return PCFA_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int Q = H * W, S = P.slab;
+  const float div = sqrtf((float)D);
+  float* part1 = (float*)workspace;
+  float* part2 = part1 + (size_t)BWD_SPLITS * B * D * Q;
+  float* df2ext = part2 + (size_t)BWD_SPLITS * B * D * S;
+
+  // (a) dfmap1[d][q] = sum_n f2ext[d][n] * dpyr[q][n] / sqrt(D):  A=[M=D][K=S], B=[N=Q][K=S]
+  {
+    const int kchunk = choose_kchunk(S, BWD_SPLITS);
+    const int vec = aligned16(f2ext) && aligned16(dpyr);
+    dim3 grid(pcfa_cdiv(Q, BN), pcfa_cdiv(D, BM), B * BWD_SPLITS);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(256), 0, s, f2ext, dpyr,
+                       part1, D, Q, S, (long long)S, (long long)S, (long long)Q,
+                       (long long)D * S, (long long)Q * S, (long long)D * Q, BWD_SPLITS, kchunk,
+                       (long long)B * D * Q, div, vec, vec);
+    PCFA_LAUNCH_CHECK();
+    const long long n = (long long)B * D * Q;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(min(pcfa_cdiv(n, 256), 2048)), dim3(256), 0, s,
+                       part1, dfmap1, n, BWD_SPLITS, n);
+    PCFA_LAUNCH_CHECK();
+  }
+  // (b) df2ext[d][n] = sum_q fmap1[d][q] * dpyr[q][n] / sqrt(D):  A=[M=D][K=Q], B=[K=Q][N=S]
+  {
+    const int kchunk = choose_kchunk(Q, BWD_SPLITS);
+    const int vecA = (Q % 4 == 0) && aligned16(fmap1);
+    const int vecB = aligned16(dpyr);
+    dim3 grid(pcfa_cdiv(S, BN), pcfa_cdiv(D, BM), B * BWD_SPLITS);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(256), 0, s, fmap1, dpyr,
+                       part2, D, S, Q, (long long)Q, (long long)S, (long long)S,
+                       (long long)D * Q, (long long)Q * S, (long long)D * S, BWD_SPLITS, kchunk,
+                       (long long)B * D * S, div, vecA, vecB);
+    PCFA_LAUNCH_CHECK();
+    const long long n = (long long)B * D * S;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(min(pcfa_cdiv(n, 256), 2048)), dim3(256), 0, s,
+                       part2, df2ext, n, BWD_SPLITS, n);
+    PCFA_LAUNCH_CHECK();
+  }
+  // (c) adjoint of the pooling chain
+  {
+    const size_t lds = (size_t)(P.slab - Q + 4) * sizeof(float);
+    if (lds > 64 * 1024) return PCFA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(f2ext_bwd_kernel, dim3(B * D), dim3(256), lds, s, df2ext, dfmap2, Q, P);
+    PCFA_LAUNCH_CHECK();
+  }
+  return PCFA_OK;
+}

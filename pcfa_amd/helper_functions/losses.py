@@ -1,0 +1,31 @@
+"""PCFA loss terms (reference helper_functions/losses.py) on the fused HIP kernels.
+
+Same function names and signatures as the reference module; the arithmetic runs
+in pcfa_amd/csrc/attack_math.hip through :mod:`pcfa_amd.ops`.
+"""
+from .. import ops
+
+
+def avg_epe(flow1, flow2):
+    """Average endpoint error, losses.py:3-30 (as a metric; the differentiable use is loss_delta_constraint)."""
+    return ops.get().avg_epe(flow1, flow2)
+
+
+def f_epe(pred, target):
+    return avg_epe(pred, target)
+
+
+def two_norm_avg_delta(delta1, delta2):
+    """losses.py:91-107."""
+    return ops.get().two_norm_avg_delta(delta1, delta2)
+
+
+def two_norm_avg(x):
+    """losses.py:129-142."""
+    return ops.get().two_norm_avg(x)
+
+
+def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound=0.001, mu=100., f_type="aee"):
+    """similarity(pred, target) + mu * relu(mean(delta^2) - delta_bound^2), losses.py:200-230."""
+    return ops.get().loss_delta_constraint(pred, target, delta1, delta2, device, delta_bound=delta_bound, mu=mu,
+                                           f_type=f_type)

@@ -1,0 +1,420 @@
+"""Autograd-aware operators of the PCFA hot path, backed by libpcfa_hip.so.
+
+This is the ONLY operator implementation inside the package.  Every op checks
+that its tensors live on a HIP device and raises otherwise (no CPU fallback);
+launches go to torch's current stream through the C-ABI, so they order with
+the surrounding MIOpen/hipBLASLt work and can be captured into a hipGraph.
+
+Operator boundaries mirrored (reference file:line):
+  CorrBlock                      models/raft/corr.py:12-60 (== models/gma/corr.py:15-63)
+  spatial_correlation_sample     .../spatial_correlation_sampler/spatial_correlation_sampler.py:9-91
+  box_transform                  helper_functions/own_models.py:62-85
+  extract_deltas(_joint)         attack_PCFA.py:20-37
+  loss_delta_constraint, avg_epe, two_norm_*   helper_functions/losses.py
+"""
+import ctypes
+
+import torch
+
+from . import _hip
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "pcfa_amd HIP operator called with a %s tensor: the MI355X path has no CPU fallback"
+                % t.device)
+        if t.dtype != torch.float32:
+            raise TypeError("pcfa_amd kernels compute in float32, got %s" % t.dtype)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+# --------------------------------------------------------------------------- #
+# RAFT / GMA correlation pyramid
+# --------------------------------------------------------------------------- #
+class _CorrState:
+    """Device buffers shared by the build node and its lookup nodes."""
+    __slots__ = ("B", "D", "H", "W", "L", "r", "slab", "pyr", "f2ext", "dpyr")
+
+
+class _CorrBuild(torch.autograd.Function):
+    """fmap1, fmap2 -> 1-element token; the pyramid itself lives in `state`.
+
+    The token only carries the autograd dependency: every lookup consumes it, so
+    this node's backward runs after ALL lookup backwards have accumulated into
+    state.dpyr, and performs the two GEMMs of the volume's backward once.
+    """
+
+    @staticmethod
+    def forward(ctx, fmap1, fmap2, state):
+        lib = _hip.load()
+        B, D, H, W = fmap1.shape
+        f1 = fmap1.contiguous()
+        f2 = fmap2.contiguous()
+        slab = state.slab
+        state.f2ext = torch.empty((B, D, slab), device=f1.device, dtype=torch.float32)
+        state.pyr = torch.empty((B * H * W, slab), device=f1.device, dtype=torch.float32)
+        _hip.check(lib.pcfa_corr_f2ext_fwd(_ptr(f2), _ptr(state.f2ext), B, D, H, W, state.L, _stream()),
+                   "pcfa_corr_f2ext_fwd")
+        _hip.check(lib.pcfa_corr_pyramid_fwd(_ptr(f1), _ptr(state.f2ext), _ptr(state.pyr), B, D, H, W,
+                                             state.L, _stream()), "pcfa_corr_pyramid_fwd")
+        ctx.state = state
+        ctx.save_for_backward(f1)
+        return torch.zeros(1, device=f1.device, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_token):
+        st = ctx.state
+        (f1,) = ctx.saved_tensors
+        if st.dpyr is None:  # no lookup contributed a gradient
+            z = torch.zeros_like(f1)
+            return z, z.clone(), None
+        lib = _hip.load()
+        B, D, H, W = st.B, st.D, st.H, st.W
+        df1 = torch.empty_like(f1)
+        df2 = torch.empty_like(f1)
+        nbytes = lib.pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, st.L)
+        ws = torch.empty((nbytes + 3) // 4, device=f1.device, dtype=torch.float32)
+        _hip.check(lib.pcfa_corr_pyramid_bwd(_ptr(st.dpyr), _ptr(f1), _ptr(st.f2ext), _ptr(df1), _ptr(df2),
+                                             _ptr(ws), ctypes.c_size_t(nbytes), B, D, H, W, st.L, _stream()),
+                   "pcfa_corr_pyramid_bwd")
+        st.dpyr = None
+        return df1, df2, None
+
+
+class _CorrLookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, token, coords, state):
+        lib = _hip.load()
+        st = state
+        c = coords.contiguous()
+        n1 = 2 * st.r + 1
+        out = torch.empty((st.B, st.L * n1 * n1, st.H, st.W), device=c.device, dtype=torch.float32)
+        _hip.check(lib.pcfa_corr_lookup_fwd(_ptr(st.pyr), _ptr(c), _ptr(out), st.B, st.H, st.W, st.L, st.r,
+                                            _stream()), "pcfa_corr_lookup_fwd")
+        ctx.state = st
+        ctx.save_for_backward(c)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        st = ctx.state
+        (c,) = ctx.saved_tensors
+        lib = _hip.load()
+        if st.dpyr is None:
+            st.dpyr = torch.zeros_like(st.pyr)
+        g = grad_out.contiguous()
+        _hip.check(lib.pcfa_corr_lookup_bwd(_ptr(st.dpyr), _ptr(c), _ptr(g), st.B, st.H, st.W, st.L, st.r,
+                                            _stream()), "pcfa_corr_lookup_bwd")
+        return torch.zeros(1, device=g.device, dtype=torch.float32), None, None
+
+
+class CorrBlock:
+    """Drop-in for models/raft/corr.py:12-50 -- same constructor and __call__."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        _dev(fmap1, fmap2)
+        if fmap1.shape != fmap2.shape or fmap1.dim() != 4:
+            raise ValueError("CorrBlock expects two [B,D,H,W] feature maps of equal shape")
+        lib = _hip.load()
+        self.num_levels = num_levels
+        self.radius = radius
+        st = _CorrState()
+        st.B, st.D, st.H, st.W = fmap1.shape
+        st.L, st.r = num_levels, radius
+        st.slab = lib.pcfa_corr_slab_floats(st.H, st.W, num_levels)
+        if st.slab <= 0 or (st.H >> (num_levels - 1)) < 1 or (st.W >> (num_levels - 1)) < 1:
+            raise ValueError("feature map %dx%d too small for %d pyramid levels" % (st.H, st.W, num_levels))
+        st.dpyr = None
+        self._state = st
+        self._token = _CorrBuild.apply(fmap1, fmap2, st)
+
+    def __call__(self, coords):
+        _dev(coords)
+        return _CorrLookup.apply(self._token, coords, self._state)
+
+    @property
+    def corr_pyramid(self):
+        """Per-level views [B*Q,1,H_l,W_l] of the slab matrix (for inspection/tests)."""
+        lib = _hip.load()
+        st = self._state
+        out = []
+        for l in range(st.L):
+            h, w = ctypes.c_int(), ctypes.c_int()
+            off = lib.pcfa_corr_level_offset(st.H, st.W, st.L, l, ctypes.byref(h), ctypes.byref(w))
+            out.append(st.pyr[:, off:off + h.value * w.value].reshape(-1, 1, h.value, w.value))
+        return out
+
+
+# --------------------------------------------------------------------------- #
+# PWC-Net cost volume
+# --------------------------------------------------------------------------- #
+class SpatialCorrelationSamplerFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input1, input2, kernel_size=1, patch_size=1, stride=1, padding=0, dilation=1,
+                dilation_patch=1):
+        _dev(input1, input2)
+        # the reference's CPU build reads through accessors (any strides); the kernels want dense NCHW
+        input1, input2 = input1.contiguous(), input2.contiguous()
+        lib = _hip.load()
+        kH, kW = _pair(kernel_size)
+        pH, pW = _pair(patch_size)
+        padH, padW = _pair(padding)
+        dilH, dilW = _pair(dilation)
+        dpH, dpW = _pair(dilation_patch)
+        dH, dW = _pair(stride)
+        B, C, iH, iW = input1.shape
+        oH, oW = ctypes.c_int(), ctypes.c_int()
+        _hip.check(lib.pcfa_spatial_corr_out_size(iH, iW, kH, kW, padH, padW, dilH, dilW, dH, dW,
+                                                  ctypes.byref(oH), ctypes.byref(oW)), "pcfa_spatial_corr_out_size")
+        out = torch.empty((B, pH, pW, oH.value, oW.value), device=input1.device, dtype=torch.float32)
+        ctx.params = (B, C, iH, iW, kH, kW, pH, pW, padH, padW, dilH, dilW, dpH, dpW, dH, dW)
+        _hip.check(lib.pcfa_spatial_corr_fwd(_ptr(input1), _ptr(input2), _ptr(out), *ctx.params, _stream()),
+                   "pcfa_spatial_corr_fwd")
+        ctx.save_for_backward(input1, input2)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        input1, input2 = ctx.saved_tensors
+        lib = _hip.load()
+        g = grad_output.contiguous()
+        g1 = torch.empty_like(input1)
+        g2 = torch.empty_like(input2)
+        _hip.check(lib.pcfa_spatial_corr_bwd(_ptr(input1), _ptr(input2), _ptr(g), _ptr(g1), _ptr(g2),
+                                             *ctx.params, _stream()), "pcfa_spatial_corr_bwd")
+        return g1, g2, None, None, None, None, None, None
+
+
+def spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=1, stride=1, padding=0, dilation=1,
+                               dilation_patch=1):
+    return SpatialCorrelationSamplerFunction.apply(input1, input2, kernel_size, patch_size, stride, padding,
+                                                   dilation, dilation_patch)
+
+
+# --------------------------------------------------------------------------- #
+# attack math
+# --------------------------------------------------------------------------- #
+class _BoxTransform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, delta, cov, eps_box, scale):
+        _dev(image, delta)
+        lib = _hip.load()
+        img = image.contiguous()
+        d = None if delta is None else delta.contiguous()
+        B = img.shape[0]
+        n = img.numel() // B
+        if d is not None and d.numel() != n:
+            raise ValueError("delta must broadcast over the batch: %s vs %s" % (tuple(d.shape), tuple(img.shape)))
+        out = torch.empty_like(img)
+        _hip.check(lib.pcfa_box_transform_fwd(_ptr(img), _ptr(d), _ptr(out), B, n, int(cov), float(eps_box),
+                                              float(scale), _stream()), "pcfa_box_transform_fwd")
+        ctx.args = (B, n, int(cov), float(eps_box), float(scale))
+        ctx.delta_shape = None if delta is None else delta.shape
+        ctx.save_for_backward(img, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        img, d = ctx.saved_tensors
+        lib = _hip.load()
+        B, n, cov, eps, scale = ctx.args
+        g = grad_out.contiguous()
+        need_img, need_delta = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and d is not None
+        gi = torch.empty_like(img) if need_img else None
+        gd = torch.empty(ctx.delta_shape, device=img.device, dtype=torch.float32) if need_delta else None
+        _hip.check(lib.pcfa_box_transform_bwd(_ptr(img), _ptr(d), _ptr(g), _ptr(gi), _ptr(gd), B, n, cov, eps,
+                                              scale, _stream()), "pcfa_box_transform_bwd")
+        return gi, gd, None, None, None
+
+
+def box_transform(image, delta=None, change_of_variables=False, eps_box=0., scale=1.):
+    """clamp(cov(image + delta), 0, 1) * scale -- ScaledInputModel.forward prologue for one image."""
+    return _BoxTransform.apply(image, delta, change_of_variables, eps_box, scale)
+
+
+class _ExtractDeltas(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nw_input, image, cov, eps_box):
+        _dev(nw_input, image)
+        lib = _hip.load()
+        w = nw_input.contiguous()
+        img = image.contiguous()
+        out = torch.empty_like(w)
+        _hip.check(lib.pcfa_extract_deltas_fwd(_ptr(w), _ptr(img), _ptr(out), w.numel(), int(cov),
+                                               float(eps_box), _stream()), "pcfa_extract_deltas_fwd")
+        ctx.args = (int(cov), float(eps_box))
+        ctx.save_for_backward(w)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_delta):
+        (w,) = ctx.saved_tensors
+        lib = _hip.load()
+        g = grad_delta.contiguous()
+        gw = torch.empty_like(w)
+        _hip.check(lib.pcfa_extract_deltas_bwd(_ptr(w), _ptr(g), _ptr(gw), w.numel(), ctx.args[0], ctx.args[1],
+                                               _stream()), "pcfa_extract_deltas_bwd")
+        return gw, None, None, None
+
+
+class _ExtractDeltasJoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nw_delta, images_max, images_min):
+        _dev(nw_delta, images_max, images_min)
+        lib = _hip.load()
+        nd, mx, mn = nw_delta.contiguous(), images_max.contiguous(), images_min.contiguous()
+        out = torch.empty_like(nd)
+        _hip.check(lib.pcfa_extract_deltas_joint_fwd(_ptr(nd), _ptr(mx), _ptr(mn), _ptr(out), nd.numel(),
+                                                     _stream()), "pcfa_extract_deltas_joint_fwd")
+        ctx.save_for_backward(nd, mx, mn)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_delta):
+        nd, mx, mn = ctx.saved_tensors
+        lib = _hip.load()
+        g = grad_delta.contiguous()
+        gnd = torch.empty_like(nd)
+        _hip.check(lib.pcfa_extract_deltas_joint_bwd(_ptr(nd), _ptr(mx), _ptr(mn), _ptr(g), _ptr(gnd), nd.numel(),
+                                                     _stream()), "pcfa_extract_deltas_joint_bwd")
+        return gnd, None, None
+
+
+def extract_deltas(nw_input1, nw_input2, image1, image2, boxconstraint, eps_box=0.):
+    cov = boxconstraint in ['change_of_variables']
+    return (_ExtractDeltas.apply(nw_input1, image1, cov, eps_box),
+            _ExtractDeltas.apply(nw_input2, image2, cov, eps_box))
+
+
+def extract_deltas_joint(nw_delta, images_max, images_min):
+    delta = _ExtractDeltasJoint.apply(nw_delta, images_max, images_min)
+    return delta, delta
+
+
+_WS = {}
+
+
+def _workspace(device):
+    """Per-(device, stream) reduction scratch (allocated once, never freed)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WS.get(key)
+    if ws is None:
+        nbytes = _hip.load().pcfa_flow_loss_workspace_bytes()
+        ws = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+        _WS[key] = ws
+    return ws
+
+
+def _flow4(t):
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    if t.dim() != 4 or t.shape[1] != 2:
+        raise ValueError("The flow tensors do not have a valid number of dimensions "
+                         "(either [b,2,M,N] or [2,M,N]). Here: %s" % str(t.size()))
+    return t
+
+
+class _LossDeltaConstraint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, delta1, delta2, delta_bound, mu, f_type):
+        _dev(pred, target, delta1, delta2)
+        lib = _hip.load()
+        p, t = _flow4(pred), _flow4(target)
+        if p.shape != t.shape:
+            raise ValueError("pred/target shape mismatch: %s vs %s" % (tuple(p.shape), tuple(t.shape)))
+        d1, d2 = delta1.contiguous(), delta2.contiguous()
+        B, _, H, W = p.shape
+        scal = torch.empty(8, device=p.device, dtype=torch.float32)
+        ft = _hip.PCFA_LOSS[f_type]
+        _hip.check(lib.pcfa_flow_loss_fwd(_ptr(p), _hip.strides4(p), _ptr(t), _hip.strides4(t), B, H, W,
+                                          _ptr(d1), d1.numel(), _ptr(d2), d2.numel(), float(delta_bound),
+                                          float(mu), ft, _ptr(scal), _ptr(_workspace(p.device)), _stream()),
+                   "pcfa_flow_loss_fwd")
+        ctx.joint = d1.data_ptr() == d2.data_ptr() and d1.numel() == d2.numel()
+        ctx.args = (B, H, W, float(mu), ft)
+        ctx.pred_shape = pred.shape
+        ctx.save_for_backward(p, t, d1, d2, scal)
+        return scal[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        p, t, d1, d2, scal = ctx.saved_tensors
+        lib = _hip.load()
+        B, H, W, mu, ft = ctx.args
+        gl = grad_loss.contiguous().reshape(1)
+        need_p, need_d1, need_d2 = ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        gp = torch.empty((B, 2, H, W), device=p.device, dtype=torch.float32) if need_p else None
+        gd1 = torch.empty_like(d1) if need_d1 else None
+        gd2 = torch.empty_like(d2) if (need_d2 and not ctx.joint) else None
+        if ctx.joint and need_d2 and gd1 is None:
+            gd1 = torch.empty_like(d1)
+        _hip.check(lib.pcfa_flow_loss_bwd(_ptr(p), _hip.strides4(p), _ptr(t), _hip.strides4(t), B, H, W,
+                                          _ptr(d1), d1.numel(), _ptr(d2), d2.numel(), mu, ft, 0,
+                                          _ptr(scal), _ptr(gl), _ptr(gp), _ptr(gd1), _ptr(gd2), _stream()),
+                   "pcfa_flow_loss_bwd")
+        if gp is not None:
+            gp = gp.reshape(ctx.pred_shape)
+        if ctx.joint:
+            # extract_deltas_joint hands the SAME tensor in twice (attack_PCFA.py:37): autograd adds the
+            # two slots, which reproduces the reference's d/d(delta) of |delta|^2 + |delta|^2.
+            return gp, None, (gd1 if need_d1 else None), (gd1 if need_d2 else None), None, None, None
+        return gp, None, gd1, gd2, None, None, None
+
+
+def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound=0.001, mu=100., f_type="aee"):
+    """helper_functions/losses.py:200-230 (device argument kept for signature compatibility)."""
+    if f_type not in _hip.PCFA_LOSS:
+        raise NotImplementedError(
+            "The requested loss type %s does not exist. Please choose one of 'aee', 'mse' or 'cosim'" % f_type)
+    return _LossDeltaConstraint.apply(pred, target, delta1, delta2, delta_bound, mu, f_type)
+
+
+def avg_epe(flow1, flow2):
+    """helper_functions/losses.py:3-30 (metric use: no gradient)."""
+    _dev(flow1, flow2)
+    lib = _hip.load()
+    a, b = _flow4(flow1.detach()), _flow4(flow2.detach())
+    if a.shape != b.shape:
+        raise ValueError("flow shape mismatch")
+    B, _, H, W = a.shape
+    out = torch.empty(1, device=a.device, dtype=torch.float32)
+    _hip.check(lib.pcfa_avg_epe(_ptr(a), _hip.strides4(a), _ptr(b), _hip.strides4(b), B, H, W, _ptr(out),
+                                _ptr(_workspace(a.device)), _stream()), "pcfa_avg_epe")
+    return out[0]
+
+
+def sum_squares(x):
+    _dev(x)
+    lib = _hip.load()
+    xc = x.detach().contiguous()
+    out = torch.empty(1, device=xc.device, dtype=torch.float32)
+    _hip.check(lib.pcfa_sum_squares(_ptr(xc), xc.numel(), _ptr(out), _ptr(_workspace(xc.device)), _stream()),
+               "pcfa_sum_squares")
+    return out[0]
+
+
+def two_norm_avg(x):
+    """helper_functions/losses.py:129-142."""
+    return torch.sqrt(sum_squares(x)) / (torch.numel(x) ** 0.5)
+
+
+def two_norm_avg_delta(delta1, delta2):
+    """helper_functions/losses.py:91-107."""
+    sqrt_numels = (torch.numel(delta1) + torch.numel(delta2)) ** 0.5
+    return torch.sqrt(sum_squares(delta1) + sum_squares(delta2)) / sqrt_numels

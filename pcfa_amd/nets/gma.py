@@ -1,0 +1,159 @@
+"""GMA (Jiang et al. 2021) = RAFT + global motion aggregation, for the PCFA hot path.
+
+Behavioural reference (cv-stuttgart/PCFA):
+    models/gma/network.py:26-129     RAFTGMA wiring (6 iterations in PCFA, ownutilities.py:327)
+    models/gma/gma.py:7-115          RelPosEmb, Attention, Aggregate
+    models/gma/update.py:112-139     GMAUpdateBlock
+    models/gma/corr.py:15-63         -> pcfa_amd.ops.get().CorrBlock (same HIP kernels as RAFT)
+
+Parameter names follow the public gma-sintel.pth checkpoint.  The reference
+config enables fp16 autocast on CUDA (models/_config/gma_config.json:5); the CPU
+path the parity target is defined on runs fp32, so this implementation is fp32
+on MI355X as well.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .raft import BasicEncoder, BasicMotionEncoder, FlowHead, SepConvGRU, _mask_head, convex_upsample, coords_grid
+
+
+class RelPosEmb(nn.Module):
+    def __init__(self, max_pos_size, dim_head):
+        super().__init__()
+        self.rel_height = nn.Embedding(2 * max_pos_size - 1, dim_head)
+        self.rel_width = nn.Embedding(2 * max_pos_size - 1, dim_head)
+        deltas = torch.arange(max_pos_size).view(1, -1) - torch.arange(max_pos_size).view(-1, 1)
+        self.register_buffer('rel_ind', deltas + max_pos_size - 1)
+
+    def forward(self, q):
+        # q: [b, heads, h, w, c] -> scores [b, heads, h, w, h, w]
+        b, heads, h, w, c = q.shape
+        height_emb = self.rel_height(self.rel_ind[:h, :h].reshape(-1)).view(h, h, 1, c)  # x u () d
+        width_emb = self.rel_width(self.rel_ind[:w, :w].reshape(-1)).view(w, 1, w, c)    # y () v d
+        height_score = torch.einsum('bhxyd,xuvd->bhxyuv', q, height_emb)
+        width_score = torch.einsum('bhxyd,yuvd->bhxyuv', q, width_emb)
+        return height_score + width_score
+
+
+class Attention(nn.Module):
+    def __init__(self, *, args, dim, max_pos_size=100, heads=4, dim_head=128):
+        super().__init__()
+        self.args = args
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.to_qk = nn.Conv2d(dim, heads * dim_head * 2, 1, bias=False)
+        self.pos_emb = RelPosEmb(max_pos_size, dim_head)
+
+    def forward(self, fmap):
+        b, c, h, w = fmap.shape
+        heads = self.heads
+        q, k = self.to_qk(fmap).chunk(2, dim=1)
+        # 'b (h d) x y -> b h (x y) d'
+        q = q.reshape(b, heads, -1, h * w).transpose(-1, -2)
+        k = k.reshape(b, heads, -1, h * w).transpose(-1, -2)
+        q = self.scale * q
+        if getattr(self.args, "position_only", False):
+            sim = self.pos_emb(q.reshape(b, heads, h, w, -1)).reshape(b, heads, h * w, h * w)
+        elif getattr(self.args, "position_and_content", False):
+            sim = torch.matmul(q, k.transpose(-1, -2))
+            sim = sim + self.pos_emb(q.reshape(b, heads, h, w, -1)).reshape(b, heads, h * w, h * w)
+        else:
+            sim = torch.matmul(q, k.transpose(-1, -2))
+        return sim.softmax(dim=-1)
+
+
+class Aggregate(nn.Module):
+    def __init__(self, args, dim, heads=4, dim_head=128):
+        super().__init__()
+        self.args = args
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        inner_dim = heads * dim_head
+        self.to_v = nn.Conv2d(dim, inner_dim, 1, bias=False)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.project = nn.Conv2d(inner_dim, dim, 1, bias=False) if dim != inner_dim else None
+
+    def forward(self, attn, fmap):
+        b, c, h, w = fmap.shape
+        heads = self.heads
+        v = self.to_v(fmap).reshape(b, heads, -1, h * w).transpose(-1, -2)  # b h (x y) d
+        out = torch.matmul(attn, v)                                          # b h (x y) d
+        out = out.transpose(-1, -2).reshape(b, -1, h, w)                     # b (h d) x y
+        if self.project is not None:
+            out = self.project(out)
+        return fmap + self.gamma * out
+
+
+class GMAUpdateBlock(nn.Module):
+    def __init__(self, args, hidden_dim=128):
+        super().__init__()
+        self.args = args
+        self.encoder = BasicMotionEncoder(4, 4)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = _mask_head()
+        self.aggregator = Aggregate(args=args, dim=128, dim_head=128, heads=args.num_heads)
+
+    def forward(self, net, inp, corr, flow, attention, want_mask=True):
+        motion_features = self.encoder(flow, corr)
+        motion_features_global = self.aggregator(attention, motion_features)
+        net = self.gru(net, torch.cat([inp, motion_features, motion_features_global], dim=1))
+        delta_flow = self.flow_head(net)
+        mask = .25 * self.mask(net) if want_mask else None
+        return net, mask, delta_flow
+
+
+class RAFTGMA(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.hidden_dim = hdim = 128
+        self.context_dim = cdim = 128
+        args.corr_levels = 4
+        args.corr_radius = 4
+        if not hasattr(args, 'dropout'):
+            args.dropout = 0
+        self.fnet = BasicEncoder(output_dim=256, norm_fn='instance', dropout=args.dropout)
+        self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn='batch', dropout=args.dropout)
+        self.update_block = GMAUpdateBlock(args, hidden_dim=hdim)
+        self.att = Attention(args=args, dim=cdim, heads=args.num_heads, max_pos_size=160, dim_head=cdim)
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        hdim, cdim = self.hidden_dim, self.context_dim
+
+        fmap1, fmap2 = self.fnet([image1, image2])
+        corr_fn = ops.get().CorrBlock(fmap1.float(), fmap2.float(), num_levels=4, radius=self.args.corr_radius)
+
+        net, inp = torch.split(self.cnet(image1), [hdim, cdim], dim=1)
+        net, inp = torch.tanh(net), torch.relu(inp)
+        attention = self.att(inp)
+
+        N, _, H, W = image1.shape
+        coords0 = coords_grid(N, H // 8, W // 8, image1.device)
+        coords1 = coords_grid(N, H // 8, W // 8, image1.device)
+        if flow_init is not None:
+            coords1 = coords1 + flow_init
+
+        flow_predictions = []
+        flow_up = None
+        for itr in range(iters):
+            coords1 = coords1.detach()
+            corr = corr_fn(coords1)
+            flow = coords1 - coords0
+            need_up = (not test_mode) or itr == iters - 1
+            net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, attention, want_mask=need_up)
+            coords1 = coords1 + delta_flow
+            if need_up:
+                flow_up = convex_upsample(coords1 - coords0, up_mask)
+                flow_predictions.append(flow_up)
+        if test_mode:
+            return coords1 - coords0, flow_up
+        return flow_predictions

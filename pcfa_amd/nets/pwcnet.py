@@ -1,0 +1,143 @@
+"""PWC-DC-Net (Sun et al. 2018) for the PCFA hot path, written against pcfa_amd.ops.
+
+Behavioural reference (cv-stuttgart/PCFA): models/PWCNet/PWCNet.py
+    :29-43  conv / predict_flow / deconv builders      :45-58   correlate
+    :65-164 layer table                                :166-206 warp
+    :227-330 forward
+Parameter names follow pwc_net_chairs.pth.tar.
+
+The five 9x9 cost volumes run in the HIP spatial-correlation kernel on the
+device the features live on; the reference's default bounces every one of them
+through a CPU-only sampler (config_paths.py:30, PWCNet.py:18-21).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
+    return nn.Sequential(
+        nn.Conv2d(int(in_planes), int(out_planes), kernel_size=kernel_size, stride=stride, padding=padding,
+                  dilation=dilation, bias=True),
+        nn.LeakyReLU(0.1))
+
+
+def predict_flow(in_planes):
+    return nn.Conv2d(int(in_planes), 2, kernel_size=3, stride=1, padding=1, bias=True)
+
+
+def deconv(in_planes, out_planes, kernel_size=4, stride=2, padding=1):
+    return nn.ConvTranspose2d(int(in_planes), int(out_planes), kernel_size, stride, padding, bias=True)
+
+
+def correlate(input1, input2):
+    """9x9 cost volume averaged over channels (PWCNet.py:45-58)."""
+    out = ops.get().spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=9, stride=1)
+    b, ph, pw, h, w = out.size()
+    return out.view(b, ph * pw, h, w) / input1.size(1)
+
+
+_PYRAMID = [(3, 16), (16, 32), (32, 64), (64, 96), (96, 128), (128, 196)]
+
+
+class PWCDCNet(nn.Module):
+    def __init__(self, md=4):
+        super().__init__()
+        self.upsample = nn.Upsample(scale_factor=4, mode='bilinear')
+        for lvl, (cin, cout) in enumerate(_PYRAMID, start=1):
+            # level 6 names its stride-2 conv "aa" and the next one "a" (checkpoint quirk, PWCNet.py:90-92)
+            first, second = ("aa", "a") if lvl == 6 else ("a", "aa")
+            setattr(self, "conv%d%s" % (lvl, first), conv(cin, cout, kernel_size=3, stride=2))
+            setattr(self, "conv%d%s" % (lvl, second), conv(cout, cout, kernel_size=3, stride=1))
+            setattr(self, "conv%db" % lvl, conv(cout, cout, kernel_size=3, stride=1))
+        self.corr = correlate
+        self.leakyRELU = nn.LeakyReLU(0.1)
+
+        nd = (2 * md + 1) ** 2
+        dd = np.cumsum([128, 128, 96, 64, 32])
+        for lvl, extra in ((6, 0), (5, 128 + 4), (4, 96 + 4), (3, 64 + 4), (2, 32 + 4)):
+            od = nd + extra
+            for i, (cin, cout) in enumerate(((od, 128), (od + dd[0], 128), (od + dd[1], 96), (od + dd[2], 64),
+                                             (od + dd[3], 32))):
+                setattr(self, "conv%d_%d" % (lvl, i), conv(cin, cout, kernel_size=3, stride=1))
+            setattr(self, "predict_flow%d" % lvl, predict_flow(od + dd[4]))
+            setattr(self, "deconv%d" % lvl, deconv(2, 2, kernel_size=4, stride=2, padding=1))
+            if lvl > 2:
+                setattr(self, "upfeat%d" % lvl, deconv(od + dd[4], 2, kernel_size=4, stride=2, padding=1))
+        od = nd + 32 + 4
+        self.dc_conv1 = conv(od + dd[4], 128, kernel_size=3, stride=1, padding=1, dilation=1)
+        self.dc_conv2 = conv(128, 128, kernel_size=3, stride=1, padding=2, dilation=2)
+        self.dc_conv3 = conv(128, 128, kernel_size=3, stride=1, padding=4, dilation=4)
+        self.dc_conv4 = conv(128, 96, kernel_size=3, stride=1, padding=8, dilation=8)
+        self.dc_conv5 = conv(96, 64, kernel_size=3, stride=1, padding=16, dilation=16)
+        self.dc_conv6 = conv(64, 32, kernel_size=3, stride=1, padding=1, dilation=1)
+        self.dc_conv7 = predict_flow(32)
+
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight.data, mode='fan_in')
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+    def warp(self, x, flo):
+        """Backward-warp x by flo with a validity mask (PWCNet.py:166-206)."""
+        B, C, H, W = x.size()
+        xx = torch.arange(0, W, device=x.device).view(1, -1).repeat(H, 1).view(1, 1, H, W).repeat(B, 1, 1, 1)
+        yy = torch.arange(0, H, device=x.device).view(-1, 1).repeat(1, W).view(1, 1, H, W).repeat(B, 1, 1, 1)
+        vgrid = torch.cat((xx, yy), 1).float() + flo
+        vx = 2.0 * vgrid[:, 0, :, :] / max(W - 1, 1) - 1.0
+        vy = 2.0 * vgrid[:, 1, :, :] / max(H - 1, 1) - 1.0
+        grid = torch.stack((vx, vy), dim=3)
+        output = nn.functional.grid_sample(x, grid, align_corners=False)
+        mask = nn.functional.grid_sample(torch.ones_like(x), grid, align_corners=False)
+        mask = (mask >= 0.0001).float()
+        return output * mask
+
+    def _decode(self, lvl, x):
+        for i in range(5):
+            x = torch.cat((getattr(self, "conv%d_%d" % (lvl, i))(x), x), 1)
+        return x
+
+    def forward(self, im1, im2):
+        # RGB -> BGR
+        im1 = torch.stack((im1[:, 2, :, :], im1[:, 1, :, :], im1[:, 0, :, :]), 1)
+        im2 = torch.stack((im2[:, 2, :, :], im2[:, 1, :, :], im2[:, 0, :, :]), 1)
+
+        def pyramid(im):
+            feats, x = [], im
+            for lvl in range(1, 7):
+                first, second = ("aa", "a") if lvl == 6 else ("a", "aa")
+                x = getattr(self, "conv%d%s" % (lvl, first))(x)
+                x = getattr(self, "conv%d%s" % (lvl, second))(x)
+                x = getattr(self, "conv%db" % lvl)(x)
+                feats.append(x)
+            return feats
+
+        c1, c2 = pyramid(im1), pyramid(im2)  # index 0 = level 1 ... index 5 = level 6
+
+        corr6 = self.leakyRELU(self.corr(c1[5], c2[5]))
+        x = self._decode(6, corr6)
+        flow = self.predict_flow6(x)
+        flows = {6: flow}
+        up_flow, up_feat = self.deconv6(flow), self.upfeat6(x)
+
+        for lvl, scale in ((5, 0.625), (4, 1.25), (3, 2.5), (2, 5.0)):
+            f1, f2 = c1[lvl - 1], c2[lvl - 1]
+            warped = self.warp(f2, up_flow * scale)
+            corr = self.leakyRELU(self.corr(f1, warped))
+            x = self._decode(lvl, torch.cat((corr, f1, up_flow, up_feat), 1))
+            flow = getattr(self, "predict_flow%d" % lvl)(x)
+            flows[lvl] = flow
+            if lvl > 2:
+                up_flow = getattr(self, "deconv%d" % lvl)(flow)
+                up_feat = getattr(self, "upfeat%d" % lvl)(x)
+
+        x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(x))))
+        flow2 = flows[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))
+
+        flow2 = 20 * self.upsample(flow2)
+        if self.training:
+            return (flow2,) + tuple(20 * self.upsample(flows[l]) for l in (3, 4, 5, 6))
+        return flow2

@@ -1,0 +1,243 @@
+"""RAFT (Teed & Deng 2020) for the PCFA hot path, written against pcfa_amd.ops.
+
+Parameter names are those of the public RAFT checkpoints (raft-sintel.pth), so
+`load_state_dict` works on them after stripping DataParallel's "module."
+prefix.  Behavioural reference (cv-stuttgart/PCFA):
+    models/raft/raft.py:24-144      network wiring, 12 refinement iterations
+    models/raft/extractor.py:6-58,118-192   residual encoder
+    models/raft/update.py:6-16,33-60,79-136 motion encoder, SepConvGRU, heads
+    models/raft/corr.py:12-60       -> pcfa_amd.ops.get().CorrBlock (HIP)
+
+Differences that do not change results:
+  * convolutions / norms run on MIOpen through torch; the all-pairs volume,
+    its pyramid and the lookups run in the hand-written HIP kernels;
+  * in test_mode the convex-upsampling mask head and upsample_flow are only
+    evaluated for the last iteration (the reference computes all 12 and drops
+    11, raft.py:131-142);
+  * only the full-size model ("small": false in models/_config/raft_config.json).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def _norm(kind, planes):
+    if kind == 'batch':
+        return nn.BatchNorm2d(planes)
+    if kind == 'instance':
+        return nn.InstanceNorm2d(planes)
+    if kind == 'group':
+        return nn.GroupNorm(num_groups=planes // 8, num_channels=planes)
+    if kind == 'none':
+        return nn.Sequential()
+    raise ValueError("unknown norm_fn %r" % kind)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_planes, planes, norm_fn='group', stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.norm1 = _norm(norm_fn, planes)
+        self.norm2 = _norm(norm_fn, planes)
+        self.downsample = None
+        if stride != 1:
+            # registered twice (norm3 and downsample.1) like the checkpoints expect
+            self.norm3 = _norm(norm_fn, planes)
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+
+    def forward(self, x):
+        y = self.relu(self.norm1(self.conv1(x)))
+        y = self.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.relu(x + y)
+
+
+class BasicEncoder(nn.Module):
+    """1/8-resolution feature / context encoder."""
+
+    def __init__(self, output_dim=128, norm_fn='batch', dropout=0.0):
+        super().__init__()
+        self.norm_fn = norm_fn
+        self.norm1 = nn.GroupNorm(num_groups=8, num_channels=64) if norm_fn == 'group' else _norm(norm_fn, 64)
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.layer1 = self._stage(64, 64, 1)
+        self.layer2 = self._stage(64, 96, 2)
+        self.layer3 = self._stage(96, 128, 2)
+        self.conv2 = nn.Conv2d(128, output_dim, kernel_size=1)
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def _stage(self, cin, cout, stride):
+        return nn.Sequential(ResidualBlock(cin, cout, self.norm_fn, stride=stride),
+                             ResidualBlock(cout, cout, self.norm_fn, stride=1))
+
+    def forward(self, x):
+        pair = isinstance(x, (tuple, list))
+        if pair:
+            n = x[0].shape[0]
+            x = torch.cat(x, dim=0)
+        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        x = self.conv2(x)
+        if self.training and self.dropout is not None:
+            x = self.dropout(x)
+        if pair:
+            x = torch.split(x, [n, n], dim=0)
+        return x
+
+
+class FlowHead(nn.Module):
+    def __init__(self, input_dim=128, hidden_dim=256):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.conv2(self.relu(self.conv1(x)))
+
+
+class SepConvGRU(nn.Module):
+    """Two GRU half-steps with 1x5 then 5x1 gates (update.py:33-60)."""
+
+    def __init__(self, hidden_dim=128, input_dim=192 + 128):
+        super().__init__()
+        c = hidden_dim + input_dim
+        self.convz1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convr1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convq1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convz2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self.convr2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self.convq2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+
+    @staticmethod
+    def _half(h, x, convz, convr, convq):
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(convz(hx))
+        r = torch.sigmoid(convr(hx))
+        q = torch.tanh(convq(torch.cat([r * h, x], dim=1)))
+        return (1 - z) * h + z * q
+
+    def forward(self, h, x):
+        h = self._half(h, x, self.convz1, self.convr1, self.convq1)
+        return self._half(h, x, self.convz2, self.convr2, self.convq2)
+
+
+class BasicMotionEncoder(nn.Module):
+    def __init__(self, corr_levels=4, corr_radius=4):
+        super().__init__()
+        cor_planes = corr_levels * (2 * corr_radius + 1) ** 2
+        self.convc1 = nn.Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = nn.Conv2d(256, 192, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 128, 7, padding=3)
+        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
+
+    def forward(self, flow, corr):
+        cor = F.relu(self.convc2(F.relu(self.convc1(corr))))
+        flo = F.relu(self.convf2(F.relu(self.convf1(flow))))
+        out = F.relu(self.conv(torch.cat([cor, flo], dim=1)))
+        return torch.cat([out, flow], dim=1)
+
+
+def _mask_head():
+    return nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(256, 64 * 9, 1, padding=0))
+
+
+class BasicUpdateBlock(nn.Module):
+    def __init__(self, corr_levels=4, corr_radius=4, hidden_dim=128):
+        super().__init__()
+        self.encoder = BasicMotionEncoder(corr_levels, corr_radius)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = _mask_head()
+
+    def forward(self, net, inp, corr, flow, want_mask=True):
+        motion_features = self.encoder(flow, corr)
+        net = self.gru(net, torch.cat([inp, motion_features], dim=1))
+        delta_flow = self.flow_head(net)
+        mask = .25 * self.mask(net) if want_mask else None  # .25: "scale mask to balance gradients"
+        return net, mask, delta_flow
+
+
+def coords_grid(batch, ht, wd, device):
+    """[B,2,ht,wd] pixel grid, channel 0 = x, channel 1 = y (models/raft/utils/utils.py:74-77)."""
+    ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
+    return torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1)
+
+
+def convex_upsample(flow, mask):
+    """[N,2,H,W] -> [N,2,8H,8W] by a softmax-weighted 3x3 combination (raft.py:72-83)."""
+    N, _, H, W = flow.shape
+    mask = torch.softmax(mask.view(N, 1, 9, 8, 8, H, W), dim=2)
+    up = F.unfold(8 * flow, [3, 3], padding=1).view(N, 2, 9, 1, 1, H, W)
+    up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3)
+    return up.reshape(N, 2, 8 * H, 8 * W)
+
+
+class RAFT(nn.Module):
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = dict(args or {})
+        if self.args.get("small", False):
+            raise NotImplementedError("RAFT-small is not part of the PCFA configurations (raft_config.json: small=false)")
+        self.hidden_dim = hdim = 128
+        self.context_dim = cdim = 128
+        self.args["corr_levels"] = 4
+        self.args["corr_radius"] = 4
+        self.args.setdefault("dropout", 0)
+        self.fnet = BasicEncoder(output_dim=256, norm_fn='instance', dropout=self.args["dropout"])
+        self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn='batch', dropout=self.args["dropout"])
+        self.update_block = BasicUpdateBlock(4, 4, hidden_dim=hdim)
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        hdim, cdim = self.hidden_dim, self.context_dim
+
+        fmap1, fmap2 = self.fnet([image1, image2])
+        corr_fn = ops.get().CorrBlock(fmap1.float(), fmap2.float(), num_levels=self.args["corr_levels"],
+                                      radius=self.args["corr_radius"])
+
+        net, inp = torch.split(self.cnet(image1), [hdim, cdim], dim=1)
+        net, inp = torch.tanh(net), torch.relu(inp)
+
+        N, _, H, W = image1.shape
+        coords0 = coords_grid(N, H // 8, W // 8, image1.device)
+        coords1 = coords_grid(N, H // 8, W // 8, image1.device)
+        if flow_init is not None:
+            coords1 = coords1 + flow_init
+
+        flow_predictions = []
+        flow_up = None
+        for itr in range(iters):
+            coords1 = coords1.detach()  # the lookup gets no coordinate gradient (raft.py:122-123)
+            corr = corr_fn(coords1)
+            flow = coords1 - coords0
+            need_up = (not test_mode) or itr == iters - 1
+            net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, want_mask=need_up)
+            coords1 = coords1 + delta_flow
+            if need_up:
+                flow_up = convex_upsample(coords1 - coords0, up_mask)
+                flow_predictions.append(flow_up)
+        if test_mode:
+            return coords1 - coords0, flow_up
+        return flow_predictions

@@ -1,0 +1,82 @@
+"""Shared by the CPU tests, the GPU tests and __graft_entry__.smoke(): evaluate ONE PCFA closure with
+pcfa_amd exactly as make_golden.closure_case() does with the reference (same seeds, same inputs)."""
+import torch
+
+from pcfa_amd import attack_PCFA
+from pcfa_amd.helper_functions import losses, ownutilities, targets
+from pcfa_amd.helper_functions.datasets import synthetic_pair
+
+WEIGHT_SEED = 1234
+_MODELS = {}
+
+
+def test_images(seed, h, w):
+    i1, i2, _ = synthetic_pair(seed, h, w)
+    return i1.round().clamp(0, 255)[None], i2.round().clamp(0, 255)[None]
+
+
+def load_model(net, variable_change, device, eps_box=1e-7):
+    key = (net, variable_change, str(device))
+    if key not in _MODELS:
+        unit = ownutilities.model_takes_unit_input(net)
+        kw = {"eps_box": eps_box} if variable_change else {}
+        m = ownutilities.import_and_load(net, make_unit_input=not unit, variable_change=variable_change,
+                                         make_scaled_input_model=True, device=device,
+                                         weights="random:%d" % WEIGHT_SEED, **kw)
+        m.eval()
+        for p in m.parameters():
+            p.requires_grad = False
+        _MODELS[key] = m
+    return _MODELS[key]
+
+
+def run_closure(net, h, w, boxconstraint, joint, target_name, loss_name, seed, device, images=None, leaves=None):
+    cov = boxconstraint == "change_of_variables"
+    eps = 1e-7
+    model = load_model(net, cov, device, eps)
+    im1, im2 = images if images is not None else test_images(seed, h, w)
+    a, b = im1.clone().float().to(device), im2.clone().float().to(device)
+    if not ownutilities.model_takes_unit_input(net):
+        a, b = a / 255., b / 255.
+    padder, [a, b] = ownutilities.preprocess_img(net, a, b)
+    mu = 2500. / 0.005 * (1.0 if target_name == "zero" else 1.5)
+    g = torch.Generator().manual_seed(seed + 100)
+    if joint:
+        nw_delta = (0.01 * torch.randn(a.shape, generator=g)) if leaves is None else leaves[0]
+        nw_delta = nw_delta.to(device).requires_grad_(True)
+        imax, imin = torch.max(a, b), torch.min(a, b)
+        n1, n2, fwd, lv = a, b, dict(delta1=nw_delta), [nw_delta]
+    else:
+        if leaves is None:
+            if cov:
+                n1 = torch.atanh(2. * (1. - eps) * a - (1 - eps))
+                n2 = torch.atanh(2. * (1. - eps) * b - (1 - eps))
+            else:
+                n1, n2 = a.clone(), b.clone()
+            n1 = n1.cpu() + 0.02 * torch.randn(a.shape, generator=g)
+            n2 = n2.cpu() + 0.02 * torch.randn(a.shape, generator=g)
+        else:
+            n1, n2 = leaves
+        n1 = n1.to(device).requires_grad_(True)
+        n2 = n2.to(device).requires_grad_(True)
+        fwd, lv = {}, [n1, n2]
+    with torch.no_grad():
+        if joint or not cov:
+            c1, c2 = a, b
+        else:
+            c1 = torch.atanh(2. * (1. - eps) * a - (1 - eps))
+            c2 = torch.atanh(2. * (1. - eps) * b - (1 - eps))
+        f0 = ownutilities.compute_flow(model, "scaled_input_model", c1, c2, test_mode=True)
+        [f0] = ownutilities.postprocess_flow(net, padder, f0)
+        f0 = f0.clone()
+    target = targets.get_target(target_name, f0, device=device)
+    flow = ownutilities.compute_flow(model, "scaled_input_model", n1, n2, test_mode=True, **fwd)
+    [flow] = ownutilities.postprocess_flow(net, padder, flow)
+    if joint:
+        d1, d2 = attack_PCFA.extract_deltas_joint(nw_delta, imax, imin)
+    else:
+        d1, d2 = attack_PCFA.extract_deltas(n1, n2, a, b, boxconstraint, eps_box=eps)
+    loss = losses.loss_delta_constraint(flow, target, d1, d2, device, delta_bound=0.005, mu=mu, f_type=loss_name)
+    loss.backward()
+    return {"flow_init": f0.detach(), "target": target.detach(), "flow": flow.detach(), "loss": float(loss),
+            "grads": [x.grad.detach() for x in lv], "leaves": [x.detach() for x in lv]}

@@ -1,0 +1,62 @@
+"""The C-ABI library loads and exports every symbol include/pcfa_hip.h declares (no GPU needed)."""
+import os
+import re
+
+import pytest
+
+from tests.util import REPO
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "pcfa_hip.h")).read()
+    return sorted(set(re.findall(r"PCFA_API[^;(]*?\b(pcfa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_hot_path():
+    syms = declared_symbols()
+    for must in ("pcfa_corr_pyramid_fwd", "pcfa_corr_pyramid_bwd", "pcfa_corr_lookup_fwd", "pcfa_corr_lookup_bwd",
+                 "pcfa_spatial_corr_fwd", "pcfa_spatial_corr_bwd", "pcfa_flow_loss_fwd", "pcfa_flow_loss_bwd",
+                 "pcfa_box_transform_fwd", "pcfa_box_transform_bwd"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from pcfa_amd import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _hip.load()
+    assert lib.pcfa_abi_version() == _hip.ABI_VERSION
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert set(_hip.SIGNATURES) == set(declared_symbols())
+
+
+def test_host_only_entry_points():
+    """Pure host helpers can be called without a GPU."""
+    import ctypes
+    from pcfa_amd import _hip
+    lib = _hip.load()
+    assert lib.pcfa_corr_slab_floats(55, 128, 4) == 9280          # 7040+1728+416+96
+    h, w = ctypes.c_int(), ctypes.c_int()
+    assert lib.pcfa_corr_level_offset(55, 128, 4, 2, ctypes.byref(h), ctypes.byref(w)) == 7040 + 1728
+    assert (h.value, w.value) == (13, 32)
+    assert lib.pcfa_corr_slab_floats(17, 21, 4) % 4 == 0
+    oh, ow = ctypes.c_int(), ctypes.c_int()
+    assert lib.pcfa_spatial_corr_out_size(11, 9, 3, 3, 1, 1, 1, 1, 2, 2, ctypes.byref(oh), ctypes.byref(ow)) == 0
+    assert (oh.value, ow.value) == (6, 5)
+    assert lib.pcfa_status_string(-2).decode().startswith("unsupported")
+    # argument validation happens before any launch
+    assert lib.pcfa_corr_lookup_fwd(None, None, None, 1, 8, 8, 4, 4, None) == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from pcfa_amd import hip_ops
+    x = torch.zeros(1, 4, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip_ops.CorrBlock(x, x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip_ops.spatial_correlation_sample(x, x, patch_size=9)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip_ops.loss_delta_constraint(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4), x, x)
