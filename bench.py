@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""PCFA attack-steps/sec on MI355X (BASELINE.json metric; workload = configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one `--steps` iteration of pcfa_attack on one synthetic 436x1024 image pair with RAFT
+(seeded random weights -- no checkpoints exist offline): torch.optim.LBFGS(max_iter=10).step =
+10 closure evaluations (box transform -> RAFT forward -> AEE + L2 penalty -> backward) + 1 re-prediction
+forward + the step's metrics.  Inputs are resident in HBM before the timed region.
+Every rank attacks its own pair (disjoint perturbations, no data-path collective): weak scaling,
+value = N*K / max-over-ranks time.
+
+The JSON line also carries
+  roofline      the correlation-lookup forward kernel (the kernel BASELINE's north_star names):
+                algorithmic bytes/launch (20.44 MB at 55x128) / mean launch duration measured
+                with HIP events around every launch inside the timed steps, against 8 TB/s HBM;
+  cpu_baseline  this repo's CPU port (pcfa_amd host code + oracle operators, torch fp32 on all host cores)
+                timed on a bounded sample of the same workload, extrapolated to the 10+1 schedule.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--net", default="RAFT", choices=["RAFT", "GMA", "PWCNet", "SpyNet"])
+    ap.add_argument("--size", default="436x1024")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-closures", type=int, default=2, help="closure evaluations in the CPU sample")
+    return ap.parse_args()
+
+
+class AttackStepper:
+    """The body of pcfa_attack's step loop (attack_PCFA.py:155-247) on pre-resident tensors."""
+
+    def __init__(self, net, h, w, device, seed, boxconstraint="change_of_variables"):
+        from pcfa_amd import attack_PCFA
+        from pcfa_amd.helper_functions import datasets, losses, ownutilities, targets, logging as plog
+        self.A, self.losses, self.own, self.plog = attack_PCFA, losses, ownutilities, plog
+        self.net, self.device, self.box = net, device, boxconstraint
+        self.eps = attack_PCFA.EPS_BOX
+        cov = boxconstraint == "change_of_variables"
+        unit = ownutilities.model_takes_unit_input(net)
+        kw = {"eps_box": self.eps} if cov else {}
+        self.model = ownutilities.import_and_load(net, make_unit_input=not unit, variable_change=cov,
+                                                  make_scaled_input_model=True, device=device,
+                                                  weights="random:1234", **kw)
+        self.model.eval()
+        for p in self.model.parameters():
+            p.requires_grad = False
+        i1, i2, _ = datasets.synthetic_pair(seed, h, w)
+        i1, i2 = i1[None].to(device), i2[None].to(device)
+        if not unit:
+            i1, i2 = i1 / 255., i2 / 255.
+        self.padder, [self.image1, self.image2] = ownutilities.preprocess_img(net, i1, i2)
+        if cov:
+            self.nw1 = torch.atanh(2. * (1. - self.eps) * self.image1 - (1 - self.eps))
+            self.nw2 = torch.atanh(2. * (1. - self.eps) * self.image2 - (1 - self.eps))
+        else:
+            self.nw1, self.nw2 = self.image1.clone(), self.image2.clone()
+        self.nw1.requires_grad = True
+        self.nw2.requires_grad = True
+        self.optimizer = torch.optim.LBFGS([self.nw1, self.nw2], max_iter=10)
+        self.delta_bound = 0.005
+        self.mu = 2500. / self.delta_bound
+        with torch.no_grad():
+            self.flow_init = self.predict().clone()
+        self.target = targets.get_target("zero", self.flow_init, device=device)
+        self.closures = 0
+
+    def predict(self):
+        out = self.own.compute_flow(self.model, "scaled_input_model", self.nw1, self.nw2, test_mode=True)
+        [out] = self.own.postprocess_flow(self.net, self.padder, out)
+        return out
+
+    def closure(self):
+        self.optimizer.zero_grad()
+        flow = self.predict()
+        d1, d2 = self.A.extract_deltas(self.nw1, self.nw2, self.image1, self.image2, self.box, eps_box=self.eps)
+        loss = self.losses.loss_delta_constraint(flow, self.target, d1, d2, self.device,
+                                                 delta_bound=self.delta_bound, mu=self.mu, f_type="aee")
+        loss.backward()
+        self.closures += 1
+        return loss
+
+    def step(self):
+        self.optimizer.step(self.closure)
+        with torch.no_grad():
+            d1, d2 = self.A.extract_deltas(self.nw1, self.nw2, self.image1, self.image2, self.box, eps_box=self.eps)
+            flow = self.predict()
+        aee_tgt, aee_init = self.plog.calc_metrics_adv(flow, self.target, self.flow_init)
+        l2 = self.plog.calc_delta_metrics(d1, d2)
+        return aee_tgt, aee_init, l2[2]
+
+
+def lookup_algorithmic_bytes(hf, wf, levels=4, radius=4):
+    """unique texels (Q * levels * (2r+2)^2 * 4 B) + coords + output."""
+    q = hf * wf
+    n1 = 2 * radius + 1
+    return q * levels * (2 * radius + 2) ** 2 * 4 + q * 2 * 4 + q * levels * n1 * n1 * 4
+
+
+def cpu_baseline(net, h, w, nclosures):
+    """Time the CPU port (pcfa_amd host code + oracle operators) on a bounded sample of the workload."""
+    from oracle import ops as oracle_ops
+    from pcfa_amd import ops
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with ops.override_for_testing(oracle_ops):
+        st = AttackStepper(net, h, w, torch.device("cpu"), seed=0)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            st.predict()
+        t_fwd = time.perf_counter() - t0  # forward only (includes first-touch warm-up)
+        times = []
+        for _ in range(nclosures):
+            t0 = time.perf_counter()
+            st.closure()
+            times.append(time.perf_counter() - t0)
+    t_c = min(times)
+    step_s = 10 * t_c + t_fwd
+    return {"value": 1.0 / step_s, "unit": "attack_steps_per_sec", "cores": cores, "kind": "port",
+            "closure_s": t_c, "forward_s": t_fwd,
+            "sample": "%d closure evals + 1 forward of %s %dx%d on %d host threads, extrapolated to the "
+                      "10 closures + 1 forward of one step" % (nclosures, net, h, w, cores)}
+
+
+def main():
+    a = parse()
+    from pcfa_amd import sharding
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        sharding.init_from_env("nccl")
+    rank = sharding.rank()
+    if world != a.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    dev = torch.device("cuda", sharding.local_rank() if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = True
+    h, w = (int(v) for v in a.size.lower().split("x"))
+
+    st = AttackStepper(a.net, h, w, dev, seed=rank)
+    from pcfa_amd import hip_ops
+    corr_net = a.net in ("RAFT", "GMA")
+    # HIP events around every launch of the named kernel, on the stream it is launched on
+    prof = hip_ops.LaunchProfiler(names=["pcfa_corr_lookup_fwd"]) if corr_net else None
+    for _ in range(a.warmup):
+        st.step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    hip_ops.set_launch_profiler(prof)
+    c0 = st.closures
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(a.steps):
+        last = st.step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    elapsed = time.perf_counter() - t0
+    hip_ops.set_launch_profiler(None)
+    elapsed = sharding.max_scalar(elapsed, dev)
+    closures = st.closures - c0
+
+    out = None
+    if rank == 0:
+        hp, wp = st.image1.shape[-2:]
+        out = {
+            "metric": "attack_steps_per_sec", "value": world * a.steps / elapsed, "unit": "attack_steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s, 1 synthetic %dx%d pair per GPU (padded %dx%d), disjoint delta, "
+                                   "change_of_variables, delta_bound=0.005, zero target, L-BFGS max_iter=10"
+                                   % (a.net, h, w, hp, wp), "weights": "random:1234",
+                       "closure_evals_per_step": closures / a.steps, "parallelism": "pairs sharded 1/GPU"},
+            "closure_evals_per_sec": world * closures / elapsed,
+            "final": {"aee_adv_tgt": last[0], "aee_adv_init": last[1], "l2_delta": last[2]},
+        }
+        if corr_net:
+            us, n = prof.summary()["pcfa_corr_lookup_fwd"]
+            nbytes = lookup_algorithmic_bytes(hp // 8, wp // 8)
+            ach = nbytes / (us * 1e-6) / 1e9
+            out["roofline"] = {"kernel": "corr_lookup_fwd_kernel<4>", "bound": "hbm", "achieved": ach,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "bytes_per_launch": nbytes, "mean_launch_us": us, "launches_timed": n}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.net, h, w, a.cpu_closures)
+        print(json.dumps(out))
+    sharding.shutdown()
+    return out
+
+
+if __name__ == "__main__":
+    main()

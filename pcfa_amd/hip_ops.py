@@ -43,6 +43,50 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+class LaunchProfiler:
+    """Optional per-launch timing: HIP events recorded on the launch stream around every C-ABI call.
+    Used by bench.py to measure kernel durations live inside the timed region (off by default)."""
+
+    def __init__(self, names=None):
+        self.names = set(names) if names else None
+        self.events = {}
+
+    def wants(self, name):
+        return self.names is None or name in self.names
+
+    def summary(self):
+        """name -> (mean microseconds, launches); synchronises the device."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, pairs in self.events.items():
+            tot = sum(s.elapsed_time(e) for s, e in pairs)
+            out[name] = (1e3 * tot / len(pairs), len(pairs))
+        return out
+
+
+_profiler = None
+
+
+def set_launch_profiler(profiler):
+    global _profiler
+    _profiler = profiler
+
+
+def _call(name, *args):
+    """Invoke C-ABI entry point `name` on torch's current stream and raise on a non-zero status."""
+    fn = getattr(_hip.load(), name)
+    prof = _profiler
+    if prof is not None and prof.wants(name):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        status = fn(*args, _stream())
+        e.record()
+        prof.events.setdefault(name, []).append((s, e))
+    else:
+        status = fn(*args, _stream())
+    _hip.check(status, name)
+
+
 # --------------------------------------------------------------------------- #
 # RAFT / GMA correlation pyramid
 # --------------------------------------------------------------------------- #
@@ -68,10 +112,9 @@ class _CorrBuild(torch.autograd.Function):
         slab = state.slab
         state.f2ext = torch.empty((B, D, slab), device=f1.device, dtype=torch.float32)
         state.pyr = torch.empty((B * H * W, slab), device=f1.device, dtype=torch.float32)
-        _hip.check(lib.pcfa_corr_f2ext_fwd(_ptr(f2), _ptr(state.f2ext), B, D, H, W, state.L, _stream()),
-                   "pcfa_corr_f2ext_fwd")
-        _hip.check(lib.pcfa_corr_pyramid_fwd(_ptr(f1), _ptr(state.f2ext), _ptr(state.pyr), B, D, H, W,
-                                             state.L, _stream()), "pcfa_corr_pyramid_fwd")
+        _call("pcfa_corr_f2ext_fwd", _ptr(f2), _ptr(state.f2ext), B, D, H, W, state.L)
+        _call("pcfa_corr_pyramid_fwd", _ptr(f1), _ptr(state.f2ext), _ptr(state.pyr), B, D, H, W,
+                                             state.L)
         ctx.state = state
         ctx.save_for_backward(f1)
         return torch.zeros(1, device=f1.device, dtype=torch.float32)
@@ -89,9 +132,8 @@ class _CorrBuild(torch.autograd.Function):
         df2 = torch.empty_like(f1)
         nbytes = lib.pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, st.L)
         ws = torch.empty((nbytes + 3) // 4, device=f1.device, dtype=torch.float32)
-        _hip.check(lib.pcfa_corr_pyramid_bwd(_ptr(st.dpyr), _ptr(f1), _ptr(st.f2ext), _ptr(df1), _ptr(df2),
-                                             _ptr(ws), ctypes.c_size_t(nbytes), B, D, H, W, st.L, _stream()),
-                   "pcfa_corr_pyramid_bwd")
+        _call("pcfa_corr_pyramid_bwd", _ptr(st.dpyr), _ptr(f1), _ptr(st.f2ext), _ptr(df1), _ptr(df2),
+                                             _ptr(ws), ctypes.c_size_t(nbytes), B, D, H, W, st.L)
         st.dpyr = None
         return df1, df2, None
 
@@ -104,8 +146,7 @@ class _CorrLookup(torch.autograd.Function):
         c = coords.contiguous()
         n1 = 2 * st.r + 1
         out = torch.empty((st.B, st.L * n1 * n1, st.H, st.W), device=c.device, dtype=torch.float32)
-        _hip.check(lib.pcfa_corr_lookup_fwd(_ptr(st.pyr), _ptr(c), _ptr(out), st.B, st.H, st.W, st.L, st.r,
-                                            _stream()), "pcfa_corr_lookup_fwd")
+        _call("pcfa_corr_lookup_fwd", _ptr(st.pyr), _ptr(c), _ptr(out), st.B, st.H, st.W, st.L, st.r)
         ctx.state = st
         ctx.save_for_backward(c)
         return out
@@ -118,8 +159,7 @@ class _CorrLookup(torch.autograd.Function):
         if st.dpyr is None:
             st.dpyr = torch.zeros_like(st.pyr)
         g = grad_out.contiguous()
-        _hip.check(lib.pcfa_corr_lookup_bwd(_ptr(st.dpyr), _ptr(c), _ptr(g), st.B, st.H, st.W, st.L, st.r,
-                                            _stream()), "pcfa_corr_lookup_bwd")
+        _call("pcfa_corr_lookup_bwd", _ptr(st.dpyr), _ptr(c), _ptr(g), st.B, st.H, st.W, st.L, st.r)
         return torch.zeros(1, device=g.device, dtype=torch.float32), None, None
 
 
@@ -183,8 +223,7 @@ class SpatialCorrelationSamplerFunction(torch.autograd.Function):
                                                   ctypes.byref(oH), ctypes.byref(oW)), "pcfa_spatial_corr_out_size")
         out = torch.empty((B, pH, pW, oH.value, oW.value), device=input1.device, dtype=torch.float32)
         ctx.params = (B, C, iH, iW, kH, kW, pH, pW, padH, padW, dilH, dilW, dpH, dpW, dH, dW)
-        _hip.check(lib.pcfa_spatial_corr_fwd(_ptr(input1), _ptr(input2), _ptr(out), *ctx.params, _stream()),
-                   "pcfa_spatial_corr_fwd")
+        _call("pcfa_spatial_corr_fwd", _ptr(input1), _ptr(input2), _ptr(out), *ctx.params)
         ctx.save_for_backward(input1, input2)
         return out
 
@@ -196,8 +235,8 @@ class SpatialCorrelationSamplerFunction(torch.autograd.Function):
         g = grad_output.contiguous()
         g1 = torch.empty_like(input1)
         g2 = torch.empty_like(input2)
-        _hip.check(lib.pcfa_spatial_corr_bwd(_ptr(input1), _ptr(input2), _ptr(g), _ptr(g1), _ptr(g2),
-                                             *ctx.params, _stream()), "pcfa_spatial_corr_bwd")
+        _call("pcfa_spatial_corr_bwd", _ptr(input1), _ptr(input2), _ptr(g), _ptr(g1), _ptr(g2),
+                                             *ctx.params)
         return g1, g2, None, None, None, None, None, None
 
 
@@ -222,8 +261,8 @@ class _BoxTransform(torch.autograd.Function):
         if d is not None and d.numel() != n:
             raise ValueError("delta must broadcast over the batch: %s vs %s" % (tuple(d.shape), tuple(img.shape)))
         out = torch.empty_like(img)
-        _hip.check(lib.pcfa_box_transform_fwd(_ptr(img), _ptr(d), _ptr(out), B, n, int(cov), float(eps_box),
-                                              float(scale), _stream()), "pcfa_box_transform_fwd")
+        _call("pcfa_box_transform_fwd", _ptr(img), _ptr(d), _ptr(out), B, n, int(cov), float(eps_box),
+                                              float(scale))
         ctx.args = (B, n, int(cov), float(eps_box), float(scale))
         ctx.delta_shape = None if delta is None else delta.shape
         ctx.save_for_backward(img, d)
@@ -238,8 +277,8 @@ class _BoxTransform(torch.autograd.Function):
         need_img, need_delta = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and d is not None
         gi = torch.empty_like(img) if need_img else None
         gd = torch.empty(ctx.delta_shape, device=img.device, dtype=torch.float32) if need_delta else None
-        _hip.check(lib.pcfa_box_transform_bwd(_ptr(img), _ptr(d), _ptr(g), _ptr(gi), _ptr(gd), B, n, cov, eps,
-                                              scale, _stream()), "pcfa_box_transform_bwd")
+        _call("pcfa_box_transform_bwd", _ptr(img), _ptr(d), _ptr(g), _ptr(gi), _ptr(gd), B, n, cov, eps,
+                                              scale)
         return gi, gd, None, None, None
 
 
@@ -256,8 +295,8 @@ class _ExtractDeltas(torch.autograd.Function):
         w = nw_input.contiguous()
         img = image.contiguous()
         out = torch.empty_like(w)
-        _hip.check(lib.pcfa_extract_deltas_fwd(_ptr(w), _ptr(img), _ptr(out), w.numel(), int(cov),
-                                               float(eps_box), _stream()), "pcfa_extract_deltas_fwd")
+        _call("pcfa_extract_deltas_fwd", _ptr(w), _ptr(img), _ptr(out), w.numel(), int(cov),
+                                               float(eps_box))
         ctx.args = (int(cov), float(eps_box))
         ctx.save_for_backward(w)
         return out
@@ -268,8 +307,7 @@ class _ExtractDeltas(torch.autograd.Function):
         lib = _hip.load()
         g = grad_delta.contiguous()
         gw = torch.empty_like(w)
-        _hip.check(lib.pcfa_extract_deltas_bwd(_ptr(w), _ptr(g), _ptr(gw), w.numel(), ctx.args[0], ctx.args[1],
-                                               _stream()), "pcfa_extract_deltas_bwd")
+        _call("pcfa_extract_deltas_bwd", _ptr(w), _ptr(g), _ptr(gw), w.numel(), ctx.args[0], ctx.args[1])
         return gw, None, None, None
 
 
@@ -280,8 +318,7 @@ class _ExtractDeltasJoint(torch.autograd.Function):
         lib = _hip.load()
         nd, mx, mn = nw_delta.contiguous(), images_max.contiguous(), images_min.contiguous()
         out = torch.empty_like(nd)
-        _hip.check(lib.pcfa_extract_deltas_joint_fwd(_ptr(nd), _ptr(mx), _ptr(mn), _ptr(out), nd.numel(),
-                                                     _stream()), "pcfa_extract_deltas_joint_fwd")
+        _call("pcfa_extract_deltas_joint_fwd", _ptr(nd), _ptr(mx), _ptr(mn), _ptr(out), nd.numel())
         ctx.save_for_backward(nd, mx, mn)
         return out
 
@@ -291,8 +328,7 @@ class _ExtractDeltasJoint(torch.autograd.Function):
         lib = _hip.load()
         g = grad_delta.contiguous()
         gnd = torch.empty_like(nd)
-        _hip.check(lib.pcfa_extract_deltas_joint_bwd(_ptr(nd), _ptr(mx), _ptr(mn), _ptr(g), _ptr(gnd), nd.numel(),
-                                                     _stream()), "pcfa_extract_deltas_joint_bwd")
+        _call("pcfa_extract_deltas_joint_bwd", _ptr(nd), _ptr(mx), _ptr(mn), _ptr(g), _ptr(gnd), nd.numel())
         return gnd, None, None
 
 
@@ -342,10 +378,9 @@ class _LossDeltaConstraint(torch.autograd.Function):
         B, _, H, W = p.shape
         scal = torch.empty(8, device=p.device, dtype=torch.float32)
         ft = _hip.PCFA_LOSS[f_type]
-        _hip.check(lib.pcfa_flow_loss_fwd(_ptr(p), _hip.strides4(p), _ptr(t), _hip.strides4(t), B, H, W,
+        _call("pcfa_flow_loss_fwd", _ptr(p), _hip.strides4(p), _ptr(t), _hip.strides4(t), B, H, W,
                                           _ptr(d1), d1.numel(), _ptr(d2), d2.numel(), float(delta_bound),
-                                          float(mu), ft, _ptr(scal), _ptr(_workspace(p.device)), _stream()),
-                   "pcfa_flow_loss_fwd")
+                                          float(mu), ft, _ptr(scal), _ptr(_workspace(p.device)))
         ctx.joint = d1.data_ptr() == d2.data_ptr() and d1.numel() == d2.numel()
         ctx.args = (B, H, W, float(mu), ft)
         ctx.pred_shape = pred.shape
@@ -364,10 +399,9 @@ class _LossDeltaConstraint(torch.autograd.Function):
         gd2 = torch.empty_like(d2) if (need_d2 and not ctx.joint) else None
         if ctx.joint and need_d2 and gd1 is None:
             gd1 = torch.empty_like(d1)
-        _hip.check(lib.pcfa_flow_loss_bwd(_ptr(p), _hip.strides4(p), _ptr(t), _hip.strides4(t), B, H, W,
+        _call("pcfa_flow_loss_bwd", _ptr(p), _hip.strides4(p), _ptr(t), _hip.strides4(t), B, H, W,
                                           _ptr(d1), d1.numel(), _ptr(d2), d2.numel(), mu, ft, 0,
-                                          _ptr(scal), _ptr(gl), _ptr(gp), _ptr(gd1), _ptr(gd2), _stream()),
-                   "pcfa_flow_loss_bwd")
+                                          _ptr(scal), _ptr(gl), _ptr(gp), _ptr(gd1), _ptr(gd2))
         if gp is not None:
             gp = gp.reshape(ctx.pred_shape)
         if ctx.joint:
@@ -394,8 +428,8 @@ def avg_epe(flow1, flow2):
         raise ValueError("flow shape mismatch")
     B, _, H, W = a.shape
     out = torch.empty(1, device=a.device, dtype=torch.float32)
-    _hip.check(lib.pcfa_avg_epe(_ptr(a), _hip.strides4(a), _ptr(b), _hip.strides4(b), B, H, W, _ptr(out),
-                                _ptr(_workspace(a.device)), _stream()), "pcfa_avg_epe")
+    _call("pcfa_avg_epe", _ptr(a), _hip.strides4(a), _ptr(b), _hip.strides4(b), B, H, W, _ptr(out),
+                                _ptr(_workspace(a.device)))
     return out[0]
 
 
@@ -404,8 +438,7 @@ def sum_squares(x):
     lib = _hip.load()
     xc = x.detach().contiguous()
     out = torch.empty(1, device=xc.device, dtype=torch.float32)
-    _hip.check(lib.pcfa_sum_squares(_ptr(xc), xc.numel(), _ptr(out), _ptr(_workspace(xc.device)), _stream()),
-               "pcfa_sum_squares")
+    _call("pcfa_sum_squares", _ptr(xc), xc.numel(), _ptr(out), _ptr(_workspace(xc.device)))
     return out[0]
 
 

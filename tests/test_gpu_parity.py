@@ -1,0 +1,310 @@
+"""Parity of the HIP kernels (through the C-ABI) with the oracle and the reference's golden vectors.
+All tests here need a real MI355X:  python -m pytest tests -m gpu
+
+Tolerances (fp32 everywhere; stated per test):
+  * elementwise kernels: <= 4 ulp-ish (2e-6 relative) -- device tanhf vs Sleef tanh;
+  * lookup given the same pyramid: 2e-5 * max|corr| -- the kernel interpolates at cx/2^l + a - r directly,
+    the reference round-trips the coordinate through grid_sample's [-1,1] normalisation (<= 2 ulp of x);
+  * pyramid GEMM (K = D = 256, fp32 MFMA fma chain vs MKL sgemm): 2e-6 * sqrt(D) * max|corr|;
+  * reductions (loss): 1e-6 relative;  gradients through GEMMs: 1e-5 relative L2.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from pcfa_amd import hip_ops, ops
+from tests import closure_util
+from tests.util import load_golden, max_abs, rel_l2, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _grid(B, H, W):
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    return torch.stack([xs, ys], 0).float()[None].repeat(B, 1, 1, 1)
+
+
+# --------------------------------------------------------------------------- correlation pyramid + lookup
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_corr_block_vs_reference_golden(tag):
+    g = load_golden("corr_block_" + tag)
+    f1, f2 = t(g["fmap1"], DEV).requires_grad_(True), t(g["fmap2"], DEV).requires_grad_(True)
+    blk = hip_ops.CorrBlock(f1, f2, num_levels=4, radius=4)
+    pyr = blk.corr_pyramid
+    cmax = float(np.abs(g["pyr1"]).max())
+    D = f1.shape[1]
+    for lvl in (1, 2, 3):
+        assert pyr[lvl].shape == g["pyr%d" % lvl].shape
+        assert max_abs(pyr[lvl], t(g["pyr%d" % lvl])) <= 2e-6 * np.sqrt(D) * cmax + 1e-6
+    if "pyr0" in g:
+        assert max_abs(pyr[0], t(g["pyr0"])) <= 2e-6 * np.sqrt(D) * float(np.abs(g["pyr0"]).max())
+    outs = [blk(t(g[k], DEV)) for k in ("coords0", "coords1", "coords2")]
+    omax = float(np.abs(g["out1"]).max())
+    for i, o in enumerate(outs):
+        assert o.shape == g["out%d" % i].shape
+        assert max_abs(o, t(g["out%d" % i])) <= 3e-5 * omax, i
+    go = t(g["grad_out"], DEV)
+    ((outs[1] * go).sum() + (outs[2] * go.flip(1)).sum()).backward()
+    assert rel_l2(f1.grad, t(g["dfmap1"])) < 2e-5
+    assert rel_l2(f2.grad, t(g["dfmap2"])) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 16, 20), (2, 256, 23, 37), (1, 64, 55, 128)])
+def test_corr_block_vs_oracle(oracle_ops, shape):
+    B, D, H, W = shape
+    gen = torch.Generator().manual_seed(H * W)
+    f1c = torch.randn(B, D, H, W, generator=gen).requires_grad_(True)
+    f2c = torch.randn(B, D, H, W, generator=gen).requires_grad_(True)
+    coords = [_grid(B, H, W), _grid(B, H, W) + 2.5 * torch.randn(B, 2, H, W, generator=gen),
+              _grid(B, H, W) + 40 * torch.randn(B, 2, H, W, generator=gen)]
+    gos = [torch.randn(B, 324, H, W, generator=gen) for _ in coords]
+    ref = oracle_ops.CorrBlock(f1c, f2c)
+    ro = [ref(c) for c in coords]
+    sum((o * g).sum() for o, g in zip(ro, gos)).backward()
+
+    f1g = f1c.detach().to(DEV).requires_grad_(True)
+    f2g = f2c.detach().to(DEV).requires_grad_(True)
+    blk = hip_ops.CorrBlock(f1g, f2g)
+    go_ = [blk(c.to(DEV)) for c in coords]
+    omax = max(float(o.abs().max()) for o in ro)
+    for a, b in zip(go_, ro):
+        assert max_abs(a, b) <= 3e-5 * omax
+    sum((o * g.to(DEV)).sum() for o, g in zip(go_, gos)).backward()
+    assert rel_l2(f1g.grad, f1c.grad) < 2e-5
+    assert rel_l2(f2g.grad, f2c.grad) < 2e-5
+
+
+def test_lookup_given_same_pyramid_is_tight(oracle_ops):
+    """Feed the ORACLE's pyramid into the HIP lookup: isolates the lookup kernel from the GEMM."""
+    from pcfa_amd import _hip
+    lib = _hip.load()
+    B, D, H, W = 1, 32, 24, 40
+    gen = torch.Generator().manual_seed(1)
+    f1, f2 = torch.randn(B, D, H, W, generator=gen), torch.randn(B, D, H, W, generator=gen)
+    pyr_levels = oracle_ops.corr_pyramid(f1, f2, 4)
+    slab = lib.pcfa_corr_slab_floats(H, W, 4)
+    pyr = torch.zeros(B * H * W, slab)
+    for l, lv in enumerate(pyr_levels):
+        off = lib.pcfa_corr_level_offset(H, W, 4, l, None, None)
+        pyr[:, off:off + lv[0, 0].numel()] = lv.reshape(B * H * W, -1)
+    pyr = pyr.to(DEV)
+    for spread in (0.0, 1.7, 25.0):
+        coords = _grid(B, H, W) + spread * torch.randn(B, 2, H, W, generator=gen)
+        want = oracle_ops.corr_lookup(pyr_levels, coords, 4)
+        got = torch.empty(B, 324, H, W, device=DEV)
+        st = lib.pcfa_corr_lookup_fwd(ctypes.c_void_p(pyr.data_ptr()), ctypes.c_void_p(coords.to(DEV).data_ptr()),
+                                      ctypes.c_void_p(got.data_ptr()), B, H, W, 4, 4,
+                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert st == 0
+        assert max_abs(got, want) <= 2e-5 * float(want.abs().max())
+
+
+def test_lookup_properties_full_size():
+    """BASELINE size (55x128 features, D=256): linearity in the feature map and <bwd(g), .> adjointness."""
+    B, D, H, W = 1, 256, 55, 128
+    gen = torch.Generator().manual_seed(0)
+    f1 = torch.randn(B, D, H, W, generator=gen).to(DEV)
+    f2 = torch.randn(B, D, H, W, generator=gen).to(DEV)
+    f2b = torch.randn(B, D, H, W, generator=gen).to(DEV)
+    coords = (_grid(B, H, W) + 4 * torch.randn(B, 2, H, W, generator=gen)).to(DEV)
+    la = hip_ops.CorrBlock(f1, f2)(coords)
+    lb = hip_ops.CorrBlock(f1, f2b)(coords)
+    lab = hip_ops.CorrBlock(f1, f2 + 2 * f2b)(coords)
+    assert max_abs(lab, la + 2 * lb) <= 2e-5 * float(lab.abs().max())
+    # adjoint: <lookup(f1,f2), g> differentiated w.r.t. f1 equals the analytic contraction
+    f1r = f1.clone().requires_grad_(True)
+    g = torch.randn(la.shape, generator=gen).to(DEV)
+    out = hip_ops.CorrBlock(f1r, f2)(coords)
+    (out * g).sum().backward()
+    eps_dir = torch.randn(f1.shape, generator=gen).to(DEV)
+    lhs = float((f1r.grad * eps_dir).sum())
+    rhs = float((hip_ops.CorrBlock(eps_dir, f2)(coords) * g).sum())  # linear in f1
+    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0)
+    # determinism: two backward passes give identical bits
+    f1s = f1.clone().requires_grad_(True)
+    (hip_ops.CorrBlock(f1s, f2)(coords) * g).sum().backward()
+    assert torch.equal(f1s.grad, f1r.grad)
+
+
+def test_corr_block_edge_cases():
+    with pytest.raises(ValueError):
+        hip_ops.CorrBlock(torch.zeros(1, 8, 4, 4, device=DEV), torch.zeros(1, 8, 4, 4, device=DEV))  # level 3 empty
+    # NaN / huge coordinates must not fault: everything out of range reads as zero
+    f = torch.randn(1, 16, 16, 16, device=DEV)
+    c = _grid(1, 16, 16).to(DEV)
+    c[0, 0, 0, 0] = 1e30
+    c[0, 1, 1, 1] = -1e30
+    out = hip_ops.CorrBlock(f, f)(c)
+    assert torch.isfinite(out[:, :, 2:, 2:]).all()
+    assert float(out[0, :, 0, 0].abs().max()) == 0.0
+
+
+# --------------------------------------------------------------------------- PWC cost volume
+@pytest.mark.parametrize("tag", ["pwc_a", "pwc_b", "pwc_c", "gen_a", "gen_b"])
+def test_spatial_corr_vs_reference_golden(tag):
+    g = load_golden("spatial_corr_" + tag)
+    ks, ps, st, pad, dil, dp = (int(v) for v in g["params"])
+    a, b = t(g["in1"], DEV).requires_grad_(True), t(g["in2"], DEV).requires_grad_(True)
+    out = hip_ops.spatial_correlation_sample(a, b, ks, ps, st, pad, dil, dp)
+    assert out.shape == g["out"].shape
+    C = a.shape[1]
+    assert max_abs(out, t(g["out"])) <= 1e-6 * C * float(np.abs(g["out"]).max()) + 1e-6
+    out.backward(t(g["grad_out"], DEV))
+    assert rel_l2(a.grad, t(g["gin1"])) < 1e-5
+    assert rel_l2(b.grad, t(g["gin2"])) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 196, 6, 20), (1, 128, 12, 40), (2, 96, 24, 80), (1, 64, 48, 160),
+                                   (1, 32, 96, 320), (1, 5, 7, 33)])
+def test_spatial_corr_pwc_levels_vs_oracle(oracle_ops, shape):
+    """The five PWC-Net level shapes at KITTI size + one ragged shape."""
+    gen = torch.Generator().manual_seed(shape[1])
+    a = torch.randn(*shape, generator=gen).requires_grad_(True)
+    b = torch.randn(*shape, generator=gen).requires_grad_(True)
+    want = oracle_ops.spatial_correlation_sample(a, b, 1, 9, 1)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    ag, bg = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.spatial_correlation_sample(ag, bg, kernel_size=1, patch_size=9, stride=1)
+    assert max_abs(got, want) <= 2e-6 * shape[1] * float(want.abs().max())
+    got.backward(go.to(DEV))
+    assert rel_l2(ag.grad, a.grad) < 1e-5 and rel_l2(bg.grad, b.grad) < 1e-5
+    # determinism
+    ag2, bg2 = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    hip_ops.spatial_correlation_sample(ag2, bg2, 1, 9, 1).backward(go.to(DEV))
+    assert torch.equal(ag2.grad, ag.grad) and torch.equal(bg2.grad, bg.grad)
+
+
+# --------------------------------------------------------------------------- attack math
+def test_attack_math_vs_reference_golden():
+    g = load_golden("attack_math")
+    pred, target = t(g["pred"], DEV), t(g["target"], DEV)
+    img1, img2 = t(g["image1"], DEV), t(g["image2"], DEV)
+    for box, (ka, kb) in (("change_of_variables", ("w1", "w2")), ("clipping", ("c1", "c2"))):
+        a, b = t(g[ka], DEV).requires_grad_(True), t(g[kb], DEV).requires_grad_(True)
+        d1, d2 = hip_ops.extract_deltas(a, b, img1, img2, box, eps_box=1e-7)
+        assert max_abs(d1, t(g["delta1_" + box])) <= 2e-7 and max_abs(d2, t(g["delta2_" + box])) <= 2e-7
+        gd = t(g["gdelta"], DEV)
+        ((d1 * gd).sum() + (d2 * gd.flip(-1)).sum()).backward()
+        assert rel_l2(a.grad, t(g["gw1_" + box])) < 2e-6 and rel_l2(b.grad, t(g["gw2_" + box])) < 2e-6
+        for f_type in ("aee", "mse", "cosim"):
+            for bound in (0.005, 10.0):
+                key = "%s_%s_%g" % (box, f_type, bound)
+                p = pred.clone().requires_grad_(True)
+                dd1 = t(g["delta1_" + box], DEV).requires_grad_(True)
+                dd2 = t(g["delta2_" + box], DEV).requires_grad_(True)
+                loss = hip_ops.loss_delta_constraint(p, target, dd1, dd2, None, delta_bound=bound, mu=5e5,
+                                                     f_type=f_type)
+                loss.backward()
+                want = float(g["loss_" + key])
+                assert abs(float(loss) - want) <= 2e-6 * abs(want), key
+                assert rel_l2(p.grad, t(g["gpred_" + key])) < 2e-6, key
+                if float(np.abs(g["gd1_" + key]).max()) == 0:
+                    assert float(dd1.grad.abs().max()) == 0 and float(dd2.grad.abs().max()) == 0
+                else:
+                    assert rel_l2(dd1.grad, t(g["gd1_" + key])) < 2e-6, key
+                    assert rel_l2(dd2.grad, t(g["gd2_" + key])) < 2e-6, key
+    nd = t(g["nw_delta"], DEV).requires_grad_(True)
+    dj, dj2 = hip_ops.extract_deltas_joint(nd, torch.max(img1, img2), torch.min(img1, img2))
+    assert dj is dj2 and max_abs(dj, t(g["delta_joint"])) <= 1e-7
+    pj = pred.clone().requires_grad_(True)
+    lj = hip_ops.loss_delta_constraint(pj, target, dj, dj2, None, delta_bound=0.005, mu=5e5, f_type="aee")
+    lj.backward()
+    assert abs(float(lj) - float(g["loss_joint"])) <= 2e-6 * abs(float(g["loss_joint"]))
+    assert rel_l2(nd.grad, t(g["gnd_joint"])) < 2e-6
+    assert rel_l2(pj.grad, t(g["gpred_joint"])) < 2e-6
+    assert abs(float(hip_ops.avg_epe(pred, target)) - float(g["aee"])) < 2e-6 * float(g["aee"])
+    assert abs(float(hip_ops.avg_epe(pred[0], target[0])) - float(g["aee3"])) < 2e-6 * float(g["aee3"])
+    assert abs(float(hip_ops.two_norm_avg(d1)) - float(g["l2_1"])) < 2e-6 * float(g["l2_1"])
+    assert abs(float(hip_ops.two_norm_avg_delta(d1, d2)) - float(g["l2_12"])) < 2e-6 * float(g["l2_12"])
+
+
+def test_box_transform_vs_oracle(oracle_ops):
+    gen = torch.Generator().manual_seed(2)
+    img = torch.rand(3, 3, 37, 53, generator=gen)
+    for cov, scale, with_delta in ((True, 255., False), (False, 255., True), (False, 1., True), (True, 1., False)):
+        x = (torch.atanh(2 * (1 - 1e-7) * img - (1 - 1e-7)) if cov else img + 0.3 * torch.randn(img.shape, generator=gen))
+        x = x.requires_grad_(True)
+        delta = (0.2 * torch.randn(3, 37, 53, generator=gen)).requires_grad_(True) if with_delta else None
+        want = oracle_ops.box_transform(x, delta, cov, 1e-7, scale)
+        go = torch.randn(want.shape, generator=gen)
+        want.backward(go)
+        xg = x.detach().to(DEV).requires_grad_(True)
+        dg = delta.detach().to(DEV).requires_grad_(True) if with_delta else None
+        got = hip_ops.box_transform(xg, dg, cov, 1e-7, scale)
+        assert max_abs(got, want) <= 2e-6 * scale
+        got.backward(go.to(DEV))
+        assert rel_l2(xg.grad, x.grad) < 2e-6
+        if with_delta:
+            assert rel_l2(dg.grad, delta.grad) < 2e-6
+
+
+def test_loss_on_unpadded_view_full_size():
+    """BASELINE size: the loss reads the 436x1024 crop of a 440x1024 flow in place (strided)."""
+    gen = torch.Generator().manual_seed(4)
+    full = (5 * torch.randn(1, 2, 440, 1024, generator=gen)).to(DEV).requires_grad_(True)
+    crop = full[..., 2:438, :]
+    target = torch.zeros(1, 2, 436, 1024, device=DEV)
+    d = (0.01 * torch.randn(1, 3, 440, 1024, generator=gen)).to(DEV).requires_grad_(True)
+    loss = hip_ops.loss_delta_constraint(crop, target, d, d.detach().clone(), None, delta_bound=0.005, mu=5e5)
+    want_sim = crop.detach().double().pow(2).sum(1).sqrt().mean()
+    msq = d.detach().double().pow(2).sum() * 2 / (2 * d.numel())
+    want = float(want_sim + 5e5 * max(0.0, float(msq) - 0.005 ** 2))
+    assert abs(float(loss) - want) <= 2e-6 * want
+    loss.backward()
+    assert float(full.grad[..., :2, :].abs().max()) == 0 and float(full.grad[..., 438:, :].abs().max()) == 0
+    # checksum-of-checksums: reproducible bits
+    loss2 = hip_ops.loss_delta_constraint(crop, target, d, d.detach().clone(), None, delta_bound=0.005, mu=5e5)
+    assert float(loss2) == float(loss)
+
+
+# --------------------------------------------------------------------------- whole closure + attack
+CASES = {
+    "raft": ("RAFT", 128, 160, "change_of_variables", False, "zero", "aee", 1),
+    "gma": ("GMA", 128, 160, "change_of_variables", False, "neg_flow", "aee", 2),
+    "pwcnet": ("PWCNet", 120, 180, "clipping", True, "zero", "aee", 3),
+    "spynet": ("SpyNet", 100, 150, "change_of_variables", False, "zero", "mse", 4),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_closure_on_gpu_vs_reference_golden(name):
+    """One full closure on the MI355X vs the REFERENCE's CPU closure (golden): flow 1e-3 of its range
+    (north_star's AEE tolerance), loss 1e-4 relative, gradient 1e-2 relative L2 (MIOpen vs MKL-DNN convs)."""
+    g = load_golden("closure_" + name)
+    net, h, w, box, joint, tgt, loss, seed = CASES[name]
+    leaves = [t(g["leaf0"])] if joint else [t(g["leaf0"]), t(g["leaf1"])]
+    torch.backends.cudnn.allow_tf32 = False
+    r = closure_util.run_closure(net, h, w, box, joint, tgt, loss, seed, torch.device(DEV),
+                                 images=(t(g["image1"].astype(np.float32)), t(g["image2"].astype(np.float32))),
+                                 leaves=leaves)
+    scale = float(np.abs(g["flow"]).max())
+    assert max_abs(r["flow"], t(g["flow"])) <= 1e-3 * scale
+    aee = float((r["flow"].cpu() - t(g["flow"])).pow(2).sum(1).sqrt().mean())
+    assert aee <= 1e-3
+    assert abs(r["loss"] - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    for i, gr in enumerate(r["grads"]):
+        assert rel_l2(gr, t(g["grad%d" % i])) < 1e-2
+
+
+def test_pcfa_attack_on_gpu_vs_reference_trajectory():
+    from argparse import Namespace
+    from pcfa_amd import attack_PCFA
+    g = load_golden("trajectory_raft")
+    ref8, ref3 = g["threads8"], g["threads3"]
+    args = Namespace(net="RAFT", steps=5, joint_perturbation=False, boxconstraint="change_of_variables",
+                     delta_bound=0.005, target="zero", custom_target_path="", loss="aee", save_frequency=1,
+                     small_save=False, no_save=True, unregistered_artifacts=True, universal_perturbation=False,
+                     mu=-1, weights="random:1234")
+    model = closure_util.load_model("RAFT", True, torch.device(DEV))
+    res = attack_PCFA.pcfa_attack(model, t(g["image1"].astype(np.float32)), t(g["image2"].astype(np.float32)),
+                                  torch.zeros(1, 2, 128, 160), 0, None, 1e-7, torch.device(DEV), False,
+                                  2500. / 0.005, args)
+    res = np.array([np.nan if v is None else float(v) for v in res])
+    assert abs(res[1] - ref8[1]) < 1e-3
+    for idx in (4, 5, 8, 9, 10, 11):
+        tol = max(1e-3, 3 * abs(ref8[idx] - ref3[idx])) * max(1.0, abs(ref8[idx]))
+        assert abs(res[idx] - ref8[idx]) <= tol, (idx, res[idx], ref8[idx], ref3[idx])
