@@ -56,19 +56,26 @@ PCFA_API const char* pcfa_status_string(int status);
  * identical models/gma/corr.py:15-30,55-63).
  *
  * HBM layout ("slab per query"): the 4D volume and its pooled levels are kept
- * as ONE matrix  pyr[B*Q][slab]  (Q = H*W), row q holding level 0 (H*W
- * floats), then level 1 ((H/2)*(W/2)), ... concatenated; `slab` is the sum
- * rounded up to a multiple of 4 floats.  Level l of the reference's
- * corr_pyramid[l] ([B*Q,1,H_l,W_l]) is  pyr[:, off_l : off_l + H_l*W_l].
+ * as ONE matrix  pyr[B*Q][slab]  (Q = H*W), row q holding level 0, level 1
+ * ((H/2)x(W/2)), ... back to back.  Inside a row every level is stored as
+ * 4x4-texel tiles (64 B), tiles row-major, texels row-major inside a tile,
+ * levels padded to whole tiles (pad texels are 0):
+ *   index(l, y, x) = off_l + ((y>>2)*ceil(W_l/4) + (x>>2))*16 + (y&3)*4 + (x&3)
+ * pcfa_corr_tiled_index() evaluates it.  Element (q, index(l,y,x)) is the
+ * reference's corr_pyramid[l][q, 0, y, x].
  * ------------------------------------------------------------------------- */
 
-/* floats per query row (multiple of 4) */
+/* floats per query row (multiple of 16) */
 PCFA_API long long pcfa_corr_slab_floats(int H, int W, int num_levels);
 /* offset (floats) of level l inside a row; *h_l,*w_l receive its extent */
 PCFA_API long long pcfa_corr_level_offset(int H, int W, int num_levels, int level, int* h_l, int* w_l);
 
-/* f2ext[B][D][slab] = fmap2 followed by its successively 2x2-average-pooled
- * copies (floor semantics of F.avg_pool2d(.,2,stride=2)); pad columns are 0. */
+/* index of texel (y, x) of level l inside a query row, or -1 */
+PCFA_API long long pcfa_corr_tiled_index(int H, int W, int num_levels, int level, int y, int x);
+
+/* f2ext[B][D][slab] = fmap2 and its successively 2x2-average-pooled copies
+ * (floor semantics of F.avg_pool2d(.,2,stride=2)), columns in the tiled order
+ * above; tile-padding columns are 0. */
 PCFA_API int pcfa_corr_f2ext_fwd(const float* fmap2, float* f2ext, int B, int D, int H, int W,
                         int num_levels, void* stream);
 

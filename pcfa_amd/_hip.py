@@ -27,6 +27,7 @@ SIGNATURES = {
     "pcfa_status_string": (c_char_p, [c_int]),
     "pcfa_corr_slab_floats": (c_longlong, [c_int, c_int, c_int]),
     "pcfa_corr_level_offset": (c_longlong, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "pcfa_corr_tiled_index": (c_longlong, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "pcfa_corr_f2ext_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_corr_pyramid_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_corr_pyramid_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -12,12 +12,21 @@
   } while (0)
 
 // Pyramid layout shared by every corr kernel (passed by value as a kernel arg).
+//
+// One row ("slab") of the pyramid matrix per query.  Inside a slab every level is stored as
+// 4x4-texel TILES (64 B = one HBM/L2 sector each), tiles row-major, texels row-major inside a
+// tile:   idx(l, y, x) = off[l] + ((y>>2)*tw[l] + (x>>2))*16 + (y&3)*4 + (x&3).
+// A (2r+2)^2 lookup window then touches ~11 sectors instead of ~16-20 with plain rows, and a
+// wave fetches a whole window with ONE 16-B-per-lane load (lane = tile row).  Levels are padded
+// to whole tiles; pad texels hold 0 (the GEMM multiplies zero columns of f2ext).
 struct PyrLayout {
   int L;
   int h[PCFA_MAX_LEVELS];
   int w[PCFA_MAX_LEVELS];
-  int off[PCFA_MAX_LEVELS];
-  int slab;  // floats per query row, multiple of 4
+  int tw[PCFA_MAX_LEVELS];   // tiles per tile-row
+  int off[PCFA_MAX_LEVELS];  // floats, multiple of 16
+  int zero;                  // offset of a tile that is always 0 (f2ext has zero columns there)
+  int slab;                  // floats per query row, multiple of 16
 };
 
 static inline bool pcfa_make_layout(PyrLayout& P, int H, int W, int L) {
@@ -29,20 +38,30 @@ static inline bool pcfa_make_layout(PyrLayout& P, int H, int W, int L) {
     if (l < L) {
       P.h[l] = h;
       P.w[l] = w;
+      P.tw[l] = (w + 3) / 4;
       P.off[l] = (int)off;
-      off += (long long)h * w;
+      off += (long long)((h + 3) / 4) * ((w + 3) / 4) * 16;
       h /= 2;
       w /= 2;
     } else {
       P.h[l] = 0;
       P.w[l] = 0;
+      P.tw[l] = 0;
       P.off[l] = (int)off;
     }
   }
-  off = (off + 3) & ~3LL;
-  if (off > 0x7fffffffLL) return false;
+  P.zero = (int)off;  // one all-zero tile closes every slab (out-of-window lanes load it branch-free)
+  off += 16;
+  if (off > 0x7fffffffLL / 4) return false;
   P.slab = (int)off;
   return true;
+}
+
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline int pcfa_tiled_index(const PyrLayout& P, int l, int y, int x) {
+  return P.off[l] + (((y >> 2) * P.tw[l] + (x >> 2)) << 4) + ((y & 3) << 2) + (x & 3);
 }
 
 static inline int pcfa_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -3,113 +3,229 @@
 // Replaces CorrBlock.__call__ (reference models/raft/corr.py:29-50) and the
 // grid_sample inside bilinear_sampler (models/raft/utils/utils.py:57-71).
 //
-// Work decomposition (wave64): one workgroup = 64 consecutive queries x one
-// pyramid level, (2r+1) waves.  All (2r+1)^2 taps of a (query, level) share
-// one fractional offset, so the workgroup
-//   0. derives each query's window origin + fractions from coords,
-//   A. gathers the (2r+2)^2 texel windows into LDS with lanes running ALONG the
-//      window rows (7 row segments per wave-load instead of 64 scattered lines),
-//   B. lets thread (query, b) blend two LDS rows into the 2r+1 taps of row b and
-//      store them with lanes running along the query index (256-B stores).
-// The backward is the exact transpose with the same ownership, so the
-// read-modify-write of dpyr needs no atomics and is deterministic.
+// Data: the pyramid is one slab per query, each level stored as 4x4-texel tiles
+// (common.hpp).  All (2r+1)^2 taps of a (query, level) share one fractional
+// offset, so a lookup is "fetch a (2r+2)^2 window, blend it 4 ways".
+//
+// Work decomposition (wave64): workgroup = 64 consecutive queries x one level,
+// 2r+1 waves.
+//   A. one WAVE fetches one window per instruction: lane = (tile row, tile col,
+//      row in tile) of the 4x4 tile block that covers the window, a single
+//      16-B load per lane -> whole 64-B sectors, ~11 per window.  A wave issues
+//      the loads of all its windows back to back (8 in flight per lane) before
+//      touching LDS.  Window origins are wave-uniform (readlane of the coords),
+//      no barrier is needed to share them.
+//   B. after one barrier, thread (query, b) reads two window rows from LDS
+//      (4 x ds_read_b128 each, conflict-free strides), shifts them by the
+//      window's sub-tile offset and blends the 2r+1 taps of row b; stores run
+//      along the query index (256-B per wave-instruction).
+// The backward is the exact transpose with the same ownership: every window
+// texel is owned by one lane of one workgroup, so dpyr += ... needs no atomics
+// and is bitwise reproducible.
 #include "common.hpp"
 
 namespace {
 
-constexpr int QB = 64;  // queries per workgroup
+constexpr int QB = 64;      // queries (= windows) per workgroup
+constexpr int WROWS = 13;   // window rows kept in LDS: sub-tile offset (<=3) + 2r+2 (<=10)
+constexpr int RS = 20;      // LDS row stride (floats): b128 writes of a tile row block stay conflict-light
+constexpr int WS = WROWS * RS;  // 260 floats per window: 260 mod 64 == 4 -> b128 reads of 16 windows conflict-free
 
 template <int R>
-struct LookupShared {
+struct Geo {
   static constexpr int N1 = 2 * R + 1;
   static constexpr int WIN = 2 * R + 2;
-  static constexpr int WSTRIDE = WIN * WIN + 1;  // odd -> conflict-free per-query stride
-  static constexpr int GSTRIDE = N1 * N1 + ((N1 * N1) % 2 == 0 ? 1 : 0);
-  int x0[QB];
-  int y0[QB];
-  float fx[QB];
-  float fy[QB];
+  static constexpr int NWIN = (QB + N1 - 1) / N1;  // windows per wave
 };
 
-template <int R>
-__device__ __forceinline__ void lookup_origins(const float* __restrict__ coords, int b_img, int Q,
-                                               int q0, int level, int* sx0, int* sy0, float* sfx,
-                                               float* sfy) {
-  const int t = threadIdx.x;
-  if (threadIdx.y == 0) {
-    int q = q0 + t;
-    float cx = 0.f, cy = 0.f;
-    if (q < Q) {
-      cx = coords[((size_t)b_img * 2 + 0) * Q + q];
-      cy = coords[((size_t)b_img * 2 + 1) * Q + q];
-    }
-    // reference: coords / 2**i  (exact power-of-two scaling)
-    const float inv = 1.0f / (float)(1 << level);
-    const float xl = cx * inv, yl = cy * inv;
-    const float flx = floorf(xl), fly = floorf(yl);
-    sfx[t] = xl - flx;
-    sfy[t] = yl - fly;
-    sx0[t] = (int)fminf(fmaxf(flx, -1.0e8f), 1.0e8f) - R;
-    sy0[t] = (int)fminf(fmaxf(fly, -1.0e8f), 1.0e8f) - R;
+struct Origin {
+  int x0, y0;    // window origin (texels, level coordinates)
+  float fx, fy;  // shared bilinear fractions
+};
+
+// reference: coords / 2**i  (exact power-of-two scaling), then floor / fraction
+__device__ __forceinline__ Origin make_origin(float cx, float cy, int level, int R) {
+  const float inv = 1.0f / (float)(1 << level);
+  const float xl = cx * inv, yl = cy * inv;
+  const float flx = floorf(xl), fly = floorf(yl);
+  Origin o;
+  o.fx = xl - flx;
+  o.fy = yl - fly;
+  o.x0 = (int)fminf(fmaxf(flx, -1.0e8f), 1.0e8f) - R;
+  o.y0 = (int)fminf(fmaxf(fly, -1.0e8f), 1.0e8f) - R;
+  return o;
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int srclane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), srclane));
+}
+
+// Element I (compile-time) of a 16-float row held as four float4 -- keeps the row in SSA values so
+// the shift below stays a chain of v_cndmask (an indexable array here ends up in scratch memory).
+template <int I>
+__device__ __forceinline__ float elem16(const float4& a, const float4& b, const float4& c, const float4& d) {
+  constexpr int quad = I >> 2, comp = I & 3;
+  const float4& v = quad == 0 ? a : quad == 1 ? b : quad == 2 ? c : d;
+  return comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
+}
+
+template <int WIN, int C>
+struct ShiftRow {
+  __device__ __forceinline__ static void run(const float4& a, const float4& b, const float4& c, const float4& d,
+                                             bool by2, bool by1, float* t) {
+    // element ox + C of the row, ox = 2*by2 + by1
+    const float e0 = by2 ? elem16<C + 2>(a, b, c, d) : elem16<C>(a, b, c, d);
+    const float e1 = by2 ? elem16<C + 3>(a, b, c, d) : elem16<C + 1>(a, b, c, d);
+    t[C] = by1 ? e1 : e0;
+    ShiftRow<WIN, C + 1>::run(a, b, c, d, by2, by1, t);
   }
+};
+template <int WIN>
+struct ShiftRow<WIN, WIN> {
+  __device__ __forceinline__ static void run(const float4&, const float4&, const float4&, const float4&, bool,
+                                             bool, float*) {}
+};
+
+// t[c] = row[ox + c], c < WIN, ox in 0..3: four aligned ds_read_b128 + selects (no unaligned LDS access)
+template <int WIN>
+__device__ __forceinline__ void shifted_row(const float* row, int ox, float* t) {
+  const float4 a = *reinterpret_cast<const float4*>(row);
+  const float4 b = *reinterpret_cast<const float4*>(row + 4);
+  const float4 c = *reinterpret_cast<const float4*>(row + 8);
+  const float4 d = *reinterpret_cast<const float4*>(row + 12);
+  ShiftRow<WIN, 0>::run(a, b, c, d, (ox & 2) != 0, (ox & 1) != 0, t);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16-B load at (64-bit scalar base) + (32-bit per-lane byte offset).  Inline asm so that the compiler
+// neither predicates it back into a branch nor waits between the back-to-back loads of a wave; the
+// caller drains them with wait_all_loads() before the first use (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ f32x4 load_tile_row(const float* sbase, unsigned voff_bytes) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff_bytes), "s"(sbase) : "memory");
+  return v;
+}
+
+// Pin a wave-uniform pointer into SGPRs (the "s" asm operand above needs it there).
+__device__ __forceinline__ const float* scalar_ptr(const float* p) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_all_loads(f32x4 (&v)[N]) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));  // uses of v[k] stay below the wait
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Per-window scalar bookkeeping shared by forward and backward: which lanes of the 4x4-tile block
+// (lane = (ty, tx, r), row ry = 4*ty + r) hold texels of the window, and where the block starts.
+struct WindowBlock {
+  int tile_off;        // floats from the slab's level start to tile (ty0, tx0); valid lanes only
+  int lo_tx, n_tx;     // needed tile columns: tx - lo_tx < n_tx   (unsigned compare)
+  int lo_ry, n_ry;     // needed rows:         ry - lo_ry < n_ry
+};
+
+template <int WIN>
+__device__ __forceinline__ WindowBlock window_block(int x0, int y0, int tw, int hrows, bool valid) {
+  const int tx0 = x0 >> 2, ty0 = y0 >> 2;
+  WindowBlock w;
+  w.tile_off = (ty0 * tw + tx0) * 16;
+  const int lo_t = max(0, tx0), hi_t = min(tw, ((x0 + WIN - 1) >> 2) + 1);
+  const int lo_y = max(0, y0), hi_y = min(hrows, y0 + WIN);
+  w.lo_tx = lo_t - tx0;
+  w.n_tx = valid ? max(0, hi_t - lo_t) : 0;
+  w.lo_ry = lo_y - ty0 * 4;
+  w.n_ry = valid ? max(0, hi_y - lo_y) : 0;
+  return w;
 }
 
 template <int R>
 __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
     int Q, PyrLayout P) {
-  using S = LookupShared<R>;
-  constexpr int N1 = S::N1, WIN = S::WIN, WS = S::WSTRIDE;
-  __shared__ int s_x0[QB], s_y0[QB];
+  using G = Geo<R>;
+  constexpr int N1 = G::N1, WIN = G::WIN, NWIN = G::NWIN;
+  __shared__ __attribute__((aligned(16))) float s_win[QB * WS];
+  __shared__ int s_ox[QB], s_oy[QB];
   __shared__ float s_fx[QB], s_fy[QB];
-  __shared__ float s_win[QB * WS];
 
-  const int level = blockIdx.y;
-  const int b_img = blockIdx.z;
+  const int level = blockIdx.y, b_img = blockIdx.z;
   const int q0 = blockIdx.x * QB;
-  const int hl = P.h[level], wl = P.w[level], off = P.off[level];
-  const int tid = threadIdx.y * QB + threadIdx.x;
-  constexpr int NT = QB * N1;
+  const int hl = P.h[level], tw = P.tw[level], off = P.off[level];
+  const int th4 = ((hl + 3) >> 2) << 2;  // padded height (pad rows hold zeros)
+  const int lane = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // blockDim.x == 64: one wave per y
 
-  lookup_origins<R>(coords, b_img, Q, q0, level, s_x0, s_y0, s_fx, s_fy);
-  __syncthreads();
-
-  // Phase A: window gather, lanes along (row, col) of the window.
-  const float* base = pyr + (size_t)b_img * Q * P.slab + off;
-  for (int e = tid; e < QB * WIN * WIN; e += NT) {
-    const int ql = e / (WIN * WIN);
-    const int rc = e - ql * (WIN * WIN);
-    const int r = rc / WIN;
-    const int c = rc - r * WIN;
-    const int q = q0 + ql;
-    const int x = s_x0[ql] + c;
-    const int y = s_y0[ql] + r;
-    float v = 0.f;
-    if (q < Q && x >= 0 && x < wl && y >= 0 && y < hl)
-      v = base[(size_t)q * P.slab + (size_t)y * wl + x];
-    s_win[ql * WS + rc] = v;
+  // ---- Phase A: window fetch, one window per wave-instruction -----------------------------
+  // Lane k (< NWIN) does ALL the bookkeeping of this wave's k-th window (j = wv + k*N1) once, in
+  // vector registers; the loop below only broadcasts two packed words per window (v_readlane).
+  int myT = 0, myP = 0;
+  {
+    const int j = wv + lane * N1;
+    if (lane < NWIN && j < QB) {
+      const bool valid = q0 + j < Q;
+      float cx = 0.f, cy = 0.f;
+      if (valid) {
+        cx = coords[((size_t)b_img * 2 + 0) * Q + q0 + j];
+        cy = coords[((size_t)b_img * 2 + 1) * Q + q0 + j];
+      }
+      const Origin o = make_origin(cx, cy, level, R);
+      s_ox[j] = o.x0 & 3;  // offset of the window inside its first tile (floor mod)
+      s_oy[j] = o.y0 & 3;
+      s_fx[j] = o.fx;
+      s_fy[j] = o.fy;
+      const WindowBlock w = window_block<WIN>(o.x0, o.y0, tw, th4, valid);
+      myT = (off + w.tile_off + (valid ? j : 0) * P.slab) * 4;  // bytes from this workgroup's first slab
+      myP = w.lo_tx | (w.n_tx << 4) | (w.lo_ry << 8) | (w.n_ry << 16);
+    }
+  }
+  const int ty = lane >> 4, tx = (lane >> 2) & 3, r = lane & 3;
+  const int ry = ty * 4 + r;                                      // row inside the 16x16 texel block
+  const int lane_goff4 = (((ty * tw + tx) << 4) + (r << 2)) * 4;  // bytes, relative to tile (ty0, tx0)
+  float* lds_row = &s_win[wv * WS + ry * RS + tx * 4];            // window j = wv + k*N1 adds k*N1*WS
+  const float* slab0 = scalar_ptr(pyr + ((size_t)b_img * Q + q0) * P.slab);  // SGPR base of every load below
+  const unsigned zero4 = (unsigned)P.zero * 4u;
+  f32x4 v[NWIN];
+#pragma unroll
+  for (int k = 0; k < NWIN; ++k) {
+    const int sT = __builtin_amdgcn_readlane(myT, k), sP = __builtin_amdgcn_readlane(myP, k);
+    const bool need = (unsigned)(tx - (sP & 15)) < (unsigned)((sP >> 4) & 15) &&
+                      (unsigned)(ry - ((sP >> 8) & 255)) < (unsigned)(sP >> 16);
+    // lanes outside the window read the all-zero tile of slab q0: branch-free, no select afterwards
+    v[k] = load_tile_row(slab0, need ? (unsigned)(sT + lane_goff4) : zero4);
+  }
+  wait_all_loads(v);
+#pragma unroll
+  for (int k = 0; k < NWIN; ++k) {
+    const int j = wv + k * N1;
+    if (j < QB && ry < WROWS) *reinterpret_cast<f32x4*>(lds_row + k * N1 * WS) = v[k];
   }
   __syncthreads();
 
-  // Phase B: thread (query, b) produces the 2r+1 taps a = 0..2r of window row b.
-  const int ql = threadIdx.x, b = threadIdx.y;
-  const int q = q0 + ql;
-  if (q >= Q) return;
-  const float fx = s_fx[ql], fy = s_fy[ql];
+  // ---- Phase B: thread (query, b) blends the 2r+1 taps of window row b ---------------------
+  const int j = lane, b = wv;
+  if (q0 + j >= Q) return;
+  const int ox = s_ox[j], oy = s_oy[j];
+  const float fx = s_fx[j], fy = s_fy[j];
+  const float* row0 = &s_win[j * WS + (oy + b) * RS];
+  float t0[WIN], t1[WIN];
+  shifted_row<WIN>(row0, ox, t0);
+  shifted_row<WIN>(row0 + RS, ox, t1);
   const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
   const float w10 = (1.f - fx) * fy, w11 = fx * fy;
-  float t0[WIN], t1[WIN];
-#pragma unroll
-  for (int c = 0; c < WIN; ++c) {
-    t0[c] = s_win[ql * WS + b * WIN + c];
-    t1[c] = s_win[ql * WS + (b + 1) * WIN + c];
-  }
   const int C = P.L * N1 * N1;
-  float* o = out + ((size_t)b_img * C + (size_t)level * N1 * N1 + b) * Q + q;
+  // scalar output base (b_img, level, b are wave-uniform) + one per-lane offset
+  float* ob = out + ((size_t)b_img * C + (size_t)level * N1 * N1 + b) * Q + q0;
 #pragma unroll
   for (int a = 0; a < N1; ++a) {
-    const float v = t0[a] * w00 + t0[a + 1] * w01 + t1[a] * w10 + t1[a + 1] * w11;
-    o[(size_t)a * N1 * Q] = v;
+    float* oa = ob + (size_t)a * N1 * Q;  // scalar
+    oa[j] = t0[a] * w00 + t0[a + 1] * w01 + t1[a] * w10 + t1[a + 1] * w11;
   }
 }
 
@@ -117,59 +233,92 @@ template <int R>
 __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_bwd_kernel(
     float* __restrict__ dpyr, const float* __restrict__ coords,
     const float* __restrict__ grad_out, int Q, PyrLayout P) {
-  using S = LookupShared<R>;
-  constexpr int N1 = S::N1, WIN = S::WIN, GS = S::GSTRIDE;
-  __shared__ int s_x0[QB], s_y0[QB];
-  __shared__ float s_fx[QB], s_fy[QB];
+  using G = Geo<R>;
+  constexpr int N1 = G::N1, WIN = G::WIN, NWIN = G::NWIN;
+  constexpr int GS = N1 * N1 + ((N1 * N1) % 2 == 0 ? 1 : 0);  // odd stride
   __shared__ float s_g[QB * GS];
 
-  const int level = blockIdx.y;
-  const int b_img = blockIdx.z;
+  const int level = blockIdx.y, b_img = blockIdx.z;
   const int q0 = blockIdx.x * QB;
-  const int hl = P.h[level], wl = P.w[level], off = P.off[level];
-  const int tid = threadIdx.y * QB + threadIdx.x;
-  constexpr int NT = QB * N1;
+  const int hl = P.h[level], wl = P.w[level], tw = P.tw[level], off = P.off[level];
+  const int lane = threadIdx.x, wv = threadIdx.y;
 
-  lookup_origins<R>(coords, b_img, Q, q0, level, s_x0, s_y0, s_fx, s_fy);
-
-  // Phase A': coalesced read of the (2r+1)^2 tap gradients of every query.
+  // ---- Phase A': tap gradients, lanes along the query index (coalesced) --------------------
   {
-    const int ql = threadIdx.x, b = threadIdx.y;
-    const int q = q0 + ql;
+    const int q = q0 + lane;
     const int C = P.L * N1 * N1;
-    const float* g = grad_out + ((size_t)b_img * C + (size_t)level * N1 * N1 + b) * Q + q;
+    const float* g = grad_out + ((size_t)b_img * C + (size_t)level * N1 * N1 + wv) * Q + q;
+    float gv[N1];
 #pragma unroll
-    for (int a = 0; a < N1; ++a) s_g[ql * GS + b * N1 + a] = (q < Q) ? g[(size_t)a * N1 * Q] : 0.f;
+    for (int a = 0; a < N1; ++a) gv[a] = (q < Q) ? g[(size_t)a * N1 * Q] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);  // keep the 2r+1 loads in flight together
+#pragma unroll
+    for (int a = 0; a < N1; ++a) s_g[lane * GS + wv * N1 + a] = gv[a];
+  }
+  float mycx = 0.f, mycy = 0.f;
+  {
+    const int j = wv + lane * N1;
+    if (lane < NWIN && j < QB && q0 + j < Q) {
+      mycx = coords[((size_t)b_img * 2 + 0) * Q + q0 + j];
+      mycy = coords[((size_t)b_img * 2 + 1) * Q + q0 + j];
+    }
   }
   __syncthreads();
 
-  // Phase B': every window texel gathers its <= 4 taps, then owns its RMW.
+  // ---- Phase B': one window per wave-instruction; a lane owns 4 texels of a tile row --------
   float* base = dpyr + (size_t)b_img * Q * P.slab + off;
-  for (int e = tid; e < QB * WIN * WIN; e += NT) {
-    const int ql = e / (WIN * WIN);
-    const int rc = e - ql * (WIN * WIN);
-    const int r = rc / WIN;
-    const int c = rc - r * WIN;
-    const int q = q0 + ql;
-    const int x = s_x0[ql] + c;
-    const int y = s_y0[ql] + r;
-    if (!(q < Q && x >= 0 && x < wl && y >= 0 && y < hl)) continue;
-    const float fx = s_fx[ql], fy = s_fy[ql];
-    const float* g = s_g + ql * GS;
-    float acc = 0.f;
-    // tap (a, b) touches texels (r, c) in {b, b+1} x {a, a+1}
-    if (r < N1) {
-      const float wy = 1.f - fy;
-      if (c < N1) acc += g[r * N1 + c] * ((1.f - fx) * wy);
-      if (c > 0) acc += g[r * N1 + c - 1] * (fx * wy);
+  const int ty = lane >> 4, tx = (lane >> 2) & 3, r = lane & 3;
+  const int ry = ty * 4 + r;
+  float4 v[NWIN];
+  float* ptr[NWIN];
+  Origin org[NWIN];
+#pragma unroll
+  for (int k = 0; k < NWIN; ++k) {
+    const int j = wv + k * N1;
+    org[k] = make_origin(lane_bcast(mycx, k), lane_bcast(mycy, k), level, R);
+    const int tx0 = org[k].x0 >> 2, ty0 = org[k].y0 >> 2;
+    const int gy = ty0 * 4 + ry, gtx = tx0 + tx;
+    const bool need = (j < QB) && (q0 + j < Q) && gtx >= 0 && gtx < tw && gy >= 0 && gy < hl &&
+                      gy >= org[k].y0 && gy < org[k].y0 + WIN && gtx * 4 + 3 >= org[k].x0 &&
+                      gtx * 4 < org[k].x0 + WIN;
+    ptr[k] = need ? base + (size_t)(q0 + j) * P.slab + (((gy >> 2) * tw + gtx) << 4) + ((gy & 3) << 2)
+                  : nullptr;
+    // branch-free load (dummy lanes read this workgroup's first sector) so all NWIN loads are in flight
+    v[k] = *reinterpret_cast<const float4*>(need ? ptr[k] : base + (size_t)q0 * P.slab);
+  }
+  __builtin_amdgcn_sched_barrier(0);  // all read-modify-write loads issued before the gather math
+#pragma unroll
+  for (int k = 0; k < NWIN; ++k) {
+    if (ptr[k] == nullptr) continue;
+    const int j = wv + k * N1;
+    const float fx = org[k].fx, fy = org[k].fy;
+    const float* g = s_g + j * GS;
+    const int tx0 = org[k].x0 >> 2, ty0 = org[k].y0 >> 2;
+    const int rr = ty0 * 4 + ry - org[k].y0;  // window row of this lane's texels, 0..WIN-1
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int gx = (tx0 + tx) * 4 + e;
+      const int cc = gx - org[k].x0;  // window column
+      float s = 0.f;
+      if (cc >= 0 && cc < WIN && gx < wl) {
+        // tap (a, b) touches window texels (row, col) in {b, b+1} x {a, a+1}
+        if (rr < N1) {
+          const float wy = 1.f - fy;
+          if (cc < N1) s += g[rr * N1 + cc] * ((1.f - fx) * wy);
+          if (cc > 0) s += g[rr * N1 + cc - 1] * (fx * wy);
+        }
+        if (rr > 0) {
+          const float wy = fy;
+          if (cc < N1) s += g[(rr - 1) * N1 + cc] * ((1.f - fx) * wy);
+          if (cc > 0) s += g[(rr - 1) * N1 + cc - 1] * (fx * wy);
+        }
+      }
+      acc[e] = s;
     }
-    if (r > 0) {
-      const float wy = fy;
-      if (c < N1) acc += g[(r - 1) * N1 + c] * ((1.f - fx) * wy);
-      if (c > 0) acc += g[(r - 1) * N1 + c - 1] * (fx * wy);
-    }
-    float* p = base + (size_t)q * P.slab + (size_t)y * wl + x;
-    *p += acc;
+    float4 t = v[k];
+    t.x += acc[0]; t.y += acc[1]; t.z += acc[2]; t.w += acc[3];
+    *reinterpret_cast<float4*>(ptr[k]) = t;
   }
 }
 

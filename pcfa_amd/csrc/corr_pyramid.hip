@@ -188,46 +188,65 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
   }
 }
 
-// One workgroup per (b, d) plane: f2ext row = [fmap2 plane | pooled levels | 0 pad].
+// One workgroup per (b, d) plane: f2ext row = the plane and its pooled copies, every level in the
+// 4x4-tiled column order of PyrLayout (so the GEMM writes tiled slabs without knowing about tiles);
+// tile-padding columns are 0.
 __global__ __launch_bounds__(256) void f2ext_fwd_kernel(const float* __restrict__ fmap2,
                                                         float* __restrict__ f2ext, int Q,
                                                         PyrLayout P) {
-  extern __shared__ float s_lv[];  // levels >= 1, indexed by (off - Q)
+  extern __shared__ float s_lv[];  // row-major copies of levels >= 1, packed back to back
   const float* src = fmap2 + (size_t)blockIdx.x * Q;
   float* dst = f2ext + (size_t)blockIdx.x * P.slab;
-  for (int i = threadIdx.x; i < Q; i += blockDim.x) dst[i] = src[i];
+  for (int i = threadIdx.x; i < P.slab; i += blockDim.x) dst[i] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < Q; i += blockDim.x) {
+    const int y = i / P.w[0], x = i - y * P.w[0];
+    dst[pcfa_tiled_index(P, 0, y, x)] = src[i];
+  }
+  int lds_off = 0, prev_off = 0;
   for (int l = 1; l < P.L; ++l) {
     const int hl = P.h[l], wl = P.w[l], wp = P.w[l - 1];
-    const float* prev = (l == 1) ? src : (s_lv + P.off[l - 1] - Q);
-    float* cur = s_lv + P.off[l] - Q;
+    const float* prev = (l == 1) ? src : (s_lv + prev_off);
+    float* cur = s_lv + lds_off;
     for (int i = threadIdx.x; i < hl * wl; i += blockDim.x) {
       const int y = i / wl, x = i - y * wl;
       const float* p = prev + (2 * y) * wp + 2 * x;
       // F.avg_pool2d: sequential sum over the window, then one division
       const float v = (((p[0] + p[1]) + p[wp]) + p[wp + 1]) / 4.0f;
       cur[i] = v;
-      dst[P.off[l] + i] = v;
+      dst[pcfa_tiled_index(P, l, y, x)] = v;
     }
+    prev_off = lds_off;
+    lds_off += hl * wl;
     __syncthreads();
   }
-  int used = P.off[P.L - 1] + P.h[P.L - 1] * P.w[P.L - 1];
-  for (int i = used + threadIdx.x; i < P.slab; i += blockDim.x) dst[i] = 0.f;
 }
 
 // Adjoint of the pooling chain: dfmap2 plane = g_0 + up(g_1)/4 + up(up(g_2)/4)/4 ...
 __global__ __launch_bounds__(256) void f2ext_bwd_kernel(const float* __restrict__ df2ext,
                                                         float* __restrict__ dfmap2, int Q,
                                                         PyrLayout P) {
-  extern __shared__ float s_lv[];
+  extern __shared__ float s_lv[];  // row-major gradients of levels >= 1
   const float* src = df2ext + (size_t)blockIdx.x * P.slab;
   float* dst = dfmap2 + (size_t)blockIdx.x * Q;
-  const int used = P.off[P.L - 1] + P.h[P.L - 1] * P.w[P.L - 1];
-  for (int i = Q + threadIdx.x; i < used; i += blockDim.x) s_lv[i - Q] = src[i];
+  int loff[PCFA_MAX_LEVELS];
+  {
+    int o = 0;
+    for (int l = 1; l < P.L; ++l) {
+      loff[l] = o;
+      o += P.h[l] * P.w[l];
+    }
+  }
+  for (int l = 1; l < P.L; ++l)
+    for (int i = threadIdx.x; i < P.h[l] * P.w[l]; i += blockDim.x) {
+      const int y = i / P.w[l], x = i - y * P.w[l];
+      s_lv[loff[l] + i] = src[pcfa_tiled_index(P, l, y, x)];
+    }
   __syncthreads();
   for (int l = P.L - 1; l >= 2; --l) {
     const int hl = P.h[l], wl = P.w[l], wp = P.w[l - 1];
-    const float* g = s_lv + P.off[l] - Q;
-    float* gp = s_lv + P.off[l - 1] - Q;
+    const float* g = s_lv + loff[l];
+    float* gp = s_lv + loff[l - 1];
     for (int i = threadIdx.x; i < 4 * hl * wl; i += blockDim.x) {
       const int y = i / (2 * wl), x = i - y * (2 * wl);
       gp[y * wp + x] += g[(y >> 1) * wl + (x >> 1)] / 4.0f;
@@ -236,14 +255,18 @@ __global__ __launch_bounds__(256) void f2ext_bwd_kernel(const float* __restrict_
   }
   const int W0 = P.w[0];
   for (int i = threadIdx.x; i < Q; i += blockDim.x) {
-    float v = src[i];
-    if (P.L > 1) {
-      const int y = i / W0, x = i - y * W0;
-      if ((y >> 1) < P.h[1] && (x >> 1) < P.w[1])
-        v += s_lv[P.off[1] - Q + (y >> 1) * P.w[1] + (x >> 1)] / 4.0f;
-    }
+    const int y = i / W0, x = i - y * W0;
+    float v = src[pcfa_tiled_index(P, 0, y, x)];
+    if (P.L > 1 && (y >> 1) < P.h[1] && (x >> 1) < P.w[1])
+      v += s_lv[loff[1] + (y >> 1) * P.w[1] + (x >> 1)] / 4.0f;
     dst[i] = v;
   }
+}
+
+size_t pooled_lds_bytes(const PyrLayout& P) {
+  size_t n = 4;
+  for (int l = 1; l < P.L; ++l) n += (size_t)P.h[l] * P.w[l];
+  return n * sizeof(float);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -272,6 +295,14 @@ extern "C" long long pcfa_corr_level_offset(int H, int W, int num_levels, int le
   return P.off[level];
 }
 
+extern "C" long long pcfa_corr_tiled_index(int H, int W, int num_levels, int level, int y, int x) {
+  PyrLayout P;
+  if (!pcfa_make_layout(P, H, W, num_levels) || level < 0 || level >= num_levels || y < 0 ||
+      x < 0 || y >= P.h[level] || x >= P.w[level])
+    return -1;
+  return pcfa_tiled_index(P, level, y, x);
+}
+
 extern "C" int pcfa_corr_f2ext_fwd(const float* fmap2, float* f2ext, int B, int D, int H, int W,
                                    int num_levels, void* stream) {
   PyrLayout P;
@@ -280,7 +311,7 @@ extern "C" int pcfa_corr_f2ext_fwd(const float* fmap2, float* f2ext, int B, int 
   for (int l = 0; l < P.L; ++l)
     if (P.h[l] < 1 || P.w[l] < 1) return PCFA_ERR_INVALID_ARG;
   const int Q = H * W;
-  const size_t lds = (size_t)(P.slab - Q + 4) * sizeof(float);
+  const size_t lds = pooled_lds_bytes(P);
   if (lds > 64 * 1024) return PCFA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(f2ext_fwd_kernel, dim3(B * D), dim3(256), lds, (hipStream_t)stream, fmap2,
                      f2ext, Q, P);
@@ -295,7 +326,7 @@ extern "C" int pcfa_corr_pyramid_fwd(const float* fmap1, const float* f2ext, flo
     return PCFA_ERR_INVALID_ARG;
   const int Q = H * W, S = P.slab;
   const int vecA = (Q % 4 == 0) && aligned16(fmap1);
-  const int vecB = aligned16(f2ext);  // slab % 4 == 0 by construction
+  const int vecB = aligned16(f2ext);  // slab % 16 == 0 by construction
   dim3 grid(pcfa_cdiv(S, BN), pcfa_cdiv(Q, BM), B);
   hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0,
                      (hipStream_t)stream, fmap1, f2ext, pyr, Q, S, D, (long long)Q,
@@ -366,7 +397,7 @@ extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, cons
   }
   // (c) adjoint of the pooling chain
   {
-    const size_t lds = (size_t)(P.slab - Q + 4) * sizeof(float);
+    const size_t lds = pooled_lds_bytes(P);
     if (lds > 64 * 1024) return PCFA_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(f2ext_bwd_kernel, dim3(B * D), dim3(256), lds, s, df2ext, dfmap2, Q, P);
     PCFA_LAUNCH_CHECK();

@@ -189,15 +189,23 @@ class CorrBlock:
 
     @property
     def corr_pyramid(self):
-        """Per-level views [B*Q,1,H_l,W_l] of the slab matrix (for inspection/tests)."""
-        lib = _hip.load()
+        """Per-level tensors [B*Q,1,H_l,W_l] gathered out of the tiled slab matrix (for inspection/tests)."""
         st = self._state
-        out = []
-        for l in range(st.L):
-            h, w = ctypes.c_int(), ctypes.c_int()
-            off = lib.pcfa_corr_level_offset(st.H, st.W, st.L, l, ctypes.byref(h), ctypes.byref(w))
-            out.append(st.pyr[:, off:off + h.value * w.value].reshape(-1, 1, h.value, w.value))
-        return out
+        return [st.pyr[:, idx.to(st.pyr.device)].reshape(-1, 1, h, w)
+                for (idx, h, w) in tiled_index_maps(st.H, st.W, st.L)]
+
+
+def tiled_index_maps(H, W, num_levels):
+    """[(index tensor [H_l*W_l] into a query slab, H_l, W_l)] -- the 4x4-tile layout of include/pcfa_hip.h."""
+    out, off, h, w = [], 0, H, W
+    for _ in range(num_levels):
+        tw = (w + 3) // 4
+        ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        idx = off + ((ys // 4) * tw + xs // 4) * 16 + (ys % 4) * 4 + xs % 4
+        out.append((idx.reshape(-1), h, w))
+        off += ((h + 3) // 4) * tw * 16
+        h, w = h // 2, w // 2
+    return out
 
 
 # --------------------------------------------------------------------------- #

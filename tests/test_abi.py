@@ -37,11 +37,19 @@ def test_host_only_entry_points():
     import ctypes
     from pcfa_amd import _hip
     lib = _hip.load()
-    assert lib.pcfa_corr_slab_floats(55, 128, 4) == 9280          # 7040+1728+416+96
+    # 4x4-tiled levels padded to whole tiles: 56x128 + 28x64 + 16x32 + 8x16
+    assert lib.pcfa_corr_slab_floats(55, 128, 4) == 7168 + 1792 + 512 + 128 + 16   # + one zero tile
     h, w = ctypes.c_int(), ctypes.c_int()
-    assert lib.pcfa_corr_level_offset(55, 128, 4, 2, ctypes.byref(h), ctypes.byref(w)) == 7040 + 1728
+    assert lib.pcfa_corr_level_offset(55, 128, 4, 2, ctypes.byref(h), ctypes.byref(w)) == 7168 + 1792
     assert (h.value, w.value) == (13, 32)
-    assert lib.pcfa_corr_slab_floats(17, 21, 4) % 4 == 0
+    assert lib.pcfa_corr_slab_floats(17, 21, 4) % 16 == 0
+    assert lib.pcfa_corr_tiled_index(55, 128, 4, 0, 0, 0) == 0
+    assert lib.pcfa_corr_tiled_index(55, 128, 4, 0, 5, 6) == ((1 * 32 + 1) * 16 + 1 * 4 + 2)
+    assert lib.pcfa_corr_tiled_index(55, 128, 4, 0, 55, 0) == -1
+    from pcfa_amd import hip_ops
+    for l, (idx, hl, wl) in enumerate(hip_ops.tiled_index_maps(17, 21, 4)):
+        assert int(idx[-1]) == lib.pcfa_corr_tiled_index(17, 21, 4, l, hl - 1, wl - 1)
+        assert int(idx[wl + 1]) == lib.pcfa_corr_tiled_index(17, 21, 4, l, 1, 1)
     oh, ow = ctypes.c_int(), ctypes.c_int()
     assert lib.pcfa_spatial_corr_out_size(11, 9, 3, 3, 1, 1, 1, 1, 2, 2, ctypes.byref(oh), ctypes.byref(ow)) == 0
     assert (oh.value, ow.value) == (6, 5)

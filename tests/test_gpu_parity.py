@@ -87,9 +87,8 @@ def test_lookup_given_same_pyramid_is_tight(oracle_ops):
     pyr_levels = oracle_ops.corr_pyramid(f1, f2, 4)
     slab = lib.pcfa_corr_slab_floats(H, W, 4)
     pyr = torch.zeros(B * H * W, slab)
-    for l, lv in enumerate(pyr_levels):
-        off = lib.pcfa_corr_level_offset(H, W, 4, l, None, None)
-        pyr[:, off:off + lv[0, 0].numel()] = lv.reshape(B * H * W, -1)
+    for (idx, h_l, w_l), lv in zip(hip_ops.tiled_index_maps(H, W, 4), pyr_levels):
+        pyr[:, idx] = lv.reshape(B * H * W, -1)
     pyr = pyr.to(DEV)
     for spread in (0.0, 1.7, 25.0):
         coords = _grid(B, H, W) + spread * torch.randn(B, 2, H, W, generator=gen)

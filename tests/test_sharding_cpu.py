@@ -1,0 +1,152 @@
+"""Multi-GPU paths on CPU: world_size-2 `gloo` process groups (one process per "GPU").
+
+  * per-pair attacks shard round-robin over ranks with no data-path collective; rank 0 gathers the result rows
+    and must report exactly what a single process reports for the same pairs;
+  * the universal attack is data parallel over the batch with one all-reduce of d(loss)/d(delta) per closure and
+    must reproduce the single-process run on the global batch (the reference's formulation,
+    attack_PCFA.py:469-490) up to fp32 reduction-order noise.
+The oracle operators are injected (no GPU here)."""
+import json
+import os
+import socket
+import sys
+import tempfile
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(**kw):
+    base = dict(net="SpyNet", weights="random:1234", dataset="Synthetic", dataset_stage="evaluation", small_run=False,
+                synthetic_size="64x64", synthetic_pairs=4, dstype="final", output_folder="experiment_data",
+                small_save=False, save_frequency=1, no_save=True, unregistered_artifacts=True,
+                joint_perturbation=False, steps=1, universal_perturbation=False, boxconstraint="change_of_variables",
+                batch_size=2, delta_bound=0.005, mu=-1, epochs=1, target="zero", custom_target_path="", loss="aee")
+    base.update(kw)
+    return Namespace(**base)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, kwargs, outdir):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), PCFA_USE_CPU="1")
+    torch.set_num_threads(2)
+    from oracle import ops as oracle_ops
+    from pcfa_amd import attack_PCFA, ops, sharding
+    if world > 1:
+        assert sharding.init_from_env("gloo")
+    with ops.override_for_testing(oracle_ops):
+        if mode == "pairs":
+            res = attack_PCFA.attack_l2(_args(**kwargs))
+            if rank == 0:
+                json.dump(res, open(os.path.join(outdir, "pairs_w%d.json" % world), "w"))
+            else:
+                assert res is None
+        elif mode == "closure":
+            # one universal-attack closure at a fixed, non-zero delta (attack_PCFA.py:469-490)
+            from pcfa_amd.helper_functions import datasets, losses, ownutilities
+            a = _args(universal_perturbation=True, boxconstraint="clipping", **kwargs)
+            dev = torch.device("cpu")
+            model = attack_PCFA._load_model(a, dev, variable_change=False)
+            pairs = [datasets.synthetic_pair(i, 64, 64) for i in range(2)]
+            mine = pairs if world == 1 else pairs[rank:rank + 1]
+            im1 = torch.stack([p[0] for p in mine]) / 255.
+            im2 = torch.stack([p[1] for p in mine]) / 255.
+            padder, [im1, im2] = ownutilities.preprocess_img("SpyNet", im1 * 255., im2 * 255.)
+            g = torch.Generator().manual_seed(0)
+            d1 = (0.02 * torch.randn(im1.shape[1:], generator=g)).requires_grad_(True)
+            d2 = (0.02 * torch.randn(im1.shape[1:], generator=g)).requires_grad_(True)
+            flow = ownutilities.compute_flow(model, "scaled_input_model", im1, im2, test_mode=True, delta1=d1,
+                                             delta2=d2)
+            [flow] = ownutilities.postprocess_flow("SpyNet", padder, flow)
+            loss = losses.loss_delta_constraint(flow, torch.zeros_like(flow), d1, d2, dev, delta_bound=0.005,
+                                                mu=5e5, f_type="aee")
+            loss.backward()
+            red = sharding.allreduce_closure([d1, d2], loss)
+            np.save(os.path.join(outdir, "clos_w%d_r%d.npy" % (world, rank)),
+                    np.concatenate([d1.grad.numpy().ravel(), d2.grad.numpy().ravel(), [float(red)]]))
+        else:
+            res = attack_PCFA.attack_l2_universal(_args(universal_perturbation=True, boxconstraint="clipping",
+                                                        **kwargs))
+            np.save(os.path.join(outdir, "univ_w%d_r%d.npy" % (world, rank)),
+                    torch.stack([res["delta1"], res["delta2"]]).numpy())
+    sharding.shutdown()
+
+
+def _run(world, mode, kwargs, outdir):
+    port = _free_port()
+    if world == 1:
+        _worker(0, 1, port, mode, kwargs, outdir)
+    else:
+        mp.spawn(_worker, args=(world, port, mode, kwargs, outdir), nprocs=world, join=True)
+
+
+@pytest.fixture(autouse=True)
+def _clean_env():
+    keep = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                            "PCFA_USE_CPU")}
+    yield
+    for k, v in keep.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def test_pair_sharding_two_ranks_equals_single_process():
+    with tempfile.TemporaryDirectory() as d:
+        _run(2, "pairs", dict(synthetic_pairs=3), d)     # ragged: rank 0 gets pairs 0,2 ; rank 1 gets pair 1
+        _run(1, "pairs", dict(synthetic_pairs=3), d)
+        two = json.load(open(os.path.join(d, "pairs_w2.json")))
+        one = json.load(open(os.path.join(d, "pairs_w1.json")))
+    assert two["pairs"] == one["pairs"] == 3
+    for k, v in one.items():
+        if isinstance(v, float) and not np.isnan(v):
+            assert abs(two[k] - v) <= 1e-9 + 1e-7 * abs(v), k
+
+
+def test_universal_allreduce_equals_single_process_global_batch():
+    with tempfile.TemporaryDirectory() as d:
+        _run(2, "universal", dict(synthetic_pairs=2, batch_size=2), d)
+        _run(1, "universal", dict(synthetic_pairs=2, batch_size=2), d)
+        r0 = np.load(os.path.join(d, "univ_w2_r0.npy"))
+        r1 = np.load(os.path.join(d, "univ_w2_r1.npy"))
+        single = np.load(os.path.join(d, "univ_w1_r0.npy"))
+    assert np.array_equal(r0, r1), "replicas of delta diverged across ranks"
+    assert np.abs(single).max() > 0
+    # 10 L-BFGS iterations on a stiff penalty amplify summation-order noise: loose here,
+    # tight at the closure level below
+    rel = np.linalg.norm(r0 - single) / np.linalg.norm(single)
+    assert rel < 1e-2, rel
+
+
+def test_universal_closure_allreduce_is_exact_to_rounding():
+    with tempfile.TemporaryDirectory() as d:
+        _run(2, "closure", {}, d)
+        _run(1, "closure", {}, d)
+        r0 = np.load(os.path.join(d, "clos_w2_r0.npy"))
+        r1 = np.load(os.path.join(d, "clos_w2_r1.npy"))
+        single = np.load(os.path.join(d, "clos_w1_r0.npy"))
+    assert np.array_equal(r0, r1)
+    assert abs(r0[-1] - single[-1]) <= 1e-6 * abs(single[-1])             # averaged loss
+    assert np.linalg.norm(r0[:-1] - single[:-1]) <= 1e-5 * np.linalg.norm(single[:-1])  # averaged gradient
+
+
+def test_universal_rejects_indivisible_batch_and_cosim():
+    from pcfa_amd import sharding
+    assert sharding.world_size() == 1 and sharding.rank() == 0
+    assert sharding.gather_rows([(1.0, 2.0)], 2, torch.device("cpu")) == [(1.0, 2.0)]
+    assert sharding.mean_scalar(3.0, torch.device("cpu")) == 3.0

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Condense a rocprofv3 `*_kernel_stats.csv` into a short text table (kernel names truncated) that is
+small enough to commit under profiles/.  Usage: summarize_rocprof.py <kernel_stats.csv> [top_n] > out.txt"""
+import csv
+import sys
+
+OURS = ("corr_lookup", "gemm_f32_mfma", "f2ext", "splitk_reduce", "scorr_", "loss_", "box_", "deltas_")
+
+
+def main():
+    path = sys.argv[1]
+    top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    print("# source: %s" % path)
+    print("# kernels: %d   total device time: %.3f ms" % (len(rows), tot / 1e6))
+    fmt = "%-72s %8s %12s %12s %12s %12s %7s"
+    print(fmt % ("name", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct"))
+
+    def line(r):
+        return fmt % (r["Name"][:72], r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6),
+                      "%.2f" % (float(r["AverageNs"]) / 1e3), "%.2f" % (float(r["MinNs"]) / 1e3),
+                      "%.2f" % (float(r["MaxNs"]) / 1e3), "%.2f" % float(r["Percentage"]))
+
+    print("## top %d by total time" % top)
+    for r in rows[:top]:
+        print(line(r))
+    print("## pcfa_amd HIP kernels (libpcfa_hip.so)")
+    ours = [r for r in rows if any(k in r["Name"] for k in OURS)]
+    for r in ours:
+        print(line(r))
+    print("# pcfa_amd kernels: %.3f ms = %.2f%% of device time" %
+          (sum(float(r["TotalDurationNs"]) for r in ours) / 1e6,
+           100 * sum(float(r["TotalDurationNs"]) for r in ours) / max(tot, 1)))
+
+
+if __name__ == "__main__":
+    main()
