@@ -138,10 +138,13 @@ __device__ __forceinline__ WindowBlock window_block(int x0, int y0, int tw, int 
   w.tile_off = (ty0 * tw + tx0) * 16;
   const int lo_t = max(0, tx0), hi_t = min(tw, ((x0 + WIN - 1) >> 2) + 1);
   const int lo_y = max(0, y0), hi_y = min(hrows, y0 + WIN);
-  w.lo_tx = lo_t - tx0;
-  w.n_tx = valid ? max(0, hi_t - lo_t) : 0;
-  w.lo_ry = lo_y - ty0 * 4;
-  w.n_ry = valid ? max(0, hi_y - lo_y) : 0;
+  const bool hit = valid && hi_t > lo_t && hi_y > lo_y;  // window intersects the level at all
+  // (far-away / NaN coordinates: keep every field inside its packed bit range)
+  w.lo_tx = hit ? lo_t - tx0 : 0;      // 0..3
+  w.n_tx = hit ? hi_t - lo_t : 0;      // 0..4
+  w.lo_ry = hit ? lo_y - ty0 * 4 : 0;  // 0..12
+  w.n_ry = hit ? hi_y - lo_y : 0;      // 0..WIN
+  if (!hit) w.tile_off = 0;
   return w;
 }
 
@@ -157,10 +160,16 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
 
   const int level = blockIdx.y, b_img = blockIdx.z;
   const int q0 = blockIdx.x * QB;
-  const int hl = P.h[level], tw = P.tw[level], off = P.off[level];
+  // wave-uniform layout fields, pinned to SGPRs before any divergent branch
+  const int hl = __builtin_amdgcn_readfirstlane(P.h[level]);
+  const int tw = __builtin_amdgcn_readfirstlane(P.tw[level]);
+  const int off = __builtin_amdgcn_readfirstlane(P.off[level]);
+  const int slab = __builtin_amdgcn_readfirstlane(P.slab);
+  const unsigned zero4 = (unsigned)__builtin_amdgcn_readfirstlane(P.zero) * 4u;
   const int th4 = ((hl + 3) >> 2) << 2;  // padded height (pad rows hold zeros)
   const int lane = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // blockDim.x == 64: one wave per y
+  const float* slab0 = scalar_ptr(pyr + ((size_t)b_img * Q + q0) * slab);  // SGPR base of every window load
 
   // ---- Phase A: window fetch, one window per wave-instruction -----------------------------
   // Lane k (< NWIN) does ALL the bookkeeping of this wave's k-th window (j = wv + k*N1) once, in
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
       s_fx[j] = o.fx;
       s_fy[j] = o.fy;
       const WindowBlock w = window_block<WIN>(o.x0, o.y0, tw, th4, valid);
-      myT = (off + w.tile_off + (valid ? j : 0) * P.slab) * 4;  // bytes from this workgroup's first slab
+      myT = (off + w.tile_off + (valid ? j : 0) * slab) * 4;  // bytes from this workgroup's first slab
       myP = w.lo_tx | (w.n_tx << 4) | (w.lo_ry << 8) | (w.n_ry << 16);
     }
   }
@@ -189,8 +198,6 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
   const int ry = ty * 4 + r;                                      // row inside the 16x16 texel block
   const int lane_goff4 = (((ty * tw + tx) << 4) + (r << 2)) * 4;  // bytes, relative to tile (ty0, tx0)
   float* lds_row = &s_win[wv * WS + ry * RS + tx * 4];            // window j = wv + k*N1 adds k*N1*WS
-  const float* slab0 = scalar_ptr(pyr + ((size_t)b_img * Q + q0) * P.slab);  // SGPR base of every load below
-  const unsigned zero4 = (unsigned)P.zero * 4u;
   f32x4 v[NWIN];
 #pragma unroll
   for (int k = 0; k < NWIN; ++k) {
@@ -220,13 +227,10 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
   const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
   const float w10 = (1.f - fx) * fy, w11 = fx * fy;
   const int C = P.L * N1 * N1;
-  // scalar output base (b_img, level, b are wave-uniform) + one per-lane offset
-  float* ob = out + ((size_t)b_img * C + (size_t)level * N1 * N1 + b) * Q + q0;
+  float* o = out + ((size_t)b_img * C + (size_t)level * N1 * N1 + b) * Q + q0 + j;
 #pragma unroll
-  for (int a = 0; a < N1; ++a) {
-    float* oa = ob + (size_t)a * N1 * Q;  // scalar
-    oa[j] = t0[a] * w00 + t0[a + 1] * w01 + t1[a] * w10 + t1[a + 1] * w11;
-  }
+  for (int a = 0; a < N1; ++a)
+    o[(size_t)a * N1 * Q] = t0[a] * w00 + t0[a + 1] * w01 + t1[a] * w10 + t1[a + 1] * w11;
 }
 
 template <int R>
