@@ -41,7 +41,12 @@ def parse():
     ap.add_argument("--net", default="RAFT", choices=["RAFT", "GMA", "PWCNet", "SpyNet"])
     ap.add_argument("--size", default="436x1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-closures", type=int, default=2, help="closure evaluations in the CPU sample")
+    ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC convolutions")
+    ap.add_argument("--no-miopen-find", action="store_true", help="experiment: cudnn.benchmark = False")
+    ap.add_argument("--cpu-closures", type=int, default=8, help="closure evaluations in the CPU sample")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="host threads of the CPU baseline (0 = min(cores, 16): the 55x128-feature convolutions "
+                         "stop scaling there; 64 threads measured 3x SLOWER than 16 on the 256-core box)")
     return ap.parse_args()
 
 
@@ -108,6 +113,28 @@ class AttackStepper:
         return aee_tgt, aee_init, l2[2]
 
 
+def event_overhead_us(reps=200):
+    """Mean HIP-event interval around an EMPTY kernel launched the same way (C-ABI, same stream): the fixed
+    cost the event bracket adds to every per-launch figure below (reported, not subtracted)."""
+    from pcfa_amd import hip_ops
+    prof = hip_ops.LaunchProfiler(names=["pcfa_null_launch"])
+    hip_ops.set_launch_profiler(prof)
+    for _ in range(reps):
+        hip_ops._call("pcfa_null_launch")
+    hip_ops.set_launch_profiler(None)
+    return prof.summary()["pcfa_null_launch"][0]
+
+
+def lookup_traffic():
+    """HBM bytes per launch of the lookup kernel from rocprofv3 PMC counters (collected offline by
+    tools/pmc_traffic.sh with the guide's gfx950 corrections, committed under profiles/); None if absent."""
+    path = os.path.join(REPO, "profiles", "lookup_traffic.json")
+    try:
+        return json.load(open(path))["corr_lookup_fwd"]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def lookup_algorithmic_bytes(hf, wf, levels=4, radius=4):
     """unique texels (Q * levels * (2r+2)^2 * 4 B) + coords + output."""
     q = hf * wf
@@ -115,11 +142,11 @@ def lookup_algorithmic_bytes(hf, wf, levels=4, radius=4):
     return q * levels * (2 * radius + 2) ** 2 * 4 + q * 2 * 4 + q * levels * n1 * n1 * 4
 
 
-def cpu_baseline(net, h, w, nclosures):
+def cpu_baseline(net, h, w, nclosures, threads=0):
     """Time the CPU port (pcfa_amd host code + oracle operators) on a bounded sample of the workload."""
     from oracle import ops as oracle_ops
     from pcfa_amd import ops
-    cores = os.cpu_count() or 1
+    cores = threads if threads > 0 else min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     with ops.override_for_testing(oracle_ops):
         st = AttackStepper(net, h, w, torch.device("cpu"), seed=0)
@@ -132,10 +159,10 @@ def cpu_baseline(net, h, w, nclosures):
             t0 = time.perf_counter()
             st.closure()
             times.append(time.perf_counter() - t0)
-    t_c = min(times)
+    t_c = sum(times[1:]) / max(len(times) - 1, 1) if len(times) > 1 else times[0]  # first one warms up
     step_s = 10 * t_c + t_fwd
-    return {"value": 1.0 / step_s, "unit": "attack_steps_per_sec", "cores": cores, "kind": "port",
-            "closure_s": t_c, "forward_s": t_fwd,
+    return {"value": 1.0 / step_s, "unit": "attack_steps/s", "cores": cores, "kind": "port",
+            "host_cores_available": os.cpu_count(), "closure_s": t_c, "forward_s": t_fwd,
             "sample": "%d closure evals + 1 forward of %s %dx%d on %d host threads, extrapolated to the "
                       "10 closures + 1 forward of one step" % (nclosures, net, h, w, cores)}
 
@@ -152,10 +179,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     dev = torch.device("cuda", sharding.local_rank() if world > 1 else 0)
     torch.cuda.set_device(dev)
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = not a.no_miopen_find
     h, w = (int(v) for v in a.size.lower().split("x"))
 
     st = AttackStepper(a.net, h, w, dev, seed=rank)
+    if a.channels_last:
+        st.model = st.model.to(memory_format=torch.channels_last)
     from pcfa_amd import hip_ops
     corr_net = a.net in ("RAFT", "GMA")
     # HIP events around every launch of the named kernel, on the stream it is launched on
@@ -196,11 +225,13 @@ def main():
             us, n = prof.summary()["pcfa_corr_lookup_fwd"]
             nbytes = lookup_algorithmic_bytes(hp // 8, wp // 8)
             ach = nbytes / (us * 1e-6) / 1e9
+            ev = event_overhead_us()
             out["roofline"] = {"kernel": "corr_lookup_fwd_kernel<4>", "bound": "hbm", "achieved": ach,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "event_bracket_overhead_us": ev,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": lookup_traffic(),
                                "bytes_per_launch": nbytes, "mean_launch_us": us, "launches_timed": n}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.net, h, w, a.cpu_closures)
+            out["cpu_baseline"] = cpu_baseline(a.net, h, w, a.cpu_closures, a.cpu_threads)
         print(json.dumps(out))
     sharding.shutdown()
     return out

@@ -47,6 +47,9 @@ extern "C" {
 #define PCFA_BOX_CHANGE_OF_VARIABLES 1
 
 PCFA_API int pcfa_abi_version(void);
+/* Launches an empty kernel on `stream`: lets a caller calibrate the fixed cost of bracketing one launch with
+ * HIP events (bench.py reports it next to the per-launch timings). */
+PCFA_API int pcfa_null_launch(void* stream);
 /* Human-readable text for a return code (static storage). */
 PCFA_API const char* pcfa_status_string(int status);
 

@@ -24,6 +24,7 @@ _S4 = POINTER(c_longlong)  # long long[4]
 # name -> (restype, argtypes); kept in lock-step with include/pcfa_hip.h
 SIGNATURES = {
     "pcfa_abi_version": (c_int, []),
+    "pcfa_null_launch": (c_int, [_P]),
     "pcfa_status_string": (c_char_p, [c_int]),
     "pcfa_corr_slab_floats": (c_longlong, [c_int, c_int, c_int]),
     "pcfa_corr_level_offset": (c_longlong, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),

@@ -307,9 +307,17 @@ inline int ew_blocks(long long n) {
 
 inline View4 mkview(const long long s[4]) { return View4{s[0], s[1], s[2], s[3]}; }
 
+__global__ void null_kernel() {}
+
 }  // namespace
 
 extern "C" int pcfa_abi_version(void) { return PCFA_ABI_VERSION; }
+
+extern "C" int pcfa_null_launch(void* stream) {
+  hipLaunchKernelGGL(null_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
 
 extern "C" const char* pcfa_status_string(int status) {
   switch (status) {

@@ -119,7 +119,9 @@ __global__ __launch_bounds__(TH* TW) void scorr_bwd_fast_kernel(
   constexpr int S2 = HW2 + 1;
   __shared__ float sx[CC][HH2][S2];
 
-  const int b = blockIdx.z;
+  const int ngroups = (C + CC - 1) / CC;
+  const int b = blockIdx.z / ngroups;
+  const int c0 = (blockIdx.z - b * ngroups) * CC;
   const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
   const int lx = threadIdx.x, ly = threadIdx.y;
   const int tid = lx + TW * ly;
@@ -147,9 +149,11 @@ __global__ __launch_bounds__(TH* TW) void scorr_bwd_fast_kernel(
       G[i][j] = v;
     }
 
+  // The channels are independent in both gradients, so blockIdx.z also splits them: a workgroup stages
+  // ONE chunk of CC channels (no serial channel loop -- the small pyramid levels have only 1-4 pixel tiles).
   const float* px = X + (size_t)b * C * plane;
   float* po = gin + (size_t)b * C * plane;
-  for (int c0 = 0; c0 < C; c0 += CC) {
+  {
     for (int e = tid; e < CC * HH2 * HW2; e += NT) {
       const int c = e / (HH2 * HW2), r = (e / HW2) % HH2, x = e % HW2;
       const int yy = y0 + r - R, xx = x0 + x - R;
@@ -173,7 +177,6 @@ __global__ __launch_bounds__(TH* TW) void scorr_bwd_fast_kernel(
         }
       if (inside) po[(size_t)(c0 + c) * plane + (size_t)gy * W + gx] = s;
     }
-    __syncthreads();
   }
 }
 
@@ -330,7 +333,7 @@ extern "C" int pcfa_spatial_corr_bwd(const float* in1, const float* in2, const f
     return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (is_fast(p, 9)) {
-    dim3 grid(pcfa_cdiv(iW, TW), pcfa_cdiv(iH, TH), B), block(TW, TH, 1);
+    dim3 grid(pcfa_cdiv(iW, TW), pcfa_cdiv(iH, TH), B * pcfa_cdiv(C, CC)), block(TW, TH, 1);
     hipLaunchKernelGGL((scorr_bwd_fast_kernel<9, +1>), grid, block, 0, s, in2, grad_out, grad_in1,
                        C, iH, iW);
     PCFA_LAUNCH_CHECK();
