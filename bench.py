@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--size", default="436x1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC convolutions")
-    ap.add_argument("--no-miopen-find", action="store_true", help="experiment: cudnn.benchmark = False")
+    ap.add_argument("--miopen-find", action="store_true",
+                    help="cudnn.benchmark = True (MIOpen exhaustive find; measured equal to the default "
+                         "immediate mode on this workload, but costs ~60 s of warm-up)")
     ap.add_argument("--cpu-closures", type=int, default=8, help="closure evaluations in the CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="host threads of the CPU baseline (0 = min(cores, 16): the 55x128-feature convolutions "
@@ -114,8 +116,9 @@ class AttackStepper:
 
 
 def event_overhead_us(reps=200):
-    """Mean HIP-event interval around an EMPTY kernel launched the same way (C-ABI, same stream): the fixed
-    cost the event bracket adds to every per-launch figure below (reported, not subtracted)."""
+    """Mean interval of an event BRACKET (record, launch, record) around an empty kernel: what per-launch
+    figures would carry if they were taken with bracketing events instead of dispatch-attached ones
+    (informational; nothing is subtracted anywhere)."""
     from pcfa_amd import hip_ops
     prof = hip_ops.LaunchProfiler(names=["pcfa_null_launch"])
     hip_ops.set_launch_profiler(prof)
@@ -179,7 +182,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     dev = torch.device("cuda", sharding.local_rank() if world > 1 else 0)
     torch.cuda.set_device(dev)
-    torch.backends.cudnn.benchmark = not a.no_miopen_find
+    torch.backends.cudnn.benchmark = a.miopen_find
     h, w = (int(v) for v in a.size.lower().split("x"))
 
     st = AttackStepper(a.net, h, w, dev, seed=rank)
@@ -187,13 +190,13 @@ def main():
         st.model = st.model.to(memory_format=torch.channels_last)
     from pcfa_amd import hip_ops
     corr_net = a.net in ("RAFT", "GMA")
-    # HIP events around every launch of the named kernel, on the stream it is launched on
-    prof = hip_ops.LaunchProfiler(names=["pcfa_corr_lookup_fwd"]) if corr_net else None
+    # HIP events attached to every dispatch of the named kernel (on the stream it is launched on)
+    prof = hip_ops.DispatchTimer() if corr_net else None
     for _ in range(a.warmup):
         st.step()
     torch.cuda.synchronize()
     sharding.barrier()
-    hip_ops.set_launch_profiler(prof)
+    hip_ops.set_dispatch_timer(prof)
     c0 = st.closures
     t0 = time.perf_counter()
     last = None
@@ -202,7 +205,7 @@ def main():
     torch.cuda.synchronize()
     sharding.barrier()
     elapsed = time.perf_counter() - t0
-    hip_ops.set_launch_profiler(None)
+    hip_ops.set_dispatch_timer(None)
     elapsed = sharding.max_scalar(elapsed, dev)
     closures = st.closures - c0
 
@@ -225,9 +228,10 @@ def main():
             us, n = prof.summary()["pcfa_corr_lookup_fwd"]
             nbytes = lookup_algorithmic_bytes(hp // 8, wp // 8)
             ach = nbytes / (us * 1e-6) / 1e9
-            ev = event_overhead_us()
             out["roofline"] = {"kernel": "corr_lookup_fwd_kernel<4>", "bound": "hbm", "achieved": ach,
-                               "event_bracket_overhead_us": ev,
+                               "timing": "hipEvents on the dispatch packet (hipExtLaunchKernel), every launch "
+                                         "of the timed steps",
+                               "event_bracket_overhead_us": event_overhead_us(),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": lookup_traffic(),
                                "bytes_per_launch": nbytes, "mean_launch_us": us, "launches_timed": n}
         if world == 1 and not a.no_cpu_baseline:

@@ -103,6 +103,12 @@ PCFA_API int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, const 
 PCFA_API int pcfa_corr_lookup_fwd(const float* pyr, const float* coords, float* out, int B, int H, int W,
                          int num_levels, int radius, void* stream);
 
+/* Same launch with two hipEvent_t (created by the caller, may be NULL) attached to the kernel's dispatch packet
+ * (hipExtLaunchKernel): after completion hipEventElapsedTime(start, stop) is the kernel's own duration,
+ * without the barrier packets an event bracket around the launch would add.  For measurement. */
+PCFA_API int pcfa_corr_lookup_fwd_timed(const float* pyr, const float* coords, float* out, int B, int H, int W,
+                               int num_levels, int radius, void* start_event, void* stop_event, void* stream);
+
 /* dpyr += d out / d pyr ^T * grad_out   (no gradient w.r.t. coords: the
  * reference detaches them, models/raft/raft.py:122-123).  Deterministic: every
  * (query, level) window is owned by one workgroup, no atomics.  dpyr must have
@@ -186,6 +192,21 @@ PCFA_API int pcfa_flow_loss_bwd(const float* pred, const long long pred_strides[
                        float mu, int f_type, int joint, const float* fwd_scalars,
                        const float* grad_loss, float* grad_pred, float* grad_delta1,
                        float* grad_delta2, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * SepConvGRU gate arithmetic (models/raft/update.py:45-60 == models/gma/update.py:51-66), fused:
+ *   gates : z = sigmoid(zc), r = sigmoid(rc), rh = r * h            (zc, rc = convz(hx), convr(hx))
+ *   update: q = tanh(qc), hnew = (1 - z) * h + z * q                (qc = convq(cat[rh, x]))
+ * and their backward passes.  All arrays have n floats and must be 16-byte aligned.
+ * ------------------------------------------------------------------------- */
+PCFA_API int pcfa_gru_gates_fwd(const float* zc, const float* rc, const float* h, float* z, float* r, float* rh,
+                       long long n, void* stream);
+PCFA_API int pcfa_gru_gates_bwd(const float* z, const float* r, const float* h, const float* dz, const float* drh,
+                       float* dzc, float* drc, float* dh, long long n, void* stream);
+PCFA_API int pcfa_gru_update_fwd(const float* z, const float* qc, const float* h, float* q, float* hnew,
+                        long long n, void* stream);
+PCFA_API int pcfa_gru_update_bwd(const float* z, const float* q, const float* h, const float* g, float* dz,
+                        float* dqc, float* dh, long long n, void* stream);
 
 /* Metric helpers (helper_functions/losses.py:3-30,129-142): out[0] = sum over
  * pixels of sqrt(du^2+dv^2) / (B*H*W);  pcfa_sum_squares: out[0] = sum x^2. */

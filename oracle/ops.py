@@ -196,6 +196,20 @@ def spatial_correlation_shift_sum(input1, input2, patch_size=9):
 
 
 # --------------------------------------------------------------------------- #
+# SepConvGRU gate arithmetic
+# --------------------------------------------------------------------------- #
+def gru_gates(zc, rc, h):
+    """models/raft/update.py:47-49 / :54-56 -- z = sigmoid(convz(hx)), r = sigmoid(convr(hx)); returns (z, r*h)."""
+    return torch.sigmoid(zc), torch.sigmoid(rc) * h
+
+
+def gru_update(z, qc, h):
+    """models/raft/update.py:49-50 / :57-58 -- q = tanh(convq(.)); h = (1-z) * h + z * q."""
+    q = torch.tanh(qc)
+    return (1 - z) * h + z * q
+
+
+# --------------------------------------------------------------------------- #
 # attack math
 # --------------------------------------------------------------------------- #
 def box_transform(image, delta=None, change_of_variables=False, eps_box=0., scale=1.):

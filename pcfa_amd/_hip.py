@@ -34,6 +34,7 @@ SIGNATURES = {
     "pcfa_corr_pyramid_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "pcfa_corr_pyramid_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_corr_lookup_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_corr_lookup_fwd_timed": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "pcfa_corr_lookup_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_spatial_corr_out_size": (c_int, [c_int] * 10 + [POINTER(c_int), POINTER(c_int)]),
     "pcfa_spatial_corr_fwd": (c_int, [_P, _P, _P] + [c_int] * 16 + [_P]),
@@ -49,6 +50,10 @@ SIGNATURES = {
                                    c_float, c_float, c_int, _P, _P, _P]),
     "pcfa_flow_loss_bwd": (c_int, [_P, _S4, _P, _S4, c_int, c_int, c_int, _P, c_longlong, _P, c_longlong,
                                    c_float, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "pcfa_gru_gates_fwd": (c_int, [_P] * 6 + [c_longlong, _P]),
+    "pcfa_gru_gates_bwd": (c_int, [_P] * 8 + [c_longlong, _P]),
+    "pcfa_gru_update_fwd": (c_int, [_P] * 5 + [c_longlong, _P]),
+    "pcfa_gru_update_bwd": (c_int, [_P] * 7 + [c_longlong, _P]),
     "pcfa_avg_epe": (c_int, [_P, _S4, _P, _S4, c_int, c_int, c_int, _P, _P, _P]),
     "pcfa_sum_squares": (c_int, [_P, c_longlong, _P, _P, _P]),
 }

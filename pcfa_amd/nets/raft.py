@@ -125,11 +125,12 @@ class SepConvGRU(nn.Module):
 
     @staticmethod
     def _half(h, x, convz, convr, convq):
+        # z = sigmoid(convz(hx)); r = sigmoid(convr(hx)); q = tanh(convq([r*h, x])); h' = (1-z)*h + z*q
+        # -- the elementwise part runs as two fused HIP kernels (pcfa_amd/csrc/gru_math.hip)
+        o = ops.get()
         hx = torch.cat([h, x], dim=1)
-        z = torch.sigmoid(convz(hx))
-        r = torch.sigmoid(convr(hx))
-        q = torch.tanh(convq(torch.cat([r * h, x], dim=1)))
-        return (1 - z) * h + z * q
+        z, rh = o.gru_gates(convz(hx), convr(hx), h)
+        return o.gru_update(z, convq(torch.cat([rh, x], dim=1)), h)
 
     def forward(self, h, x):
         h = self._half(h, x, self.convz1, self.convr1, self.convq1)

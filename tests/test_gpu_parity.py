@@ -221,6 +221,26 @@ def test_attack_math_vs_reference_golden():
     assert abs(float(hip_ops.two_norm_avg_delta(d1, d2)) - float(g["l2_12"])) < 2e-6 * float(g["l2_12"])
 
 
+def test_gru_gate_kernels_vs_oracle(oracle_ops):
+    """SepConvGRU elementwise chain (update.py:45-60): device expf/tanhf vs torch CPU -> 2e-6 relative."""
+    gen = torch.Generator().manual_seed(8)
+    for shape in ((1, 128, 55, 128), (2, 7, 5, 3)):   # BASELINE size and a ragged one (n % 4 != 0)
+        zc, rc, qc = (2 * torch.randn(shape, generator=gen) for _ in range(3))
+        h = torch.tanh(torch.randn(shape, generator=gen))
+        lv = [t_.clone().requires_grad_(True) for t_ in (zc, rc, qc, h)]
+        z, rh = oracle_ops.gru_gates(lv[0], lv[1], lv[3])
+        want = oracle_ops.gru_update(z, lv[2] + rh, lv[3])          # rh enters q's pre-activation like convq would
+        go = torch.randn(shape, generator=gen)
+        want.backward(go)
+        gv = [t_.clone().to(DEV).requires_grad_(True) for t_ in (zc, rc, qc, h)]
+        zg, rhg = hip_ops.gru_gates(gv[0], gv[1], gv[3])
+        got = hip_ops.gru_update(zg, gv[2] + rhg, gv[3])
+        assert max_abs(got, want) <= 2e-6
+        got.backward(go.to(DEV))
+        for a, b in zip(gv, lv):
+            assert rel_l2(a.grad, b.grad) < 2e-6
+
+
 def test_box_transform_vs_oracle(oracle_ops):
     gen = torch.Generator().manual_seed(2)
     img = torch.rand(3, 3, 37, 53, generator=gen)
