@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--size", default="436x1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC convolutions")
+    ap.add_argument("--no-graph", action="store_true", help="launch the closure eagerly instead of replaying "
+                                                            "its hipGraph")
     ap.add_argument("--miopen-find", action="store_true",
                     help="cudnn.benchmark = True (MIOpen exhaustive find; measured equal to the default "
                          "immediate mode on this workload, but costs ~60 s of warm-up)")
@@ -89,27 +91,46 @@ class AttackStepper:
             self.flow_init = self.predict().clone()
         self.target = targets.get_target("zero", self.flow_init, device=device)
         self.closures = 0
+        self.graphed = self.repredict = None
+
+    def enable_graph(self):
+        """Capture forward+loss+backward (and the re-prediction forward) once; later evaluations replay the
+        hipGraphs -- exactly what pcfa_attack does on the GPU."""
+        from pcfa_amd.graphed import GraphedClosure, GraphedForward
+        self.graphed = GraphedClosure(self._closure_body, [self.nw1, self.nw2])
+        self.repredict = GraphedForward(self._repredict_body, self.device)
+
+    def _repredict_body(self):
+        d1, d2 = self.A.extract_deltas(self.nw1, self.nw2, self.image1, self.image2, self.box, eps_box=self.eps)
+        return d1, d2, self.predict()
 
     def predict(self):
         out = self.own.compute_flow(self.model, "scaled_input_model", self.nw1, self.nw2, test_mode=True)
         [out] = self.own.postprocess_flow(self.net, self.padder, out)
         return out
 
-    def closure(self):
-        self.optimizer.zero_grad()
+    def _closure_body(self):
         flow = self.predict()
         d1, d2 = self.A.extract_deltas(self.nw1, self.nw2, self.image1, self.image2, self.box, eps_box=self.eps)
         loss = self.losses.loss_delta_constraint(flow, self.target, d1, d2, self.device,
                                                  delta_bound=self.delta_bound, mu=self.mu, f_type="aee")
         loss.backward()
-        self.closures += 1
         return loss
+
+    def closure(self):
+        self.closures += 1
+        if self.graphed is not None:
+            return self.graphed()
+        self.optimizer.zero_grad()
+        return self._closure_body()
 
     def step(self):
         self.optimizer.step(self.closure)
-        with torch.no_grad():
-            d1, d2 = self.A.extract_deltas(self.nw1, self.nw2, self.image1, self.image2, self.box, eps_box=self.eps)
-            flow = self.predict()
+        if self.repredict is not None:
+            d1, d2, flow = self.repredict()
+        else:
+            with torch.no_grad():
+                d1, d2, flow = self._repredict_body()
         aee_tgt, aee_init = self.plog.calc_metrics_adv(flow, self.target, self.flow_init)
         l2 = self.plog.calc_delta_metrics(d1, d2)
         return aee_tgt, aee_init, l2[2]
@@ -174,14 +195,22 @@ def main():
     a = parse()
     from pcfa_amd import sharding
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    # one process per GPU; PCFA_BENCH_BACKEND=gloo + PCFA_BENCH_SHARE_GPU=1 only exist to exercise the
+    # multi-process path on a single-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("PCFA_BENCH_BACKEND", "nccl")
+    share = os.environ.get("PCFA_BENCH_SHARE_GPU", "0") == "1"
+    dev = torch.device("cuda", 0 if (world == 1 or share) else sharding.local_rank())
+    torch.cuda.set_device(dev)
     if world > 1:
-        sharding.init_from_env("nccl")
+        if backend == "nccl":
+            sharding.init_from_env("nccl")
+        else:
+            torch.distributed.init_process_group(backend=backend)
     rank = sharding.rank()
     if world != a.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    dev = torch.device("cuda", sharding.local_rank() if world > 1 else 0)
-    torch.cuda.set_device(dev)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the two scalar collectives live
     torch.backends.cudnn.benchmark = a.miopen_find
     h, w = (int(v) for v in a.size.lower().split("x"))
 
@@ -194,9 +223,14 @@ def main():
     prof = hip_ops.DispatchTimer() if corr_net else None
     for _ in range(a.warmup):
         st.step()
+    use_graph = not a.no_graph
+    if use_graph:
+        st.enable_graph()
+        st.step()  # one untimed step on the graph
     torch.cuda.synchronize()
     sharding.barrier()
-    hip_ops.set_dispatch_timer(prof)
+    if not use_graph:
+        hip_ops.set_dispatch_timer(prof)
     c0 = st.closures
     t0 = time.perf_counter()
     last = None
@@ -206,8 +240,16 @@ def main():
     sharding.barrier()
     elapsed = time.perf_counter() - t0
     hip_ops.set_dispatch_timer(None)
-    elapsed = sharding.max_scalar(elapsed, dev)
+    elapsed = sharding.max_scalar(elapsed, cdev)
     closures = st.closures - c0
+    if use_graph and corr_net:
+        # dispatch-attached events cannot ride inside a captured graph: time the same kernel on the same
+        # data in one extra, eagerly launched step right after the timed region
+        st.graphed = st.repredict = None
+        hip_ops.set_dispatch_timer(prof)
+        st.step()
+        torch.cuda.synchronize()
+        hip_ops.set_dispatch_timer(None)
 
     out = None
     if rank == 0:
@@ -220,7 +262,8 @@ def main():
             "config": {"workload": "%s, 1 synthetic %dx%d pair per GPU (padded %dx%d), disjoint delta, "
                                    "change_of_variables, delta_bound=0.005, zero target, L-BFGS max_iter=10"
                                    % (a.net, h, w, hp, wp), "weights": "random:1234",
-                       "closure_evals_per_step": closures / a.steps, "parallelism": "pairs sharded 1/GPU"},
+                       "closure_evals_per_step": closures / a.steps, "parallelism": "pairs sharded 1/GPU",
+                       "closure_launch": "hipGraph replay" if use_graph else "eager"},
             "closure_evals_per_sec": world * closures / elapsed,
             "final": {"aee_adv_tgt": last[0], "aee_adv_init": last[1], "l2_delta": last[2]},
         }

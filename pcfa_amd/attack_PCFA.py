@@ -148,8 +148,7 @@ def pcfa_attack(model, image1, image2, flow, batch, distortion_folder, eps_box, 
     delta1_min = delta2_min = flow_pred_min = None
     flow_pred = flow_pred_init
 
-    def closure():
-        optimizer.zero_grad()
+    def closure_body():
         flow_closure = predict()
         d1, d2 = current_deltas()
         loss_closure = losses.loss_delta_constraint(flow_closure, target, d1, d2, device,
@@ -157,15 +156,32 @@ def pcfa_attack(model, image1, image2, flow, batch, distortion_folder, eps_box, 
         loss_closure.backward()
         return loss_closure
 
+    # On the GPU the closure (static shapes, variables updated in place by L-BFGS) is captured once per pair
+    # into a hipGraph and replayed: bit-identical results, no per-launch host work (PCFA_HIP_GRAPH=0 disables).
+    graphed = repredict = None
+    if torch.device(device).type == "cuda" and os.environ.get("PCFA_HIP_GRAPH", "1") == "1" and args.steps > 0:
+        from .graphed import GraphedClosure, GraphedForward
+        graphed = GraphedClosure(closure_body, optimizer.param_groups[0]["params"])
+        repredict = GraphedForward(lambda: (current_deltas(), predict()), device)
+
+    def closure():
+        if graphed is not None:
+            return graphed()
+        optimizer.zero_grad()
+        return closure_body()
+
     for steps in range(args.steps):
         curr_step = batch * args.steps + steps
         logging.log_metrics(curr_step, ("batch", batch), ("steps", steps), ("epoch", 0))
 
         optimizer.step(closure)
 
-        with torch.no_grad():
-            delta1, delta2 = current_deltas()
-            flow_pred = predict()
+        if repredict is not None:
+            (delta1, delta2), flow_pred = repredict()
+        else:
+            with torch.no_grad():
+                delta1, delta2 = current_deltas()
+                flow_pred = predict()
 
         aee_adv_tgt, aee_adv_pred = logging.calc_metrics_adv(flow_pred, target, flow_pred_init)
         aee_adv_gt = logging.calc_metrics_adv_gt(flow_pred, flow) if has_gt else None

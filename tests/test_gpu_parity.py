@@ -327,3 +327,70 @@ def test_pcfa_attack_on_gpu_vs_reference_trajectory():
     for idx in (4, 5, 8, 9, 10, 11):
         tol = max(1e-3, 3 * abs(ref8[idx] - ref3[idx])) * max(1.0, abs(ref8[idx]))
         assert abs(res[idx] - ref8[idx]) <= tol, (idx, res[idx], ref8[idx], ref3[idx])
+
+
+def _cli_args(**kw):
+    from argparse import Namespace
+    base = dict(net="SpyNet", weights="random:1234", dataset="Synthetic", dataset_stage="evaluation", small_run=False,
+                synthetic_size="64x96", synthetic_pairs=2, dstype="final", output_folder="experiment_data",
+                small_save=False, save_frequency=1, no_save=True, unregistered_artifacts=True,
+                joint_perturbation=False, steps=2, universal_perturbation=False, boxconstraint="change_of_variables",
+                batch_size=2, delta_bound=0.005, mu=-1, epochs=1, target="zero", custom_target_path="", loss="aee")
+    base.update(kw)
+    return Namespace(**base)
+
+
+@pytest.mark.parametrize("net,joint,box", [("SpyNet", False, "change_of_variables"), ("PWCNet", True, "clipping"),
+                                           ("RAFT", False, "clipping")])
+def test_attack_l2_end_to_end_on_gpu_vs_cpu_port(oracle_ops, net, joint, box):
+    """The whole driver (dataset -> model -> pcfa_attack per pair -> averages) on the GPU vs the same host code with
+    the oracle operators on CPU: 2 pairs x 1 step (10 closures; longer runs amplify fp32 noise chaotically --
+    SURVEY.md D10 -- and are covered by the trajectory test against the reference's own noise floor)."""
+    from pcfa_amd import attack_PCFA
+    size = "128x160" if net == "RAFT" else "64x96"
+    a = _cli_args(net=net, joint_perturbation=joint, boxconstraint=box, synthetic_size=size, steps=1)
+    got = attack_PCFA.attack_l2(a)
+    import os
+    os.environ["PCFA_USE_CPU"] = "1"
+    try:
+        import importlib
+        from pcfa_amd.helper_functions import config_paths
+        importlib.reload(config_paths)
+        importlib.reload(attack_PCFA)
+        with ops.override_for_testing(oracle_ops):
+            want = attack_PCFA.attack_l2(a)
+    finally:
+        os.environ.pop("PCFA_USE_CPU")
+        importlib.reload(config_paths)
+        importlib.reload(attack_PCFA)
+    assert got["pairs"] == want["pairs"] == 2
+    for k in ("aee_avg_pred-tgt", "aee_avg_predadv-tgt", "aee_avg_pred-predadv", "l2_avg_delta12",
+              "aee_avg_predadv-tgt_min", "l2_avg_delta12_min"):
+        assert abs(got[k] - want[k]) <= 5e-3 * max(1.0, abs(want[k])), (k, got[k], want[k])
+
+
+def test_universal_attack_runs_on_gpu():
+    from pcfa_amd import attack_PCFA
+    res = attack_PCFA.attack_l2_universal(_cli_args(universal_perturbation=True, boxconstraint="clipping", steps=1))
+    d = res["delta1"]
+    assert d.is_cuda and d.shape == (3, 64, 128) and float(d.abs().max()) > 0
+    assert len(res["history"]) == 1 and np.isfinite(res["history"][0]["aee_predadv-tgt"])
+
+
+def test_graphed_closure_is_bit_identical():
+    """The hipGraph replay of a RAFT closure reproduces the eager launch bit for bit (same kernels, same order)."""
+    import bench
+    torch.backends.cudnn.benchmark = False
+    st = bench.AttackStepper("RAFT", 128, 160, torch.device(DEV), seed=3)
+    st.optimizer.zero_grad()
+    l_eager = st._closure_body().clone()
+    g_eager = [st.nw1.grad.clone(), st.nw2.grad.clone()]
+    st.enable_graph()
+    with torch.no_grad():
+        st.nw1.add_(0.01)          # move the variables in place, as L-BFGS does
+    l_graph_moved = float(st.closure())
+    with torch.no_grad():
+        st.nw1.sub_(0.01)
+    l_graph = st.closure().clone()
+    assert float(l_graph) == float(l_eager) and l_graph_moved != float(l_eager)
+    assert torch.equal(st.nw1.grad, g_eager[0]) and torch.equal(st.nw2.grad, g_eager[1])
