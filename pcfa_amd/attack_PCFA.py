@@ -157,7 +157,7 @@ def pcfa_attack(model, image1, image2, flow, batch, distortion_folder, eps_box, 
         return loss_closure
 
     # On the GPU the closure (static shapes, variables updated in place by L-BFGS) is captured once per pair
-    # into a hipGraph and replayed: bit-identical results, no per-launch host work (PCFA_HIP_GRAPH=0 disables).
+    # into a hipGraph and replayed: same kernels in the same order, no per-launch host work (PCFA_HIP_GRAPH=0 disables).
     graphed = repredict = None
     if torch.device(device).type == "cuda" and os.environ.get("PCFA_HIP_GRAPH", "1") == "1" and args.steps > 0:
         from .graphed import GraphedClosure, GraphedForward
