@@ -280,17 +280,21 @@ def two_norm_avg_delta_squared(delta1, delta2):
     return (torch.sum(torch.pow(torch.flatten(delta1), 2)) + torch.sum(torch.pow(torch.flatten(delta2), 2))) / n
 
 
-def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound=0.001, mu=100., f_type="aee"):
-    """helper_functions/losses.py:145-230."""
+def get_loss(f_type, pred, target):
+    """helper_functions/losses.py:145-174."""
     if f_type == "aee":
-        sim = avg_epe(pred, target)
-    elif f_type == "cosim":
-        sim = f_cosim(pred, target)
-    elif f_type == "mse":
-        sim = avg_mse(pred, target)
-    else:
-        raise NotImplementedError(
-            "The requested loss type %s does not exist. Please choose one of 'aee', 'mse' or 'cosim'" % f_type)
+        return avg_epe(pred, target)
+    if f_type == "cosim":
+        return f_cosim(pred, target)
+    if f_type == "mse":
+        return avg_mse(pred, target)
+    raise NotImplementedError(
+        "The requested loss type %s does not exist. Please choose one of 'aee', 'mse' or 'cosim'" % f_type)
+
+
+def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound=0.001, mu=100., f_type="aee"):
+    """helper_functions/losses.py:200-230."""
+    sim = get_loss(f_type, pred, target)
     excess = two_norm_avg_delta_squared(delta1, delta2) - torch.tensor(delta_bound ** 2).to(pred.device)
     penalty = torch.max(torch.tensor(0.).to(pred.device), excess)
     return sim + mu * penalty

@@ -29,3 +29,11 @@ def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound
     """similarity(pred, target) + mu * relu(mean(delta^2) - delta_bound^2), losses.py:200-230."""
     return ops.get().loss_delta_constraint(pred, target, delta1, delta2, device, delta_bound=delta_bound, mu=mu,
                                            f_type=f_type)
+
+
+def get_loss(f_type, pred, target):
+    """Similarity term alone (losses.py:145-174), differentiable -- used by the I-FGSM baseline."""
+    if f_type not in ("aee", "mse", "cosim"):
+        raise NotImplementedError(
+            "The requested loss type %s does not exist. Please choose one of 'aee', 'mse' or 'cosim'" % f_type)
+    return ops.get().get_loss(f_type, pred, target)

@@ -531,6 +531,12 @@ def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound
     return _LossDeltaConstraint.apply(pred, target, delta1, delta2, delta_bound, mu, f_type)
 
 
+def get_loss(f_type, pred, target):
+    """helper_functions/losses.py:145-174: the similarity term alone (penalty weight 0 on a dummy perturbation)."""
+    z = torch.zeros(4, device=pred.device, dtype=torch.float32)
+    return _LossDeltaConstraint.apply(pred, target, z, z, 1.0, 0.0, f_type)
+
+
 def avg_epe(flow1, flow2):
     """helper_functions/losses.py:3-30 (metric use: no gradient)."""
     _dev(flow1, flow2)

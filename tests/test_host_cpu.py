@@ -4,6 +4,7 @@ The package has no CPU operators, so these tests inject the oracle through
 pcfa_amd.ops.override_for_testing and compare against golden vectors recorded from the real reference
 (same seeded weights: tests/golden/make_golden.py loads pcfa_amd's state_dict into the reference's
 modules, which also pins parameter-name compatibility)."""
+import os
 from argparse import Namespace
 
 import numpy as np
@@ -131,3 +132,53 @@ def test_joint_cov_is_rejected():
     with pytest.raises(ValueError, match="joint_perturbation"):
         attack_PCFA.pcfa_attack(model, i1, i2, torch.zeros(1, 2, 64, 64), 0, None, 1e-7, torch.device("cpu"), False,
                                 5e5, _args(net="SpyNet", joint_perturbation=True))
+
+
+def _cli(**kw):
+    base = dict(net="SpyNet", weights="random:1234", dataset="Synthetic", dataset_stage="evaluation", small_run=False,
+                synthetic_size="64x64", synthetic_pairs=2, dstype="final", output_folder="experiment_data",
+                small_save=False, save_frequency=1, no_save=True, unregistered_artifacts=True,
+                joint_perturbation=False, steps=2, universal_perturbation=False, boxconstraint="clipping",
+                batch_size=2, delta_bound=0.005, mu=-1, epochs=2, target="zero", custom_target_path="", loss="aee",
+                epsilon=0.00025, perturbation_sourcefolder=None, origin_net=None)
+    base.update(kw)
+    return Namespace(**base)
+
+
+def test_fgsm_step_and_driver():
+    """attack_FGSM.py:21-56 semantics + the per-pair driver (2 pairs x 2 iterations)."""
+    from pcfa_amd import attack_FGSM
+    a, b = torch.full((1, 3, 2, 2), 0.5), torch.full((1, 3, 2, 2), 0.9999)
+    g1, g2 = torch.tensor([[[[1., -1.], [0., 2.]]]]).expand(1, 3, 2, 2), -torch.ones(1, 3, 2, 2)
+    p1, p2 = attack_FGSM.fgsm_attack_step(a, b, 0.01, g1, g2)
+    assert torch.allclose(p1[0, 0], torch.tensor([[0.49, 0.51], [0.5, 0.49]])) and float(p2.max()) == 1.0
+    j1, j2 = attack_FGSM.fgsm_attack_step(a, b, 0.01, g1, g2, common_perturb=True)
+    assert torch.equal(a - j1, (b - j2).clamp(max=0.01)) or torch.allclose(a - j1, 0.01 * (0.5 * (g1 + g2)).sign())
+    res = attack_FGSM.attack(_cli(loss="mse"))
+    assert res["pairs"] == 2 and 0 < res["l2_delta-avg"] <= 2 * 0.00025 + 1e-9
+    assert res["aee_predadv-tgt"] <= res["aee_pred-tgt"] + 1e-3      # two descent steps do not move away
+
+
+def test_universal_artifacts_round_trip_through_evaluate(tmp_path):
+    """attack_l2_universal writes NNNNN_delta1_e{E}.npy; evaluate_PCFA reads them back, also across padding families."""
+    from pcfa_amd import evaluate_PCFA
+    args = _cli(universal_perturbation=True, no_save=False, output_folder=str(tmp_path), steps=1, epochs=2)
+    res = attack_PCFA.attack_l2_universal(args)
+    run_dir = None
+    for root, dirs, files in os.walk(str(tmp_path)):
+        if os.path.basename(root) == "patches" and any(f.endswith("_delta1_e1.npy") for f in files):
+            run_dir = os.path.dirname(root)
+    assert run_dir is not None
+    epochs, d1, d2 = evaluate_PCFA.extract_epoch_patchlist(run_dir)
+    assert epochs == 2 and len(d1) == 2 and len(d2) == 2
+    assert np.array_equal(np.load(d1[-1]), res["delta1"].numpy())
+    ev = evaluate_PCFA.eval_l2_universal(_cli(universal_perturbation=True, perturbation_sourcefolder=run_dir,
+                                              origin_net="SpyNet"))
+    assert len(ev) == 2 and ev[0]["images"] == 2 and np.isfinite(ev[1]["epoch_aee_pred-predadv"])
+    # cross-family re-padding: SpyNet (div 64) -> RAFT (div 8) keeps the un-padded core of delta
+    delta = torch.from_numpy(np.load(d1[0]))                       # [3, 64, 64] (64 is already a multiple of 64)
+    img = torch.zeros(1, 3, 60, 70)
+    padded64 = torch.randn(3, 64, 128)
+    re8 = evaluate_PCFA.convert_perturbationsizes(padded64, img, "SpyNet", "RAFT")
+    assert re8.shape == (1, 3, 64, 72) and torch.equal(re8[0, :, 2:62, 1:71], padded64[:, 2:62, 29:99])
+    assert evaluate_PCFA.convert_perturbationsizes(delta, img, "RAFT", "GMA") is delta
