@@ -153,7 +153,7 @@ __device__ __forceinline__ WindowBlock window_block(int x0, int y0, int tw, int 
 template <int R>
 __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
-    int Q, PyrLayout P) {
+    int Q, int qb, PyrLayout P) {
   using G = Geo<R>;
   constexpr int N1 = G::N1, WIN = G::WIN, NWIN = G::NWIN;
   __shared__ __attribute__((aligned(16))) float s_win[QB * WS];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
   __shared__ float s_fx[QB], s_fy[QB];
 
   const int level = blockIdx.y, b_img = blockIdx.z;
-  const int q0 = blockIdx.x * QB;
+  const int q0 = blockIdx.x * qb;  // qb <= QB queries per workgroup, chosen on the host for an even CU load
   // wave-uniform layout fields, pinned to SGPRs before any divergent branch
   const int hl = __builtin_amdgcn_readfirstlane(P.h[level]);
   const int tw = __builtin_amdgcn_readfirstlane(P.tw[level]);
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
   int myT = 0, myP = 0;
   {
     const int j = wv + lane * N1;
-    if (lane < NWIN && j < QB) {
+    if (lane < NWIN && j < qb) {
       const bool valid = q0 + j < Q;
       float cx = 0.f, cy = 0.f;
       if (valid) {
@@ -213,13 +213,13 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
 #pragma unroll
   for (int k = 0; k < NWIN; ++k) {
     const int j = wv + k * N1;
-    if (j < QB && ry < WROWS) *reinterpret_cast<f32x4*>(lds_row + k * N1 * WS) = v[k];
+    if (j < qb && ry < WROWS) *reinterpret_cast<f32x4*>(lds_row + k * N1 * WS) = v[k];
   }
   __syncthreads();
 
   // ---- Phase B: thread (query, b) blends the 2r+1 taps of window row b ---------------------
   const int j = lane, b = wv;
-  if (q0 + j >= Q) return;
+  if (j >= qb || q0 + j >= Q) return;
   const int ox = s_ox[j], oy = s_oy[j];
   const float fx = s_fx[j], fy = s_fy[j];
   const float* row0 = &s_win[j * WS + (oy + b) * RS];
@@ -328,14 +328,20 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_bwd_kernel(
   }
 }
 
+// Queries per workgroup.  64 (= one wave of queries in phase B) measured best on MI355X at Q = 7040, 4 levels:
+// 440 workgroups, 9.9 us; a CU-balanced 55 (512 workgroups, exactly 2 per CU) was SLOWER, 10.8 us -- the kernel is
+// bound by per-workgroup latency, not by the most loaded CU.
+int balanced_queries_per_group(int /*Q*/, int /*planes*/) { return QB; }
+
 template <int R>
 int launch_fwd(const float* pyr, const float* coords, float* out, int B, int Q,
                const PyrLayout& P, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-  dim3 grid(pcfa_cdiv(Q, QB), P.L, B), block(QB, 2 * R + 1, 1);
+  const int qb = balanced_queries_per_group(Q, P.L * B);
+  dim3 grid(pcfa_cdiv(Q, qb), P.L, B), block(QB, 2 * R + 1, 1);
   if (ev0 || ev1)  // events attached to the dispatch packet itself: they time the kernel, not the bracket
-    hipExtLaunchKernelGGL(corr_lookup_fwd_kernel<R>, grid, block, 0, s, ev0, ev1, 0, pyr, coords, out, Q, P);
+    hipExtLaunchKernelGGL(corr_lookup_fwd_kernel<R>, grid, block, 0, s, ev0, ev1, 0, pyr, coords, out, Q, qb, P);
   else
-    hipLaunchKernelGGL(corr_lookup_fwd_kernel<R>, grid, block, 0, s, pyr, coords, out, Q, P);
+    hipLaunchKernelGGL(corr_lookup_fwd_kernel<R>, grid, block, 0, s, pyr, coords, out, Q, qb, P);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
