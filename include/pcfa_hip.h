@@ -197,16 +197,25 @@ PCFA_API int pcfa_flow_loss_bwd(const float* pred, const long long pred_strides[
  * SepConvGRU gate arithmetic (models/raft/update.py:45-60 == models/gma/update.py:51-66), fused:
  *   gates : z = sigmoid(zc), r = sigmoid(rc), rh = r * h            (zc, rc = convz(hx), convr(hx))
  *   update: q = tanh(qc), hnew = (1 - z) * h + z * q                (qc = convq(cat[rh, x]))
- * and their backward passes.  All arrays have n floats and must be 16-byte aligned.
+ * and their backward passes.  All arrays have n floats (NCHW, plane = H*W, `channels` channels) and must be
+ * 16-byte aligned.  zc/rc/qc are the convolution outputs WITHOUT bias; bias_z/r/q ([channels], may be NULL) are
+ * added here, which saves the separate bias-add launch torch would issue per convolution.
  * ------------------------------------------------------------------------- */
-PCFA_API int pcfa_gru_gates_fwd(const float* zc, const float* rc, const float* h, float* z, float* r, float* rh,
-                       long long n, void* stream);
+PCFA_API int pcfa_gru_gates_fwd(const float* zc, const float* rc, const float* h, const float* bias_z,
+                       const float* bias_r, float* z, float* r, float* rh, long long n, int plane, int channels,
+                       void* stream);
 PCFA_API int pcfa_gru_gates_bwd(const float* z, const float* r, const float* h, const float* dz, const float* drh,
                        float* dzc, float* drc, float* dh, long long n, void* stream);
-PCFA_API int pcfa_gru_update_fwd(const float* z, const float* qc, const float* h, float* q, float* hnew,
-                        long long n, void* stream);
+PCFA_API int pcfa_gru_update_fwd(const float* z, const float* qc, const float* h, const float* bias_q, float* q,
+                        float* hnew, long long n, int plane, int channels, void* stream);
 PCFA_API int pcfa_gru_update_bwd(const float* z, const float* q, const float* h, const float* g, float* dz,
                         float* dqc, float* dh, long long n, void* stream);
+
+/* out = relu(x + bias[c]) and its backward gx = grad_out * (out > 0): the "conv -> +bias -> ReLU" tail of the
+ * motion encoder / flow head convolutions (models/raft/update.py:12-16,91-101) in one pass. */
+PCFA_API int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out, long long n, int plane, int channels,
+                       void* stream);
+PCFA_API int pcfa_relu_bwd(const float* out, const float* grad_out, float* grad_x, long long n, void* stream);
 
 /* Metric helpers (helper_functions/losses.py:3-30,129-142): out[0] = sum over
  * pixels of sqrt(du^2+dv^2) / (B*H*W);  pcfa_sum_squares: out[0] = sum x^2. */

@@ -198,15 +198,25 @@ def spatial_correlation_shift_sum(input1, input2, patch_size=9):
 # --------------------------------------------------------------------------- #
 # SepConvGRU gate arithmetic
 # --------------------------------------------------------------------------- #
-def gru_gates(zc, rc, h):
-    """models/raft/update.py:47-49 / :54-56 -- z = sigmoid(convz(hx)), r = sigmoid(convr(hx)); returns (z, r*h)."""
-    return torch.sigmoid(zc), torch.sigmoid(rc) * h
+def _cb(bias):
+    return 0 if bias is None else bias.view(1, -1, 1, 1)
 
 
-def gru_update(z, qc, h):
+def gru_gates(zc, rc, h, bias_z=None, bias_r=None):
+    """models/raft/update.py:47-49 / :54-56 -- z = sigmoid(convz(hx)), r = sigmoid(convr(hx)); returns (z, r*h).
+    zc / rc are the convolutions without their bias, which is added here (conv(x) + b == conv_with_bias(x))."""
+    return torch.sigmoid(zc + _cb(bias_z)), torch.sigmoid(rc + _cb(bias_r)) * h
+
+
+def gru_update(z, qc, h, bias_q=None):
     """models/raft/update.py:49-50 / :57-58 -- q = tanh(convq(.)); h = (1-z) * h + z * q."""
-    q = torch.tanh(qc)
+    q = torch.tanh(qc + _cb(bias_q))
     return (1 - z) * h + z * q
+
+
+def bias_relu(x, bias=None):
+    """F.relu(conv(x)) with the convolution's bias split off (models/raft/update.py:12-16,91-101)."""
+    return torch.relu(x + _cb(bias))
 
 
 # --------------------------------------------------------------------------- #

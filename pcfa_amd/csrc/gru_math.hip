@@ -26,19 +26,29 @@ __device__ __forceinline__ void for_each4(long long n, F f) {
 #define LD4(p, i) (*reinterpret_cast<const float4*>((p) + ((i) << 2)))
 #define ST4(p, i, v) (*reinterpret_cast<float4*>((p) + ((i) << 2)) = (v))
 
+// channel of flat NCHW index e (plane = H*W, C channels); bias pointers may be null
+__device__ __forceinline__ float bias_at(const float* __restrict__ b, long long e, int plane, int C) {
+  return b ? b[(e / plane) % C] : 0.f;
+}
+
 __global__ void gru_gates_fwd_kernel(const float* __restrict__ zc, const float* __restrict__ rc,
-                                     const float* __restrict__ h, float* __restrict__ z,
-                                     float* __restrict__ r, float* __restrict__ rh, long long n) {
+                                     const float* __restrict__ h, const float* __restrict__ bz,
+                                     const float* __restrict__ br, float* __restrict__ z,
+                                     float* __restrict__ r, float* __restrict__ rh, long long n,
+                                     int plane, int C) {
   for_each4(n, [&](long long i, bool vec) {
     if (vec) {
       const float4 a = LD4(zc, i), b = LD4(rc, i), hh = LD4(h, i);
+      const long long e = i << 2;
       float4 zz, rr, o;
-      zz.x = sigmoidf_(a.x); zz.y = sigmoidf_(a.y); zz.z = sigmoidf_(a.z); zz.w = sigmoidf_(a.w);
-      rr.x = sigmoidf_(b.x); rr.y = sigmoidf_(b.y); rr.z = sigmoidf_(b.z); rr.w = sigmoidf_(b.w);
+      zz.x = sigmoidf_(a.x + bias_at(bz, e, plane, C)); zz.y = sigmoidf_(a.y + bias_at(bz, e + 1, plane, C));
+      zz.z = sigmoidf_(a.z + bias_at(bz, e + 2, plane, C)); zz.w = sigmoidf_(a.w + bias_at(bz, e + 3, plane, C));
+      rr.x = sigmoidf_(b.x + bias_at(br, e, plane, C)); rr.y = sigmoidf_(b.y + bias_at(br, e + 1, plane, C));
+      rr.z = sigmoidf_(b.z + bias_at(br, e + 2, plane, C)); rr.w = sigmoidf_(b.w + bias_at(br, e + 3, plane, C));
       o.x = rr.x * hh.x; o.y = rr.y * hh.y; o.z = rr.z * hh.z; o.w = rr.w * hh.w;
       ST4(z, i, zz); ST4(r, i, rr); ST4(rh, i, o);
     } else {
-      const float zz = sigmoidf_(zc[i]), rr = sigmoidf_(rc[i]);
+      const float zz = sigmoidf_(zc[i] + bias_at(bz, i, plane, C)), rr = sigmoidf_(rc[i] + bias_at(br, i, plane, C));
       z[i] = zz; r[i] = rr; rh[i] = rr * h[i];
     }
   });
@@ -71,20 +81,23 @@ __global__ void gru_gates_bwd_kernel(const float* __restrict__ z, const float* _
 }
 
 __global__ void gru_update_fwd_kernel(const float* __restrict__ z, const float* __restrict__ qc,
-                                      const float* __restrict__ h, float* __restrict__ q,
-                                      float* __restrict__ hnew, long long n) {
+                                      const float* __restrict__ h, const float* __restrict__ bq,
+                                      float* __restrict__ q, float* __restrict__ hnew, long long n,
+                                      int plane, int C) {
   for_each4(n, [&](long long i, bool vec) {
     if (vec) {
       const float4 zz = LD4(z, i), c = LD4(qc, i), hh = LD4(h, i);
+      const long long e = i << 2;
       float4 qq, o;
-      qq.x = tanhf(c.x); qq.y = tanhf(c.y); qq.z = tanhf(c.z); qq.w = tanhf(c.w);
+      qq.x = tanhf(c.x + bias_at(bq, e, plane, C)); qq.y = tanhf(c.y + bias_at(bq, e + 1, plane, C));
+      qq.z = tanhf(c.z + bias_at(bq, e + 2, plane, C)); qq.w = tanhf(c.w + bias_at(bq, e + 3, plane, C));
       o.x = (1.f - zz.x) * hh.x + zz.x * qq.x;
       o.y = (1.f - zz.y) * hh.y + zz.y * qq.y;
       o.z = (1.f - zz.z) * hh.z + zz.z * qq.z;
       o.w = (1.f - zz.w) * hh.w + zz.w * qq.w;
       ST4(q, i, qq); ST4(hnew, i, o);
     } else {
-      const float qq = tanhf(qc[i]);
+      const float qq = tanhf(qc[i] + bias_at(bq, i, plane, C));
       q[i] = qq;
       hnew[i] = (1.f - z[i]) * h[i] + z[i] * qq;
     }
@@ -116,6 +129,40 @@ __global__ void gru_update_bwd_kernel(const float* __restrict__ z, const float* 
   });
 }
 
+// out = relu(x + bias[c])  /  gx = gout * (out > 0)   (conv bias add + ReLU of the update block in one pass)
+__global__ void bias_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                     float* __restrict__ out, long long n, int plane, int C) {
+  for_each4(n, [&](long long i, bool vec) {
+    if (vec) {
+      const float4 a = LD4(x, i);
+      const long long e = i << 2;
+      float4 o;
+      o.x = fmaxf(a.x + bias_at(bias, e, plane, C), 0.f);
+      o.y = fmaxf(a.y + bias_at(bias, e + 1, plane, C), 0.f);
+      o.z = fmaxf(a.z + bias_at(bias, e + 2, plane, C), 0.f);
+      o.w = fmaxf(a.w + bias_at(bias, e + 3, plane, C), 0.f);
+      ST4(out, i, o);
+    } else {
+      out[i] = fmaxf(x[i] + bias_at(bias, i, plane, C), 0.f);
+    }
+  });
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ out, const float* __restrict__ gout,
+                                float* __restrict__ gx, long long n) {
+  for_each4(n, [&](long long i, bool vec) {
+    if (vec) {
+      const float4 o = LD4(out, i), g = LD4(gout, i);
+      float4 r;
+      r.x = o.x > 0.f ? g.x : 0.f; r.y = o.y > 0.f ? g.y : 0.f;
+      r.z = o.z > 0.f ? g.z : 0.f; r.w = o.w > 0.f ? g.w : 0.f;
+      ST4(gx, i, r);
+    } else {
+      gx[i] = out[i] > 0.f ? gout[i] : 0.f;
+    }
+  });
+}
+
 inline int blocks_for(long long n) {
   long long b = ((n >> 2) + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -125,12 +172,13 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
-extern "C" int pcfa_gru_gates_fwd(const float* zc, const float* rc, const float* h, float* z, float* r,
-                                  float* rh, long long n, void* stream) {
-  if (!zc || !rc || !h || !z || !r || !rh || n < 1) return PCFA_ERR_INVALID_ARG;
+extern "C" int pcfa_gru_gates_fwd(const float* zc, const float* rc, const float* h, const float* bias_z,
+                                  const float* bias_r, float* z, float* r, float* rh, long long n,
+                                  int plane, int channels, void* stream) {
+  if (!zc || !rc || !h || !z || !r || !rh || n < 1 || plane < 1 || channels < 1) return PCFA_ERR_INVALID_ARG;
   if (!(al16(zc) && al16(rc) && al16(h) && al16(z) && al16(r) && al16(rh))) return PCFA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, zc,
-                     rc, h, z, r, rh, n);
+                     rc, h, bias_z, bias_r, z, r, rh, n, plane, channels);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -147,12 +195,13 @@ extern "C" int pcfa_gru_gates_bwd(const float* z, const float* r, const float* h
   return PCFA_OK;
 }
 
-extern "C" int pcfa_gru_update_fwd(const float* z, const float* qc, const float* h, float* q,
-                                   float* hnew, long long n, void* stream) {
-  if (!z || !qc || !h || !q || !hnew || n < 1) return PCFA_ERR_INVALID_ARG;
+extern "C" int pcfa_gru_update_fwd(const float* z, const float* qc, const float* h, const float* bias_q,
+                                   float* q, float* hnew, long long n, int plane, int channels,
+                                   void* stream) {
+  if (!z || !qc || !h || !q || !hnew || n < 1 || plane < 1 || channels < 1) return PCFA_ERR_INVALID_ARG;
   if (!(al16(z) && al16(qc) && al16(h) && al16(q) && al16(hnew))) return PCFA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gru_update_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, qc,
-                     h, q, hnew, n);
+                     h, bias_q, q, hnew, n, plane, channels);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -164,6 +213,26 @@ extern "C" int pcfa_gru_update_bwd(const float* z, const float* q, const float* 
     return PCFA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gru_update_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, q,
                      h, g, dz, dqc, dh, n);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out, long long n, int plane,
+                                  int channels, void* stream) {
+  if (!x || !out || n < 1 || plane < 1 || channels < 1) return PCFA_ERR_INVALID_ARG;
+  if (!(al16(x) && al16(out))) return PCFA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(bias_relu_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, bias,
+                     out, n, plane, channels);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_relu_bwd(const float* out, const float* grad_out, float* grad_x, long long n,
+                             void* stream) {
+  if (!out || !grad_out || !grad_x || n < 1) return PCFA_ERR_INVALID_ARG;
+  if (!(al16(out) && al16(grad_out) && al16(grad_x))) return PCFA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, out, grad_out,
+                     grad_x, n);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }

@@ -308,13 +308,19 @@ def spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=1, stri
 # --------------------------------------------------------------------------- #
 # SepConvGRU gate arithmetic (models/raft/update.py:45-60)
 # --------------------------------------------------------------------------- #
+def _plane_channels(t):
+    return t.shape[-2] * t.shape[-1], t.shape[-3]
+
+
 class _GruGates(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, zc, rc, h):
-        _dev(zc, rc, h)
+    def forward(ctx, zc, rc, h, bias_z, bias_r):
+        _dev(zc, rc, h, bias_z, bias_r)
         zc, rc, h = zc.contiguous(), rc.contiguous(), h.contiguous()
         z, r, rh = torch.empty_like(zc), torch.empty_like(zc), torch.empty_like(zc)
-        _call("pcfa_gru_gates_fwd", _ptr(zc), _ptr(rc), _ptr(h), _ptr(z), _ptr(r), _ptr(rh), zc.numel())
+        plane, C = _plane_channels(zc)
+        _call("pcfa_gru_gates_fwd", _ptr(zc), _ptr(rc), _ptr(h), _ptr(bias_z), _ptr(bias_r), _ptr(z), _ptr(r),
+              _ptr(rh), zc.numel(), plane, C)
         ctx.save_for_backward(z, r, h)
         return z, rh
 
@@ -326,16 +332,18 @@ class _GruGates(torch.autograd.Function):
         dzc, drc, dh = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
         _call("pcfa_gru_gates_bwd", _ptr(z), _ptr(r), _ptr(h), _ptr(dz), _ptr(drh), _ptr(dzc), _ptr(drc), _ptr(dh),
               z.numel())
-        return dzc, drc, dh
+        return dzc, drc, dh, None, None
 
 
 class _GruUpdate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z, qc, h):
-        _dev(z, qc, h)
+    def forward(ctx, z, qc, h, bias_q):
+        _dev(z, qc, h, bias_q)
         z, qc, h = z.contiguous(), qc.contiguous(), h.contiguous()
         q, hnew = torch.empty_like(z), torch.empty_like(z)
-        _call("pcfa_gru_update_fwd", _ptr(z), _ptr(qc), _ptr(h), _ptr(q), _ptr(hnew), z.numel())
+        plane, C = _plane_channels(z)
+        _call("pcfa_gru_update_fwd", _ptr(z), _ptr(qc), _ptr(h), _ptr(bias_q), _ptr(q), _ptr(hnew), z.numel(),
+              plane, C)
         ctx.save_for_backward(z, q, h)
         return hnew
 
@@ -345,17 +353,42 @@ class _GruUpdate(torch.autograd.Function):
         g = g.contiguous()
         dz, dqc, dh = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
         _call("pcfa_gru_update_bwd", _ptr(z), _ptr(q), _ptr(h), _ptr(g), _ptr(dz), _ptr(dqc), _ptr(dh), z.numel())
-        return dz, dqc, dh
+        return dz, dqc, dh, None
 
 
-def gru_gates(zc, rc, h):
-    """(z, r*h) with z = sigmoid(zc), r = sigmoid(rc)."""
-    return _GruGates.apply(zc, rc, h)
+class _BiasRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        _dev(x, bias)
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        plane, C = _plane_channels(x)
+        _call("pcfa_bias_relu_fwd", _ptr(x), _ptr(bias), _ptr(out), x.numel(), plane, C)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(out)
+        _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gx), out.numel())
+        return gx, None
 
 
-def gru_update(z, qc, h):
-    """(1 - z) * h + z * tanh(qc)."""
-    return _GruUpdate.apply(z, qc, h)
+def gru_gates(zc, rc, h, bias_z=None, bias_r=None):
+    """(z, r*h) with z = sigmoid(zc + bias_z), r = sigmoid(rc + bias_r); biases are frozen parameters."""
+    return _GruGates.apply(zc, rc, h, bias_z, bias_r)
+
+
+def gru_update(z, qc, h, bias_q=None):
+    """(1 - z) * h + z * tanh(qc + bias_q)."""
+    return _GruUpdate.apply(z, qc, h, bias_q)
+
+
+def bias_relu(x, bias=None):
+    """relu(x + bias[None, :, None, None]) for a frozen bias (conv -> +bias -> ReLU in one pass)."""
+    return _BiasRelu.apply(x, bias)
 
 
 # --------------------------------------------------------------------------- #

@@ -99,6 +99,16 @@ class BasicEncoder(nn.Module):
         return x
 
 
+def _conv_nobias(conv, x):
+    """conv(x) without its bias: the bias add is folded into the fused HIP kernel that consumes the result."""
+    return conv._conv_forward(x, conv.weight, None)
+
+
+def _conv_relu(conv, x):
+    """relu(conv(x)): convolution on MIOpen, bias + ReLU in one fused pass."""
+    return ops.get().bias_relu(_conv_nobias(conv, x), conv.bias)
+
+
 class FlowHead(nn.Module):
     def __init__(self, input_dim=128, hidden_dim=256):
         super().__init__()
@@ -107,7 +117,7 @@ class FlowHead(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return self.conv2(self.relu(self.conv1(x)))
+        return self.conv2(_conv_relu(self.conv1, x))
 
 
 class SepConvGRU(nn.Module):
@@ -129,8 +139,8 @@ class SepConvGRU(nn.Module):
         # -- the elementwise part runs as two fused HIP kernels (pcfa_amd/csrc/gru_math.hip)
         o = ops.get()
         hx = torch.cat([h, x], dim=1)
-        z, rh = o.gru_gates(convz(hx), convr(hx), h)
-        return o.gru_update(z, convq(torch.cat([rh, x], dim=1)), h)
+        z, rh = o.gru_gates(_conv_nobias(convz, hx), _conv_nobias(convr, hx), h, convz.bias, convr.bias)
+        return o.gru_update(z, _conv_nobias(convq, torch.cat([rh, x], dim=1)), h, convq.bias)
 
     def forward(self, h, x):
         h = self._half(h, x, self.convz1, self.convr1, self.convq1)
@@ -148,9 +158,9 @@ class BasicMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
     def forward(self, flow, corr):
-        cor = F.relu(self.convc2(F.relu(self.convc1(corr))))
-        flo = F.relu(self.convf2(F.relu(self.convf1(flow))))
-        out = F.relu(self.conv(torch.cat([cor, flo], dim=1)))
+        cor = _conv_relu(self.convc2, _conv_relu(self.convc1, corr))
+        flo = _conv_relu(self.convf2, _conv_relu(self.convf1, flow))
+        out = _conv_relu(self.conv, torch.cat([cor, flo], dim=1))
         return torch.cat([out, flow], dim=1)
 
 

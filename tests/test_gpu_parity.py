@@ -228,17 +228,28 @@ def test_gru_gate_kernels_vs_oracle(oracle_ops):
         zc, rc, qc = (2 * torch.randn(shape, generator=gen) for _ in range(3))
         h = torch.tanh(torch.randn(shape, generator=gen))
         lv = [t_.clone().requires_grad_(True) for t_ in (zc, rc, qc, h)]
-        z, rh = oracle_ops.gru_gates(lv[0], lv[1], lv[3])
-        want = oracle_ops.gru_update(z, lv[2] + rh, lv[3])          # rh enters q's pre-activation like convq would
+        C = shape[1]
+        bz, br, bq = (torch.randn(C, generator=gen) for _ in range(3))
+        z, rh = oracle_ops.gru_gates(lv[0], lv[1], lv[3], bz, br)
+        want = oracle_ops.gru_update(z, lv[2] + rh, lv[3], bq)      # rh enters q's pre-activation like convq would
         go = torch.randn(shape, generator=gen)
         want.backward(go)
         gv = [t_.clone().to(DEV).requires_grad_(True) for t_ in (zc, rc, qc, h)]
-        zg, rhg = hip_ops.gru_gates(gv[0], gv[1], gv[3])
-        got = hip_ops.gru_update(zg, gv[2] + rhg, gv[3])
+        zg, rhg = hip_ops.gru_gates(gv[0], gv[1], gv[3], bz.to(DEV), br.to(DEV))
+        got = hip_ops.gru_update(zg, gv[2] + rhg, gv[3], bq.to(DEV))
         assert max_abs(got, want) <= 2e-6
         got.backward(go.to(DEV))
         for a, b in zip(gv, lv):
             assert rel_l2(a.grad, b.grad) < 2e-6
+        # conv -> +bias -> ReLU tail
+        x = torch.randn(shape, generator=gen).requires_grad_(True)
+        wantr = oracle_ops.bias_relu(x, bz)
+        wantr.backward(go)
+        xg = x.detach().to(DEV).requires_grad_(True)
+        gotr = hip_ops.bias_relu(xg, bz.to(DEV))
+        assert max_abs(gotr, wantr) == 0.0
+        gotr.backward(go.to(DEV))
+        assert max_abs(xg.grad, x.grad) == 0.0
 
 
 def test_box_transform_vs_oracle(oracle_ops):
