@@ -185,7 +185,12 @@ def cpu_baseline(net, h, w, nclosures, threads=0):
             times.append(time.perf_counter() - t0)
     t_c = sum(times[1:]) / max(len(times) - 1, 1) if len(times) > 1 else times[0]  # first one warms up
     step_s = 10 * t_c + t_fwd
-    return {"value": 1.0 / step_s, "unit": "attack_steps/s", "cores": cores, "kind": "port",
+    model_name = "?"
+    try:
+        model_name = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return {"value": 1.0 / step_s, "unit": "attack_steps/s", "cores": cores, "kind": "port", "cpu": model_name,
             "host_cores_available": os.cpu_count(), "closure_s": t_c, "forward_s": t_fwd,
             "sample": "%d closure evals + 1 forward of %s %dx%d on %d host threads, extrapolated to the "
                       "10 closures + 1 forward of one step" % (nclosures, net, h, w, cores)}

@@ -77,6 +77,25 @@ def test_corr_block_vs_oracle(oracle_ops, shape):
     assert rel_l2(f2g.grad, f2c.grad) < 2e-5
 
 
+@pytest.mark.parametrize("levels,radius", [(4, 3), (3, 2), (2, 1), (1, 4)])
+def test_corr_block_other_radii_and_levels(oracle_ops, levels, radius):
+    """The kernels are instantiated for radius 1..4 and any level count <= 8 (RAFT-small uses r = 3)."""
+    B, D, H, W = 1, 48, 18, 27
+    gen = torch.Generator().manual_seed(levels * 10 + radius)
+    f1c = torch.randn(B, D, H, W, generator=gen).requires_grad_(True)
+    f2c = torch.randn(B, D, H, W, generator=gen).requires_grad_(True)
+    coords = _grid(B, H, W) + 2.0 * torch.randn(B, 2, H, W, generator=gen)
+    want = oracle_ops.CorrBlock(f1c, f2c, num_levels=levels, radius=radius)(coords)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    f1g, f2g = f1c.detach().to(DEV).requires_grad_(True), f2c.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.CorrBlock(f1g, f2g, num_levels=levels, radius=radius)(coords.to(DEV))
+    assert got.shape == want.shape == (B, levels * (2 * radius + 1) ** 2, H, W)
+    assert max_abs(got, want) <= 3e-5 * float(want.abs().max())
+    got.backward(go.to(DEV))
+    assert rel_l2(f1g.grad, f1c.grad) < 2e-5 and rel_l2(f2g.grad, f2c.grad) < 2e-5
+
+
 def test_lookup_given_same_pyramid_is_tight(oracle_ops):
     """Feed the ORACLE's pyramid into the HIP lookup: isolates the lookup kernel from the GEMM."""
     from pcfa_amd import _hip

@@ -4,16 +4,25 @@ small enough to commit under profiles/.  Usage: summarize_rocprof.py <kernel_sta
 import csv
 import sys
 
-OURS = ("corr_lookup", "gemm_f32_mfma", "f2ext", "splitk_reduce", "scorr_", "loss_", "box_", "deltas_")
+OURS = ("corr_lookup", "gemm_f32_mfma", "f2ext", "splitk_reduce", "scorr_", "loss_", "box_", "deltas_", "gru_", "bias_relu", "relu_bwd", "null_kernel")
 
 
 def main():
     path = sys.argv[1]
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     rows = list(csv.DictReader(open(path)))
+    raw = sum(float(r["TotalDurationNs"]) for r in rows)
+    # MIOpen runs a slow generic kernel the FIRST time it meets a convolution configuration (immediate-mode
+    # fallback while the tuned kernel is built); those one-off launches of the warm-up step are listed separately
+    # and excluded from the percentages so that the table describes the steady state.
+    naive = [r for r in rows if "naive_conv" in r["Name"]]
+    rows = [r for r in rows if "naive_conv" not in r["Name"]]
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    for r in rows:
+        r["Percentage"] = "%.4f" % (100.0 * float(r["TotalDurationNs"]) / max(tot, 1))
     print("# source: %s" % path)
-    print("# kernels: %d   total device time: %.3f ms" % (len(rows), tot / 1e6))
+    print("# kernels: %d   device time: %.3f ms steady state + %.3f ms in %d MIOpen first-call fallback launches"
+          % (len(rows), tot / 1e6, (raw - tot) / 1e6, sum(int(r["Calls"]) for r in naive)))
     fmt = "%-72s %8s %12s %12s %12s %12s %7s"
     print(fmt % ("name", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct"))
 

@@ -25,9 +25,19 @@ def main():
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    t_end = rows[-1][1]
-    t0 = t_end - int(window * 1e9)
-    sel = [r for r in rows if r[0] >= t0]
+    # the busiest `window` seconds of the run = the timed steps (the tail of a bench.py run is the CPU baseline)
+    w_ns = int(window * 1e9)
+    starts = [r[0] for r in rows]
+    import bisect
+    best, best_t0 = -1, rows[0][0]
+    t = rows[0][0]
+    while t + w_ns <= rows[-1][1]:
+        i, j = bisect.bisect_left(starts, t), bisect.bisect_left(starts, t + w_ns)
+        busy_t = sum(e - s for s, e, _ in rows[i:j])
+        if busy_t > best:
+            best, best_t0 = busy_t, t
+        t += w_ns // 4
+    sel = [r for r in rows if best_t0 <= r[0] < best_t0 + w_ns]
     busy = sum(e - s for s, e, _ in sel)
     span = sel[-1][1] - sel[0][0]
     gaps = [sel[i + 1][0] - sel[i][1] for i in range(len(sel) - 1)]
