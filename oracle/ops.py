@@ -208,6 +208,14 @@ def gru_gates(zc, rc, h, bias_z=None, bias_r=None):
     return torch.sigmoid(zc + _cb(bias_z)), torch.sigmoid(rc + _cb(bias_r)) * h
 
 
+def gru_gates_packed(zr, h, bias_zr=None):
+    """gru_gates on the stacked pre-activations [zc | rc] of one convolution with weights [Wz; Wr]."""
+    c = zr.shape[1] // 2
+    bz = None if bias_zr is None else bias_zr[:c]
+    br = None if bias_zr is None else bias_zr[c:]
+    return gru_gates(zr[:, :c], zr[:, c:], h, bz, br)
+
+
 def gru_update(z, qc, h, bias_q=None):
     """models/raft/update.py:49-50 / :57-58 -- q = tanh(convq(.)); h = (1-z) * h + z * q."""
     q = torch.tanh(qc + _cb(bias_q))

@@ -39,6 +39,10 @@ def _ptr(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+def _ptr_off(t, offset_floats):
+    return ctypes.c_void_p(t.data_ptr() + 4 * offset_floats)
+
+
 def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
@@ -374,6 +378,49 @@ class _BiasRelu(torch.autograd.Function):
         gx = torch.empty_like(out)
         _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gx), out.numel())
         return gx, None
+
+
+class _GruGatesPacked(torch.autograd.Function):
+    """Same arithmetic as _GruGates on ONE convolution output zr = [zc | rc] (channels 0..C-1 and C..2C-1):
+    the z and r gate convolutions share their input, so they run as a single convolution with stacked weights;
+    the halves are addressed in place (no slicing copies) and the gradient comes back packed as well."""
+
+    @staticmethod
+    def forward(ctx, zr, h, bias_zr):
+        _dev(zr, h, bias_zr)
+        zr, h = zr.contiguous(), h.contiguous()
+        B, C2, H, W = zr.shape
+        C, plane = C2 // 2, H * W
+        z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        bz = None if bias_zr is None else bias_zr[:C]
+        br = None if bias_zr is None else bias_zr[C:]
+        n = C * plane
+        for b in range(B):  # per batch item the two halves of zr are contiguous blocks
+            o, oz = b * n, b * 2 * n
+            _call("pcfa_gru_gates_fwd", _ptr_off(zr, oz), _ptr_off(zr, oz + n), _ptr_off(h, o), _ptr(bz), _ptr(br),
+                  _ptr_off(z, o), _ptr_off(r, o), _ptr_off(rh, o), n, plane, C)
+        ctx.save_for_backward(z, r, h)
+        return z, rh
+
+    @staticmethod
+    def backward(ctx, dz, drh):
+        z, r, h = ctx.saved_tensors
+        B, C, H, W = z.shape
+        n = C * H * W
+        dz = torch.zeros_like(z) if dz is None else dz.contiguous()
+        drh = torch.zeros_like(z) if drh is None else drh.contiguous()
+        dzr = torch.empty((B, 2 * C, H, W), device=z.device, dtype=torch.float32)
+        dh = torch.empty_like(z)
+        for b in range(B):
+            o, oz = b * n, b * 2 * n
+            _call("pcfa_gru_gates_bwd", _ptr_off(z, o), _ptr_off(r, o), _ptr_off(h, o), _ptr_off(dz, o),
+                  _ptr_off(drh, o), _ptr_off(dzr, oz), _ptr_off(dzr, oz + n), _ptr_off(dh, o), n)
+        return dzr, dh, None
+
+
+def gru_gates_packed(zr, h, bias_zr=None):
+    """(z, r*h) from the stacked gate pre-activations zr = conv_{[Wz;Wr]}(hx) of shape [B, 2C, H, W]."""
+    return _GruGatesPacked.apply(zr, h, bias_zr)
 
 
 def gru_gates(zc, rc, h, bias_z=None, bias_r=None):

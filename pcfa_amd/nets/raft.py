@@ -132,14 +132,33 @@ class SepConvGRU(nn.Module):
         self.convz2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
         self.convr2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
         self.convq2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self._zr_cache = {}
 
-    @staticmethod
-    def _half(h, x, convz, convr, convq):
+    def _stacked(self, convz, convr):
+        """[Wz; Wr] and [bz; br]: the z and r gates read the same input, so they run as ONE convolution with 2C
+        output channels (one im2col/GEMM instead of two, forward and backward).  Cached while the (frozen)
+        parameters are unchanged."""
+        key = (convz.weight.data_ptr(), convz.weight._version, convr.weight.data_ptr(), convr.weight._version,
+               convz.weight.device)
+        hit = self._zr_cache.get(id(convz))
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w = torch.cat([convz.weight, convr.weight], dim=0).contiguous()
+                b = torch.cat([convz.bias, convr.bias], dim=0).contiguous()
+            hit = (key, w, b)
+            self._zr_cache[id(convz)] = hit
+        return hit[1], hit[2]
+
+    def _half(self, h, x, convz, convr, convq):
         # z = sigmoid(convz(hx)); r = sigmoid(convr(hx)); q = tanh(convq([r*h, x])); h' = (1-z)*h + z*q
-        # -- the elementwise part runs as two fused HIP kernels (pcfa_amd/csrc/gru_math.hip)
+        # -- convolutions on MIOpen (z and r stacked), everything elementwise in two fused HIP kernels
         o = ops.get()
         hx = torch.cat([h, x], dim=1)
-        z, rh = o.gru_gates(_conv_nobias(convz, hx), _conv_nobias(convr, hx), h, convz.bias, convr.bias)
+        if convz.weight.requires_grad or convr.weight.requires_grad:  # training: keep the parameters separate
+            z, rh = o.gru_gates(_conv_nobias(convz, hx), _conv_nobias(convr, hx), h, convz.bias, convr.bias)
+        else:
+            w_zr, b_zr = self._stacked(convz, convr)
+            z, rh = o.gru_gates_packed(convz._conv_forward(hx, w_zr, None), h, b_zr)
         return o.gru_update(z, _conv_nobias(convq, torch.cat([rh, x], dim=1)), h, convq.bias)
 
     def forward(self, h, x):
