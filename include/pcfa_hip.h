@@ -199,15 +199,19 @@ PCFA_API int pcfa_flow_loss_bwd(const float* pred, const long long pred_strides[
  *   update: q = tanh(qc), hnew = (1 - z) * h + z * q                (qc = convq(cat[rh, x]))
  * and their backward passes.  All arrays have n floats (NCHW, plane = H*W, `channels` channels) and must be
  * 16-byte aligned.  zc/rc/qc are the convolution outputs WITHOUT bias; bias_z/r/q ([channels], may be NULL) are
- * added here, which saves the separate bias-add launch torch would issue per convolution.
+ * added here, which saves the separate bias-add launch torch would issue per convolution.  add_z/r/q (n floats,
+ * may be NULL) are added to the pre-activations as well: the gate convolutions are linear in their input
+ * [h | inp | motion], and `inp` does not change over the refinement iterations, so its contribution
+ * conv(inp, W[:, inp-slice]) is computed once per forward and enters every iteration through these pointers.
  * ------------------------------------------------------------------------- */
 PCFA_API int pcfa_gru_gates_fwd(const float* zc, const float* rc, const float* h, const float* bias_z,
-                       const float* bias_r, float* z, float* r, float* rh, long long n, int plane, int channels,
-                       void* stream);
+                       const float* bias_r, const float* add_z, const float* add_r, float* z, float* r,
+                       float* rh, long long n, int plane, int channels, void* stream);
 PCFA_API int pcfa_gru_gates_bwd(const float* z, const float* r, const float* h, const float* dz, const float* drh,
                        float* dzc, float* drc, float* dh, long long n, void* stream);
-PCFA_API int pcfa_gru_update_fwd(const float* z, const float* qc, const float* h, const float* bias_q, float* q,
-                        float* hnew, long long n, int plane, int channels, void* stream);
+PCFA_API int pcfa_gru_update_fwd(const float* z, const float* qc, const float* h, const float* bias_q,
+                        const float* add_q, float* q, float* hnew, long long n, int plane, int channels,
+                        void* stream);
 PCFA_API int pcfa_gru_update_bwd(const float* z, const float* q, const float* h, const float* g, float* dz,
                         float* dqc, float* dh, long long n, void* stream);
 

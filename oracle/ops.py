@@ -202,23 +202,30 @@ def _cb(bias):
     return 0 if bias is None else bias.view(1, -1, 1, 1)
 
 
-def gru_gates(zc, rc, h, bias_z=None, bias_r=None):
+def _opt(t):
+    return 0 if t is None else t
+
+
+def gru_gates(zc, rc, h, bias_z=None, bias_r=None, add_z=None, add_r=None):
     """models/raft/update.py:47-49 / :54-56 -- z = sigmoid(convz(hx)), r = sigmoid(convr(hx)); returns (z, r*h).
-    zc / rc are the convolutions without their bias, which is added here (conv(x) + b == conv_with_bias(x))."""
-    return torch.sigmoid(zc + _cb(bias_z)), torch.sigmoid(rc + _cb(bias_r)) * h
+    The convolution is linear in hx = [h | inp | motion]: zc / rc carry the part that changes per iteration,
+    add_z / add_r the part of the constant context features, bias_z / bias_r the bias."""
+    return torch.sigmoid(zc + _opt(add_z) + _cb(bias_z)), torch.sigmoid(rc + _opt(add_r) + _cb(bias_r)) * h
 
 
-def gru_gates_packed(zr, h, bias_zr=None):
+def gru_gates_packed(zr, h, bias_zr=None, add_zr=None):
     """gru_gates on the stacked pre-activations [zc | rc] of one convolution with weights [Wz; Wr]."""
     c = zr.shape[1] // 2
     bz = None if bias_zr is None else bias_zr[:c]
     br = None if bias_zr is None else bias_zr[c:]
-    return gru_gates(zr[:, :c], zr[:, c:], h, bz, br)
+    az = None if add_zr is None else add_zr[:, :c]
+    ar = None if add_zr is None else add_zr[:, c:]
+    return gru_gates(zr[:, :c], zr[:, c:], h, bz, br, az, ar)
 
 
-def gru_update(z, qc, h, bias_q=None):
+def gru_update(z, qc, h, bias_q=None, add_q=None):
     """models/raft/update.py:49-50 / :57-58 -- q = tanh(convq(.)); h = (1-z) * h + z * q."""
-    q = torch.tanh(qc + _cb(bias_q))
+    q = torch.tanh(qc + _opt(add_q) + _cb(bias_q))
     return (1 - z) * h + z * q
 
 

@@ -50,9 +50,9 @@ SIGNATURES = {
                                    c_float, c_float, c_int, _P, _P, _P]),
     "pcfa_flow_loss_bwd": (c_int, [_P, _S4, _P, _S4, c_int, c_int, c_int, _P, c_longlong, _P, c_longlong,
                                    c_float, c_int, c_int, _P, _P, _P, _P, _P, _P]),
-    "pcfa_gru_gates_fwd": (c_int, [_P] * 8 + [c_longlong, c_int, c_int, _P]),
+    "pcfa_gru_gates_fwd": (c_int, [_P] * 10 + [c_longlong, c_int, c_int, _P]),
     "pcfa_gru_gates_bwd": (c_int, [_P] * 8 + [c_longlong, _P]),
-    "pcfa_gru_update_fwd": (c_int, [_P] * 6 + [c_longlong, c_int, c_int, _P]),
+    "pcfa_gru_update_fwd": (c_int, [_P] * 7 + [c_longlong, c_int, c_int, _P]),
     "pcfa_gru_update_bwd": (c_int, [_P] * 7 + [c_longlong, _P]),
     "pcfa_bias_relu_fwd": (c_int, [_P, _P, _P, c_longlong, c_int, c_int, _P]),
     "pcfa_relu_bwd": (c_int, [_P, _P, _P, c_longlong, _P]),

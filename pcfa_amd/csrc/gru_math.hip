@@ -31,14 +31,23 @@ __device__ __forceinline__ float bias_at(const float* __restrict__ b, long long 
   return b ? b[(e / plane) % C] : 0.f;
 }
 
+__device__ __forceinline__ float4 add4(float4 a, const float* __restrict__ p, long long i) {
+  if (p) {
+    const float4 b = LD4(p, i);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  return a;
+}
+
 __global__ void gru_gates_fwd_kernel(const float* __restrict__ zc, const float* __restrict__ rc,
                                      const float* __restrict__ h, const float* __restrict__ bz,
-                                     const float* __restrict__ br, float* __restrict__ z,
+                                     const float* __restrict__ br, const float* __restrict__ az,
+                                     const float* __restrict__ ar, float* __restrict__ z,
                                      float* __restrict__ r, float* __restrict__ rh, long long n,
                                      int plane, int C) {
   for_each4(n, [&](long long i, bool vec) {
     if (vec) {
-      const float4 a = LD4(zc, i), b = LD4(rc, i), hh = LD4(h, i);
+      const float4 a = add4(LD4(zc, i), az, i), b = add4(LD4(rc, i), ar, i), hh = LD4(h, i);
       const long long e = i << 2;
       float4 zz, rr, o;
       zz.x = sigmoidf_(a.x + bias_at(bz, e, plane, C)); zz.y = sigmoidf_(a.y + bias_at(bz, e + 1, plane, C));
@@ -48,7 +57,8 @@ __global__ void gru_gates_fwd_kernel(const float* __restrict__ zc, const float* 
       o.x = rr.x * hh.x; o.y = rr.y * hh.y; o.z = rr.z * hh.z; o.w = rr.w * hh.w;
       ST4(z, i, zz); ST4(r, i, rr); ST4(rh, i, o);
     } else {
-      const float zz = sigmoidf_(zc[i] + bias_at(bz, i, plane, C)), rr = sigmoidf_(rc[i] + bias_at(br, i, plane, C));
+      const float zz = sigmoidf_(zc[i] + (az ? az[i] : 0.f) + bias_at(bz, i, plane, C));
+      const float rr = sigmoidf_(rc[i] + (ar ? ar[i] : 0.f) + bias_at(br, i, plane, C));
       z[i] = zz; r[i] = rr; rh[i] = rr * h[i];
     }
   });
@@ -82,11 +92,11 @@ __global__ void gru_gates_bwd_kernel(const float* __restrict__ z, const float* _
 
 __global__ void gru_update_fwd_kernel(const float* __restrict__ z, const float* __restrict__ qc,
                                       const float* __restrict__ h, const float* __restrict__ bq,
-                                      float* __restrict__ q, float* __restrict__ hnew, long long n,
-                                      int plane, int C) {
+                                      const float* __restrict__ aq, float* __restrict__ q,
+                                      float* __restrict__ hnew, long long n, int plane, int C) {
   for_each4(n, [&](long long i, bool vec) {
     if (vec) {
-      const float4 zz = LD4(z, i), c = LD4(qc, i), hh = LD4(h, i);
+      const float4 zz = LD4(z, i), c = add4(LD4(qc, i), aq, i), hh = LD4(h, i);
       const long long e = i << 2;
       float4 qq, o;
       qq.x = tanhf(c.x + bias_at(bq, e, plane, C)); qq.y = tanhf(c.y + bias_at(bq, e + 1, plane, C));
@@ -97,7 +107,7 @@ __global__ void gru_update_fwd_kernel(const float* __restrict__ z, const float* 
       o.w = (1.f - zz.w) * hh.w + zz.w * qq.w;
       ST4(q, i, qq); ST4(hnew, i, o);
     } else {
-      const float qq = tanhf(qc[i] + bias_at(bq, i, plane, C));
+      const float qq = tanhf(qc[i] + (aq ? aq[i] : 0.f) + bias_at(bq, i, plane, C));
       q[i] = qq;
       hnew[i] = (1.f - z[i]) * h[i] + z[i] * qq;
     }
@@ -173,12 +183,14 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 }  // namespace
 
 extern "C" int pcfa_gru_gates_fwd(const float* zc, const float* rc, const float* h, const float* bias_z,
-                                  const float* bias_r, float* z, float* r, float* rh, long long n,
-                                  int plane, int channels, void* stream) {
+                                  const float* bias_r, const float* add_z, const float* add_r, float* z,
+                                  float* r, float* rh, long long n, int plane, int channels,
+                                  void* stream) {
   if (!zc || !rc || !h || !z || !r || !rh || n < 1 || plane < 1 || channels < 1) return PCFA_ERR_INVALID_ARG;
-  if (!(al16(zc) && al16(rc) && al16(h) && al16(z) && al16(r) && al16(rh))) return PCFA_ERR_UNSUPPORTED;
+  if (!(al16(zc) && al16(rc) && al16(h) && al16(z) && al16(r) && al16(rh) && al16(add_z) && al16(add_r)))
+    return PCFA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, zc,
-                     rc, h, bias_z, bias_r, z, r, rh, n, plane, channels);
+                     rc, h, bias_z, bias_r, add_z, add_r, z, r, rh, n, plane, channels);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -196,12 +208,12 @@ extern "C" int pcfa_gru_gates_bwd(const float* z, const float* r, const float* h
 }
 
 extern "C" int pcfa_gru_update_fwd(const float* z, const float* qc, const float* h, const float* bias_q,
-                                   float* q, float* hnew, long long n, int plane, int channels,
-                                   void* stream) {
+                                   const float* add_q, float* q, float* hnew, long long n, int plane,
+                                   int channels, void* stream) {
   if (!z || !qc || !h || !q || !hnew || n < 1 || plane < 1 || channels < 1) return PCFA_ERR_INVALID_ARG;
-  if (!(al16(z) && al16(qc) && al16(h) && al16(q) && al16(hnew))) return PCFA_ERR_UNSUPPORTED;
+  if (!(al16(z) && al16(qc) && al16(h) && al16(q) && al16(hnew) && al16(add_q))) return PCFA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gru_update_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, qc,
-                     h, bias_q, q, hnew, n, plane, channels);
+                     h, bias_q, add_q, q, hnew, n, plane, channels);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }

@@ -40,7 +40,7 @@ def _ptr(t):
 
 
 def _ptr_off(t, offset_floats):
-    return ctypes.c_void_p(t.data_ptr() + 4 * offset_floats)
+    return ctypes.c_void_p(0 if t is None else t.data_ptr() + 4 * offset_floats)
 
 
 def _pair(v):
@@ -318,14 +318,17 @@ def _plane_channels(t):
 
 class _GruGates(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, zc, rc, h, bias_z, bias_r):
-        _dev(zc, rc, h, bias_z, bias_r)
+    def forward(ctx, zc, rc, h, bias_z, bias_r, add_z, add_r):
+        _dev(zc, rc, h, bias_z, bias_r, add_z, add_r)
         zc, rc, h = zc.contiguous(), rc.contiguous(), h.contiguous()
+        az = None if add_z is None else add_z.contiguous()
+        ar = None if add_r is None else add_r.contiguous()
         z, r, rh = torch.empty_like(zc), torch.empty_like(zc), torch.empty_like(zc)
         plane, C = _plane_channels(zc)
-        _call("pcfa_gru_gates_fwd", _ptr(zc), _ptr(rc), _ptr(h), _ptr(bias_z), _ptr(bias_r), _ptr(z), _ptr(r),
-              _ptr(rh), zc.numel(), plane, C)
+        _call("pcfa_gru_gates_fwd", _ptr(zc), _ptr(rc), _ptr(h), _ptr(bias_z), _ptr(bias_r), _ptr(az), _ptr(ar),
+              _ptr(z), _ptr(r), _ptr(rh), zc.numel(), plane, C)
         ctx.save_for_backward(z, r, h)
+        ctx.has_add = (add_z is not None, add_r is not None)
         return z, rh
 
     @staticmethod
@@ -336,19 +339,63 @@ class _GruGates(torch.autograd.Function):
         dzc, drc, dh = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
         _call("pcfa_gru_gates_bwd", _ptr(z), _ptr(r), _ptr(h), _ptr(dz), _ptr(drh), _ptr(dzc), _ptr(drc), _ptr(dh),
               z.numel())
-        return dzc, drc, dh, None, None
+        # the addends enter the pre-activations with weight 1: their gradient IS the pre-activation gradient
+        return dzc, drc, dh, None, None, (dzc if ctx.has_add[0] else None), (drc if ctx.has_add[1] else None)
+
+
+class _GruGatesPacked(torch.autograd.Function):
+    """Same arithmetic as _GruGates on ONE convolution output zr = [zc | rc] (channels 0..C-1 and C..2C-1):
+    the z and r gate convolutions share their input, so they run as a single convolution with stacked weights;
+    the halves are addressed in place (no slicing copies) and the gradient comes back packed as well."""
+
+    @staticmethod
+    def forward(ctx, zr, h, bias_zr, add_zr):
+        _dev(zr, h, bias_zr, add_zr)
+        zr, h = zr.contiguous(), h.contiguous()
+        add = None if add_zr is None else add_zr.contiguous()
+        B, C2, H, W = zr.shape
+        C, plane = C2 // 2, H * W
+        z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        bz = None if bias_zr is None else bias_zr[:C]
+        br = None if bias_zr is None else bias_zr[C:]
+        n = C * plane
+        for b in range(B):  # per batch item the two halves of zr are contiguous blocks
+            o, oz = b * n, b * 2 * n
+            _call("pcfa_gru_gates_fwd", _ptr_off(zr, oz), _ptr_off(zr, oz + n), _ptr_off(h, o), _ptr(bz), _ptr(br),
+                  _ptr_off(add, oz), _ptr_off(add, oz + n), _ptr_off(z, o), _ptr_off(r, o), _ptr_off(rh, o), n,
+                  plane, C)
+        ctx.save_for_backward(z, r, h)
+        ctx.has_add = add_zr is not None
+        return z, rh
+
+    @staticmethod
+    def backward(ctx, dz, drh):
+        z, r, h = ctx.saved_tensors
+        B, C, H, W = z.shape
+        n = C * H * W
+        dz = torch.zeros_like(z) if dz is None else dz.contiguous()
+        drh = torch.zeros_like(z) if drh is None else drh.contiguous()
+        dzr = torch.empty((B, 2 * C, H, W), device=z.device, dtype=torch.float32)
+        dh = torch.empty_like(z)
+        for b in range(B):
+            o, oz = b * n, b * 2 * n
+            _call("pcfa_gru_gates_bwd", _ptr_off(z, o), _ptr_off(r, o), _ptr_off(h, o), _ptr_off(dz, o),
+                  _ptr_off(drh, o), _ptr_off(dzr, oz), _ptr_off(dzr, oz + n), _ptr_off(dh, o), n)
+        return dzr, dh, None, (dzr if ctx.has_add else None)
 
 
 class _GruUpdate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z, qc, h, bias_q):
-        _dev(z, qc, h, bias_q)
+    def forward(ctx, z, qc, h, bias_q, add_q):
+        _dev(z, qc, h, bias_q, add_q)
         z, qc, h = z.contiguous(), qc.contiguous(), h.contiguous()
+        aq = None if add_q is None else add_q.contiguous()
         q, hnew = torch.empty_like(z), torch.empty_like(z)
         plane, C = _plane_channels(z)
-        _call("pcfa_gru_update_fwd", _ptr(z), _ptr(qc), _ptr(h), _ptr(bias_q), _ptr(q), _ptr(hnew), z.numel(),
-              plane, C)
+        _call("pcfa_gru_update_fwd", _ptr(z), _ptr(qc), _ptr(h), _ptr(bias_q), _ptr(aq), _ptr(q), _ptr(hnew),
+              z.numel(), plane, C)
         ctx.save_for_backward(z, q, h)
+        ctx.has_add = add_q is not None
         return hnew
 
     @staticmethod
@@ -357,7 +404,7 @@ class _GruUpdate(torch.autograd.Function):
         g = g.contiguous()
         dz, dqc, dh = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
         _call("pcfa_gru_update_bwd", _ptr(z), _ptr(q), _ptr(h), _ptr(g), _ptr(dz), _ptr(dqc), _ptr(dh), z.numel())
-        return dz, dqc, dh, None
+        return dz, dqc, dh, None, (dqc if ctx.has_add else None)
 
 
 class _BiasRelu(torch.autograd.Function):
@@ -380,57 +427,19 @@ class _BiasRelu(torch.autograd.Function):
         return gx, None
 
 
-class _GruGatesPacked(torch.autograd.Function):
-    """Same arithmetic as _GruGates on ONE convolution output zr = [zc | rc] (channels 0..C-1 and C..2C-1):
-    the z and r gate convolutions share their input, so they run as a single convolution with stacked weights;
-    the halves are addressed in place (no slicing copies) and the gradient comes back packed as well."""
-
-    @staticmethod
-    def forward(ctx, zr, h, bias_zr):
-        _dev(zr, h, bias_zr)
-        zr, h = zr.contiguous(), h.contiguous()
-        B, C2, H, W = zr.shape
-        C, plane = C2 // 2, H * W
-        z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
-        bz = None if bias_zr is None else bias_zr[:C]
-        br = None if bias_zr is None else bias_zr[C:]
-        n = C * plane
-        for b in range(B):  # per batch item the two halves of zr are contiguous blocks
-            o, oz = b * n, b * 2 * n
-            _call("pcfa_gru_gates_fwd", _ptr_off(zr, oz), _ptr_off(zr, oz + n), _ptr_off(h, o), _ptr(bz), _ptr(br),
-                  _ptr_off(z, o), _ptr_off(r, o), _ptr_off(rh, o), n, plane, C)
-        ctx.save_for_backward(z, r, h)
-        return z, rh
-
-    @staticmethod
-    def backward(ctx, dz, drh):
-        z, r, h = ctx.saved_tensors
-        B, C, H, W = z.shape
-        n = C * H * W
-        dz = torch.zeros_like(z) if dz is None else dz.contiguous()
-        drh = torch.zeros_like(z) if drh is None else drh.contiguous()
-        dzr = torch.empty((B, 2 * C, H, W), device=z.device, dtype=torch.float32)
-        dh = torch.empty_like(z)
-        for b in range(B):
-            o, oz = b * n, b * 2 * n
-            _call("pcfa_gru_gates_bwd", _ptr_off(z, o), _ptr_off(r, o), _ptr_off(h, o), _ptr_off(dz, o),
-                  _ptr_off(drh, o), _ptr_off(dzr, oz), _ptr_off(dzr, oz + n), _ptr_off(dh, o), n)
-        return dzr, dh, None
+def gru_gates_packed(zr, h, bias_zr=None, add_zr=None):
+    """(z, r*h) from the stacked gate pre-activations zr (+ add_zr) = conv_{[Wz;Wr]}(.) of shape [B, 2C, H, W]."""
+    return _GruGatesPacked.apply(zr, h, bias_zr, add_zr)
 
 
-def gru_gates_packed(zr, h, bias_zr=None):
-    """(z, r*h) from the stacked gate pre-activations zr = conv_{[Wz;Wr]}(hx) of shape [B, 2C, H, W]."""
-    return _GruGatesPacked.apply(zr, h, bias_zr)
+def gru_gates(zc, rc, h, bias_z=None, bias_r=None, add_z=None, add_r=None):
+    """(z, r*h) with z = sigmoid(zc + add_z + bias_z), r = sigmoid(rc + add_r + bias_r); biases are frozen."""
+    return _GruGates.apply(zc, rc, h, bias_z, bias_r, add_z, add_r)
 
 
-def gru_gates(zc, rc, h, bias_z=None, bias_r=None):
-    """(z, r*h) with z = sigmoid(zc + bias_z), r = sigmoid(rc + bias_r); biases are frozen parameters."""
-    return _GruGates.apply(zc, rc, h, bias_z, bias_r)
-
-
-def gru_update(z, qc, h, bias_q=None):
-    """(1 - z) * h + z * tanh(qc + bias_q)."""
-    return _GruUpdate.apply(z, qc, h, bias_q)
+def gru_update(z, qc, h, bias_q=None, add_q=None):
+    """(1 - z) * h + z * tanh(qc + add_q + bias_q)."""
+    return _GruUpdate.apply(z, qc, h, bias_q, add_q)
 
 
 def bias_relu(x, bias=None):

@@ -95,10 +95,13 @@ class GMAUpdateBlock(nn.Module):
         self.mask = _mask_head()
         self.aggregator = Aggregate(args=args, dim=128, dim_head=128, heads=args.num_heads)
 
-    def forward(self, net, inp, corr, flow, attention, want_mask=True):
+    def forward(self, net, inp, corr, flow, attention, want_mask=True, gru_ctx=None):
         motion_features = self.encoder(flow, corr)
         motion_features_global = self.aggregator(attention, motion_features)
-        net = self.gru(net, torch.cat([inp, motion_features, motion_features_global], dim=1))
+        if gru_ctx is not None:
+            net = self.gru.step(net, gru_ctx, torch.cat([motion_features, motion_features_global], dim=1))
+        else:
+            net = self.gru(net, torch.cat([inp, motion_features, motion_features_global], dim=1))
         delta_flow = self.flow_head(net)
         mask = .25 * self.mask(net) if want_mask else None
         return net, mask, delta_flow
@@ -142,6 +145,8 @@ class RAFTGMA(nn.Module):
         if flow_init is not None:
             coords1 = coords1 + flow_init
 
+        gru = self.update_block.gru
+        gru_ctx = gru.precompute(inp) if gru.frozen() else None
         flow_predictions = []
         flow_up = None
         for itr in range(iters):
@@ -149,7 +154,8 @@ class RAFTGMA(nn.Module):
             corr = corr_fn(coords1)
             flow = coords1 - coords0
             need_up = (not test_mode) or itr == iters - 1
-            net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, attention, want_mask=need_up)
+            net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, attention, want_mask=need_up,
+                                                         gru_ctx=gru_ctx)
             coords1 = coords1 + delta_flow
             if need_up:
                 flow_up = convex_upsample(coords1 - coords0, up_mask)

@@ -121,49 +121,78 @@ class FlowHead(nn.Module):
 
 
 class SepConvGRU(nn.Module):
-    """Two GRU half-steps with 1x5 then 5x1 gates (update.py:33-60)."""
+    """Two GRU half-steps with 1x5 then 5x1 gates (update.py:33-60):
+        z = sigmoid(convz(hx)); r = sigmoid(convr(hx)); q = tanh(convq([r*h, x])); h' = (1-z)*h + z*q,   hx = [h, x].
 
-    def __init__(self, hidden_dim=128, input_dim=192 + 128):
+    Frozen-weight fast path (what the attack runs): the gate convolutions are linear in their input channels and
+    x = [inp | rest] starts with the context features `inp`, which do not change over the refinement
+    iterations.  `precompute(inp)` evaluates conv(inp, W[:, inp-slice]) + bias once per forward; every iteration
+    then only convolves [h | rest] (2/3 of the channels for RAFT) and the fused HIP gate kernels add the cached
+    part.  z and r share their input, so they run as one convolution with stacked weights.  Identical to the
+    reference in exact arithmetic; in fp32 it regroups the channel sum (covered by the closure parity tests).
+    """
+
+    def __init__(self, hidden_dim=128, input_dim=192 + 128, const_dim=128):
         super().__init__()
         c = hidden_dim + input_dim
+        self.hidden_dim, self.const_dim = hidden_dim, const_dim
         self.convz1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
         self.convr1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
         self.convq1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
         self.convz2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
         self.convr2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
         self.convq2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
-        self._zr_cache = {}
+        self._split_cache = {}
 
-    def _stacked(self, convz, convr):
-        """[Wz; Wr] and [bz; br]: the z and r gates read the same input, so they run as ONE convolution with 2C
-        output channels (one im2col/GEMM instead of two, forward and backward).  Cached while the (frozen)
-        parameters are unchanged."""
-        key = (convz.weight.data_ptr(), convz.weight._version, convr.weight.data_ptr(), convr.weight._version,
-               convz.weight.device)
-        hit = self._zr_cache.get(id(convz))
-        if hit is None or hit[0] != key:
-            with torch.no_grad():
-                w = torch.cat([convz.weight, convr.weight], dim=0).contiguous()
-                b = torch.cat([convz.bias, convr.bias], dim=0).contiguous()
-            hit = (key, w, b)
-            self._zr_cache[id(convz)] = hit
-        return hit[1], hit[2]
-
-    def _half(self, h, x, convz, convr, convq):
-        # z = sigmoid(convz(hx)); r = sigmoid(convr(hx)); q = tanh(convq([r*h, x])); h' = (1-z)*h + z*q
-        # -- convolutions on MIOpen (z and r stacked), everything elementwise in two fused HIP kernels
+    # ---- reference formulation (also used when the weights are being trained) ----------------
+    @staticmethod
+    def _half(h, x, convz, convr, convq):
         o = ops.get()
         hx = torch.cat([h, x], dim=1)
-        if convz.weight.requires_grad or convr.weight.requires_grad:  # training: keep the parameters separate
-            z, rh = o.gru_gates(_conv_nobias(convz, hx), _conv_nobias(convr, hx), h, convz.bias, convr.bias)
-        else:
-            w_zr, b_zr = self._stacked(convz, convr)
-            z, rh = o.gru_gates_packed(convz._conv_forward(hx, w_zr, None), h, b_zr)
+        z, rh = o.gru_gates(_conv_nobias(convz, hx), _conv_nobias(convr, hx), h, convz.bias, convr.bias)
         return o.gru_update(z, _conv_nobias(convq, torch.cat([rh, x], dim=1)), h, convq.bias)
 
     def forward(self, h, x):
         h = self._half(h, x, self.convz1, self.convr1, self.convq1)
         return self._half(h, x, self.convz2, self.convr2, self.convq2)
+
+    # ---- frozen-weight fast path -------------------------------------------------------------
+    def frozen(self):
+        return not any(p.requires_grad for p in self.parameters())
+
+    def _split(self, tag, convs):
+        """(W_dyn over [h | rest], W_const over inp, bias) for the output-stacked convolutions `convs`."""
+        key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs) + (convs[0].weight.device,)
+        hit = self._split_cache.get(tag)
+        if hit is None or hit[0] != key:
+            hd, cd = self.hidden_dim, self.const_dim
+            with torch.no_grad():
+                w = torch.cat([c.weight for c in convs], dim=0)
+                b = torch.cat([c.bias for c in convs], dim=0).contiguous()
+                w_dyn = torch.cat([w[:, :hd], w[:, hd + cd:]], dim=1).contiguous()
+                w_const = w[:, hd:hd + cd].contiguous()
+            hit = (key, w_dyn, w_const, b)
+            self._split_cache[tag] = hit
+        return hit[1:]
+
+    def precompute(self, inp):
+        """Per forward: the contribution of the constant context features to the six gate pre-activations."""
+        ctx = {}
+        for tag, convs in (("zr1", (self.convz1, self.convr1)), ("q1", (self.convq1,)),
+                           ("zr2", (self.convz2, self.convr2)), ("q2", (self.convq2,))):
+            w_dyn, w_const, b = self._split(tag, convs)
+            ctx[tag] = (w_dyn, convs[0]._conv_forward(inp, w_const, b))
+        return ctx
+
+    def step(self, h, ctx, rest):
+        """One GRU update given precompute()'s context; `rest` = the per-iteration part of x (motion features)."""
+        o = ops.get()
+        for zr, q, conv in (("zr1", "q1", self.convz1), ("zr2", "q2", self.convz2)):
+            w_zr, p_zr = ctx[zr]
+            w_q, p_q = ctx[q]
+            z, rh = o.gru_gates_packed(conv._conv_forward(torch.cat([h, rest], dim=1), w_zr, None), h, None, p_zr)
+            h = o.gru_update(z, conv._conv_forward(torch.cat([rh, rest], dim=1), w_q, None), h, None, p_q)
+        return h
 
 
 class BasicMotionEncoder(nn.Module):
@@ -195,9 +224,12 @@ class BasicUpdateBlock(nn.Module):
         self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
         self.mask = _mask_head()
 
-    def forward(self, net, inp, corr, flow, want_mask=True):
+    def forward(self, net, inp, corr, flow, want_mask=True, gru_ctx=None):
         motion_features = self.encoder(flow, corr)
-        net = self.gru(net, torch.cat([inp, motion_features], dim=1))
+        if gru_ctx is not None:   # frozen weights: context-feature part of the gate convolutions hoisted
+            net = self.gru.step(net, gru_ctx, motion_features)
+        else:
+            net = self.gru(net, torch.cat([inp, motion_features], dim=1))
         delta_flow = self.flow_head(net)
         mask = .25 * self.mask(net) if want_mask else None  # .25: "scale mask to balance gradients"
         return net, mask, delta_flow
@@ -256,6 +288,8 @@ class RAFT(nn.Module):
         if flow_init is not None:
             coords1 = coords1 + flow_init
 
+        gru = self.update_block.gru
+        gru_ctx = gru.precompute(inp) if gru.frozen() else None
         flow_predictions = []
         flow_up = None
         for itr in range(iters):
@@ -263,7 +297,7 @@ class RAFT(nn.Module):
             corr = corr_fn(coords1)
             flow = coords1 - coords0
             need_up = (not test_mode) or itr == iters - 1
-            net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, want_mask=need_up)
+            net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, want_mask=need_up, gru_ctx=gru_ctx)
             coords1 = coords1 + delta_flow
             if need_up:
                 flow_up = convex_upsample(coords1 - coords0, up_mask)

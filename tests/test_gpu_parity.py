@@ -260,6 +260,20 @@ def test_gru_gate_kernels_vs_oracle(oracle_ops):
         got.backward(go.to(DEV))
         for a, b in zip(gv, lv):
             assert rel_l2(a.grad, b.grad) < 2e-6
+        # stacked z|r pre-activations + the hoisted constant-input addends (SepConvGRU.step)
+        zr = torch.randn(shape[0], 2 * C, *shape[2:], generator=gen)
+        add_zr, add_q = torch.randn(zr.shape, generator=gen), torch.randn(shape, generator=gen)
+        cl = [t_.clone().requires_grad_(True) for t_ in (zr, add_zr, qc, add_q, h)]
+        zz, rhh = oracle_ops.gru_gates_packed(cl[0], cl[4], None, cl[1])
+        want2 = oracle_ops.gru_update(zz, cl[2] + rhh, cl[4], None, cl[3])
+        want2.backward(go)
+        gl = [t_.clone().to(DEV).requires_grad_(True) for t_ in (zr, add_zr, qc, add_q, h)]
+        zg2, rhg2 = hip_ops.gru_gates_packed(gl[0], gl[4], None, gl[1])
+        got2 = hip_ops.gru_update(zg2, gl[2] + rhg2, gl[4], None, gl[3])
+        assert max_abs(got2, want2) <= 2e-6
+        got2.backward(go.to(DEV))
+        for a, b in zip(gl, cl):
+            assert rel_l2(a.grad, b.grad) < 2e-6
         # conv -> +bias -> ReLU tail
         x = torch.randn(shape, generator=gen).requires_grad_(True)
         wantr = oracle_ops.bias_relu(x, bz)
