@@ -197,8 +197,8 @@ PCFA_API int pcfa_flow_loss_bwd(const float* pred, const long long pred_strides[
  * SepConvGRU gate arithmetic (models/raft/update.py:45-60 == models/gma/update.py:51-66), fused:
  *   gates : z = sigmoid(zc), r = sigmoid(rc), rh = r * h            (zc, rc = convz(hx), convr(hx))
  *   update: q = tanh(qc), hnew = (1 - z) * h + z * q                (qc = convq(cat[rh, x]))
- * and their backward passes.  All arrays have n floats (NCHW, plane = H*W, `channels` channels) and must be
- * 16-byte aligned.  zc/rc/qc are the convolution outputs WITHOUT bias; bias_z/r/q ([channels], may be NULL) are
+ * and their backward passes.  All arrays have n floats (NCHW, plane = H*W, `channels` channels) ; 16-byte aligned
+ * arrays take the vectorised path, anything else a scalar loop.  zc/rc/qc are the convolution outputs WITHOUT bias; bias_z/r/q ([channels], may be NULL) are
  * added here, which saves the separate bias-add launch torch would issue per convolution.  add_z/r/q (n floats,
  * may be NULL) are added to the pre-activations as well: the gate convolutions are linear in their input
  * [h | inp | motion], and `inp` does not change over the refinement iterations, so its contribution

@@ -13,11 +13,17 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// f(i, true) handles floats 4i..4i+3 with 16-B accesses, f(i, false) the single float i.  `vec_ok` = every
+// pointer of the call is 16-B aligned (always true for the BASELINE shapes; ragged test shapes take the scalar loop).
 template <typename F>
-__device__ __forceinline__ void for_each4(long long n, F f) {
-  const long long n4 = n >> 2;
+__device__ __forceinline__ void for_each4(long long n, int vec_ok, F f) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (!vec_ok) {
+    for (long long i = gid; i < n; i += stride) f(i, false);
+    return;
+  }
+  const long long n4 = n >> 2;
   for (long long i = gid; i < n4; i += stride) f(i, true);
   // tail (n not a multiple of 4): one scalar element per thread of the first block
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) f((n4 << 2) + threadIdx.x, false);
@@ -44,8 +50,8 @@ __global__ void gru_gates_fwd_kernel(const float* __restrict__ zc, const float* 
                                      const float* __restrict__ br, const float* __restrict__ az,
                                      const float* __restrict__ ar, float* __restrict__ z,
                                      float* __restrict__ r, float* __restrict__ rh, long long n,
-                                     int plane, int C) {
-  for_each4(n, [&](long long i, bool vec) {
+                                     int plane, int C, int vec_ok) {
+  for_each4(n, vec_ok, [&](long long i, bool vec) {
     if (vec) {
       const float4 a = add4(LD4(zc, i), az, i), b = add4(LD4(rc, i), ar, i), hh = LD4(h, i);
       const long long e = i << 2;
@@ -68,14 +74,14 @@ __global__ void gru_gates_fwd_kernel(const float* __restrict__ zc, const float* 
 __global__ void gru_gates_bwd_kernel(const float* __restrict__ z, const float* __restrict__ r,
                                      const float* __restrict__ h, const float* __restrict__ dz,
                                      const float* __restrict__ drh, float* __restrict__ dzc,
-                                     float* __restrict__ drc, float* __restrict__ dh, long long n) {
+                                     float* __restrict__ drc, float* __restrict__ dh, long long n, int vec_ok) {
   auto one = [](float z_, float r_, float h_, float dz_, float drh_, float& a, float& b, float& c) {
     a = dz_ * (1.f - z_) * z_;
     const float dr = drh_ * h_;
     b = dr * (1.f - r_) * r_;
     c = drh_ * r_;
   };
-  for_each4(n, [&](long long i, bool vec) {
+  for_each4(n, vec_ok, [&](long long i, bool vec) {
     if (vec) {
       const float4 zz = LD4(z, i), rr = LD4(r, i), hh = LD4(h, i), gz = LD4(dz, i), gr = LD4(drh, i);
       float4 a, b, c;
@@ -93,8 +99,8 @@ __global__ void gru_gates_bwd_kernel(const float* __restrict__ z, const float* _
 __global__ void gru_update_fwd_kernel(const float* __restrict__ z, const float* __restrict__ qc,
                                       const float* __restrict__ h, const float* __restrict__ bq,
                                       const float* __restrict__ aq, float* __restrict__ q,
-                                      float* __restrict__ hnew, long long n, int plane, int C) {
-  for_each4(n, [&](long long i, bool vec) {
+                                      float* __restrict__ hnew, long long n, int plane, int C, int vec_ok) {
+  for_each4(n, vec_ok, [&](long long i, bool vec) {
     if (vec) {
       const float4 zz = LD4(z, i), c = add4(LD4(qc, i), aq, i), hh = LD4(h, i);
       const long long e = i << 2;
@@ -118,13 +124,13 @@ __global__ void gru_update_fwd_kernel(const float* __restrict__ z, const float* 
 __global__ void gru_update_bwd_kernel(const float* __restrict__ z, const float* __restrict__ q,
                                       const float* __restrict__ h, const float* __restrict__ g,
                                       float* __restrict__ dz, float* __restrict__ dqc,
-                                      float* __restrict__ dh, long long n) {
+                                      float* __restrict__ dh, long long n, int vec_ok) {
   auto one = [](float z_, float q_, float h_, float g_, float& a, float& b, float& c) {
     a = g_ * q_ - g_ * h_;
     b = (g_ * z_) * (1.f - q_ * q_);
     c = g_ * (1.f - z_);
   };
-  for_each4(n, [&](long long i, bool vec) {
+  for_each4(n, vec_ok, [&](long long i, bool vec) {
     if (vec) {
       const float4 zz = LD4(z, i), qq = LD4(q, i), hh = LD4(h, i), gg = LD4(g, i);
       float4 a, b, c;
@@ -141,8 +147,8 @@ __global__ void gru_update_bwd_kernel(const float* __restrict__ z, const float* 
 
 // out = relu(x + bias[c])  /  gx = gout * (out > 0)   (conv bias add + ReLU of the update block in one pass)
 __global__ void bias_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
-                                     float* __restrict__ out, long long n, int plane, int C) {
-  for_each4(n, [&](long long i, bool vec) {
+                                     float* __restrict__ out, long long n, int plane, int C, int vec_ok) {
+  for_each4(n, vec_ok, [&](long long i, bool vec) {
     if (vec) {
       const float4 a = LD4(x, i);
       const long long e = i << 2;
@@ -159,8 +165,8 @@ __global__ void bias_relu_fwd_kernel(const float* __restrict__ x, const float* _
 }
 
 __global__ void relu_bwd_kernel(const float* __restrict__ out, const float* __restrict__ gout,
-                                float* __restrict__ gx, long long n) {
-  for_each4(n, [&](long long i, bool vec) {
+                                float* __restrict__ gx, long long n, int vec_ok) {
+  for_each4(n, vec_ok, [&](long long i, bool vec) {
     if (vec) {
       const float4 o = LD4(out, i), g = LD4(gout, i);
       float4 r;
@@ -178,7 +184,7 @@ inline int blocks_for(long long n) {
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
-inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }  // nullptr counts as aligned
 
 }  // namespace
 
@@ -187,10 +193,9 @@ extern "C" int pcfa_gru_gates_fwd(const float* zc, const float* rc, const float*
                                   float* r, float* rh, long long n, int plane, int channels,
                                   void* stream) {
   if (!zc || !rc || !h || !z || !r || !rh || n < 1 || plane < 1 || channels < 1) return PCFA_ERR_INVALID_ARG;
-  if (!(al16(zc) && al16(rc) && al16(h) && al16(z) && al16(r) && al16(rh) && al16(add_z) && al16(add_r)))
-    return PCFA_ERR_UNSUPPORTED;
+  const int vec_ok = al16(zc) && al16(rc) && al16(h) && al16(z) && al16(r) && al16(rh) && al16(add_z) && al16(add_r);
   hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, zc,
-                     rc, h, bias_z, bias_r, add_z, add_r, z, r, rh, n, plane, channels);
+                     rc, h, bias_z, bias_r, add_z, add_r, z, r, rh, n, plane, channels, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -199,10 +204,9 @@ extern "C" int pcfa_gru_gates_bwd(const float* z, const float* r, const float* h
                                   const float* drh, float* dzc, float* drc, float* dh, long long n,
                                   void* stream) {
   if (!z || !r || !h || !dz || !drh || !dzc || !drc || !dh || n < 1) return PCFA_ERR_INVALID_ARG;
-  if (!(al16(z) && al16(r) && al16(h) && al16(dz) && al16(drh) && al16(dzc) && al16(drc) && al16(dh)))
-    return PCFA_ERR_UNSUPPORTED;
+  const int vec_ok = al16(z) && al16(r) && al16(h) && al16(dz) && al16(drh) && al16(dzc) && al16(drc) && al16(dh);
   hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, r,
-                     h, dz, drh, dzc, drc, dh, n);
+                     h, dz, drh, dzc, drc, dh, n, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -211,9 +215,9 @@ extern "C" int pcfa_gru_update_fwd(const float* z, const float* qc, const float*
                                    const float* add_q, float* q, float* hnew, long long n, int plane,
                                    int channels, void* stream) {
   if (!z || !qc || !h || !q || !hnew || n < 1 || plane < 1 || channels < 1) return PCFA_ERR_INVALID_ARG;
-  if (!(al16(z) && al16(qc) && al16(h) && al16(q) && al16(hnew) && al16(add_q))) return PCFA_ERR_UNSUPPORTED;
+  const int vec_ok = al16(z) && al16(qc) && al16(h) && al16(q) && al16(hnew) && al16(add_q);
   hipLaunchKernelGGL(gru_update_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, qc,
-                     h, bias_q, add_q, q, hnew, n, plane, channels);
+                     h, bias_q, add_q, q, hnew, n, plane, channels, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -221,10 +225,9 @@ extern "C" int pcfa_gru_update_fwd(const float* z, const float* qc, const float*
 extern "C" int pcfa_gru_update_bwd(const float* z, const float* q, const float* h, const float* g,
                                    float* dz, float* dqc, float* dh, long long n, void* stream) {
   if (!z || !q || !h || !g || !dz || !dqc || !dh || n < 1) return PCFA_ERR_INVALID_ARG;
-  if (!(al16(z) && al16(q) && al16(h) && al16(g) && al16(dz) && al16(dqc) && al16(dh)))
-    return PCFA_ERR_UNSUPPORTED;
+  const int vec_ok = al16(z) && al16(q) && al16(h) && al16(g) && al16(dz) && al16(dqc) && al16(dh);
   hipLaunchKernelGGL(gru_update_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, q,
-                     h, g, dz, dqc, dh, n);
+                     h, g, dz, dqc, dh, n, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -232,9 +235,9 @@ extern "C" int pcfa_gru_update_bwd(const float* z, const float* q, const float* 
 extern "C" int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out, long long n, int plane,
                                   int channels, void* stream) {
   if (!x || !out || n < 1 || plane < 1 || channels < 1) return PCFA_ERR_INVALID_ARG;
-  if (!(al16(x) && al16(out))) return PCFA_ERR_UNSUPPORTED;
+  const int vec_ok = al16(x) && al16(out);
   hipLaunchKernelGGL(bias_relu_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, bias,
-                     out, n, plane, channels);
+                     out, n, plane, channels, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -242,9 +245,9 @@ extern "C" int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out,
 extern "C" int pcfa_relu_bwd(const float* out, const float* grad_out, float* grad_x, long long n,
                              void* stream) {
   if (!out || !grad_out || !grad_x || n < 1) return PCFA_ERR_INVALID_ARG;
-  if (!(al16(out) && al16(grad_out) && al16(grad_x))) return PCFA_ERR_UNSUPPORTED;
+  const int vec_ok = al16(out) && al16(grad_out) && al16(grad_x);
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, out, grad_out,
-                     grad_x, n);
+                     grad_x, n, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
