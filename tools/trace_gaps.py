@@ -23,6 +23,8 @@ def main():
     window = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
     rows = []
     for r in csv.DictReader(open(path)):
+        if "naive_conv" in r["Kernel_Name"]:
+            continue  # MIOpen's one-off first-call fallback kernels of the warm-up step
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     # the busiest `window` seconds of the run = the timed steps (the tail of a bench.py run is the CPU baseline)
