@@ -166,6 +166,44 @@ def lookup_algorithmic_bytes(hf, wf, levels=4, radius=4):
     return q * levels * (2 * radius + 2) ** 2 * 4 + q * 2 * 4 + q * levels * n1 * n1 * 4
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def kernel_table(timings, hf, wf, hp, wp, dim=256, levels=4, radius=4):
+    """Per-kernel roofline rows for the RAFT/GMA path: algorithmic work per launch (SURVEY 8d figures, stated
+    in DESIGN.md section 4) / mean dispatch duration measured with hipEvents on the dispatch packets."""
+    q = hf * wf
+    n1 = 2 * radius + 1
+    out_b = q * levels * n1 * n1 * 4
+    win_b = q * levels * (2 * radius + 2) ** 2 * 4
+    gemm = 2.0 * q * q * dim  # level 0 only: the pooled levels cost no multiplies in the reference (avg_pool2d)
+    img = 3 * hp * wp * 4
+    work = {  # label -> (bound, algorithmic bytes or flop per launch)
+        "corr_lookup_fwd": ("hbm", win_b + q * 8 + out_b),
+        "corr_lookup_bwd": ("hbm", out_b + q * 8 + 2 * win_b),
+        "corr_pyramid_gemm_fwd": ("mfma", gemm),
+        "corr_pyramid_gemm_dfmap1": ("mfma", gemm),
+        "corr_pyramid_gemm_df2ext": ("mfma", gemm),
+        "box_transform_fwd": ("hbm", 4 * img),
+        "box_transform_bwd": ("hbm", 6 * img),
+        "gru_gates_fwd": ("hbm", 8 * q * 128 * 4),
+        "gru_update_fwd": ("hbm", 6 * q * 128 * 4),
+    }
+    rows = []
+    for label, (us, n) in sorted(timings.items()):
+        if label not in work:
+            continue
+        bound, w = work[label]
+        if bound == "hbm":
+            ach, peak, unit = w / (us * 1e-6) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = w / (us * 1e-6) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        rows.append({"kernel": label, "bound": bound, "per_launch": w, "mean_launch_us": round(us, 2),
+                     "launches_timed": n, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                     "frac": round(ach / peak, 4)})
+    return rows
+
+
 def cpu_baseline(net, h, w, nclosures, threads=0):
     """Time the CPU port (pcfa_amd host code + oracle operators) on a bounded sample of the workload."""
     from oracle import ops as oracle_ops
@@ -273,7 +311,9 @@ def main():
             "final": {"aee_adv_tgt": last[0], "aee_adv_init": last[1], "l2_delta": last[2]},
         }
         if corr_net:
-            us, n = prof.summary()["pcfa_corr_lookup_fwd"]
+            timings = prof.summary()
+            us, n = timings["corr_lookup_fwd"]
+            out["kernels"] = kernel_table(timings, hp // 8, wp // 8, hp, wp)
             nbytes = lookup_algorithmic_bytes(hp // 8, wp // 8)
             ach = nbytes / (us * 1e-6) / 1e9
             out["roofline"] = {"kernel": "corr_lookup_fwd_kernel<4>", "bound": "hbm", "achieved": ach,

@@ -47,6 +47,16 @@ extern "C" {
 #define PCFA_BOX_CHANGE_OF_VARIABLES 1
 
 PCFA_API int pcfa_abi_version(void);
+/* Measurement hook.  Queues two caller-owned hipEvent_t for the nth kernel (0 = next) that the CALLING THREAD
+ * launches through this library after the first arm of a batch (up to 8 pairs may be queued).  That kernel is
+ * dispatched with hipExtLaunchKernel, which attaches the events to its dispatch packet: after completion
+ * hipEventElapsedTime(start, stop) is the kernel's own duration -- the timestamps rocprofv3's kernel trace
+ * reads -- without the two barrier packets an event bracket around a launch adds (about 7 us on MI355X).
+ * Entry points that launch several kernels: pcfa_corr_pyramid_bwd = {GEMM dfmap1, reduce, GEMM df2ext, reduce,
+ * pooling adjoint}, pcfa_flow_loss_fwd = {partials, final}, pcfa_spatial_corr_bwd = {grad_in1, grad_in2}.
+ * nth < 0 drops every pair still queued (events of kernels that were never launched stay unrecorded). */
+PCFA_API int pcfa_timing_arm(void* start_event, void* stop_event, int nth);
+
 /* Launches an empty kernel on `stream`: lets a caller calibrate the fixed cost of bracketing one launch with
  * HIP events (bench.py reports it next to the per-launch timings). */
 PCFA_API int pcfa_null_launch(void* stream);
@@ -102,12 +112,6 @@ PCFA_API int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, const 
  * zeros outside (the reference's x-major window order). */
 PCFA_API int pcfa_corr_lookup_fwd(const float* pyr, const float* coords, float* out, int B, int H, int W,
                          int num_levels, int radius, void* stream);
-
-/* Same launch with two hipEvent_t (created by the caller, may be NULL) attached to the kernel's dispatch packet
- * (hipExtLaunchKernel): after completion hipEventElapsedTime(start, stop) is the kernel's own duration,
- * without the barrier packets an event bracket around the launch would add.  For measurement. */
-PCFA_API int pcfa_corr_lookup_fwd_timed(const float* pyr, const float* coords, float* out, int B, int H, int W,
-                               int num_levels, int radius, void* start_event, void* stop_event, void* stream);
 
 /* dpyr += d out / d pyr ^T * grad_out   (no gradient w.r.t. coords: the
  * reference detaches them, models/raft/raft.py:122-123).  Deterministic: every

@@ -24,6 +24,7 @@ _S4 = POINTER(c_longlong)  # long long[4]
 # name -> (restype, argtypes); kept in lock-step with include/pcfa_hip.h
 SIGNATURES = {
     "pcfa_abi_version": (c_int, []),
+    "pcfa_timing_arm": (c_int, [_P, _P, c_int]),
     "pcfa_null_launch": (c_int, [_P]),
     "pcfa_status_string": (c_char_p, [c_int]),
     "pcfa_corr_slab_floats": (c_longlong, [c_int, c_int, c_int]),
@@ -34,7 +35,6 @@ SIGNATURES = {
     "pcfa_corr_pyramid_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "pcfa_corr_pyramid_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_corr_lookup_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "pcfa_corr_lookup_fwd_timed": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "pcfa_corr_lookup_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_spatial_corr_out_size": (c_int, [c_int] * 10 + [POINTER(c_int), POINTER(c_int)]),
     "pcfa_spatial_corr_fwd": (c_int, [_P, _P, _P] + [c_int] * 16 + [_P]),

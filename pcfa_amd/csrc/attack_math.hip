@@ -313,8 +313,25 @@ __global__ void null_kernel() {}
 
 extern "C" int pcfa_abi_version(void) { return PCFA_ABI_VERSION; }
 
+PcfaTimingState& pcfa_timing_state() {
+  static thread_local PcfaTimingState state;
+  return state;
+}
+
+extern "C" int pcfa_timing_arm(void* start_event, void* stop_event, int nth) {
+  PcfaTimingState& t = pcfa_timing_state();
+  if (nth < 0) {  // disarm: drop whatever is still queued
+    t.n = 0;
+    return PCFA_OK;
+  }
+  if (t.n >= 8) return PCFA_ERR_INVALID_ARG;
+  if (t.n == 0) t.launched = 0;  // nth counts this thread's launches from the first arm of a batch
+  t.q[t.n++] = PcfaArmed{(hipEvent_t)start_event, (hipEvent_t)stop_event, nth};
+  return PCFA_OK;
+}
+
 extern "C" int pcfa_null_launch(void* stream) {
-  hipLaunchKernelGGL(null_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+  pcfa_launch(null_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -333,7 +350,7 @@ extern "C" int pcfa_box_transform_fwd(const float* image, const float* delta, fl
                                       long long n, int cov, double eps_box, float scale,
                                       void* stream) {
   if (!image || !out || B < 1 || n < 1) return PCFA_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(box_fwd_kernel, dim3(ew_blocks((long long)B * n)), dim3(256), 0,
+  pcfa_launch(box_fwd_kernel, dim3(ew_blocks((long long)B * n)), dim3(256), 0,
                      (hipStream_t)stream, image, delta, out, B, n, cov, make_box(eps_box), scale);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -344,7 +361,7 @@ extern "C" int pcfa_box_transform_bwd(const float* image, const float* delta,
                                       int B, long long n, int cov, double eps_box, float scale,
                                       void* stream) {
   if (!image || !grad_out || B < 1 || n < 1) return PCFA_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(box_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, image,
+  pcfa_launch(box_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, image,
                      delta, grad_out, grad_image, grad_delta, B, n, cov, make_box(eps_box), scale);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -353,7 +370,7 @@ extern "C" int pcfa_box_transform_bwd(const float* image, const float* delta,
 extern "C" int pcfa_extract_deltas_fwd(const float* nw_input, const float* image, float* delta,
                                        long long n, int cov, double eps_box, void* stream) {
   if (!nw_input || !image || !delta || n < 1) return PCFA_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(deltas_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream,
+  pcfa_launch(deltas_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream,
                      nw_input, image, delta, n, cov, make_box(eps_box));
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -363,7 +380,7 @@ extern "C" int pcfa_extract_deltas_bwd(const float* nw_input, const float* grad_
                                        float* grad_nw_input, long long n, int cov, double eps_box,
                                        void* stream) {
   if (!nw_input || !grad_delta || !grad_nw_input || n < 1) return PCFA_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(deltas_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream,
+  pcfa_launch(deltas_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream,
                      nw_input, grad_delta, grad_nw_input, n, cov, make_box(eps_box));
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -373,7 +390,7 @@ extern "C" int pcfa_extract_deltas_joint_fwd(const float* nw_delta, const float*
                                              const float* images_min, float* delta, long long n,
                                              void* stream) {
   if (!nw_delta || !images_max || !images_min || !delta || n < 1) return PCFA_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(deltas_joint_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0,
+  pcfa_launch(deltas_joint_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0,
                      (hipStream_t)stream, nw_delta, images_max, images_min, delta, n);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -384,7 +401,7 @@ extern "C" int pcfa_extract_deltas_joint_bwd(const float* nw_delta, const float*
                                              float* grad_nw_delta, long long n, void* stream) {
   if (!nw_delta || !images_max || !images_min || !grad_delta || !grad_nw_delta || n < 1)
     return PCFA_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(deltas_joint_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0,
+  pcfa_launch(deltas_joint_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0,
                      (hipStream_t)stream, nw_delta, images_max, images_min, grad_delta,
                      grad_nw_delta, n);
   PCFA_LAUNCH_CHECK();
@@ -406,12 +423,12 @@ extern "C" int pcfa_flow_loss_fwd(const float* pred, const long long pred_stride
     return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)workspace;
-  hipLaunchKernelGGL(loss_partial_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pred,
+  pcfa_launch(loss_partial_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, pred,
                      mkview(pred_strides), target, mkview(target_strides), B, H, W, delta1, n1,
                      delta2, n2, partial);
   PCFA_LAUNCH_CHECK();
   const float bound_sq = (float)((double)delta_bound * (double)delta_bound);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, RED_BLOCKS,
+  pcfa_launch(loss_final_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, RED_BLOCKS,
                      out_scalars, 0, (float)((long long)B * H * W),
                      (float)((long long)B * 2 * H * W), (float)(n1 + n2), bound_sq, mu, f_type);
   PCFA_LAUNCH_CHECK();
@@ -430,7 +447,7 @@ extern "C" int pcfa_flow_loss_bwd(const float* pred, const long long pred_stride
     return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (grad_pred) {
-    hipLaunchKernelGGL(loss_bwd_flow_kernel, dim3(ew_blocks((long long)B * H * W)), dim3(256), 0,
+    pcfa_launch(loss_bwd_flow_kernel, dim3(ew_blocks((long long)B * H * W)), dim3(256), 0,
                        s, pred, mkview(pred_strides), target, mkview(target_strides), B, H, W,
                        f_type, fwd_scalars, grad_loss, grad_pred);
     PCFA_LAUNCH_CHECK();
@@ -438,13 +455,13 @@ extern "C" int pcfa_flow_loss_bwd(const float* pred, const long long pred_stride
   const float ndelta = (float)(n1 + n2);
   if (grad_delta1) {
     if (!delta1) return PCFA_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(loss_bwd_delta_kernel, dim3(ew_blocks(n1)), dim3(256), 0, s, delta1, n1,
+    pcfa_launch(loss_bwd_delta_kernel, dim3(ew_blocks(n1)), dim3(256), 0, s, delta1, n1,
                        ndelta, mu, joint ? 2.f : 1.f, fwd_scalars, grad_loss, grad_delta1);
     PCFA_LAUNCH_CHECK();
   }
   if (grad_delta2) {
     if (!delta2) return PCFA_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(loss_bwd_delta_kernel, dim3(ew_blocks(n2)), dim3(256), 0, s, delta2, n2,
+    pcfa_launch(loss_bwd_delta_kernel, dim3(ew_blocks(n2)), dim3(256), 0, s, delta2, n2,
                        ndelta, mu, 1.f, fwd_scalars, grad_loss, grad_delta2);
     PCFA_LAUNCH_CHECK();
   }
@@ -459,11 +476,11 @@ extern "C" int pcfa_avg_epe(const float* flow1, const long long strides1[4], con
     return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)workspace;
-  hipLaunchKernelGGL(loss_partial_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, flow1,
+  pcfa_launch(loss_partial_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, flow1,
                      mkview(strides1), flow2, mkview(strides2), B, H, W, (const float*)nullptr,
                      0LL, (const float*)nullptr, 0LL, partial);
   PCFA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, RED_BLOCKS,
+  pcfa_launch(loss_final_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, RED_BLOCKS,
                      out, 1, (float)((long long)B * H * W), 0.f, 1.f, 0.f, 0.f, 0);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -474,11 +491,11 @@ extern "C" int pcfa_sum_squares(const float* x, long long n, float* out, void* w
   if (!x || !out || !workspace || n < 1) return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)workspace;
-  hipLaunchKernelGGL(loss_partial_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s,
+  pcfa_launch(loss_partial_kernel, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s,
                      (const float*)nullptr, View4{0, 0, 0, 0}, (const float*)nullptr,
                      View4{0, 0, 0, 0}, 1, 1, 1, x, n, (const float*)nullptr, 0LL, partial);
   PCFA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, RED_BLOCKS,
+  pcfa_launch(loss_final_kernel, dim3(1), dim3(RED_THREADS), 0, s, partial, RED_BLOCKS,
                      out, 2, 1.f, 1.f, 1.f, 0.f, 0.f, 0);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;

@@ -22,8 +22,6 @@
 // The backward is the exact transpose with the same ownership: every window
 // texel is owned by one lane of one workgroup, so dpyr += ... needs no atomics
 // and is bitwise reproducible.
-#include <hip/hip_ext.h>
-
 #include "common.hpp"
 
 namespace {
@@ -335,13 +333,10 @@ int balanced_queries_per_group(int /*Q*/, int /*planes*/) { return QB; }
 
 template <int R>
 int launch_fwd(const float* pyr, const float* coords, float* out, int B, int Q,
-               const PyrLayout& P, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+               const PyrLayout& P, hipStream_t s) {
   const int qb = balanced_queries_per_group(Q, P.L * B);
   dim3 grid(pcfa_cdiv(Q, qb), P.L, B), block(QB, 2 * R + 1, 1);
-  if (ev0 || ev1)  // events attached to the dispatch packet itself: they time the kernel, not the bracket
-    hipExtLaunchKernelGGL(corr_lookup_fwd_kernel<R>, grid, block, 0, s, ev0, ev1, 0, pyr, coords, out, Q, qb, P);
-  else
-    hipLaunchKernelGGL(corr_lookup_fwd_kernel<R>, grid, block, 0, s, pyr, coords, out, Q, qb, P);
+  pcfa_launch(corr_lookup_fwd_kernel<R>, grid, block, 0, s, pyr, coords, out, Q, qb, P);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -349,7 +344,7 @@ template <int R>
 int launch_bwd(float* dpyr, const float* coords, const float* go, int B, int Q,
                const PyrLayout& P, hipStream_t s) {
   dim3 grid(pcfa_cdiv(Q, QB), P.L, B), block(QB, 2 * R + 1, 1);
-  hipLaunchKernelGGL(corr_lookup_bwd_kernel<R>, grid, block, 0, s, dpyr, coords, go, Q, P);
+  pcfa_launch(corr_lookup_bwd_kernel<R>, grid, block, 0, s, dpyr, coords, go, Q, P);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -362,33 +357,21 @@ bool check_levels(const PyrLayout& P) {
 
 }  // namespace
 
-static int lookup_fwd_impl(const float* pyr, const float* coords, float* out, int B, int H, int W,
-                           int num_levels, int radius, void* ev0, void* ev1, void* stream) {
+extern "C" int pcfa_corr_lookup_fwd(const float* pyr, const float* coords, float* out, int B,
+                                    int H, int W, int num_levels, int radius, void* stream) {
   PyrLayout P;
   if (!pyr || !coords || !out || B < 1 || !pcfa_make_layout(P, H, W, num_levels) ||
       !check_levels(P))
     return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipEvent_t e0 = (hipEvent_t)ev0, e1 = (hipEvent_t)ev1;
   const int Q = H * W;
   switch (radius) {
-    case 1: return launch_fwd<1>(pyr, coords, out, B, Q, P, s, e0, e1);
-    case 2: return launch_fwd<2>(pyr, coords, out, B, Q, P, s, e0, e1);
-    case 3: return launch_fwd<3>(pyr, coords, out, B, Q, P, s, e0, e1);
-    case 4: return launch_fwd<4>(pyr, coords, out, B, Q, P, s, e0, e1);
+    case 1: return launch_fwd<1>(pyr, coords, out, B, Q, P, s);
+    case 2: return launch_fwd<2>(pyr, coords, out, B, Q, P, s);
+    case 3: return launch_fwd<3>(pyr, coords, out, B, Q, P, s);
+    case 4: return launch_fwd<4>(pyr, coords, out, B, Q, P, s);
     default: return PCFA_ERR_UNSUPPORTED;
   }
-}
-
-extern "C" int pcfa_corr_lookup_fwd(const float* pyr, const float* coords, float* out, int B,
-                                    int H, int W, int num_levels, int radius, void* stream) {
-  return lookup_fwd_impl(pyr, coords, out, B, H, W, num_levels, radius, nullptr, nullptr, stream);
-}
-
-extern "C" int pcfa_corr_lookup_fwd_timed(const float* pyr, const float* coords, float* out, int B,
-                                          int H, int W, int num_levels, int radius,
-                                          void* start_event, void* stop_event, void* stream) {
-  return lookup_fwd_impl(pyr, coords, out, B, H, W, num_levels, radius, start_event, stop_event, stream);
 }
 
 extern "C" int pcfa_corr_lookup_bwd(float* dpyr, const float* coords, const float* grad_out,

@@ -313,7 +313,7 @@ extern "C" int pcfa_corr_f2ext_fwd(const float* fmap2, float* f2ext, int B, int 
   const int Q = H * W;
   const size_t lds = pooled_lds_bytes(P);
   if (lds > 64 * 1024) return PCFA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(f2ext_fwd_kernel, dim3(B * D), dim3(256), lds, (hipStream_t)stream, fmap2,
+  pcfa_launch(f2ext_fwd_kernel, dim3(B * D), dim3(256), lds, (hipStream_t)stream, fmap2,
                      f2ext, Q, P);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -328,7 +328,7 @@ extern "C" int pcfa_corr_pyramid_fwd(const float* fmap1, const float* f2ext, flo
   const int vecA = (Q % 4 == 0) && aligned16(fmap1);
   const int vecB = aligned16(f2ext);  // slab % 16 == 0 by construction
   dim3 grid(pcfa_cdiv(S, BN), pcfa_cdiv(Q, BM), B);
-  hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, dim3(256), 0,
+  pcfa_launch(gemm_f32_mfma_kernel<true, true>, grid, dim3(256), 0,
                      (hipStream_t)stream, fmap1, f2ext, pyr, Q, S, D, (long long)Q,
                      (long long)S, (long long)S, (long long)D * Q, (long long)D * S,
                      (long long)Q * S, 1, ((D + BK - 1) / BK) * BK, 0LL, sqrtf((float)D), vecA,
@@ -369,13 +369,13 @@ extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, cons
     const int kchunk = choose_kchunk(S, BWD_SPLITS);
     const int vec = aligned16(f2ext) && aligned16(dpyr);
     dim3 grid(pcfa_cdiv(Q, BN), pcfa_cdiv(D, BM), B * BWD_SPLITS);
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, dim3(256), 0, s, f2ext, dpyr,
+    pcfa_launch(gemm_f32_mfma_kernel<false, false>, grid, dim3(256), 0, s, f2ext, dpyr,
                        part1, D, Q, S, (long long)S, (long long)S, (long long)Q,
                        (long long)D * S, (long long)Q * S, (long long)D * Q, BWD_SPLITS, kchunk,
                        (long long)B * D * Q, div, vec, vec);
     PCFA_LAUNCH_CHECK();
     const long long n = (long long)B * D * Q;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(min(pcfa_cdiv(n, 256), 2048)), dim3(256), 0, s,
+    pcfa_launch(splitk_reduce_kernel, dim3(min(pcfa_cdiv(n, 256), 2048)), dim3(256), 0, s,
                        part1, dfmap1, n, BWD_SPLITS, n);
     PCFA_LAUNCH_CHECK();
   }
@@ -385,13 +385,13 @@ extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, cons
     const int vecA = (Q % 4 == 0) && aligned16(fmap1);
     const int vecB = aligned16(dpyr);
     dim3 grid(pcfa_cdiv(S, BN), pcfa_cdiv(D, BM), B * BWD_SPLITS);
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, dim3(256), 0, s, fmap1, dpyr,
+    pcfa_launch(gemm_f32_mfma_kernel<false, true>, grid, dim3(256), 0, s, fmap1, dpyr,
                        part2, D, S, Q, (long long)Q, (long long)S, (long long)S,
                        (long long)D * Q, (long long)Q * S, (long long)D * S, BWD_SPLITS, kchunk,
                        (long long)B * D * S, div, vecA, vecB);
     PCFA_LAUNCH_CHECK();
     const long long n = (long long)B * D * S;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(min(pcfa_cdiv(n, 256), 2048)), dim3(256), 0, s,
+    pcfa_launch(splitk_reduce_kernel, dim3(min(pcfa_cdiv(n, 256), 2048)), dim3(256), 0, s,
                        part2, df2ext, n, BWD_SPLITS, n);
     PCFA_LAUNCH_CHECK();
   }
@@ -399,7 +399,7 @@ extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, cons
   {
     const size_t lds = pooled_lds_bytes(P);
     if (lds > 64 * 1024) return PCFA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(f2ext_bwd_kernel, dim3(B * D), dim3(256), lds, s, df2ext, dfmap2, Q, P);
+    pcfa_launch(f2ext_bwd_kernel, dim3(B * D), dim3(256), lds, s, df2ext, dfmap2, Q, P);
     PCFA_LAUNCH_CHECK();
   }
   return PCFA_OK;

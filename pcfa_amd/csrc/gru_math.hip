@@ -194,7 +194,7 @@ extern "C" int pcfa_gru_gates_fwd(const float* zc, const float* rc, const float*
                                   void* stream) {
   if (!zc || !rc || !h || !z || !r || !rh || n < 1 || plane < 1 || channels < 1) return PCFA_ERR_INVALID_ARG;
   const int vec_ok = al16(zc) && al16(rc) && al16(h) && al16(z) && al16(r) && al16(rh) && al16(add_z) && al16(add_r);
-  hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, zc,
+  pcfa_launch(gru_gates_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, zc,
                      rc, h, bias_z, bias_r, add_z, add_r, z, r, rh, n, plane, channels, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -205,7 +205,7 @@ extern "C" int pcfa_gru_gates_bwd(const float* z, const float* r, const float* h
                                   void* stream) {
   if (!z || !r || !h || !dz || !drh || !dzc || !drc || !dh || n < 1) return PCFA_ERR_INVALID_ARG;
   const int vec_ok = al16(z) && al16(r) && al16(h) && al16(dz) && al16(drh) && al16(dzc) && al16(drc) && al16(dh);
-  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, r,
+  pcfa_launch(gru_gates_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, r,
                      h, dz, drh, dzc, drc, dh, n, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -216,7 +216,7 @@ extern "C" int pcfa_gru_update_fwd(const float* z, const float* qc, const float*
                                    int channels, void* stream) {
   if (!z || !qc || !h || !q || !hnew || n < 1 || plane < 1 || channels < 1) return PCFA_ERR_INVALID_ARG;
   const int vec_ok = al16(z) && al16(qc) && al16(h) && al16(q) && al16(hnew) && al16(add_q);
-  hipLaunchKernelGGL(gru_update_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, qc,
+  pcfa_launch(gru_update_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, qc,
                      h, bias_q, add_q, q, hnew, n, plane, channels, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -226,7 +226,7 @@ extern "C" int pcfa_gru_update_bwd(const float* z, const float* q, const float* 
                                    float* dz, float* dqc, float* dh, long long n, void* stream) {
   if (!z || !q || !h || !g || !dz || !dqc || !dh || n < 1) return PCFA_ERR_INVALID_ARG;
   const int vec_ok = al16(z) && al16(q) && al16(h) && al16(g) && al16(dz) && al16(dqc) && al16(dh);
-  hipLaunchKernelGGL(gru_update_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, q,
+  pcfa_launch(gru_update_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, q,
                      h, g, dz, dqc, dh, n, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -236,7 +236,7 @@ extern "C" int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out,
                                   int channels, void* stream) {
   if (!x || !out || n < 1 || plane < 1 || channels < 1) return PCFA_ERR_INVALID_ARG;
   const int vec_ok = al16(x) && al16(out);
-  hipLaunchKernelGGL(bias_relu_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, bias,
+  pcfa_launch(bias_relu_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, bias,
                      out, n, plane, channels, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -246,7 +246,7 @@ extern "C" int pcfa_relu_bwd(const float* out, const float* grad_out, float* gra
                              void* stream) {
   if (!out || !grad_out || !grad_x || n < 1) return PCFA_ERR_INVALID_ARG;
   const int vec_ok = al16(out) && al16(grad_out) && al16(grad_x);
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, out, grad_out,
+  pcfa_launch(relu_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, out, grad_out,
                      grad_x, n, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;

@@ -311,11 +311,11 @@ extern "C" int pcfa_spatial_corr_fwd(const float* in1, const float* in2, float* 
   hipStream_t s = (hipStream_t)stream;
   if (is_fast(p, 9)) {
     dim3 grid(pcfa_cdiv(iW, TW), pcfa_cdiv(iH, TH), B), block(8, 8, 9);
-    hipLaunchKernelGGL(scorr_fwd_fast_kernel<9>, grid, block, 0, s, in1, in2, out, C, iH, iW);
+    pcfa_launch(scorr_fwd_fast_kernel<9>, grid, block, 0, s, in1, in2, out, C, iH, iW);
   } else {
     const long long total = (long long)B * patchH * patchW * p.oH * p.oW;
     const int blocks = (int)((total + 255) / 256 < 65535LL * 16 ? (total + 255) / 256 : 65535LL * 16);
-    hipLaunchKernelGGL(scorr_fwd_generic_kernel, dim3(blocks), dim3(256), 0, s, in1, in2, out, p);
+    pcfa_launch(scorr_fwd_generic_kernel, dim3(blocks), dim3(256), 0, s, in1, in2, out, p);
   }
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -334,18 +334,18 @@ extern "C" int pcfa_spatial_corr_bwd(const float* in1, const float* in2, const f
   hipStream_t s = (hipStream_t)stream;
   if (is_fast(p, 9)) {
     dim3 grid(pcfa_cdiv(iW, TW), pcfa_cdiv(iH, TH), B * pcfa_cdiv(C, CC)), block(TW, TH, 1);
-    hipLaunchKernelGGL((scorr_bwd_fast_kernel<9, +1>), grid, block, 0, s, in2, grad_out, grad_in1,
+    pcfa_launch(scorr_bwd_fast_kernel<9, +1>, grid, block, 0, s, in2, grad_out, grad_in1,
                        C, iH, iW);
     PCFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL((scorr_bwd_fast_kernel<9, -1>), grid, block, 0, s, in1, grad_out, grad_in2,
+    pcfa_launch(scorr_bwd_fast_kernel<9, -1>, grid, block, 0, s, in1, grad_out, grad_in2,
                        C, iH, iW);
   } else {
     const long long total = (long long)B * C * iH * iW;
     const int blocks = (int)((total + 255) / 256 < 65535LL * 16 ? (total + 255) / 256 : 65535LL * 16);
-    hipLaunchKernelGGL(scorr_bwd_generic_kernel<1>, dim3(blocks), dim3(256), 0, s, in2, grad_out,
+    pcfa_launch(scorr_bwd_generic_kernel<1>, dim3(blocks), dim3(256), 0, s, in2, grad_out,
                        grad_in1, p);
     PCFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scorr_bwd_generic_kernel<2>, dim3(blocks), dim3(256), 0, s, in1, grad_out,
+    pcfa_launch(scorr_bwd_generic_kernel<2>, dim3(blocks), dim3(256), 0, s, in1, grad_out,
                        grad_in2, p);
   }
   PCFA_LAUNCH_CHECK();

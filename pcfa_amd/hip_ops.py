@@ -69,12 +69,35 @@ class LaunchProfiler:
 
 
 class DispatchTimer:
-    """Kernel durations from hipEvents attached to the dispatch packet itself (hipExtLaunchKernel, through the
-    `*_timed` C-ABI entry points).  Unlike an event bracket around a launch, which inserts two barrier packets
+    """Kernel durations from hipEvents attached to the dispatch packet itself (pcfa_timing_arm ->
+    hipExtLaunchKernel).  Unlike an event bracket around a launch, which inserts two barrier packets
     (measured: +4..7 us per launch on MI355X), these events carry the packet's own begin/end timestamps --
-    the same source rocprofv3's kernel trace reads.  Used by bench.py for the roofline figure."""
+    the same source rocprofv3's kernel trace reads.  Used by bench.py for the roofline figures.
 
-    def __init__(self):
+    `plan` maps a C-ABI entry point to [(label, nth kernel it launches)]; see include/pcfa_hip.h for the
+    launch order of the multi-kernel entry points."""
+
+    DEFAULT_PLAN = {
+        "pcfa_corr_lookup_fwd": [("corr_lookup_fwd", 0)],
+        "pcfa_corr_lookup_bwd": [("corr_lookup_bwd", 0)],
+        "pcfa_corr_pyramid_fwd": [("corr_pyramid_gemm_fwd", 0)],
+        "pcfa_corr_pyramid_bwd": [("corr_pyramid_gemm_dfmap1", 0), ("corr_pyramid_gemm_df2ext", 2)],
+        "pcfa_corr_f2ext_fwd": [("corr_f2ext_fwd", 0)],
+        "pcfa_spatial_corr_fwd": [("spatial_corr_fwd", 0)],
+        "pcfa_spatial_corr_bwd": [("spatial_corr_bwd_in1", 0), ("spatial_corr_bwd_in2", 1)],
+        "pcfa_box_transform_fwd": [("box_transform_fwd", 0)],
+        "pcfa_box_transform_bwd": [("box_transform_bwd", 0)],
+        "pcfa_flow_loss_fwd": [("flow_loss_partial", 0)],
+        "pcfa_gru_gates_fwd": [("gru_gates_fwd", 0)],
+        "pcfa_gru_gates_bwd": [("gru_gates_bwd", 0)],
+        "pcfa_gru_update_fwd": [("gru_update_fwd", 0)],
+        "pcfa_gru_update_bwd": [("gru_update_bwd", 0)],
+        "pcfa_bias_relu_fwd": [("bias_relu_fwd", 0)],
+        "pcfa_relu_bwd": [("relu_bwd", 0)],
+    }
+
+    def __init__(self, plan=None):
+        self.plan = dict(self.DEFAULT_PLAN if plan is None else plan)
         self.hip = ctypes.CDLL("libamdhip64.so")
         self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
@@ -95,16 +118,16 @@ class DispatchTimer:
         torch.cuda.synchronize()
         out = {}
         for name, pairs in self.pairs.items():
-            tot = 0.0
+            tot, n = 0.0, 0
             for e0, e1 in pairs:
                 ms = ctypes.c_float()
-                err = self.hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1)
-                if err != 0:
-                    raise RuntimeError("hipEventElapsedTime failed: %d" % err)
-                tot += ms.value
+                if self.hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1) == 0:  # else: never launched
+                    tot += ms.value
+                    n += 1
                 self.hip.hipEventDestroy(e0)
                 self.hip.hipEventDestroy(e1)
-            out[name] = (1e3 * tot / len(pairs), len(pairs))
+            if n:
+                out[name] = (1e3 * tot / n, n)
         self.pairs = {}
         return out
 
@@ -127,7 +150,17 @@ def _call(name, *args):
     """Invoke C-ABI entry point `name` on torch's current stream and raise on a non-zero status."""
     fn = getattr(_hip.load(), name)
     prof = _profiler
-    if prof is not None and prof.wants(name):
+    timer = _dispatch_timer
+    if timer is not None and name in timer.plan:
+        lib = _hip.load()
+        for label, nth in timer.plan[name]:
+            e0, e1 = timer.new_pair(label)
+            _hip.check(lib.pcfa_timing_arm(e0, e1, nth), "pcfa_timing_arm")
+        try:
+            status = fn(*args, _stream())
+        finally:
+            lib.pcfa_timing_arm(None, None, -1)  # drop pairs the entry point did not reach
+    elif prof is not None and prof.wants(name):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         status = fn(*args, _stream())
@@ -197,11 +230,7 @@ class _CorrLookup(torch.autograd.Function):
         c = coords.contiguous()
         n1 = 2 * st.r + 1
         out = torch.empty((st.B, st.L * n1 * n1, st.H, st.W), device=c.device, dtype=torch.float32)
-        if _dispatch_timer is not None:
-            e0, e1 = _dispatch_timer.new_pair("pcfa_corr_lookup_fwd")
-            _call("pcfa_corr_lookup_fwd_timed", _ptr(st.pyr), _ptr(c), _ptr(out), st.B, st.H, st.W, st.L, st.r, e0, e1)
-        else:
-            _call("pcfa_corr_lookup_fwd", _ptr(st.pyr), _ptr(c), _ptr(out), st.B, st.H, st.W, st.L, st.r)
+        _call("pcfa_corr_lookup_fwd", _ptr(st.pyr), _ptr(c), _ptr(out), st.B, st.H, st.W, st.L, st.r)
         ctx.state = st
         ctx.save_for_backward(c)
         return out
