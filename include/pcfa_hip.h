@@ -219,6 +219,27 @@ PCFA_API int pcfa_gru_update_fwd(const float* z, const float* qc, const float* h
 PCFA_API int pcfa_gru_update_bwd(const float* z, const float* q, const float* h, const float* g, float* dz,
                         float* dqc, float* dh, long long n, void* stream);
 
+/* The 5-tap gate convolutions of SepConvGRU -- Conv2d(c, 128, (1,5), padding=(0,2)) and ((5,1), padding=(2,0)),
+ * reference models/raft/update.py:36-42 (models/gma/update.py:36-42), applied at :45-60 -- without bias, as an
+ * implicit fp32-MFMA GEMM:
+ *     out[b,co,y,x] = sum_{t<5} sum_{ci<Ca+Cb} w_packed[t][ci][co] * in[b,ci, y+dy, x+dx],   zero outside the image,
+ *     (dy,dx) = (0,t-2) if vertical == 0 (1x5), (t-2,0) if vertical != 0 (5x1),
+ * where in = [in_a | in_b] concatenated along channels and read in place (in_b may be NULL with Cb = 0): the
+ * reference's torch.cat([h, x]) is never materialised.  in_a [B,Ca,H,W], in_b [B,Cb,H,W], out [B,Cout,H,W],
+ * all contiguous fp32.  w_packed [5][Ca+Cb][Cout] comes from pcfa_sepconv5_pack_weights.
+ *
+ * The data gradient of the operator is the operator itself on grad_out with the `bwd` packing:
+ *     grad_in = pcfa_sepconv5_fwd(grad_out, Cout, NULL, 0, bwd_packed, ..., Cout := Ca+Cb, ...),
+ * channels [0,Ca) of the result belonging to in_a and the rest to in_b.  (No weight gradient: the attack
+ * freezes the network, attack_PCFA.py:573-574.)
+ *
+ * pcfa_sepconv5_pack_weights: w [Cout][Cin][5] (the Conv2d weight, either orientation, flattened) ->
+ * fwd_packed [5][Cin][Cout] and/or bwd_packed [5][Cout][Cin] (either may be NULL). */
+PCFA_API int pcfa_sepconv5_pack_weights(const float* w, float* fwd_packed, float* bwd_packed, int Cout, int Cin,
+                               void* stream);
+PCFA_API int pcfa_sepconv5_fwd(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,
+                      float* out, int B, int Cout, int H, int W, int vertical, void* stream);
+
 /* out = relu(x + bias[c]) and its backward gx = grad_out * (out > 0): the "conv -> +bias -> ReLU" tail of the
  * motion encoder / flow head convolutions (models/raft/update.py:12-16,91-101) in one pass. */
 PCFA_API int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out, long long n, int plane, int channels,

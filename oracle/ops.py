@@ -229,6 +229,12 @@ def gru_update(z, qc, h, bias_q=None, add_q=None):
     return (1 - z) * h + z * q
 
 
+def sepconv5(a, b, weight):
+    """The SepConvGRU gate convolution on hx = cat([a, b]) (models/raft/update.py:45-47,52-54) without bias."""
+    x = a if b is None else torch.cat([a, b], dim=1)
+    return F.conv2d(x, weight, None, padding=(weight.shape[2] // 2, weight.shape[3] // 2))
+
+
 def bias_relu(x, bias=None):
     """F.relu(conv(x)) with the convolution's bias split off (models/raft/update.py:12-16,91-101)."""
     return torch.relu(x + _cb(bias))

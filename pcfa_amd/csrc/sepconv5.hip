@@ -1,0 +1,317 @@
+// 5-tap separable convolution of the RAFT/GMA SepConvGRU gates for gfx950.
+//
+// Replaces the six Conv2d(c, 128, (1,5), padding=(0,2)) / ((5,1), padding=(2,0)) of
+// reference models/raft/update.py:33-60 (models/gma/update.py:33-60), forward and data gradient, which
+// the library path runs as im2col + GEMM + (col2im in the backward).
+//
+// MI355X formulation: implicit GEMM  out[Cout x pixels] = Wp[Cout x (t,ci)] . X[(t,ci) x pixels]  on
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).  A pixel tile is 64 consecutive x of one image
+// row, so the five shifted operand rows of a channel are five views of ONE halo'd LDS row (1x5) or five staged rows
+// (5x1): the 5x im2col expansion never exists in memory.  The operand may be the channel concatenation of two
+// tensors ([h | motion features]), read in place: no torch.cat.  The data gradient is the same operator with
+// the taps flipped and the channel roles swapped (pcfa_sepconv5_pack_weights emits both packings).
+//
+// Block = 4 waves, 64(out-channels) x 64(pixels) tile, one 32x32 MFMA tile per wave; K streamed in chunks of
+// 8 input channels x 5 taps through an LDS double buffer.  The global loads of a stage are issued three stages
+// before its MFMAs (ring of four register sets): with one or two workgroups per CU nothing else hides the
+// L2/HBM latency.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 64, TN = 64, KC = 8, TAPS = 5;
+constexpr int NR = 4;                       // register ring: global loads run NR-1 stages ahead of the MFMAs
+constexpr int A_STRIDE = TM;                // sA[t][ci][m]
+constexpr int A_TILE = TAPS * KC * A_STRIDE;
+constexpr int A_VEC = A_TILE / 4;           // float4 per stage (640)
+constexpr int A_REGS = (A_VEC + 255) / 256;
+// 1x5: sB[ci][4 + (x - x0)], x - x0 in [-2, 66): the 64 interior floats sit 16-B aligned, 2 halo floats either side
+constexpr int BH_ROW = 72, BH_X0 = 4;
+constexpr int B_TILE_H = KC * BH_ROW;
+// 5x1: sB[ci][t][n]
+constexpr int BV_ROW = TN;
+constexpr int B_TILE_V = KC * TAPS * BV_ROW;
+constexpr int BV_VEC = B_TILE_V / 4;
+constexpr int BV_REGS = (BV_VEC + 255) / 256;
+
+struct Operand {
+  const float* a;
+  const float* b;
+  int Ca, Cin;
+};
+
+__device__ __forceinline__ const float* channel_plane(const Operand& in, int ci, long long plane) {
+  return ci < in.Ca ? in.a + ci * plane : in.b + (ci - in.Ca) * plane;
+}
+
+__device__ __forceinline__ f32x4 load4(const float* p, int n_valid, bool vec) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (vec && n_valid >= 4) {
+    v = *reinterpret_cast<const f32x4*>(p);
+  } else if (n_valid > 0) {
+    v.x = p[0];
+    if (n_valid > 1) v.y = p[1];
+    if (n_valid > 2) v.z = p[2];
+    if (n_valid > 3) v.w = p[3];
+  }
+  return v;
+}
+
+__device__ __forceinline__ f32x4 keep_if(bool ok, f32x4 v) {
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  return ok ? v : zero;
+}
+
+// FAST: Cin % (KC * NR) == 0, Cout % 4 == 0, W % 4 == 0 and 16-B aligned operands.  Every global load is then an
+// unconditional float4/dword from a clamped (always valid) address and zero padding is applied when the value
+// is written to LDS -- no branch sits between a load and its use, so the loads really stay in flight across
+// stages.  The generic variant keeps predicated element-wise loads for ragged shapes.
+template <bool VERT, bool FAST>
+__global__ __launch_bounds__(256) void sepconv5_kernel(Operand in, const float* __restrict__ wp,
+                                                       float* __restrict__ out, int Cout, int H, int W,
+                                                       int tiles_x, int vec_w, int vec_x) {
+  __shared__ __attribute__((aligned(16))) float sA[2][A_TILE];
+  __shared__ __attribute__((aligned(16))) float sB[2][VERT ? B_TILE_V : B_TILE_H];
+
+  const long long plane = (long long)H * W;
+  const int y = blockIdx.x / tiles_x;
+  const int x0 = (blockIdx.x - y * tiles_x) * TN;
+  const int m0 = blockIdx.y * TM;
+  in.a += (long long)blockIdx.z * in.Ca * plane;
+  if (in.b) in.b += (long long)blockIdx.z * (in.Cin - in.Ca) * plane;
+  out += (long long)blockIdx.z * Cout * plane;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // 1x5 loader roles: threads [0,128) fetch the aligned interior float4 (ci = tid/16, x = x0 + 4*(tid%16)),
+  // threads [128,160) one halo float each (ci = (tid-128)/4, offsets -2,-1,64,65).
+  // (Every thread issues both loads -- the upper threads repeat addresses of the lower ones -- so that no
+  // branch surrounds a load; only the named threads write to LDS.)
+  const int ici = (tid & 127) >> 4, idx = (tid & 15) * 4;
+  const int hci = (tid & 31) >> 2, hq = tid & 3;
+  const int hdx = hq < 2 ? hq - 2 : TN + hq - 2;
+
+  // FAST-path per-thread constants: clamped source offsets and the zero-padding predicates
+  // (stage-invariant because Cin % KC == 0).
+  long long a_off[A_REGS];
+  long long bv_off[BV_REGS];
+  int bv_ci[BV_REGS];
+  bool bv_ok[BV_REGS];
+#pragma unroll
+  for (int i = 0; i < A_REGS; ++i) {
+    const int f = tid + 256 * i;
+    const int m = min(m0 + (f % (TM / 4)) * 4, Cout - 4), row = min(f / (TM / 4), TAPS * KC - 1);
+    a_off[i] = ((long long)(row / KC) * in.Cin + row % KC) * Cout + m;  // rows >= Cout are never stored
+  }
+#pragma unroll
+  for (int i = 0; i < BV_REGS; ++i) {
+    const int f = tid + 256 * i;
+    const int x = x0 + (f % (TN / 4)) * 4, row = min(f / (TN / 4), TAPS * KC - 1);
+    const int yy = y + row % TAPS - 2;
+    bv_ci[i] = row / TAPS;
+    bv_ok[i] = yy >= 0 && yy < H && x < W;
+    bv_off[i] = (long long)min(max(yy, 0), H - 1) * W + min(x, W - 4);
+  }
+  const long long i_off = (long long)y * W + min(x0 + idx, W - 4);
+  const long long h_off = (long long)y * W + min(max(x0 + hdx, 0), W - 1);
+  const bool i_ok = x0 + idx < W, h_ok = x0 + hdx >= 0 && x0 + hdx < W;
+
+  auto load_stage = [&](f32x4 (&ra)[A_REGS], f32x4 (&rb)[BV_REGS], float& halo, int c0) {
+    if (FAST) {
+#pragma unroll
+      for (int i = 0; i < A_REGS; ++i)
+        ra[i] = *reinterpret_cast<const f32x4*>(wp + a_off[i] + (long long)c0 * Cout);
+      if (VERT) {
+#pragma unroll
+        for (int i = 0; i < BV_REGS; ++i)
+          rb[i] = *reinterpret_cast<const f32x4*>(channel_plane(in, c0 + bv_ci[i], plane) + bv_off[i]);
+      } else {
+        rb[0] = *reinterpret_cast<const f32x4*>(channel_plane(in, c0 + ici, plane) + i_off);
+        halo = channel_plane(in, c0 + hci, plane)[h_off];
+      }
+    } else {
+#pragma unroll
+    for (int i = 0; i < A_REGS; ++i) {
+      const int f = tid + 256 * i;
+      const int m = m0 + (f % (TM / 4)) * 4, row = f / (TM / 4);
+      const int t = row / KC, ci = c0 + row % KC;
+      const bool ok = f < A_VEC && ci < in.Cin;
+      ra[i] = load4(wp + ((long long)t * in.Cin + ci) * Cout + m, ok ? Cout - m : 0, vec_w);
+    }
+    if (VERT) {
+#pragma unroll
+      for (int i = 0; i < BV_REGS; ++i) {
+        const int f = tid + 256 * i;
+        const int x = x0 + (f % (TN / 4)) * 4, row = f / (TN / 4);
+        const int ci = c0 + row / TAPS, yy = y + row % TAPS - 2;
+        const bool ok = f < BV_VEC && ci < in.Cin && yy >= 0 && yy < H;
+        const int cic = min(ci, in.Cin - 1), yc = min(max(yy, 0), H - 1);
+        rb[i] = load4(channel_plane(in, cic, plane) + (long long)yc * W + x, ok ? W - x : 0, vec_x);
+      }
+    } else {
+      const int ci = c0 + ici, x = x0 + idx;
+      rb[0] = load4(channel_plane(in, min(ci, in.Cin - 1), plane) + (long long)y * W + x,
+                     ci < in.Cin ? W - x : 0, vec_x);
+      const int cih = c0 + hci, xh = x0 + hdx;
+      halo = 0.f;
+      if (cih < in.Cin && xh >= 0 && xh < W) halo = channel_plane(in, cih, plane)[(long long)y * W + xh];
+    }
+    }
+  };
+
+  auto store_stage = [&](const f32x4 (&ra)[A_REGS], const f32x4 (&rb)[BV_REGS], const float& halo, int buf) {
+#pragma unroll
+    for (int i = 0; i < A_REGS; ++i) {
+      const int f = tid + 256 * i;
+      if (f < A_VEC) *reinterpret_cast<f32x4*>(&sA[buf][f * 4]) = ra[i];
+    }
+    if (VERT) {
+#pragma unroll
+      for (int i = 0; i < BV_REGS; ++i) {
+        const int f = tid + 256 * i;
+        if (f < BV_VEC)
+          *reinterpret_cast<f32x4*>(&sB[buf][f * 4]) = FAST ? keep_if(bv_ok[i], rb[i]) : rb[i];
+      }
+    } else {
+      if (tid < 128)
+        *reinterpret_cast<f32x4*>(&sB[buf][ici * BH_ROW + BH_X0 + idx]) = FAST ? keep_if(i_ok, rb[0]) : rb[0];
+      if (tid < 32) sB[buf][hci * BH_ROW + BH_X0 + hdx] = (!FAST || h_ok) ? halo : 0.f;
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  auto compute_stage = [&](int buf) {
+    const float* ap = sA[buf] + lh * A_STRIDE + wr * 32 + l31;
+    const float* bp = sB[buf] + (VERT ? lh * TAPS * BV_ROW : lh * BH_ROW + BH_X0 - 2) + wc * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int s = 0; s < KC; s += 2) {
+        const float av = ap[(t * KC + s) * A_STRIDE];
+        const float bv = VERT ? bp[s * TAPS * BV_ROW + t * BV_ROW] : bp[s * BH_ROW + t];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      }
+  };
+
+  const int nstage = (in.Cin + KC - 1) / KC;
+  f32x4 ring_a[NR][A_REGS], ring_b[NR][BV_REGS];
+  float ring_h[NR];
+  if (FAST) {
+    // nstage % NR == 0: the unrolled body has no branch at all.  Stages past the end re-load the last one
+    // (clamped) and store it to the idle LDS buffer; nothing reads it.
+    const int last = (nstage - 1) * KC;
+#pragma unroll
+    for (int j = 0; j < NR - 1; ++j) load_stage(ring_a[j], ring_b[j], ring_h[j], min(j * KC, last));
+    store_stage(ring_a[0], ring_b[0], ring_h[0], 0);
+    __syncthreads();
+    for (int s0 = 0; s0 < nstage; s0 += NR) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        load_stage(ring_a[(j + NR - 1) % NR], ring_b[(j + NR - 1) % NR], ring_h[(j + NR - 1) % NR],
+                   min((s0 + j + NR - 1) * KC, last));
+        compute_stage(j & 1);
+        store_stage(ring_a[(j + 1) % NR], ring_b[(j + 1) % NR], ring_h[(j + 1) % NR], (j + 1) & 1);
+        __syncthreads();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NR - 1; ++j)
+      if (j < nstage) load_stage(ring_a[j], ring_b[j], ring_h[j], j * KC);
+    store_stage(ring_a[0], ring_b[0], ring_h[0], 0);
+    __syncthreads();
+    for (int s0 = 0; s0 < nstage; s0 += NR) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {  // NR is even: LDS buffer of stage s0+j is j & 1
+        const int st = s0 + j;
+        if (st < nstage) {
+          if (st + NR - 1 < nstage)
+            load_stage(ring_a[(j + NR - 1) % NR], ring_b[(j + NR - 1) % NR], ring_h[(j + NR - 1) % NR],
+                       (st + NR - 1) * KC);
+          compute_stage(j & 1);
+          if (st + 1 < nstage)
+            store_stage(ring_a[(j + 1) % NR], ring_b[(j + 1) % NR], ring_h[(j + 1) % NR], (j + 1) & 1);
+          __syncthreads();
+        }
+      }
+    }
+  }
+
+  // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  const int x = x0 + wc * 32 + l31;
+  if (x < W) {
+    float* o = out + (long long)y * W + x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < Cout) o[m * plane] = acc[r];
+    }
+  }
+}
+
+// w [Cout][Cin][5] (a Conv2d (1,5) or (5,1) weight, flattened) ->
+//   fwd[t][ci][co] = w[co][ci][t]          (forward operator)
+//   bwd[t][co][ci] = w[co][ci][4 - t]      (data gradient = the same operator on grad_out)
+__global__ void sepconv5_pack_kernel(const float* __restrict__ w, float* __restrict__ fwd,
+                                     float* __restrict__ bwd, int Cout, int Cin) {
+  const long long n = (long long)Cout * Cin * TAPS;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % TAPS);
+    const int ci = (int)((i / TAPS) % Cin);
+    const int co = (int)(i / ((long long)TAPS * Cin));
+    const float v = w[i];
+    if (fwd) fwd[((long long)t * Cin + ci) * Cout + co] = v;
+    if (bwd) bwd[((long long)(TAPS - 1 - t) * Cout + co) * Cin + ci] = v;
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int pcfa_sepconv5_pack_weights(const float* w, float* fwd_packed, float* bwd_packed, int Cout,
+                                          int Cin, void* stream) {
+  if (!w || (!fwd_packed && !bwd_packed) || Cout < 1 || Cin < 1) return PCFA_ERR_INVALID_ARG;
+  const long long n = (long long)Cout * Cin * TAPS;
+  pcfa_launch(sepconv5_pack_kernel, dim3((unsigned)min((n + 255) / 256, (long long)1024)), dim3(256), 0,
+              (hipStream_t)stream, w, fwd_packed, bwd_packed, Cout, Cin);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_sepconv5_fwd(const float* in_a, int Ca, const float* in_b, int Cb,
+                                 const float* w_packed, float* out, int B, int Cout, int H, int W,
+                                 int vertical, void* stream) {
+  if (!in_a || !w_packed || !out || Ca < 1 || Cb < 0 || (Cb > 0 && !in_b) || B < 1 || Cout < 1 ||
+      H < 1 || W < 1)
+    return PCFA_ERR_INVALID_ARG;
+  const int tiles_x = pcfa_cdiv(W, TN);
+  const long long gx = (long long)tiles_x * H;
+  if (gx > 0x7fffffffLL || B > 65535 || pcfa_cdiv(Cout, TM) > 65535) return PCFA_ERR_UNSUPPORTED;
+  Operand in{in_a, Cb > 0 ? in_b : nullptr, Ca, Ca + Cb};
+  const int vec_w = (Cout % 4 == 0) && aligned16(w_packed);
+  const int vec_x = (W % 4 == 0) && aligned16(in_a) && (Cb == 0 || aligned16(in_b));
+  dim3 grid((unsigned)gx, pcfa_cdiv(Cout, TM), B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool fast = vec_w && vec_x && (Ca + Cb) % (KC * NR) == 0 && Cout >= 4 && W >= 4;
+#define PCFA_SEPCONV5(V, F) \
+  pcfa_launch(sepconv5_kernel<V, F>, grid, block, 0, s, in, w_packed, out, Cout, H, W, tiles_x, vec_w, vec_x)
+  if (vertical) {
+    if (fast) PCFA_SEPCONV5(true, true); else PCFA_SEPCONV5(true, false);
+  } else {
+    if (fast) PCFA_SEPCONV5(false, true); else PCFA_SEPCONV5(false, false);
+  }
+#undef PCFA_SEPCONV5
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}

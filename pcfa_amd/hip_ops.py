@@ -13,6 +13,7 @@ Operator boundaries mirrored (reference file:line):
   loss_delta_constraint, avg_epe, two_norm_*   helper_functions/losses.py
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -454,6 +455,63 @@ class _BiasRelu(torch.autograd.Function):
         gx = torch.empty_like(out)
         _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gx), out.numel())
         return gx, None
+
+
+_sepconv_packs = {}  # id(weight) -> (weakref, version, fwd_packed, bwd_packed)
+
+
+def _sepconv5_packed(weight):
+    """pcfa_sepconv5_pack_weights of a frozen (1,5)/(5,1) Conv2d weight, cached per tensor version."""
+    key = id(weight)
+    hit = _sepconv_packs.get(key)
+    if hit is None or hit[0]() is not weight or hit[1] != weight._version:
+        cout, cin = weight.shape[:2]
+        w = weight.detach().contiguous()
+        fwd = torch.empty((5, cin, cout), device=w.device, dtype=torch.float32)
+        bwd = torch.empty((5, cout, cin), device=w.device, dtype=torch.float32)
+        _call("pcfa_sepconv5_pack_weights", _ptr(w), _ptr(fwd), _ptr(bwd), cout, cin)
+        hit = (weakref.ref(weight, lambda _r, k=key: _sepconv_packs.pop(k, None)), weight._version, fwd, bwd)
+        _sepconv_packs[key] = hit
+    return hit[2], hit[3]
+
+
+class _SepConv5(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, weight):
+        _dev(a, b, weight)
+        if weight.dim() != 4 or tuple(weight.shape[2:]) not in ((1, 5), (5, 1)) or weight.dtype != torch.float32:
+            raise ValueError("sepconv5 expects a float32 (1,5) or (5,1) Conv2d weight, got %s" % (tuple(weight.shape),))
+        vertical = int(weight.shape[2] == 5)
+        a = a.contiguous()
+        b = None if b is None else b.contiguous()
+        B, Ca, H, W = a.shape
+        Cb = 0 if b is None else b.shape[1]
+        cout = weight.shape[0]
+        if weight.shape[1] != Ca + Cb or (b is not None and (b.shape[0], b.shape[2], b.shape[3]) != (B, H, W)):
+            raise ValueError("sepconv5: operands %s / %s do not match weight %s"
+                             % (tuple(a.shape), None if b is None else tuple(b.shape), tuple(weight.shape)))
+        fwd, bwd = _sepconv5_packed(weight)
+        out = torch.empty((B, cout, H, W), device=a.device, dtype=torch.float32)
+        _call("pcfa_sepconv5_fwd", _ptr(a), Ca, _ptr(b), Cb, _ptr(fwd), _ptr(out), B, cout, H, W, vertical)
+        ctx.bwd, ctx.dims = bwd, (B, Ca, Cb, cout, H, W, vertical)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.needs_input_grad[2]:
+            raise RuntimeError("sepconv5 is the frozen-weight path: no weight gradient (use the module's "
+                               "reference forward when training)")
+        B, Ca, Cb, cout, H, W, vertical = ctx.dims
+        g = grad_out.contiguous()
+        gin = torch.empty((B, Ca + Cb, H, W), device=g.device, dtype=torch.float32)
+        _call("pcfa_sepconv5_fwd", _ptr(g), cout, None, 0, _ptr(ctx.bwd), _ptr(gin), B, Ca + Cb, H, W, vertical)
+        return gin[:, :Ca], (gin[:, Ca:] if Cb else None), None
+
+
+def sepconv5(a, b, weight):
+    """conv2d(cat([a, b], 1), weight, bias=None, padding='same') for a frozen (1,5) or (5,1) `weight`
+    (SepConvGRU gate convolutions, models/raft/update.py:36-60); `b` may be None."""
+    return _SepConv5.apply(a, b, weight)
 
 
 def gru_gates_packed(zr, h, bias_zr=None, add_zr=None):

@@ -187,11 +187,12 @@ class SepConvGRU(nn.Module):
     def step(self, h, ctx, rest):
         """One GRU update given precompute()'s context; `rest` = the per-iteration part of x (motion features)."""
         o = ops.get()
-        for zr, q, conv in (("zr1", "q1", self.convz1), ("zr2", "q2", self.convz2)):
+        for zr, q in (("zr1", "q1"), ("zr2", "q2")):
             w_zr, p_zr = ctx[zr]
             w_q, p_q = ctx[q]
-            z, rh = o.gru_gates_packed(conv._conv_forward(torch.cat([h, rest], dim=1), w_zr, None), h, None, p_zr)
-            h = o.gru_update(z, conv._conv_forward(torch.cat([rh, rest], dim=1), w_q, None), h, None, p_q)
+            # sepconv5 reads [h | rest] in place: no torch.cat, no im2col
+            z, rh = o.gru_gates_packed(o.sepconv5(h, rest, w_zr), h, None, p_zr)
+            h = o.gru_update(z, o.sepconv5(rh, rest, w_q), h, None, p_q)
         return h
 
 

@@ -240,6 +240,49 @@ def test_attack_math_vs_reference_golden():
     assert abs(float(hip_ops.two_norm_avg_delta(d1, d2)) - float(g["l2_12"])) < 2e-6 * float(g["l2_12"])
 
 
+@pytest.mark.parametrize("shape", [
+    # (B, Ca, Cb, Cout, H, W): RAFT z|r and q at the BASELINE feature size, GMA q, ragged everything, no second input
+    (1, 128, 128, 256, 55, 128), (1, 128, 128, 128, 55, 128), (1, 128, 256, 128, 55, 128),
+    (2, 5, 6, 7, 9, 70), (1, 12, 0, 66, 6, 3), (1, 3, 2, 4, 1, 1)])
+@pytest.mark.parametrize("vertical", [False, True])
+def test_sepconv5_vs_oracle(oracle_ops, shape, vertical):
+    """SepConvGRU (1,5)/(5,1) gate convolutions (update.py:36-60) as implicit MFMA GEMM over [a | b]: exact fp32
+    products, different summation order than conv2d -> 2e-6 relative L2 forward and data gradients."""
+    B, Ca, Cb, Cout, H, W = shape
+    gen = torch.Generator().manual_seed(31 + Ca + W)
+    a = torch.randn(B, Ca, H, W, generator=gen)
+    b = torch.randn(B, Cb, H, W, generator=gen) if Cb else None
+    w = torch.randn((Cout, Ca + Cb) + ((5, 1) if vertical else (1, 5)), generator=gen) / (5 * (Ca + Cb)) ** .5
+    go = torch.randn(B, Cout, H, W, generator=gen)
+    ca = a.clone().requires_grad_(True)
+    cb = None if b is None else b.clone().requires_grad_(True)
+    want = oracle_ops.sepconv5(ca, cb, w)
+    want.backward(go)
+    ga = a.clone().to(DEV).requires_grad_(True)
+    gb = None if b is None else b.clone().to(DEV).requires_grad_(True)
+    got = hip_ops.sepconv5(ga, gb, w.to(DEV))
+    assert got.shape == want.shape
+    assert rel_l2(got, want) < 2e-6
+    got.backward(go.to(DEV))
+    assert rel_l2(ga.grad, ca.grad) < 2e-6
+    if b is not None:
+        assert rel_l2(gb.grad, cb.grad) < 2e-6
+
+
+def test_sepconv5_rejects_bad_operands():
+    w = torch.zeros(4, 3, 1, 5, device=DEV)
+    with pytest.raises(ValueError):
+        hip_ops.sepconv5(torch.zeros(1, 2, 4, 4, device=DEV), None, w)          # channel mismatch
+    with pytest.raises(ValueError):
+        hip_ops.sepconv5(torch.zeros(1, 3, 4, 4, device=DEV), None, torch.zeros(4, 3, 3, 3, device=DEV))
+    with pytest.raises(RuntimeError):
+        hip_ops.sepconv5(torch.zeros(1, 3, 4, 4), None, w.cpu())               # no CPU fallback
+    wg = w.clone().requires_grad_(True)
+    out = hip_ops.sepconv5(torch.zeros(1, 3, 4, 4, device=DEV, requires_grad=True), None, wg)
+    with pytest.raises(RuntimeError):
+        out.sum().backward()                                                    # frozen-weight path only
+
+
 def test_gru_gate_kernels_vs_oracle(oracle_ops):
     """SepConvGRU elementwise chain (update.py:45-60): device expf/tanhf vs torch CPU -> 2e-6 relative."""
     gen = torch.Generator().manual_seed(8)

@@ -74,6 +74,19 @@ def main():
     t = timeit(full_bwd, iters=10)
     print("lookup fwd + lookup bwd + pyramid bwd (2 GEMMs) %9.1f us" % t)
 
+    # SepConvGRU gate convolutions at 55x128 (RAFT: [h | motion] = 128+128 channels), against the library conv
+    import torch.nn.functional as F
+    for name, cout, cb in (("z|r", 256, 128), ("q", 128, 128), ("GMA z|r", 256, 256)):
+        for kh, kw in ((1, 5), (5, 1)):
+            a = torch.randn(1, 128, H, W, device=DEV)
+            b = torch.randn(1, cb, H, W, device=DEV)
+            wgt = torch.randn(cout, 128 + cb, kh, kw, device=DEV) * 0.03
+            gf = 2 * 5 * (128 + cb) * cout * Q
+            t = timeit(lambda: hip_ops.sepconv5(a, b, wgt))
+            tl = timeit(lambda: F.conv2d(torch.cat([a, b], 1), wgt, None, padding=(kh // 2, kw // 2)))
+            print("sepconv5 %-8s %dx%d  %7.1f us  %5.1f TFLOP/s   | cat + library conv2d %7.1f us" %
+                  (name, kh, kw, t, gf / t / 1e6, tl))
+
     # PWC cost volume at KITTI level shapes
     for (C, h, w) in ((196, 6, 20), (128, 12, 40), (96, 24, 80), (64, 48, 160), (32, 96, 320)):
         a = torch.randn(1, C, h, w, device=DEV, requires_grad=True)
