@@ -237,6 +237,7 @@ def cpu_baseline(net, h, w, nclosures, threads=0):
 def main():
     a = parse()
     from pcfa_amd import sharding
+    json_out, sys.stdout = sys.stdout, sys.stderr  # stdout carries the ONE JSON line; the mirrors' chatter goes to stderr
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # one process per GPU; PCFA_BENCH_BACKEND=gloo + PCFA_BENCH_SHARE_GPU=1 only exist to exercise the
@@ -324,7 +325,8 @@ def main():
                                "bytes_per_launch": nbytes, "mean_launch_us": us, "launches_timed": n}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.net, h, w, a.cpu_closures, a.cpu_threads)
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
+    sys.stdout = json_out
     sharding.shutdown()
     return out
 

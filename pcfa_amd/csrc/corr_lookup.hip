@@ -148,10 +148,25 @@ __device__ __forceinline__ WindowBlock window_block(int x0, int y0, int tw, int 
   return w;
 }
 
-template <int R>
-__global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
+// Diagnostic stamps (tools/dev/lookup_stamps.*, never in the product kernel): slot k of wave w of workgroup g
+// lands in stamps[(g*NW + w)*STAMP_SLOTS + k].  STAMP == false compiles every stamp away.
+constexpr int STAMP_SLOTS = 12;
+template <bool STAMP>
+__device__ __forceinline__ void stamp(unsigned long long* st, int slot, bool drain_vm) {
+  if constexpr (STAMP) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (drain_vm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    if (threadIdx.x == 0) st[slot] = t;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int R, bool STAMP>
+__device__ __forceinline__ void corr_lookup_fwd_body(
     const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
-    int Q, int qb, PyrLayout P) {
+    int Q, int qb, const PyrLayout& P, unsigned long long* stamps) {
   using G = Geo<R>;
   constexpr int N1 = G::N1, WIN = G::WIN, NWIN = G::NWIN;
   __shared__ __attribute__((aligned(16))) float s_win[QB * WS];
@@ -170,6 +185,17 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
   const int lane = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // blockDim.x == 64: one wave per y
   const float* slab0 = scalar_ptr(pyr + ((size_t)b_img * Q + q0) * slab);  // SGPR base of every window load
+  unsigned long long* st = nullptr;
+  if constexpr (STAMP) {
+    const int g = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    st = stamps + ((size_t)g * N1 + wv) * STAMP_SLOTS;
+    unsigned long long rt;
+    unsigned hwid, xcc;
+    asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\t"
+                 "s_waitcnt lgkmcnt(0)" : "=s"(rt), "=s"(hwid), "=s"(xcc)::"memory");
+    if (lane == 0) { st[0] = rt; st[10] = ((unsigned long long)xcc << 32) | hwid; }
+  }
+  stamp<STAMP>(st, 1, false);
 
   // ---- Phase A: window fetch, one window per wave-instruction -----------------------------
   // Lane k (< NWIN) does ALL the bookkeeping of this wave's k-th window (j = wv + k*N1) once, in
@@ -194,6 +220,7 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
       myP = w.lo_tx | (w.n_tx << 4) | (w.lo_ry << 8) | (w.n_ry << 16);
     }
   }
+  stamp<STAMP>(st, 2, true);  // coords landed, bookkeeping done
   const int ty = lane >> 4, tx = (lane >> 2) & 3, r = lane & 3;
   const int ry = ty * 4 + r;                                      // row inside the 16x16 texel block
   const int lane_goff4 = (((ty * tw + tx) << 4) + (r << 2)) * 4;  // bytes, relative to tile (ty0, tx0)
@@ -207,17 +234,24 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
     // lanes outside the window read the all-zero tile of slab q0: branch-free, no select afterwards
     v[k] = load_tile_row(slab0, need ? (unsigned)(sT + lane_goff4) : zero4);
   }
+  stamp<STAMP>(st, 3, false);  // window loads issued
   wait_all_loads(v);
+  stamp<STAMP>(st, 4, false);  // windows landed
 #pragma unroll
   for (int k = 0; k < NWIN; ++k) {
     const int j = wv + k * N1;
     if (j < qb && ry < WROWS) *reinterpret_cast<f32x4*>(lds_row + k * N1 * WS) = v[k];
   }
+  stamp<STAMP>(st, 5, false);  // LDS image written
   __syncthreads();
+  stamp<STAMP>(st, 6, false);  // barrier passed
 
   // ---- Phase B: thread (query, b) blends the 2r+1 taps of window row b ---------------------
   const int j = lane, b = wv;
-  if (j >= qb || q0 + j >= Q) return;
+  if constexpr (!STAMP) {
+    if (j >= qb || q0 + j >= Q) return;
+  }
+  const bool live = j < qb && q0 + j < Q;
   const int ox = s_ox[j], oy = s_oy[j];
   const float fx = s_fx[j], fy = s_fy[j];
   const float* row0 = &s_win[j * WS + (oy + b) * RS];
@@ -228,10 +262,42 @@ __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
   const float w10 = (1.f - fx) * fy, w11 = fx * fy;
   const int C = P.L * N1 * N1;
   float* o = out + ((size_t)b_img * C + (size_t)level * N1 * N1 + b) * Q + q0 + j;
+  float res[N1];
 #pragma unroll
-  for (int a = 0; a < N1; ++a)
-    o[(size_t)a * N1 * Q] = t0[a] * w00 + t0[a + 1] * w01 + t1[a] * w10 + t1[a + 1] * w11;
+  for (int a = 0; a < N1; ++a) res[a] = t0[a] * w00 + t0[a + 1] * w01 + t1[a] * w10 + t1[a + 1] * w11;
+  if constexpr (STAMP) {
+#pragma unroll
+    for (int a = 0; a < N1; ++a) asm volatile("" : "+v"(res[a]));
+  }
+  stamp<STAMP>(st, 7, false);  // blended
+  if (live) {
+#pragma unroll
+    for (int a = 0; a < N1; ++a) o[(size_t)a * N1 * Q] = res[a];
+  }
+  stamp<STAMP>(st, 8, false);  // stores issued
+  stamp<STAMP>(st, 9, true);   // stores acknowledged
+  if constexpr (STAMP) {
+    unsigned long long rt;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+    if (lane == 0) st[11] = rt;
+  }
 }
+
+template <int R>
+__global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
+    const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
+    int Q, int qb, PyrLayout P) {
+  corr_lookup_fwd_body<R, false>(pyr, coords, out, Q, qb, P, nullptr);
+}
+
+#ifdef PCFA_LOOKUP_DEV
+template <int R>
+__global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_stamped_kernel(
+    const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
+    int Q, int qb, PyrLayout P, unsigned long long* stamps) {
+  corr_lookup_fwd_body<R, true>(pyr, coords, out, Q, qb, P, stamps);
+}
+#endif
 
 template <int R>
 __global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_bwd_kernel(
