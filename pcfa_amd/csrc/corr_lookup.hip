@@ -107,6 +107,14 @@ __device__ __forceinline__ f32x4 load_tile_row(const float* sbase, unsigned voff
   return v;
 }
 
+// Same load for the lanes of `mask` only; the other lanes keep the previous register contents.
+__device__ __forceinline__ void load_tile_row_masked(f32x4& v, const float* sbase, unsigned voff_bytes,
+                                                     unsigned long long mask) {
+  unsigned long long save;
+  asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_load_dwordx4 %0, %2, %3\n\ts_mov_b64 exec, %1"
+               : "+v"(v), "=&s"(save) : "v"(voff_bytes), "s"(sbase), "s"(mask) : "memory");
+}
+
 // Pin a wave-uniform pointer into SGPRs (the "s" asm operand above needs it there).
 __device__ __forceinline__ const float* scalar_ptr(const float* p) {
   const unsigned long long u = reinterpret_cast<unsigned long long>(p);
@@ -163,8 +171,158 @@ __device__ __forceinline__ void stamp(unsigned long long* st, int slot, bool dra
   }
 }
 
-template <int R, bool STAMP>
+// Window image in LDS (forward): window j occupies WS2 floats = WIN rows of RS2 floats; row r holds window
+// texel (r, c) at column 4 + c -- the sub-tile offset (ox, oy) of the window inside its 16x16 fetch block is
+// removed when the fetched tile rows are WRITTEN (a wave-uniform address shift, four dword stores per lane),
+// so phase B reads aligned rows with ds_read_b128 and needs no per-lane shifting.  WS2/4 is odd: the b128
+// reads of 16 consecutive windows are bank-conflict free.
+constexpr int RS2 = 20;
+template <int R>
+struct Geo2 {
+  static constexpr int WIN = 2 * R + 2;
+  static constexpr int WS = WIN * RS2 + 4;
+  static constexpr int NRD = (WIN + 3) / 4;  // b128 reads per window row
+};
+
+template <int R, bool STAMP, bool MASKED_LOADS>
 __device__ __forceinline__ void corr_lookup_fwd_body(
+    const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
+    int Q, int qb, const PyrLayout& P, unsigned long long* stamps) {
+  using G = Geo<R>;
+  constexpr int N1 = G::N1, WIN = G::WIN, NWIN = G::NWIN;
+  constexpr int WS2 = Geo2<R>::WS, NRD = Geo2<R>::NRD;
+  __shared__ __attribute__((aligned(16))) float s_win[QB * WS2];
+  __shared__ float s_fx[QB], s_fy[QB];
+
+  const int level = blockIdx.y, b_img = blockIdx.z;
+  const int q0 = blockIdx.x * qb;  // qb <= QB queries per workgroup
+  // wave-uniform layout fields, pinned to SGPRs before any divergent branch
+  const int hl = __builtin_amdgcn_readfirstlane(P.h[level]);
+  const int tw = __builtin_amdgcn_readfirstlane(P.tw[level]);
+  const int off = __builtin_amdgcn_readfirstlane(P.off[level]);
+  const int slab = __builtin_amdgcn_readfirstlane(P.slab);
+  const unsigned zero4 = (unsigned)__builtin_amdgcn_readfirstlane(P.zero) * 4u;
+  const int th4 = ((hl + 3) >> 2) << 2;  // padded height (pad rows hold zeros)
+  const int lane = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // blockDim.x == 64: one wave per y
+  const float* slab0 = scalar_ptr(pyr + ((size_t)b_img * Q + q0) * slab);  // SGPR base of every window load
+  unsigned long long* st = nullptr;
+  if constexpr (STAMP) {
+    const int g = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    st = stamps + ((size_t)g * N1 + wv) * STAMP_SLOTS;
+    unsigned long long rt;
+    unsigned hwid, xcc;
+    asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\t"
+                 "s_waitcnt lgkmcnt(0)" : "=s"(rt), "=s"(hwid), "=s"(xcc)::"memory");
+    if (lane == 0) { st[0] = rt; st[10] = ((unsigned long long)xcc << 32) | hwid; }
+  }
+  stamp<STAMP>(st, 1, false);
+
+  // ---- Phase A: window fetch, one window per wave-instruction -----------------------------
+  // Lane k (< NWIN) does ALL the bookkeeping of this wave's k-th window (j = wv + k*N1) once, in
+  // vector registers; the loop below only broadcasts two packed words per window (v_readlane).
+  int myT = 0, myP = 0;
+  {
+    const int j = wv + lane * N1;
+    if (lane < NWIN && j < qb) {
+      const bool valid = q0 + j < Q;
+      float cx = 0.f, cy = 0.f;
+      if (valid) {
+        cx = coords[((size_t)b_img * 2 + 0) * Q + q0 + j];
+        cy = coords[((size_t)b_img * 2 + 1) * Q + q0 + j];
+      }
+      const Origin o = make_origin(cx, cy, level, R);
+      s_fx[j] = o.fx;
+      s_fy[j] = o.fy;
+      const WindowBlock w = window_block<WIN>(o.x0, o.y0, tw, th4, valid);
+      myT = (off + w.tile_off + (valid ? j : 0) * slab) * 4;  // bytes from this workgroup's first slab
+      // bits 0-3 lo_tx, 4-7 n_tx, 8-11 lo_ry, 12-15 n_ry, 16-25 LDS shift (oy*RS2 + ox)*4 bytes
+      myP = w.lo_tx | (w.n_tx << 4) | (w.lo_ry << 8) | (w.n_ry << 12) |
+            ((((o.y0 & 3) * RS2 + (o.x0 & 3)) * 4) << 16) | ((o.y0 & 3) << 28);
+    }
+  }
+  stamp<STAMP>(st, 2, true);  // coords landed, bookkeeping done
+  const int ty = lane >> 4, tx = (lane >> 2) & 3, r = lane & 3;
+  const int ry = ty * 4 + r;                                      // row inside the 16x16 texel block
+  const int lane_goff4 = (((ty * tw + tx) << 4) + (r << 2)) * 4;  // bytes, relative to tile (ty0, tx0)
+  // LDS byte address of this lane's 4 texels for a window with ox = oy = 0 (window k adds k*N1*WS2, minus the shift)
+  const unsigned lane_lds = (unsigned)((wv * WS2 + ry * RS2 + 4 + tx * 4) * 4);
+  f32x4 v[NWIN];
+#pragma unroll
+  for (int k = 0; k < NWIN; ++k) {
+    const int sT = __builtin_amdgcn_readlane(myT, k), sP = __builtin_amdgcn_readlane(myP, k);
+    const bool need = (unsigned)(tx - (sP & 15)) < (unsigned)((sP >> 4) & 15) &&
+                      (unsigned)(ry - ((sP >> 8) & 15)) < (unsigned)((sP >> 12) & 15);
+    if constexpr (MASKED_LOADS) {
+      v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      load_tile_row_masked(v[k], slab0, (unsigned)(sT + lane_goff4), __builtin_amdgcn_ballot_w64(need));
+    } else {
+      // lanes outside the window read the all-zero tile of slab q0: branch-free, no select afterwards
+      v[k] = load_tile_row(slab0, need ? (unsigned)(sT + lane_goff4) : zero4);
+    }
+  }
+  stamp<STAMP>(st, 3, false);  // window loads issued
+  wait_all_loads(v);
+  stamp<STAMP>(st, 4, false);  // windows landed
+  char* lds_bytes = reinterpret_cast<char*>(s_win);
+#pragma unroll
+  for (int k = 0; k < NWIN; ++k) {
+    const int j = wv + k * N1;
+    const int sP = __builtin_amdgcn_readlane(myP, k);
+    const int oy = (sP >> 28) & 3;
+    if (j < qb && (unsigned)(ry - oy) < (unsigned)WIN) {
+      float* dst = reinterpret_cast<float*>(lds_bytes + (lane_lds + (unsigned)(k * N1 * WS2 * 4) - (unsigned)((sP >> 16) & 1023)));
+      dst[0] = v[k].x; dst[1] = v[k].y; dst[2] = v[k].z; dst[3] = v[k].w;
+    }
+  }
+  stamp<STAMP>(st, 5, false);  // LDS image written
+  __syncthreads();
+  stamp<STAMP>(st, 6, false);  // barrier passed
+
+  // ---- Phase B: thread (query, b) blends the 2r+1 taps of window row b ---------------------
+  const int j = lane, b = wv;
+  if constexpr (!STAMP) {
+    if (j >= qb || q0 + j >= Q) return;
+  }
+  const bool live = j < qb && q0 + j < Q;
+  const float fx = s_fx[j], fy = s_fy[j];
+  const float4* row0 = reinterpret_cast<const float4*>(&s_win[j * WS2 + b * RS2 + 4]);
+  const float4* row1 = reinterpret_cast<const float4*>(&s_win[j * WS2 + (b + 1) * RS2 + 4]);
+  float t0[NRD * 4], t1[NRD * 4];
+#pragma unroll
+  for (int i = 0; i < NRD; ++i) {
+    const float4 u0 = row0[i], u1 = row1[i];
+    t0[4 * i] = u0.x; t0[4 * i + 1] = u0.y; t0[4 * i + 2] = u0.z; t0[4 * i + 3] = u0.w;
+    t1[4 * i] = u1.x; t1[4 * i + 1] = u1.y; t1[4 * i + 2] = u1.z; t1[4 * i + 3] = u1.w;
+  }
+  const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
+  const float w10 = (1.f - fx) * fy, w11 = fx * fy;
+  const int C = P.L * N1 * N1;
+  float* o = out + ((size_t)b_img * C + (size_t)level * N1 * N1 + b) * Q + q0 + j;
+  float res[N1];
+#pragma unroll
+  for (int a = 0; a < N1; ++a) res[a] = t0[a] * w00 + t0[a + 1] * w01 + t1[a] * w10 + t1[a + 1] * w11;
+  if constexpr (STAMP) {
+#pragma unroll
+    for (int a = 0; a < N1; ++a) asm volatile("" : "+v"(res[a]));
+  }
+  stamp<STAMP>(st, 7, false);  // blended
+  if (live) {
+#pragma unroll
+    for (int a = 0; a < N1; ++a) o[(size_t)a * N1 * Q] = res[a];
+  }
+  stamp<STAMP>(st, 8, false);  // stores issued
+  stamp<STAMP>(st, 9, true);   // stores acknowledged
+  if constexpr (STAMP) {
+    unsigned long long rt;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+    if (lane == 0) st[11] = rt;
+  }
+}
+
+#ifdef PCFA_LOOKUP_DEV
+template <int R, bool STAMP>
+__device__ __forceinline__ void corr_lookup_fwd_body_v1(
     const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
     int Q, int qb, const PyrLayout& P, unsigned long long* stamps) {
   using G = Geo<R>;
@@ -283,19 +441,28 @@ __device__ __forceinline__ void corr_lookup_fwd_body(
   }
 }
 
+#endif
+
+// __launch_bounds__(1024), not the 64*(2r+1) threads actually launched: with the real bound hipcc derives an
+// LDS-limited occupancy (2 workgroups x 9 waves -> 5 waves/SIMD) and INFLATES the kernel descriptor's VGPR
+// count to cap the hardware at it (next_free_vgpr 81 for 36 live registers); a 9-wave workgroup then no longer
+// fits twice on a CU and the second half of the grid waits for the first (tools/dev/census.hip, measured).
 template <int R>
-__global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_kernel(
+__global__ __launch_bounds__(1024) void corr_lookup_fwd_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
     int Q, int qb, PyrLayout P) {
-  corr_lookup_fwd_body<R, false>(pyr, coords, out, Q, qb, P, nullptr);
+  corr_lookup_fwd_body<R, false, false>(pyr, coords, out, Q, qb, P, nullptr);
 }
 
 #ifdef PCFA_LOOKUP_DEV
-template <int R>
-__global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_fwd_stamped_kernel(
+// A/B variants for tools/dev: VAR 0 = previous kernel (bounded), 1 = previous kernel with the 1024 bound,
+// 2 = this kernel, 3 = this kernel with exec-masked window loads instead of zero-tile loads.
+template <int VAR, bool STAMP>
+__global__ __launch_bounds__(VAR == 0 ? 576 : 1024) void corr_lookup_fwd_var_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
     int Q, int qb, PyrLayout P, unsigned long long* stamps) {
-  corr_lookup_fwd_body<R, true>(pyr, coords, out, Q, qb, P, stamps);
+  if constexpr (VAR <= 1) corr_lookup_fwd_body_v1<4, STAMP>(pyr, coords, out, Q, qb, P, stamps);
+  else corr_lookup_fwd_body<4, STAMP, VAR == 3>(pyr, coords, out, Q, qb, P, stamps);
 }
 #endif
 

@@ -10,16 +10,31 @@ PcfaTimingState& pcfa_timing_state() {
   return s;
 }
 
-extern "C" __attribute__((visibility("default"))) int dev_lookup_fwd_stamped(
-    const float* pyr, const float* coords, float* out, int B, int H, int W, int num_levels,
+template <int VAR>
+static int launch_var(bool stamped, const float* pyr, const float* coords, float* out, int B, int Q, const PyrLayout& P,
+                      unsigned long long* stamps, hipStream_t s) {
+  dim3 grid(pcfa_cdiv(Q, QB), P.L, B), block(QB, 9, 1);
+  if (stamped)
+    hipLaunchKernelGGL((corr_lookup_fwd_var_kernel<VAR, true>), grid, block, 0, s, pyr, coords, out, Q, QB, P, stamps);
+  else
+    hipLaunchKernelGGL((corr_lookup_fwd_var_kernel<VAR, false>), grid, block, 0, s, pyr, coords, out, Q, QB, P, stamps);
+  return (int)hipGetLastError();
+}
+
+extern "C" __attribute__((visibility("default"))) int dev_lookup_fwd_var(
+    int var, int stamped, const float* pyr, const float* coords, float* out, int B, int H, int W, int num_levels,
     unsigned long long* stamps, void* stream) {
   PyrLayout P;
   if (!pcfa_make_layout(P, H, W, num_levels)) return -1;
+  hipStream_t s = (hipStream_t)stream;
   const int Q = H * W;
-  dim3 grid(pcfa_cdiv(Q, QB), P.L, B), block(QB, 9, 1);
-  hipLaunchKernelGGL(corr_lookup_fwd_stamped_kernel<4>, grid, block, 0, (hipStream_t)stream, pyr, coords, out, Q,
-                     QB, P, stamps);
-  return (int)hipGetLastError();
+  switch (var) {
+    case 0: return launch_var<0>(stamped, pyr, coords, out, B, Q, P, stamps, s);
+    case 1: return launch_var<1>(stamped, pyr, coords, out, B, Q, P, stamps, s);
+    case 2: return launch_var<2>(stamped, pyr, coords, out, B, Q, P, stamps, s);
+    case 3: return launch_var<3>(stamped, pyr, coords, out, B, Q, P, stamps, s);
+  }
+  return -2;
 }
 
 extern "C" __attribute__((visibility("default"))) int dev_stamp_slots() { return STAMP_SLOTS; }

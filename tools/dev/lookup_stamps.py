@@ -20,9 +20,12 @@ NAMES = ["rt0", "start", "coords+bookkeeping", "window loads issued", "windows l
 
 
 def main():
+    """usage: lookup_stamps.py stamps [variants]   -> phase tables of the stamped builds
+              lookup_stamps.py time warm|cold [variants] -> N plain launches per variant (run under rocprofv3)"""
+    what = sys.argv[1] if len(sys.argv) > 1 else "stamps"
     lib = ctypes.CDLL(os.path.join(HERE, "liblookup_dev.so"))
     P = ctypes.c_void_p
-    lib.dev_lookup_fwd_stamped.argtypes = [P, P, P] + [ctypes.c_int] * 4 + [P, P]
+    lib.dev_lookup_fwd_var.argtypes = [ctypes.c_int] * 2 + [P, P, P] + [ctypes.c_int] * 4 + [P, P]
     slots = lib.dev_stamp_slots()
     B, D, H, W = 1, 256, 55, 128
     Q = H * W
@@ -39,19 +42,41 @@ def main():
     stamps = torch.zeros(nwg * 9 * slots, dtype=torch.int64, device=DEV)
     junk = torch.empty(512 * 1024 * 1024 // 4, device=DEV)
     stream = torch.cuda.current_stream().cuda_stream
-    for mode in ("warm", "cold"):
+
+    def launch(var, stamped):
+        rc = lib.dev_lookup_fwd_var(var, stamped, pyr.data_ptr(), coords.data_ptr(), out.data_ptr(), B, H, W, 4,
+                                    stamps.data_ptr(), stream)
+        assert rc == 0, rc
+
+    if what == "time":
+        mode = sys.argv[2]
+        variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1, 2, 3]
+        for var in variants:
+            out.zero_()
+            launch(var, 0)
+            torch.cuda.synchronize()
+            print("variant %d: max |diff| vs product %.3g, bit-equal %s" %
+                  (var, float((out - want).abs().max()), torch.equal(out, want)))
+        for rep in range(30):
+            for var in variants:
+                if mode == "cold":
+                    junk.add_(1.0)
+                launch(var, 0)
+        torch.cuda.synchronize()
+        return
+    variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 2]
+    for var, mode in [(v, m) for v in variants for m in ("warm", "cold")]:
         for rep in range(3):
             if mode == "cold":
                 junk.add_(1.0)
             else:
-                blk(coords)
-            rc = lib.dev_lookup_fwd_stamped(pyr.data_ptr(), coords.data_ptr(), out.data_ptr(), B, H, W, 4,
-                                            stamps.data_ptr(), stream)
-            assert rc == 0, rc
+                launch(var, 0)
+            launch(var, 1)
             torch.cuda.synchronize()
         assert torch.equal(out, want), "stamped build changed the result"
         s = stamps.cpu().numpy().reshape(nwg, 9, slots).astype(np.int64)
-        np.save(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "lookup_stamps_%s.npy" % mode), s)
+        np.save(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "lookup_stamps_v%d_%s.npy" % (var, mode)), s)
+        print("######## variant %d" % var)
         rt0, rt1 = s[:, :, 0], s[:, :, 11]
         t0 = rt0.min()
         print("== %s: %d workgroups x 9 waves; s_memrealtime tick = 10 ns" % (mode, nwg))
