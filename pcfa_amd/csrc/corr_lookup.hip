@@ -8,34 +8,43 @@
 // offset, so a lookup is "fetch a (2r+2)^2 window, blend it 4 ways".
 //
 // Work decomposition (wave64): workgroup = 64 consecutive queries x one level,
-// 2r+1 waves.
-//   A. one WAVE fetches one window per instruction: lane = (tile row, tile col,
-//      row in tile) of the 4x4 tile block that covers the window, a single
-//      16-B load per lane -> whole 64-B sectors, ~11 per window.  A wave issues
-//      the loads of all its windows back to back (8 in flight per lane) before
-//      touching LDS.  Window origins are wave-uniform (readlane of the coords),
-//      no barrier is needed to share them.
-//   B. after one barrier, thread (query, b) reads two window rows from LDS
-//      (4 x ds_read_b128 each, conflict-free strides), shifts them by the
-//      window's sub-tile offset and blends the 2r+1 taps of row b; stores run
-//      along the query index (256-B per wave-instruction).
-// The backward is the exact transpose with the same ownership: every window
-// texel is owned by one lane of one workgroup, so dpyr += ... needs no atomics
-// and is bitwise reproducible.
+// 2r+1 waves, both directions:
+//   * a window is fetched as PIECES: one piece = the 16 B (4 texels of one tile
+//     row) that one window row crosses in one tile column, (2r+2) x TXN pieces
+//     per window (TXN = tile columns a window can cross).  A wave-instruction
+//     moves 64 consecutive pieces of the wave's windows -- whole 64-B sectors,
+//     about 11 per window, and nothing but the window's own rows;
+//   * the window image lives in LDS with the window's sub-tile offset REMOVED
+//     (the shift happens where the image is written / read piecewise, four
+//     dwords per lane at a per-lane address), so the per-query side works on
+//     aligned rows with 16-B LDS accesses and no per-lane shifting;
+//   * forward: pieces -> LDS -> barrier -> thread (query, b) blends the 2r+1
+//     taps of window row b; stores run along the query index (256 B per
+//     wave-instruction).
+//   * backward: the exact transpose with the same ownership: thread (query, row)
+//     builds one row of the window's gradient image in LDS, then each piece is
+//     read back and added to dpyr (read-modify-write of 16 B per lane).  Every
+//     window texel is owned by one lane of one workgroup: no atomics, bitwise
+//     reproducible.
 #include "common.hpp"
 
 namespace {
 
-constexpr int QB = 64;      // queries (= windows) per workgroup
-constexpr int WROWS = 13;   // window rows kept in LDS: sub-tile offset (<=3) + 2r+2 (<=10)
-constexpr int RS = 20;      // LDS row stride (floats): b128 writes of a tile row block stay conflict-light
-constexpr int WS = WROWS * RS;  // 260 floats per window: 260 mod 64 == 4 -> b128 reads of 16 windows conflict-free
+constexpr int QB = 64;  // queries (= windows) per workgroup
+constexpr int RS = 20;  // LDS row stride (floats): 4 pad + 16; window texel (r, c) sits at r*RS + 4 + c
 
 template <int R>
 struct Geo {
-  static constexpr int N1 = 2 * R + 1;
-  static constexpr int WIN = 2 * R + 2;
-  static constexpr int NWIN = (QB + N1 - 1) / N1;  // windows per wave
+  static constexpr int N1 = 2 * R + 1;                      // taps per axis = waves per workgroup
+  static constexpr int WIN = 2 * R + 2;                     // window texels per axis
+  static constexpr int NWIN = (QB + N1 - 1) / N1;           // windows staged per wave
+  static constexpr int TXN = ((WIN + 2) >> 2) + 1;          // tile columns a window can cross
+  static constexpr int PIECES = WIN * TXN;                  // 16-B pieces per window
+  static constexpr int NP = (NWIN * PIECES + 63) / 64;      // piece wave-instructions per wave
+  static constexpr int WS = WIN * RS + 4;                   // floats per window image; WS/4 odd -> the b128 accesses
+                                                            // of 16 consecutive windows hit 16 distinct bank groups
+  static constexpr int NRD = (WIN + 3) / 4;                 // b128 accesses per window row
+  static constexpr int LDS_FLOATS = QB * WS + 4;            // + a 16-B dump slot for lanes without a piece
 };
 
 struct Origin {
@@ -56,71 +65,26 @@ __device__ __forceinline__ Origin make_origin(float cx, float cy, int level, int
   return o;
 }
 
-__device__ __forceinline__ float lane_bcast(float v, int srclane) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), srclane));
-}
-
-// Element I (compile-time) of a 16-float row held as four float4 -- keeps the row in SSA values so
-// the shift below stays a chain of v_cndmask (an indexable array here ends up in scratch memory).
-template <int I>
-__device__ __forceinline__ float elem16(const float4& a, const float4& b, const float4& c, const float4& d) {
-  constexpr int quad = I >> 2, comp = I & 3;
-  const float4& v = quad == 0 ? a : quad == 1 ? b : quad == 2 ? c : d;
-  return comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
-}
-
-template <int WIN, int C>
-struct ShiftRow {
-  __device__ __forceinline__ static void run(const float4& a, const float4& b, const float4& c, const float4& d,
-                                             bool by2, bool by1, float* t) {
-    // element ox + C of the row, ox = 2*by2 + by1
-    const float e0 = by2 ? elem16<C + 2>(a, b, c, d) : elem16<C>(a, b, c, d);
-    const float e1 = by2 ? elem16<C + 3>(a, b, c, d) : elem16<C + 1>(a, b, c, d);
-    t[C] = by1 ? e1 : e0;
-    ShiftRow<WIN, C + 1>::run(a, b, c, d, by2, by1, t);
-  }
-};
-template <int WIN>
-struct ShiftRow<WIN, WIN> {
-  __device__ __forceinline__ static void run(const float4&, const float4&, const float4&, const float4&, bool,
-                                             bool, float*) {}
-};
-
-// t[c] = row[ox + c], c < WIN, ox in 0..3: four aligned ds_read_b128 + selects (no unaligned LDS access)
-template <int WIN>
-__device__ __forceinline__ void shifted_row(const float* row, int ox, float* t) {
-  const float4 a = *reinterpret_cast<const float4*>(row);
-  const float4 b = *reinterpret_cast<const float4*>(row + 4);
-  const float4 c = *reinterpret_cast<const float4*>(row + 8);
-  const float4 d = *reinterpret_cast<const float4*>(row + 12);
-  ShiftRow<WIN, 0>::run(a, b, c, d, (ox & 2) != 0, (ox & 1) != 0, t);
-}
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// 16-B load at (64-bit scalar base) + (32-bit per-lane byte offset).  Inline asm so that the compiler
-// neither predicates it back into a branch nor waits between the back-to-back loads of a wave; the
-// caller drains them with wait_all_loads() before the first use (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ f32x4 load_tile_row(const float* sbase, unsigned voff_bytes) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff_bytes), "s"(sbase) : "memory");
-  return v;
-}
-
-// Same load for the lanes of `mask` only; the other lanes keep the previous register contents.
-__device__ __forceinline__ void load_tile_row_masked(f32x4& v, const float* sbase, unsigned voff_bytes,
-                                                     unsigned long long mask) {
+// 16-B load at (64-bit scalar base) + (32-bit per-lane byte offset) for the lanes of `mask` only; the other
+// lanes keep the previous register contents.  Inline asm so that the compiler neither waits between the
+// back-to-back loads of a wave nor turns the mask into a branch; the caller drains them with wait_all_loads()
+// before the first use (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void load_piece_masked(f32x4& v, const float* sbase, unsigned voff_bytes,
+                                                  unsigned long long mask) {
   unsigned long long save;
   asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_load_dwordx4 %0, %2, %3\n\ts_mov_b64 exec, %1"
                : "+v"(v), "=&s"(save) : "v"(voff_bytes), "s"(sbase), "s"(mask) : "memory");
 }
 
 // Pin a wave-uniform pointer into SGPRs (the "s" asm operand above needs it there).
-__device__ __forceinline__ const float* scalar_ptr(const float* p) {
+template <typename T>
+__device__ __forceinline__ T* scalar_ptr(T* p) {
   const unsigned long long u = reinterpret_cast<unsigned long long>(p);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
 template <int N>
@@ -131,32 +95,7 @@ __device__ __forceinline__ void wait_all_loads(f32x4 (&v)[N]) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// Per-window scalar bookkeeping shared by forward and backward: which lanes of the 4x4-tile block
-// (lane = (ty, tx, r), row ry = 4*ty + r) hold texels of the window, and where the block starts.
-struct WindowBlock {
-  int tile_off;        // floats from the slab's level start to tile (ty0, tx0); valid lanes only
-  int lo_tx, n_tx;     // needed tile columns: tx - lo_tx < n_tx   (unsigned compare)
-  int lo_ry, n_ry;     // needed rows:         ry - lo_ry < n_ry
-};
-
-template <int WIN>
-__device__ __forceinline__ WindowBlock window_block(int x0, int y0, int tw, int hrows, bool valid) {
-  const int tx0 = x0 >> 2, ty0 = y0 >> 2;
-  WindowBlock w;
-  w.tile_off = (ty0 * tw + tx0) * 16;
-  const int lo_t = max(0, tx0), hi_t = min(tw, ((x0 + WIN - 1) >> 2) + 1);
-  const int lo_y = max(0, y0), hi_y = min(hrows, y0 + WIN);
-  const bool hit = valid && hi_t > lo_t && hi_y > lo_y;  // window intersects the level at all
-  // (far-away / NaN coordinates: keep every field inside its packed bit range)
-  w.lo_tx = hit ? lo_t - tx0 : 0;      // 0..3
-  w.n_tx = hit ? hi_t - lo_t : 0;      // 0..4
-  w.lo_ry = hit ? lo_y - ty0 * 4 : 0;  // 0..12
-  w.n_ry = hit ? hi_y - lo_y : 0;      // 0..WIN
-  if (!hit) w.tile_off = 0;
-  return w;
-}
-
-// Diagnostic stamps (tools/dev/lookup_stamps.*, never in the product kernel): slot k of wave w of workgroup g
+// Diagnostic stamps (tools/dev/lookup_stamps.py, never in the product kernels): slot k of wave w of workgroup g
 // lands in stamps[(g*NW + w)*STAMP_SLOTS + k].  STAMP == false compiles every stamp away.
 constexpr int STAMP_SLOTS = 12;
 template <bool STAMP>
@@ -170,109 +109,163 @@ __device__ __forceinline__ void stamp(unsigned long long* st, int slot, bool dra
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-
-// Window image in LDS (forward): window j occupies WS2 floats = WIN rows of RS2 floats; row r holds window
-// texel (r, c) at column 4 + c -- the sub-tile offset (ox, oy) of the window inside its 16x16 fetch block is
-// removed when the fetched tile rows are WRITTEN (a wave-uniform address shift, four dword stores per lane),
-// so phase B reads aligned rows with ds_read_b128 and needs no per-lane shifting.  WS2/4 is odd: the b128
-// reads of 16 consecutive windows are bank-conflict free.
-constexpr int RS2 = 20;
-template <int R>
-struct Geo2 {
-  static constexpr int WIN = 2 * R + 2;
-  static constexpr int WS = WIN * RS2 + 4;
-  static constexpr int NRD = (WIN + 3) / 4;  // b128 reads per window row
-};
-
-template <int R, bool STAMP, bool MASKED_LOADS>
-__device__ __forceinline__ void corr_lookup_fwd_body(
-    const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
-    int Q, int qb, const PyrLayout& P, unsigned long long* stamps) {
-  using G = Geo<R>;
-  constexpr int N1 = G::N1, WIN = G::WIN, NWIN = G::NWIN;
-  constexpr int WS2 = Geo2<R>::WS, NRD = Geo2<R>::NRD;
-  __shared__ __attribute__((aligned(16))) float s_win[QB * WS2];
-  __shared__ float s_fx[QB], s_fy[QB];
-
-  const int level = blockIdx.y, b_img = blockIdx.z;
-  const int q0 = blockIdx.x * qb;  // qb <= QB queries per workgroup
-  // wave-uniform layout fields, pinned to SGPRs before any divergent branch
-  const int hl = __builtin_amdgcn_readfirstlane(P.h[level]);
-  const int tw = __builtin_amdgcn_readfirstlane(P.tw[level]);
-  const int off = __builtin_amdgcn_readfirstlane(P.off[level]);
-  const int slab = __builtin_amdgcn_readfirstlane(P.slab);
-  const unsigned zero4 = (unsigned)__builtin_amdgcn_readfirstlane(P.zero) * 4u;
-  const int th4 = ((hl + 3) >> 2) << 2;  // padded height (pad rows hold zeros)
-  const int lane = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // blockDim.x == 64: one wave per y
-  const float* slab0 = scalar_ptr(pyr + ((size_t)b_img * Q + q0) * slab);  // SGPR base of every window load
+template <bool STAMP>
+__device__ __forceinline__ unsigned long long* stamp_begin(unsigned long long* stamps, int waves, int wv) {
   unsigned long long* st = nullptr;
   if constexpr (STAMP) {
     const int g = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    st = stamps + ((size_t)g * N1 + wv) * STAMP_SLOTS;
+    st = stamps + ((size_t)g * waves + wv) * STAMP_SLOTS;
     unsigned long long rt;
     unsigned hwid, xcc;
     asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\t"
                  "s_waitcnt lgkmcnt(0)" : "=s"(rt), "=s"(hwid), "=s"(xcc)::"memory");
-    if (lane == 0) { st[0] = rt; st[10] = ((unsigned long long)xcc << 32) | hwid; }
+    if (threadIdx.x == 0) {
+      st[0] = rt;
+      st[10] = ((unsigned long long)xcc << 32) | hwid;
+    }
   }
-  stamp<STAMP>(st, 1, false);
+  return st;
+}
+template <bool STAMP>
+__device__ __forceinline__ void stamp_end(unsigned long long* st) {
+  if constexpr (STAMP) {
+    unsigned long long rt;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+    if (threadIdx.x == 0) st[11] = rt;
+  }
+}
 
-  // ---- Phase A: window fetch, one window per wave-instruction -----------------------------
-  // Lane k (< NWIN) does ALL the bookkeeping of this wave's k-th window (j = wv + k*N1) once, in
-  // vector registers; the loop below only broadcasts two packed words per window (v_readlane).
-  int myT = 0, myP = 0;
-  {
-    const int j = wv + lane * N1;
-    if (lane < NWIN && j < qb) {
-      const bool valid = q0 + j < Q;
-      float cx = 0.f, cy = 0.f;
-      if (valid) {
-        cx = coords[((size_t)b_img * 2 + 0) * Q + q0 + j];
-        cy = coords[((size_t)b_img * 2 + 1) * Q + q0 + j];
-      }
-      const Origin o = make_origin(cx, cy, level, R);
-      s_fx[j] = o.fx;
-      s_fy[j] = o.fy;
-      const WindowBlock w = window_block<WIN>(o.x0, o.y0, tw, th4, valid);
-      myT = (off + w.tile_off + (valid ? j : 0) * slab) * 4;  // bytes from this workgroup's first slab
-      // bits 0-3 lo_tx, 4-7 n_tx, 8-11 lo_ry, 12-15 n_ry, 16-25 LDS shift (oy*RS2 + ox)*4 bytes
-      myP = w.lo_tx | (w.n_tx << 4) | (w.lo_ry << 8) | (w.n_ry << 12) |
-            ((((o.y0 & 3) * RS2 + (o.x0 & 3)) * 4) << 16) | ((o.y0 & 3) << 28);
+// Everything a workgroup derives from its (query block, level): wave-uniform layout fields in SGPRs, the
+// lane's own query (lane = query index inside the block) and, for the piece loop, each window's parameters
+// kept in the registers of the lane that owns the query (fetched cross-lane with ds_bpermute).
+template <int R>
+struct Block {
+  using G = Geo<R>;
+  int level, b_img, q0, hl, wl, tw, lane, wv;
+  bool live;     // this lane's query exists
+  Origin o;      // of this lane's query
+  int myB;       // bytes from the workgroup's first slab to this query's level
+  int myXY;      // (y0 + 16) | (x0 + 16) << 16, clamped; a window that misses the level collapses onto an
+                 // out-of-range origin so that every one of its pieces is invalid
+
+  __device__ __forceinline__ void init(const float* __restrict__ coords, int Q, const PyrLayout& P) {
+    level = blockIdx.y;
+    b_img = blockIdx.z;
+    q0 = blockIdx.x * QB;
+    hl = __builtin_amdgcn_readfirstlane(P.h[level]);
+    wl = __builtin_amdgcn_readfirstlane(P.w[level]);
+    tw = __builtin_amdgcn_readfirstlane(P.tw[level]);
+    const int off = __builtin_amdgcn_readfirstlane(P.off[level]);
+    const int slab = __builtin_amdgcn_readfirstlane(P.slab);
+    lane = threadIdx.x;
+    wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // blockDim.x == 64: one wave per y
+    live = q0 + lane < Q;
+    float cx = 0.f, cy = 0.f;
+    if (live) {
+      cx = coords[((size_t)b_img * 2 + 0) * Q + q0 + lane];
+      cy = coords[((size_t)b_img * 2 + 1) * Q + q0 + lane];
     }
+    o = make_origin(cx, cy, level, R);
+    const int th4 = ((hl + 3) >> 2) << 2;
+    const int x0 = min(max(o.x0, -16), 4 * tw), y0 = live ? min(max(o.y0, -16), th4) : th4;
+    myB = (off + lane * slab) * 4;
+    myXY = (y0 + 16) | ((x0 + 16) << 16);
   }
-  stamp<STAMP>(st, 2, true);  // coords landed, bookkeeping done
-  const int ty = lane >> 4, tx = (lane >> 2) & 3, r = lane & 3;
-  const int ry = ty * 4 + r;                                      // row inside the 16x16 texel block
-  const int lane_goff4 = (((ty * tw + tx) << 4) + (r << 2)) * 4;  // bytes, relative to tile (ty0, tx0)
-  // LDS byte address of this lane's 4 texels for a window with ox = oy = 0 (window k adds k*N1*WS2, minus the shift)
-  const unsigned lane_lds = (unsigned)((wv * WS2 + ry * RS2 + 4 + tx * 4) * 4);
-  f32x4 v[NWIN];
+};
+
+// Piece i*64 + lane of wave wv: window k = piece / PIECES of the wave's NWIN windows (query wv*NWIN + k),
+// window row rr, tile column tx.
+struct Piece {
+  unsigned goff;  // bytes from the workgroup's first slab to the piece's 16 B in the pyramid
+  unsigned lds;   // byte address in the window image of the piece's first texel (unaligned by the window's ox)
+  int mask;       // bit e (< 4): texel e of the piece is a window texel inside the level; bit 4 ("need"): the
+                  // piece holds texels of the level at all (else: zeros / nothing to add)
+  __device__ __forceinline__ bool need() const { return (mask & 16) != 0; }
+};
+
+template <int R>
+__device__ __forceinline__ void fetch_window_params(const Block<R>& blk, int (&wB)[Geo<R>::NP],
+                                                    int (&wXY)[Geo<R>::NP]) {
+  using G = Geo<R>;
 #pragma unroll
-  for (int k = 0; k < NWIN; ++k) {
-    const int sT = __builtin_amdgcn_readlane(myT, k), sP = __builtin_amdgcn_readlane(myP, k);
-    const bool need = (unsigned)(tx - (sP & 15)) < (unsigned)((sP >> 4) & 15) &&
-                      (unsigned)(ry - ((sP >> 8) & 15)) < (unsigned)((sP >> 12) & 15);
-    if constexpr (MASKED_LOADS) {
-      v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      load_tile_row_masked(v[k], slab0, (unsigned)(sT + lane_goff4), __builtin_amdgcn_ballot_w64(need));
-    } else {
-      // lanes outside the window read the all-zero tile of slab q0: branch-free, no select afterwards
-      v[k] = load_tile_row(slab0, need ? (unsigned)(sT + lane_goff4) : zero4);
+  for (int i = 0; i < G::NP; ++i) {  // all cross-lane fetches first: their latencies overlap
+    const unsigned src = (unsigned)blk.wv * G::NWIN + (i * 64u + (unsigned)blk.lane) / (unsigned)G::PIECES;
+    wB[i] = __builtin_amdgcn_ds_bpermute((int)(src * 4u), blk.myB);
+    wXY[i] = __builtin_amdgcn_ds_bpermute((int)(src * 4u), blk.myXY);
+  }
+}
+
+template <int R>
+__device__ __forceinline__ Piece make_piece(const Block<R>& blk, int i, int wB, int wXY) {
+  using G = Geo<R>;
+  // every piece slot of every staging wave belongs to a window of the block (true for r = 4: 8 waves x 8 windows
+  // x 40 pieces = 8 x 5 x 64): no "is this slot mine" logic
+  constexpr bool FULL = (QB % G::NWIN == 0) && (G::NWIN * G::PIECES == G::NP * 64);
+  const unsigned p = i * 64u + (unsigned)blk.lane;
+  const unsigned k = p / (unsigned)G::PIECES, q = p - k * (unsigned)G::PIECES;
+  const unsigned rr = q / (unsigned)G::TXN, tx = q - rr * (unsigned)G::TXN;
+  const unsigned j = (unsigned)blk.wv * G::NWIN + k;  // query inside the block
+  const int y0 = (int)((unsigned)wXY & 0xffffu) - 16, x0 = (int)((unsigned)wXY >> 16) - 16;
+  const int ox = x0 & 3, y = y0 + (int)rr, gtx = (x0 >> 2) + (int)tx;
+  const bool mine = FULL || (k < (unsigned)G::NWIN && j < (unsigned)QB);
+  Piece pc;
+  const bool need = mine && (unsigned)y < (unsigned)blk.hl && (unsigned)gtx < (unsigned)blk.tw &&
+                    (int)(4 * tx) < ox + G::WIN;
+  const int c0 = (int)(4 * tx) - ox, gx0 = 4 * gtx;  // window column / level x of the piece's first texel
+  pc.mask = need ? 16 : 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if ((unsigned)(c0 + e) < (unsigned)G::WIN && gx0 + e < blk.wl) pc.mask |= 1 << e;
+  pc.goff = (unsigned)wB + (((((unsigned)y >> 2) * (unsigned)blk.tw + (unsigned)gtx) << 4) + (((unsigned)y & 3u) << 2)) * 4u;
+  const unsigned lds = (j * G::WS + rr * RS + 4u + 4u * tx - (unsigned)ox) * 4u;
+  pc.lds = mine ? lds : (unsigned)(QB * G::WS * 4);
+  return pc;
+}
+
+// STORE: 0 = plain stores, 1 = nontemporal, 2 = write-through (agent-scope relaxed atomic store = sc1)
+template <int STORE>
+__device__ __forceinline__ void store_out(float* p, float v) {
+  if constexpr (STORE == 1) __builtin_nontemporal_store(v, p);
+  else if constexpr (STORE == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+template <int R, bool STAMP, int STORE = 0>
+__device__ __forceinline__ void corr_lookup_fwd_body(
+    const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
+    int Q, const PyrLayout& P, unsigned long long* stamps) {
+  using G = Geo<R>;
+  constexpr int N1 = G::N1, NP = G::NP, NRD = G::NRD;
+  __shared__ __attribute__((aligned(16))) float s_win[G::LDS_FLOATS];
+
+  unsigned long long* st = stamp_begin<STAMP>(stamps, N1, threadIdx.y);
+  stamp<STAMP>(st, 1, false);
+  Block<R> blk;
+  blk.init(coords, Q, P);
+  const float* slab0 = scalar_ptr(pyr + ((size_t)blk.b_img * Q + blk.q0) * P.slab);  // SGPR base of every piece
+  stamp<STAMP>(st, 2, true);  // coords landed
+
+  // ---- Phase A: stage the windows of queries wv*NWIN .. +NWIN-1, 64 pieces per wave-instruction ----
+  if (blk.wv * G::NWIN < QB) {
+    f32x4 v[NP];
+    unsigned dst[NP];
+    int wB[NP], wXY[NP];
+    fetch_window_params<R>(blk, wB, wXY);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const Piece pc = make_piece<R>(blk, i, wB[i], wXY[i]);
+      dst[i] = pc.lds;
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // pieces outside the level are zeros (reference: zero padding)
+      load_piece_masked(v[i], slab0, pc.goff, __builtin_amdgcn_ballot_w64(pc.need()));
     }
-  }
-  stamp<STAMP>(st, 3, false);  // window loads issued
-  wait_all_loads(v);
-  stamp<STAMP>(st, 4, false);  // windows landed
-  char* lds_bytes = reinterpret_cast<char*>(s_win);
+    stamp<STAMP>(st, 3, false);  // piece loads issued
+    wait_all_loads(v);
+    stamp<STAMP>(st, 4, false);  // pieces landed
+    char* lds_bytes = reinterpret_cast<char*>(s_win);
 #pragma unroll
-  for (int k = 0; k < NWIN; ++k) {
-    const int j = wv + k * N1;
-    const int sP = __builtin_amdgcn_readlane(myP, k);
-    const int oy = (sP >> 28) & 3;
-    if (j < qb && (unsigned)(ry - oy) < (unsigned)WIN) {
-      float* dst = reinterpret_cast<float*>(lds_bytes + (lane_lds + (unsigned)(k * N1 * WS2 * 4) - (unsigned)((sP >> 16) & 1023)));
-      dst[0] = v[k].x; dst[1] = v[k].y; dst[2] = v[k].z; dst[3] = v[k].w;
+    for (int i = 0; i < NP; ++i) {
+      float* d = reinterpret_cast<float*>(lds_bytes + dst[i]);
+      d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
     }
   }
   stamp<STAMP>(st, 5, false);  // LDS image written
@@ -280,14 +273,10 @@ __device__ __forceinline__ void corr_lookup_fwd_body(
   stamp<STAMP>(st, 6, false);  // barrier passed
 
   // ---- Phase B: thread (query, b) blends the 2r+1 taps of window row b ---------------------
-  const int j = lane, b = wv;
-  if constexpr (!STAMP) {
-    if (j >= qb || q0 + j >= Q) return;
-  }
-  const bool live = j < qb && q0 + j < Q;
-  const float fx = s_fx[j], fy = s_fy[j];
-  const float4* row0 = reinterpret_cast<const float4*>(&s_win[j * WS2 + b * RS2 + 4]);
-  const float4* row1 = reinterpret_cast<const float4*>(&s_win[j * WS2 + (b + 1) * RS2 + 4]);
+  const int j = blk.lane, b = blk.wv;
+  const float fx = blk.o.fx, fy = blk.o.fy;
+  const float4* row0 = reinterpret_cast<const float4*>(&s_win[j * G::WS + b * RS + 4]);
+  const float4* row1 = reinterpret_cast<const float4*>(&s_win[j * G::WS + (b + 1) * RS + 4]);
   float t0[NRD * 4], t1[NRD * 4];
 #pragma unroll
   for (int i = 0; i < NRD; ++i) {
@@ -298,7 +287,7 @@ __device__ __forceinline__ void corr_lookup_fwd_body(
   const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
   const float w10 = (1.f - fx) * fy, w11 = fx * fy;
   const int C = P.L * N1 * N1;
-  float* o = out + ((size_t)b_img * C + (size_t)level * N1 * N1 + b) * Q + q0 + j;
+  float* o = out + ((size_t)blk.b_img * C + (size_t)blk.level * N1 * N1 + b) * Q + blk.q0 + j;
   float res[N1];
 #pragma unroll
   for (int a = 0; a < N1; ++a) res[a] = t0[a] * w00 + t0[a + 1] * w01 + t1[a] * w10 + t1[a + 1] * w11;
@@ -307,141 +296,116 @@ __device__ __forceinline__ void corr_lookup_fwd_body(
     for (int a = 0; a < N1; ++a) asm volatile("" : "+v"(res[a]));
   }
   stamp<STAMP>(st, 7, false);  // blended
-  if (live) {
+  if (blk.live) {
 #pragma unroll
-    for (int a = 0; a < N1; ++a) o[(size_t)a * N1 * Q] = res[a];
+    for (int a = 0; a < N1; ++a) store_out<STORE>(o + (size_t)a * N1 * Q, res[a]);
   }
   stamp<STAMP>(st, 8, false);  // stores issued
   stamp<STAMP>(st, 9, true);   // stores acknowledged
-  if constexpr (STAMP) {
-    unsigned long long rt;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
-    if (lane == 0) st[11] = rt;
-  }
+  stamp_end<STAMP>(st);
 }
 
-#ifdef PCFA_LOOKUP_DEV
 template <int R, bool STAMP>
-__device__ __forceinline__ void corr_lookup_fwd_body_v1(
-    const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
-    int Q, int qb, const PyrLayout& P, unsigned long long* stamps) {
+__device__ __forceinline__ void corr_lookup_bwd_body(
+    float* __restrict__ dpyr, const float* __restrict__ coords, const float* __restrict__ grad_out,
+    int Q, const PyrLayout& P, unsigned long long* stamps) {
   using G = Geo<R>;
-  constexpr int N1 = G::N1, WIN = G::WIN, NWIN = G::NWIN;
-  __shared__ __attribute__((aligned(16))) float s_win[QB * WS];
-  __shared__ int s_ox[QB], s_oy[QB];
-  __shared__ float s_fx[QB], s_fy[QB];
+  constexpr int N1 = G::N1, WIN = G::WIN, NP = G::NP, NRD = G::NRD;
+  __shared__ __attribute__((aligned(16))) float s_win[G::LDS_FLOATS];
 
-  const int level = blockIdx.y, b_img = blockIdx.z;
-  const int q0 = blockIdx.x * qb;  // qb <= QB queries per workgroup, chosen on the host for an even CU load
-  // wave-uniform layout fields, pinned to SGPRs before any divergent branch
-  const int hl = __builtin_amdgcn_readfirstlane(P.h[level]);
-  const int tw = __builtin_amdgcn_readfirstlane(P.tw[level]);
-  const int off = __builtin_amdgcn_readfirstlane(P.off[level]);
-  const int slab = __builtin_amdgcn_readfirstlane(P.slab);
-  const unsigned zero4 = (unsigned)__builtin_amdgcn_readfirstlane(P.zero) * 4u;
-  const int th4 = ((hl + 3) >> 2) << 2;  // padded height (pad rows hold zeros)
-  const int lane = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // blockDim.x == 64: one wave per y
-  const float* slab0 = scalar_ptr(pyr + ((size_t)b_img * Q + q0) * slab);  // SGPR base of every window load
-  unsigned long long* st = nullptr;
-  if constexpr (STAMP) {
-    const int g = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    st = stamps + ((size_t)g * N1 + wv) * STAMP_SLOTS;
-    unsigned long long rt;
-    unsigned hwid, xcc;
-    asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\t"
-                 "s_waitcnt lgkmcnt(0)" : "=s"(rt), "=s"(hwid), "=s"(xcc)::"memory");
-    if (lane == 0) { st[0] = rt; st[10] = ((unsigned long long)xcc << 32) | hwid; }
-  }
+  unsigned long long* st = stamp_begin<STAMP>(stamps, N1, threadIdx.y);
   stamp<STAMP>(st, 1, false);
+  Block<R> blk;
+  blk.init(coords, Q, P);
+  float* slab0 = scalar_ptr(dpyr + ((size_t)blk.b_img * Q + blk.q0) * P.slab);
+  stamp<STAMP>(st, 2, true);  // coords landed
 
-  // ---- Phase A: window fetch, one window per wave-instruction -----------------------------
-  // Lane k (< NWIN) does ALL the bookkeeping of this wave's k-th window (j = wv + k*N1) once, in
-  // vector registers; the loop below only broadcasts two packed words per window (v_readlane).
-  int myT = 0, myP = 0;
-  {
-    const int j = wv + lane * N1;
-    if (lane < NWIN && j < qb) {
-      const bool valid = q0 + j < Q;
-      float cx = 0.f, cy = 0.f;
-      if (valid) {
-        cx = coords[((size_t)b_img * 2 + 0) * Q + q0 + j];
-        cy = coords[((size_t)b_img * 2 + 1) * Q + q0 + j];
-      }
-      const Origin o = make_origin(cx, cy, level, R);
-      s_ox[j] = o.x0 & 3;  // offset of the window inside its first tile (floor mod)
-      s_oy[j] = o.y0 & 3;
-      s_fx[j] = o.fx;
-      s_fy[j] = o.fy;
-      const WindowBlock w = window_block<WIN>(o.x0, o.y0, tw, th4, valid);
-      myT = (off + w.tile_off + (valid ? j : 0) * slab) * 4;  // bytes from this workgroup's first slab
-      myP = w.lo_tx | (w.n_tx << 4) | (w.lo_ry << 8) | (w.n_ry << 16);
+  // ---- the read half of the read-modify-write goes out first, next to the tap-gradient loads ----
+  const bool stager = blk.wv * G::NWIN < QB;
+  f32x4 v[NP];
+  Piece pc[NP];
+  if (stager) {
+    int wB[NP], wXY[NP];
+    fetch_window_params<R>(blk, wB, wXY);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      pc[i] = make_piece<R>(blk, i, wB[i], wXY[i]);
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      load_piece_masked(v[i], slab0, pc[i].goff, __builtin_amdgcn_ballot_w64(pc[i].need()));
     }
   }
-  stamp<STAMP>(st, 2, true);  // coords landed, bookkeeping done
-  const int ty = lane >> 4, tx = (lane >> 2) & 3, r = lane & 3;
-  const int ry = ty * 4 + r;                                      // row inside the 16x16 texel block
-  const int lane_goff4 = (((ty * tw + tx) << 4) + (r << 2)) * 4;  // bytes, relative to tile (ty0, tx0)
-  float* lds_row = &s_win[wv * WS + ry * RS + tx * 4];            // window j = wv + k*N1 adds k*N1*WS
-  f32x4 v[NWIN];
+  stamp<STAMP>(st, 3, false);  // dpyr loads issued
+
+  // ---- Phase A': thread (query, row) builds row `row` of the window's gradient image ----------------
+  // d window[r][c] = w00 g[c][r] + w01 g[c-1][r] + w10 g[c][r-1] + w11 g[c-1][r-1]   (g = 0 outside 0..2r)
+  {
+    const int j = blk.lane;
+    const float fx = blk.o.fx, fy = blk.o.fy;
+    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
+    const float w10 = (1.f - fx) * fy, w11 = fx * fy;
+    const int C = P.L * N1 * N1;
+    const float* g = grad_out + ((size_t)blk.b_img * C + (size_t)blk.level * N1 * N1) * Q + blk.q0 + j;
+    float gc[N1], gp[N1];  // tap gradients of window row `row` and of the row above, along a
+    const int row = blk.wv;
 #pragma unroll
-  for (int k = 0; k < NWIN; ++k) {
-    const int sT = __builtin_amdgcn_readlane(myT, k), sP = __builtin_amdgcn_readlane(myP, k);
-    const bool need = (unsigned)(tx - (sP & 15)) < (unsigned)((sP >> 4) & 15) &&
-                      (unsigned)(ry - ((sP >> 8) & 255)) < (unsigned)(sP >> 16);
-    // lanes outside the window read the all-zero tile of slab q0: branch-free, no select afterwards
-    v[k] = load_tile_row(slab0, need ? (unsigned)(sT + lane_goff4) : zero4);
-  }
-  stamp<STAMP>(st, 3, false);  // window loads issued
-  wait_all_loads(v);
-  stamp<STAMP>(st, 4, false);  // windows landed
+    for (int a = 0; a < N1; ++a) {
+      gc[a] = blk.live ? g[(size_t)(a * N1 + row) * Q] : 0.f;
+      gp[a] = (blk.live && row > 0) ? g[(size_t)(a * N1 + row - 1) * Q] : 0.f;
+    }
+    float4* dst0 = reinterpret_cast<float4*>(&s_win[j * G::WS + row * RS + 4]);
+    float d[NRD * 4];
 #pragma unroll
-  for (int k = 0; k < NWIN; ++k) {
-    const int j = wv + k * N1;
-    if (j < qb && ry < WROWS) *reinterpret_cast<f32x4*>(lds_row + k * N1 * WS) = v[k];
+    for (int c = 0; c < NRD * 4; ++c) {
+      float s = 0.f;
+      if (c < N1) s = gc[c] * w00;
+      if (c >= 1 && c <= N1) s = fmaf(gc[c - 1], w01, s);
+      if (c < N1) s = fmaf(gp[c], w10, s);
+      if (c >= 1 && c <= N1) s = fmaf(gp[c - 1], w11, s);
+      d[c] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < NRD; ++i) dst0[i] = make_float4(d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]);
+    if (row == N1 - 1) {  // the last wave also owns the window's last row (only the row above contributes)
+      float4* dst1 = reinterpret_cast<float4*>(&s_win[j * G::WS + (WIN - 1) * RS + 4]);
+#pragma unroll
+      for (int c = 0; c < NRD * 4; ++c) {
+        float s = 0.f;
+        if (c < N1) s = gc[c] * w10;
+        if (c >= 1 && c <= N1) s = fmaf(gc[c - 1], w11, s);
+        d[c] = s;
+      }
+#pragma unroll
+      for (int i = 0; i < NRD; ++i) dst1[i] = make_float4(d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]);
+    }
   }
-  stamp<STAMP>(st, 5, false);  // LDS image written
+  stamp<STAMP>(st, 4, false);  // gradient image rows written
   __syncthreads();
-  stamp<STAMP>(st, 6, false);  // barrier passed
+  stamp<STAMP>(st, 5, false);  // barrier passed
 
-  // ---- Phase B: thread (query, b) blends the 2r+1 taps of window row b ---------------------
-  const int j = lane, b = wv;
-  if constexpr (!STAMP) {
-    if (j >= qb || q0 + j >= Q) return;
-  }
-  const bool live = j < qb && q0 + j < Q;
-  const int ox = s_ox[j], oy = s_oy[j];
-  const float fx = s_fx[j], fy = s_fy[j];
-  const float* row0 = &s_win[j * WS + (oy + b) * RS];
-  float t0[WIN], t1[WIN];
-  shifted_row<WIN>(row0, ox, t0);
-  shifted_row<WIN>(row0 + RS, ox, t1);
-  const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
-  const float w10 = (1.f - fx) * fy, w11 = fx * fy;
-  const int C = P.L * N1 * N1;
-  float* o = out + ((size_t)b_img * C + (size_t)level * N1 * N1 + b) * Q + q0 + j;
-  float res[N1];
+  // ---- Phase B': every piece adds its 4 texels of the image to dpyr ---------------------------------
+  if (stager) {
+    wait_all_loads(v);
+    stamp<STAMP>(st, 6, false);  // dpyr pieces landed
+    const char* lds_bytes = reinterpret_cast<const char*>(s_win);
 #pragma unroll
-  for (int a = 0; a < N1; ++a) res[a] = t0[a] * w00 + t0[a + 1] * w01 + t1[a] * w10 + t1[a + 1] * w11;
-  if constexpr (STAMP) {
-#pragma unroll
-    for (int a = 0; a < N1; ++a) asm volatile("" : "+v"(res[a]));
+    for (int i = 0; i < NP; ++i) {
+      const float* src = reinterpret_cast<const float*>(lds_bytes + pc[i].lds);
+      const float e0 = src[0], e1 = src[1], e2 = src[2], e3 = src[3];
+      // image cells outside the window's columns were never written; texels beyond the level width stay zero
+      const int m = pc[i].mask;
+      f32x4 t = v[i];
+      t.x += (m & 1) ? e0 : 0.f;
+      t.y += (m & 2) ? e1 : 0.f;
+      t.z += (m & 4) ? e2 : 0.f;
+      t.w += (m & 8) ? e3 : 0.f;
+      if (pc[i].need()) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(slab0) + pc[i].goff) = t;
+    }
   }
-  stamp<STAMP>(st, 7, false);  // blended
-  if (live) {
-#pragma unroll
-    for (int a = 0; a < N1; ++a) o[(size_t)a * N1 * Q] = res[a];
-  }
-  stamp<STAMP>(st, 8, false);  // stores issued
-  stamp<STAMP>(st, 9, true);   // stores acknowledged
-  if constexpr (STAMP) {
-    unsigned long long rt;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
-    if (lane == 0) st[11] = rt;
-  }
+  stamp<STAMP>(st, 7, false);  // stores issued
+  stamp<STAMP>(st, 8, true);   // stores acknowledged
+  stamp<STAMP>(st, 9, false);
+  stamp_end<STAMP>(st);
 }
-
-#endif
 
 // __launch_bounds__(1024), not the 64*(2r+1) threads actually launched: with the real bound hipcc derives an
 // LDS-limited occupancy (2 workgroups x 9 waves -> 5 waves/SIMD) and INFLATES the kernel descriptor's VGPR
@@ -449,127 +413,42 @@ __device__ __forceinline__ void corr_lookup_fwd_body_v1(
 // fits twice on a CU and the second half of the grid waits for the first (tools/dev/census.hip, measured).
 template <int R>
 __global__ __launch_bounds__(1024) void corr_lookup_fwd_kernel(
-    const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
-    int Q, int qb, PyrLayout P) {
-  corr_lookup_fwd_body<R, false, false>(pyr, coords, out, Q, qb, P, nullptr);
+    const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out, int Q, PyrLayout P) {
+  corr_lookup_fwd_body<R, false>(pyr, coords, out, Q, P, nullptr);
+}
+
+template <int R>
+__global__ __launch_bounds__(1024) void corr_lookup_bwd_kernel(
+    float* __restrict__ dpyr, const float* __restrict__ coords, const float* __restrict__ grad_out, int Q,
+    PyrLayout P) {
+  corr_lookup_bwd_body<R, false>(dpyr, coords, grad_out, Q, P, nullptr);
 }
 
 #ifdef PCFA_LOOKUP_DEV
-// A/B variants for tools/dev: VAR 0 = previous kernel (bounded), 1 = previous kernel with the 1024 bound,
-// 2 = this kernel, 3 = this kernel with exec-masked window loads instead of zero-tile loads.
-template <int VAR, bool STAMP>
-__global__ __launch_bounds__(VAR == 0 ? 576 : 1024) void corr_lookup_fwd_var_kernel(
-    const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
-    int Q, int qb, PyrLayout P, unsigned long long* stamps) {
-  if constexpr (VAR <= 1) corr_lookup_fwd_body_v1<4, STAMP>(pyr, coords, out, Q, qb, P, stamps);
-  else corr_lookup_fwd_body<4, STAMP, VAR == 3>(pyr, coords, out, Q, qb, P, stamps);
+template <int R>
+__global__ __launch_bounds__(1024) void corr_lookup_fwd_stamped_kernel(
+    const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out, int Q, PyrLayout P,
+    unsigned long long* stamps) {
+  corr_lookup_fwd_body<R, true>(pyr, coords, out, Q, P, stamps);
+}
+template <int STORE>
+__global__ __launch_bounds__(1024) void corr_lookup_fwd_store_kernel(
+    const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out, int Q, PyrLayout P) {
+  corr_lookup_fwd_body<4, false, STORE>(pyr, coords, out, Q, P, nullptr);
+}
+template <int R>
+__global__ __launch_bounds__(1024) void corr_lookup_bwd_stamped_kernel(
+    float* __restrict__ dpyr, const float* __restrict__ coords, const float* __restrict__ grad_out, int Q,
+    PyrLayout P, unsigned long long* stamps) {
+  corr_lookup_bwd_body<R, true>(dpyr, coords, grad_out, Q, P, stamps);
 }
 #endif
 
 template <int R>
-__global__ __launch_bounds__(QB*(2 * R + 1)) void corr_lookup_bwd_kernel(
-    float* __restrict__ dpyr, const float* __restrict__ coords,
-    const float* __restrict__ grad_out, int Q, PyrLayout P) {
-  using G = Geo<R>;
-  constexpr int N1 = G::N1, WIN = G::WIN, NWIN = G::NWIN;
-  constexpr int GS = N1 * N1 + ((N1 * N1) % 2 == 0 ? 1 : 0);  // odd stride
-  __shared__ float s_g[QB * GS];
-
-  const int level = blockIdx.y, b_img = blockIdx.z;
-  const int q0 = blockIdx.x * QB;
-  const int hl = P.h[level], wl = P.w[level], tw = P.tw[level], off = P.off[level];
-  const int lane = threadIdx.x, wv = threadIdx.y;
-
-  // ---- Phase A': tap gradients, lanes along the query index (coalesced) --------------------
-  {
-    const int q = q0 + lane;
-    const int C = P.L * N1 * N1;
-    const float* g = grad_out + ((size_t)b_img * C + (size_t)level * N1 * N1 + wv) * Q + q;
-    float gv[N1];
-#pragma unroll
-    for (int a = 0; a < N1; ++a) gv[a] = (q < Q) ? g[(size_t)a * N1 * Q] : 0.f;
-    __builtin_amdgcn_sched_barrier(0);  // keep the 2r+1 loads in flight together
-#pragma unroll
-    for (int a = 0; a < N1; ++a) s_g[lane * GS + wv * N1 + a] = gv[a];
-  }
-  float mycx = 0.f, mycy = 0.f;
-  {
-    const int j = wv + lane * N1;
-    if (lane < NWIN && j < QB && q0 + j < Q) {
-      mycx = coords[((size_t)b_img * 2 + 0) * Q + q0 + j];
-      mycy = coords[((size_t)b_img * 2 + 1) * Q + q0 + j];
-    }
-  }
-  __syncthreads();
-
-  // ---- Phase B': one window per wave-instruction; a lane owns 4 texels of a tile row --------
-  float* base = dpyr + (size_t)b_img * Q * P.slab + off;
-  const int ty = lane >> 4, tx = (lane >> 2) & 3, r = lane & 3;
-  const int ry = ty * 4 + r;
-  float4 v[NWIN];
-  float* ptr[NWIN];
-  Origin org[NWIN];
-#pragma unroll
-  for (int k = 0; k < NWIN; ++k) {
-    const int j = wv + k * N1;
-    org[k] = make_origin(lane_bcast(mycx, k), lane_bcast(mycy, k), level, R);
-    const int tx0 = org[k].x0 >> 2, ty0 = org[k].y0 >> 2;
-    const int gy = ty0 * 4 + ry, gtx = tx0 + tx;
-    const bool need = (j < QB) && (q0 + j < Q) && gtx >= 0 && gtx < tw && gy >= 0 && gy < hl &&
-                      gy >= org[k].y0 && gy < org[k].y0 + WIN && gtx * 4 + 3 >= org[k].x0 &&
-                      gtx * 4 < org[k].x0 + WIN;
-    ptr[k] = need ? base + (size_t)(q0 + j) * P.slab + (((gy >> 2) * tw + gtx) << 4) + ((gy & 3) << 2)
-                  : nullptr;
-    // branch-free load (dummy lanes read this workgroup's first sector) so all NWIN loads are in flight
-    v[k] = *reinterpret_cast<const float4*>(need ? ptr[k] : base + (size_t)q0 * P.slab);
-  }
-  __builtin_amdgcn_sched_barrier(0);  // all read-modify-write loads issued before the gather math
-#pragma unroll
-  for (int k = 0; k < NWIN; ++k) {
-    if (ptr[k] == nullptr) continue;
-    const int j = wv + k * N1;
-    const float fx = org[k].fx, fy = org[k].fy;
-    const float* g = s_g + j * GS;
-    const int tx0 = org[k].x0 >> 2, ty0 = org[k].y0 >> 2;
-    const int rr = ty0 * 4 + ry - org[k].y0;  // window row of this lane's texels, 0..WIN-1
-    float acc[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int gx = (tx0 + tx) * 4 + e;
-      const int cc = gx - org[k].x0;  // window column
-      float s = 0.f;
-      if (cc >= 0 && cc < WIN && gx < wl) {
-        // tap (a, b) touches window texels (row, col) in {b, b+1} x {a, a+1}
-        if (rr < N1) {
-          const float wy = 1.f - fy;
-          if (cc < N1) s += g[rr * N1 + cc] * ((1.f - fx) * wy);
-          if (cc > 0) s += g[rr * N1 + cc - 1] * (fx * wy);
-        }
-        if (rr > 0) {
-          const float wy = fy;
-          if (cc < N1) s += g[(rr - 1) * N1 + cc] * ((1.f - fx) * wy);
-          if (cc > 0) s += g[(rr - 1) * N1 + cc - 1] * (fx * wy);
-        }
-      }
-      acc[e] = s;
-    }
-    float4 t = v[k];
-    t.x += acc[0]; t.y += acc[1]; t.z += acc[2]; t.w += acc[3];
-    *reinterpret_cast<float4*>(ptr[k]) = t;
-  }
-}
-
-// Queries per workgroup.  64 (= one wave of queries in phase B) measured best on MI355X at Q = 7040, 4 levels:
-// 440 workgroups, 9.9 us; a CU-balanced 55 (512 workgroups, exactly 2 per CU) was SLOWER, 10.8 us -- the kernel is
-// bound by per-workgroup latency, not by the most loaded CU.
-int balanced_queries_per_group(int /*Q*/, int /*planes*/) { return QB; }
-
-template <int R>
 int launch_fwd(const float* pyr, const float* coords, float* out, int B, int Q,
                const PyrLayout& P, hipStream_t s) {
-  const int qb = balanced_queries_per_group(Q, P.L * B);
-  dim3 grid(pcfa_cdiv(Q, qb), P.L, B), block(QB, 2 * R + 1, 1);
-  pcfa_launch(corr_lookup_fwd_kernel<R>, grid, block, 0, s, pyr, coords, out, Q, qb, P);
+  dim3 grid(pcfa_cdiv(Q, QB), P.L, B), block(QB, 2 * R + 1, 1);
+  pcfa_launch(corr_lookup_fwd_kernel<R>, grid, block, 0, s, pyr, coords, out, Q, P);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -584,7 +463,7 @@ int launch_bwd(float* dpyr, const float* coords, const float* go, int B, int Q,
 
 bool check_levels(const PyrLayout& P) {
   for (int l = 0; l < P.L; ++l)
-    if (P.h[l] < 1 || P.w[l] < 1) return false;
+    if (P.h[l] < 1 || P.w[l] < 1 || P.h[l] > 32000 || P.w[l] > 32000) return false;  // packed 16-bit origins
   return true;
 }
 
