@@ -84,7 +84,8 @@ class AttackStepper:
             self.nw1, self.nw2 = self.image1.clone(), self.image2.clone()
         self.nw1.requires_grad = True
         self.nw2.requires_grad = True
-        self.optimizer = torch.optim.LBFGS([self.nw1, self.nw2], max_iter=10)
+        from pcfa_amd import ops
+        self.optimizer = ops.get().LBFGS([self.nw1, self.nw2], max_iter=10)
         self.delta_bound = 0.005
         self.mu = 2500. / self.delta_bound
         with torch.no_grad():

@@ -253,6 +253,27 @@ PCFA_API int pcfa_avg_epe(const float* flow1, const long long strides1[4], const
                  void* stream);
 PCFA_API int pcfa_sum_squares(const float* x, long long n, float* out, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * L-BFGS vector math of the attack loop: the memory update and the two-loop
+ * recursion inside torch.optim.LBFGS.step (torch==1.7.1 pinned by the reference,
+ * scripts/requirements.txt:2; call sites attack_PCFA.py:97,114,382,388 with
+ * max_iter=10 and no line search).  Same operation sequence as the optimiser's
+ * Python loop, 2m+1 launches instead of 4m+3, no host round trip inside.
+ *   pair:      y = g - g_prev ; s = t*d ; scal4 = { y.s, y.y, 1/(y.s), (y.s)/(y.y) } ;
+ *              g_prev = g when update_prev != 0.  y_out / s_out are the candidate history
+ *              slot (the caller keeps it only if y.s > 1e-10, as the optimiser does).
+ *   direction: d = -H_k g by the two-loop recursion over the `count` newest pairs of the ring
+ *              S, Y [capacity][ld] (pair k-th oldest lives in row (first + k) % capacity),
+ *              ro[capacity] = 1/(y.s) per row, H = device scalar (y.s)/(y.y) of the newest
+ *              pair, al[count] scratch.  workspace: pcfa_lbfgs_workspace_floats() floats.
+ * All vectors 16-B aligned, ld % 4 == 0. */
+PCFA_API size_t pcfa_lbfgs_workspace_floats(void);
+PCFA_API int pcfa_lbfgs_pair(const float* g, float* g_prev, const float* d, float t, float* y_out, float* s_out,
+                             float* scal4, float* workspace, int update_prev, long long n, void* stream);
+PCFA_API int pcfa_lbfgs_direction(const float* g, const float* S, const float* Y, const float* ro, const float* H,
+                                  float* al, float* d, float* workspace, int first, int count, int capacity,
+                                  long long ld, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

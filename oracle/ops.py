@@ -20,6 +20,9 @@ import os
 import torch
 import torch.nn.functional as F
 
+# the optimiser of the reference attack loop (attack_PCFA.py:97,114,382,388) is torch's own
+LBFGS = torch.optim.LBFGS
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 

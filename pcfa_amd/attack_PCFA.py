@@ -6,10 +6,10 @@
     attack_l2                               attack_PCFA.py:570-701
 
 Schedule: the averaged-L2 bound is an exact penalty minimised by
-torch.optim.LBFGS(max_iter=10, no line search); one `--steps` iteration = one LBFGS.step = 10
+L-BFGS(max_iter=10, no line search: pcfa_amd.lbfgs.LBFGS = torch.optim.LBFGS semantics on HIP kernels); one `--steps` iteration = one LBFGS.step = 10
 closure evaluations (forward + loss + backward) followed by one re-prediction forward, and the
-reported result is the best iterate with ||delta|| <= bound.  Kept bit-for-bit: the optimiser,
-the closure arithmetic and the best-iterate rule.  Dropped because they cannot change a result:
+reported result is the best iterate with ||delta|| <= bound.  Kept: the optimiser's algorithm and host
+decisions, the closure arithmetic and the best-iterate rule.  Dropped because they cannot change a result:
   * the `loss.backward()` before every LBFGS.step (attack_PCFA.py:173) -- the closure's
     zero_grad() discards its gradient before anything reads it;
   * the autograd graph of the re-prediction forward (only metrics read it) -> torch.no_grad();
@@ -25,7 +25,6 @@ import time
 
 import numpy as np
 import torch
-import torch.optim as optim
 
 from . import ops, sharding
 from .helper_functions import datasets, logging, losses, ownutilities, parsing_file, targets
@@ -99,7 +98,7 @@ def pcfa_attack(model, image1, image2, flow, batch, distortion_folder, eps_box, 
         nw_delta = delta1
         nw_delta.requires_grad = True
         nw_input1, nw_input2 = image1, image2
-        optimizer = optim.LBFGS([nw_delta], max_iter=10)
+        optimizer = ops.get().LBFGS([nw_delta], max_iter=10)
         fwd_kwargs = {"delta1": nw_delta}
     else:
         if cov:
@@ -110,7 +109,7 @@ def pcfa_attack(model, image1, image2, flow, batch, distortion_folder, eps_box, 
             nw_input2 = image2 + delta2
         nw_input1.requires_grad = True
         nw_input2.requires_grad = True
-        optimizer = optim.LBFGS([nw_input1, nw_input2], max_iter=10)
+        optimizer = ops.get().LBFGS([nw_input1, nw_input2], max_iter=10)
         fwd_kwargs = {}
 
     def predict():
@@ -323,7 +322,7 @@ def attack_l2_universal(args, data_loader=None, has_gt=None):
     else:
         nw_delta2.requires_grad = True
         params = [nw_delta1, nw_delta2]
-    optimizer = optim.LBFGS(params, max_iter=10)
+    optimizer = ops.get().LBFGS(params, max_iter=10)
 
     def deltas():
         return (nw_delta1, nw_delta1) if args.joint_perturbation else (nw_delta1, nw_delta2)

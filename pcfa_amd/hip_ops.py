@@ -18,6 +18,7 @@ import weakref
 import torch
 
 from . import _hip
+from .lbfgs import LBFGS  # noqa: F401  (the attack loop's optimiser: torch.optim.LBFGS semantics, HIP vector math)
 
 
 def _stream():

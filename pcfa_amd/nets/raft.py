@@ -35,6 +35,48 @@ def _norm(kind, planes):
     raise ValueError("unknown norm_fn %r" % kind)
 
 
+def _fold_batchnorm(conv, bn, cache, tag):
+    """(W', b') with  bn(conv(x)) == conv(x; W') + b'  for an eval-mode BatchNorm2d: W' = W*s, b' = (b - mean)*s + beta,
+    s = gamma / sqrt(var + eps).  Cached per (weights, statistics) version."""
+    tensors = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t.data_ptr(), t._version) for t in tensors if t is not None) + (conv.weight.device,)
+    hit = cache.get(tag)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            s = torch.rsqrt(bn.running_var + bn.eps)
+            if bn.weight is not None:
+                s = s * bn.weight
+            b = -bn.running_mean if conv.bias is None else conv.bias - bn.running_mean
+            b = b * s
+            if bn.bias is not None:
+                b = b + bn.bias
+            hit = (key, (conv.weight * s[:, None, None, None]).contiguous(), b.contiguous())
+        cache[tag] = hit
+    return hit[1], hit[2]
+
+
+def _conv_norm(conv, norm, x, relu, cache, tag):
+    """relu?(norm(conv(x))) of the residual encoders (extractor.py:23-58,161-177).
+
+    Frozen-weight fast paths (what the attack runs), identical to the reference in exact arithmetic:
+      * eval-mode BatchNorm (context encoder) is an affine map per channel: folded into the convolution's weights,
+        the remaining bias (+ ReLU) applied by one fused pass -- no normalisation kernels in forward or backward;
+      * InstanceNorm without affine parameters (feature encoder) subtracts the per-plane mean, which cancels the
+        convolution's bias exactly: the bias add (a full pass over the activation) is skipped."""
+    frozen = not (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad))
+    if (frozen and isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats
+            and not (norm.affine and (norm.weight.requires_grad or norm.bias.requires_grad))):
+        w, b = _fold_batchnorm(conv, norm, cache, tag)
+        if relu:
+            return ops.get().bias_relu(conv._conv_forward(x, w, None), b)
+        return conv._conv_forward(x, w, b)
+    if (frozen and isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats):
+        y = norm(conv._conv_forward(x, conv.weight, None))
+    else:
+        y = norm(conv(x))
+    return F.relu(y, inplace=True) if relu else y
+
+
 class ResidualBlock(nn.Module):
     def __init__(self, in_planes, planes, norm_fn='group', stride=1):
         super().__init__()
@@ -48,12 +90,13 @@ class ResidualBlock(nn.Module):
             # registered twice (norm3 and downsample.1) like the checkpoints expect
             self.norm3 = _norm(norm_fn, planes)
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+        self._fold_cache = {}
 
     def forward(self, x):
-        y = self.relu(self.norm1(self.conv1(x)))
-        y = self.relu(self.norm2(self.conv2(y)))
+        y = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1")
+        y = _conv_norm(self.conv2, self.norm2, y, True, self._fold_cache, "2")
         if self.downsample is not None:
-            x = self.downsample(x)
+            x = _conv_norm(self.downsample[0], self.downsample[1], x, False, self._fold_cache, "d")
         return self.relu(x + y)
 
 
@@ -71,6 +114,7 @@ class BasicEncoder(nn.Module):
         self.layer3 = self._stage(96, 128, 2)
         self.conv2 = nn.Conv2d(128, output_dim, kernel_size=1)
         self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        self._fold_cache = {}
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
@@ -89,7 +133,7 @@ class BasicEncoder(nn.Module):
         if pair:
             n = x[0].shape[0]
             x = torch.cat(x, dim=0)
-        x = self.relu1(self.norm1(self.conv1(x)))
+        x = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1")
         x = self.layer3(self.layer2(self.layer1(x)))
         x = self.conv2(x)
         if self.training and self.dropout is not None:

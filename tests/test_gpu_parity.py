@@ -492,3 +492,92 @@ def test_graphed_closure_matches_eager():
     assert rel_l2(st.nw1.grad, g_eager[0]) < 1e-5 and rel_l2(st.nw2.grad, g_eager[1]) < 1e-5
     l_again = float(st.closure())
     assert abs(l_again - l_graph) <= 1e-6 * abs(l_graph)
+
+
+# --------------------------------------------------------------------------- #
+# L-BFGS: pcfa_amd.lbfgs.LBFGS (HIP vector math) against torch.optim.LBFGS, the optimiser of the reference loop
+# (attack_PCFA.py:97,114).  Tolerance: the two run the same operation sequence and differ only in the summation
+# order inside dot products, so iterates agree to ~1e-5 relative on a smooth, well-conditioned objective.
+# --------------------------------------------------------------------------- #
+def _lbfgs_problem(seed, shapes):
+    g = torch.Generator().manual_seed(seed)
+    x0 = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    c = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    w = [(0.5 + torch.rand(s, generator=g)).to(DEV) for s in shapes]
+
+    def make(params):
+        def closure():
+            for p in params:
+                p.grad = None
+            loss = 0.
+            for p, ci, wi in zip(params, c, w):
+                r = p - ci
+                v = r.reshape(-1)
+                mixed = v + 0.5 * torch.roll(v, 1) - 0.3 * torch.roll(v, 7)      # a fixed banded linear map
+                loss = loss + 0.5 * (wi.reshape(-1) * mixed * mixed).sum() + 0.01 * (v ** 4).sum()
+            loss = loss / sum(p.numel() for p in params)
+            loss.backward()
+            return loss
+        return closure
+    return x0, make
+
+
+@pytest.mark.parametrize("history", [100, 4])
+def test_lbfgs_matches_torch_optimizer(history):
+    from pcfa_amd.lbfgs import LBFGS
+    shapes = [(3, 17, 33), (1001,)]          # 2684 elements: exercises the n % 4 tail and two parameter tensors
+    x0, make = _lbfgs_problem(5, shapes)
+    pa = [x.clone().requires_grad_(True) for x in x0]
+    pb = [x.clone().requires_grad_(True) for x in x0]
+    oa = torch.optim.LBFGS(pa, max_iter=10, history_size=history)
+    ob = LBFGS(pb, max_iter=10, history_size=history)
+    ca, cb = make(pa), make(pb)
+    for step in range(4):                    # 40 iterations: the 4-pair ring wraps many times
+        la, lb = float(oa.step(ca)), float(ob.step(cb))
+        assert abs(la - lb) <= 2e-4 * abs(la) + 1e-7, (step, la, lb)
+        for a, b in zip(pa, pb):
+            assert rel_l2(b.detach(), a.detach()) < 2e-4, (step, rel_l2(b.detach(), a.detach()))
+    assert oa.state[pa[0]]["n_iter"] == ob.state[pb[0]]["n_iter"]
+    assert oa.state[pa[0]]["func_evals"] == ob.state[pb[0]]["func_evals"]
+    assert ob.state[pb[0]]["count"] == min(history, len(oa.state[pa[0]]["old_dirs"]))
+    assert la < 0.05 * float(make([x.clone().requires_grad_(True) for x in x0])())   # and it actually minimises
+
+
+def test_lbfgs_two_loop_against_dense_reference():
+    """pcfa_lbfgs_direction alone against the textbook two-loop recursion in float64 on the same (S, Y) history."""
+    from pcfa_amd.hip_ops import _call, _ptr
+    g = torch.Generator().manual_seed(11)
+    n, m, rows, first = 4099, 6, 9, 5         # ring that wraps: rows 5,6,7,8,0,1
+    ld = (n + 3) // 4 * 4
+    S = torch.randn(rows, ld, generator=g).to(DEV)
+    Y = (S + 0.3 * torch.randn(rows, ld, generator=g).to(DEV)).contiguous()   # y.s > 0
+    grad = torch.randn(ld, generator=g).to(DEV)
+    order = [(first + k) % rows for k in range(m)]
+    ro = torch.zeros(rows, device=DEV)
+    for r in order:
+        ro[r] = 1.0 / (Y[r, :n] @ S[r, :n])
+    newest = order[-1]
+    H = ((Y[newest, :n] @ S[newest, :n]) / (Y[newest, :n] @ Y[newest, :n])).reshape(1)
+    al, d = torch.empty(rows, device=DEV), torch.empty(ld, device=DEV)
+    ws = torch.empty(int(hip_ops._hip.load().pcfa_lbfgs_workspace_floats()), device=DEV)
+    _call("pcfa_lbfgs_direction", _ptr(grad), _ptr(S), _ptr(Y), _ptr(ro), _ptr(H), _ptr(al), _ptr(d), _ptr(ws),
+          first, m, rows, ld, n)
+    q = -grad[:n].double()
+    Sd, Yd, rod = S[:, :n].double(), Y[:, :n].double(), ro.double()
+    a = {}
+    for r in reversed(order):
+        a[r] = (Sd[r] @ q) * rod[r]
+        q = q - a[r] * Yd[r]
+    rr = q * H.double()
+    for r in order:
+        be = (Yd[r] @ rr) * rod[r]
+        rr = rr + (a[r] - be) * Sd[r]
+    assert rel_l2(d[:n].double(), rr) < 1e-5
+
+
+def test_lbfgs_rejects_cpu_parameters():
+    from pcfa_amd.lbfgs import LBFGS
+    with pytest.raises(RuntimeError):
+        LBFGS([torch.zeros(4, requires_grad=True)], max_iter=10)
+    with pytest.raises(NotImplementedError):
+        LBFGS([torch.zeros(4, device=DEV, requires_grad=True)], line_search_fn="strong_wolfe")
