@@ -223,6 +223,9 @@ __device__ __forceinline__ Piece make_piece(const Block<R>& blk, int i, int wB, 
 }
 
 // STORE: 0 = plain stores, 1 = nontemporal, 2 = write-through (agent-scope relaxed atomic store = sc1)
+#ifndef PCFA_LOOKUP_STORE
+#define PCFA_LOOKUP_STORE 0
+#endif
 template <int STORE>
 __device__ __forceinline__ void store_out(float* p, float v) {
   if constexpr (STORE == 1) __builtin_nontemporal_store(v, p);
@@ -414,7 +417,7 @@ __device__ __forceinline__ void corr_lookup_bwd_body(
 template <int R>
 __global__ __launch_bounds__(1024) void corr_lookup_fwd_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out, int Q, PyrLayout P) {
-  corr_lookup_fwd_body<R, false>(pyr, coords, out, Q, P, nullptr);
+  corr_lookup_fwd_body<R, false, PCFA_LOOKUP_STORE>(pyr, coords, out, Q, P, nullptr);
 }
 
 template <int R>

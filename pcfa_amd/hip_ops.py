@@ -98,10 +98,12 @@ class DispatchTimer:
         "pcfa_relu_bwd": [("relu_bwd", 0)],
     }
 
+    EVENT_FLAGS = 0x20000000  # hipEventDisableSystemFence
+
     def __init__(self, plan=None):
         self.plan = dict(self.DEFAULT_PLAN if plan is None else plan)
         self.hip = ctypes.CDLL("libamdhip64.so")
-        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
         self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
         self.pairs = {}
@@ -109,9 +111,13 @@ class DispatchTimer:
     def new_pair(self, name):
         e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
         for e in (e0, e1):
-            err = self.hip.hipEventCreate(ctypes.byref(e))
+            # timing-only events: without hipEventDisableSystemFence the dispatch they ride on ends with a
+            # SYSTEM-scope release (write-back of every dirty L2 line, also those of earlier kernels), which a
+            # plain or graph-replayed launch does not pay -- rocprofv3 shows the same kernel 1.7 us longer with
+            # default events attached (tools/dev/lookup_trace_split.py)
+            err = self.hip.hipEventCreateWithFlags(ctypes.byref(e), self.EVENT_FLAGS)
             if err != 0:
-                raise RuntimeError("hipEventCreate failed: %d" % err)
+                raise RuntimeError("hipEventCreateWithFlags failed: %d" % err)
         self.pairs.setdefault(name, []).append((e0, e1))
         return e0, e1
 

@@ -98,6 +98,22 @@ def main():
         torch.cuda.synchronize()
         assert float((out - want).abs().max()) < 1e-5
         return
+    if what == "live":  # dispatch-attached events (what bench.py reports) on the same back-to-back launches
+        mode = sys.argv[2]
+        out = torch.empty_like(want)
+        for flags in (0x20000000, 0):
+            timer = hip_ops.DispatchTimer()
+            timer.EVENT_FLAGS = flags
+            for rep in range(30):
+                for fn, buf in ((product_fwd, out), (product_bwd, dpyr)):
+                    if mode == "cold":
+                        junk.add_(1.0)
+                    if rep >= 5:
+                        hip_ops.set_dispatch_timer(timer)
+                    fn(buf)
+                    hip_ops.set_dispatch_timer(None)
+            print(mode, "event flags 0x%x:" % flags, {k: (round(v[0], 2), v[1]) for k, v in timer.summary().items()})
+        return
     if what == "time":
         mode = sys.argv[2]
         out = torch.empty_like(want)
