@@ -321,7 +321,8 @@ def main():
     elapsed = sharding.max_scalar(elapsed, cdev)
     closures = st.closures - c0
     traced = None
-    if use_graph and corr_net and rank == 0:
+    # PCFA_BENCH_NO_TRACER=1: skip the in-process tracer (set when an external profiler already owns it)
+    if use_graph and corr_net and rank == 0 and os.environ.get("PCFA_BENCH_NO_TRACER", "0") != "1":
         try:
             traced = graph_replay_kernel_times(st)
         except Exception as e:  # the tracer is an extra: fall back to the eager hipEvent figures

@@ -3,6 +3,7 @@
 # separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), no tracing domains besides
 # --kernel-trace, program directly after `--`.  Run on the GPU box:  bash tools/pmc_traffic.sh <tag>
 export TMPDIR=/tmp
+export PCFA_BENCH_NO_TRACER=1  # rocprofv3 owns the tracer in these runs
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r01}
 cd /tmp
