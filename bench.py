@@ -271,7 +271,12 @@ def cpu_baseline(net, h, w, nclosures, threads=0):
 def main():
     a = parse()
     from pcfa_amd import sharding
-    json_out, sys.stdout = sys.stdout, sys.stderr  # stdout carries the ONE JSON line; the mirrors' chatter goes to stderr
+    # stdout carries the ONE JSON line: everything else (the mirrors' chatter, native libraries writing to fd 1) goes
+    # to stderr until the line is printed
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    json_out = os.fdopen(saved_fd, "w")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # one process per GPU; PCFA_BENCH_BACKEND=gloo + PCFA_BENCH_SHARE_GPU=1 only exist to exercise the
@@ -378,7 +383,6 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.net, h, w, a.cpu_closures, a.cpu_threads)
         print(json.dumps(out), file=json_out, flush=True)
-    sys.stdout = json_out
     sharding.shutdown()
     return out
 
