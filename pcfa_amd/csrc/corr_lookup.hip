@@ -7,8 +7,8 @@
 // (common.hpp).  All (2r+1)^2 taps of a (query, level) share one fractional
 // offset, so a lookup is "fetch a (2r+2)^2 window, blend it 4 ways".
 //
-// Work decomposition (wave64): workgroup = 64 consecutive queries x one level,
-// 2r+1 waves, both directions:
+// Work decomposition (wave64): workgroup = QB (64 or 32) consecutive queries x one
+// level, 2r+1 (or r+1) waves, both directions:
 //   * a window is fetched as PIECES: one piece = the 16 B (4 texels of one tile
 //     row) that one window row crosses in one tile column, (2r+2) x TXN pieces
 //     per window (TXN = tile columns a window can cross).  A wave-instruction
@@ -30,17 +30,27 @@
 
 namespace {
 
-constexpr int QB = 64;  // queries (= windows) per workgroup
 constexpr int RS = 20;  // LDS row stride (floats): 4 pad + 16; window texel (r, c) sits at r*RS + 4 + c
 
-template <int R>
+#ifndef PCFA_LOOKUP_QB
+#define PCFA_LOOKUP_QB 32
+#endif
+
+// QB = queries (= windows) per workgroup: 64 (one wave of queries per window row, 2r+1 waves), 32 (two window
+// rows per wave, r+1 waves) or 16.  Measured on MI355X at 55x128, r = 4 (rocprofv3, L2-warm / flushed):
+// forward 7.4 / 11.9 us at 64, 6.5 / 11.7 us at 32, 7.1-7.5 / 12.4 us at 16; backward 10.6 us at 32 -- more,
+// smaller workgroups (880 x 5 waves, 3-4 per CU) overlap each other's load, LDS and store phases better.
+template <int R, int QB>
 struct Geo {
-  static constexpr int N1 = 2 * R + 1;                      // taps per axis = waves per workgroup
+  static_assert(QB == 64 || QB == 32 || QB == 16, "lane % QB = query needs QB to divide the wave");
+  static constexpr int N1 = 2 * R + 1;                      // taps per axis
   static constexpr int WIN = 2 * R + 2;                     // window texels per axis
-  static constexpr int NWIN = (QB + N1 - 1) / N1;           // windows staged per wave
+  static constexpr int RPW = 64 / QB;                       // window rows (phase B) per wave
+  static constexpr int NW = (N1 + RPW - 1) / RPW;           // waves per workgroup
   static constexpr int TXN = ((WIN + 2) >> 2) + 1;          // tile columns a window can cross
   static constexpr int PIECES = WIN * TXN;                  // 16-B pieces per window
-  static constexpr int NP = (NWIN * PIECES + 63) / 64;      // piece wave-instructions per wave
+  static constexpr int NP = (QB * PIECES + NW * 64 - 1) / (NW * 64);  // piece wave-instructions per wave
+  static constexpr bool FULL = QB * PIECES == NW * NP * 64; // every piece slot of every wave is a real piece
   static constexpr int WS = WIN * RS + 4;                   // floats per window image; WS/4 odd -> the b128 accesses
                                                             // of 16 consecutive windows hit 16 distinct bank groups
   static constexpr int NRD = (WIN + 3) / 4;                 // b128 accesses per window row
@@ -138,10 +148,11 @@ __device__ __forceinline__ void stamp_end(unsigned long long* st) {
 // Everything a workgroup derives from its (query block, level): wave-uniform layout fields in SGPRs, the
 // lane's own query (lane = query index inside the block) and, for the piece loop, each window's parameters
 // kept in the registers of the lane that owns the query (fetched cross-lane with ds_bpermute).
-template <int R>
+template <int R, int QB>
 struct Block {
-  using G = Geo<R>;
+  using G = Geo<R, QB>;
   int level, b_img, q0, hl, wl, tw, lane, wv;
+  int j;         // this lane's query inside the block (lane % QB)
   bool live;     // this lane's query exists
   Origin o;      // of this lane's query
   int myB;       // bytes from the workgroup's first slab to this query's level
@@ -159,22 +170,21 @@ struct Block {
     const int slab = __builtin_amdgcn_readfirstlane(P.slab);
     lane = threadIdx.x;
     wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // blockDim.x == 64: one wave per y
-    live = q0 + lane < Q;
+    j = lane & (QB - 1);
+    live = q0 + j < Q;
     float cx = 0.f, cy = 0.f;
     if (live) {
-      cx = coords[((size_t)b_img * 2 + 0) * Q + q0 + lane];
-      cy = coords[((size_t)b_img * 2 + 1) * Q + q0 + lane];
+      cx = coords[((size_t)b_img * 2 + 0) * Q + q0 + j];
+      cy = coords[((size_t)b_img * 2 + 1) * Q + q0 + j];
     }
     o = make_origin(cx, cy, level, R);
     const int th4 = ((hl + 3) >> 2) << 2;
     const int x0 = min(max(o.x0, -16), 4 * tw), y0 = live ? min(max(o.y0, -16), th4) : th4;
-    myB = (off + lane * slab) * 4;
+    myB = (off + j * slab) * 4;
     myXY = (y0 + 16) | ((x0 + 16) << 16);
   }
 };
 
-// Piece i*64 + lane of wave wv: window k = piece / PIECES of the wave's NWIN windows (query wv*NWIN + k),
-// window row rr, tile column tx.
 struct Piece {
   unsigned goff;  // bytes from the workgroup's first slab to the piece's 16 B in the pyramid
   unsigned lds;   // byte address in the window image of the piece's first texel (unaligned by the window's ox)
@@ -183,31 +193,30 @@ struct Piece {
   __device__ __forceinline__ bool need() const { return (mask & 16) != 0; }
 };
 
-template <int R>
-__device__ __forceinline__ void fetch_window_params(const Block<R>& blk, int (&wB)[Geo<R>::NP],
-                                                    int (&wXY)[Geo<R>::NP]) {
-  using G = Geo<R>;
+// Piece slot (wv*NP + i)*64 + lane of the workgroup: window = slot / PIECES (query inside the block), window row
+// rr, tile column tx.  The slots of a workgroup are dealt to its waves in order, so a window may be staged by two
+// waves.
+template <int R, int QB>
+__device__ __forceinline__ void fetch_window_params(const Block<R, QB>& blk, int (&wB)[Geo<R, QB>::NP],
+                                                    int (&wXY)[Geo<R, QB>::NP]) {
+  using G = Geo<R, QB>;
 #pragma unroll
   for (int i = 0; i < G::NP; ++i) {  // all cross-lane fetches first: their latencies overlap
-    const unsigned src = (unsigned)blk.wv * G::NWIN + (i * 64u + (unsigned)blk.lane) / (unsigned)G::PIECES;
+    const unsigned src = (((unsigned)blk.wv * G::NP + i) * 64u + (unsigned)blk.lane) / (unsigned)G::PIECES;
     wB[i] = __builtin_amdgcn_ds_bpermute((int)(src * 4u), blk.myB);
     wXY[i] = __builtin_amdgcn_ds_bpermute((int)(src * 4u), blk.myXY);
   }
 }
 
-template <int R>
-__device__ __forceinline__ Piece make_piece(const Block<R>& blk, int i, int wB, int wXY) {
-  using G = Geo<R>;
-  // every piece slot of every staging wave belongs to a window of the block (true for r = 4: 8 waves x 8 windows
-  // x 40 pieces = 8 x 5 x 64): no "is this slot mine" logic
-  constexpr bool FULL = (QB % G::NWIN == 0) && (G::NWIN * G::PIECES == G::NP * 64);
-  const unsigned p = i * 64u + (unsigned)blk.lane;
-  const unsigned k = p / (unsigned)G::PIECES, q = p - k * (unsigned)G::PIECES;
+template <int R, int QB>
+__device__ __forceinline__ Piece make_piece(const Block<R, QB>& blk, int i, int wB, int wXY) {
+  using G = Geo<R, QB>;
+  const unsigned p = (((unsigned)blk.wv * G::NP + i) * 64u) + (unsigned)blk.lane;
+  const unsigned k = p / (unsigned)G::PIECES, q = p - k * (unsigned)G::PIECES;   // k = query inside the block
   const unsigned rr = q / (unsigned)G::TXN, tx = q - rr * (unsigned)G::TXN;
-  const unsigned j = (unsigned)blk.wv * G::NWIN + k;  // query inside the block
   const int y0 = (int)((unsigned)wXY & 0xffffu) - 16, x0 = (int)((unsigned)wXY >> 16) - 16;
   const int ox = x0 & 3, y = y0 + (int)rr, gtx = (x0 >> 2) + (int)tx;
-  const bool mine = FULL || (k < (unsigned)G::NWIN && j < (unsigned)QB);
+  const bool mine = G::FULL || k < (unsigned)QB;
   Piece pc;
   const bool need = mine && (unsigned)y < (unsigned)blk.hl && (unsigned)gtx < (unsigned)blk.tw &&
                     (int)(4 * tx) < ox + G::WIN;
@@ -217,7 +226,7 @@ __device__ __forceinline__ Piece make_piece(const Block<R>& blk, int i, int wB, 
   for (int e = 0; e < 4; ++e)
     if ((unsigned)(c0 + e) < (unsigned)G::WIN && gx0 + e < blk.wl) pc.mask |= 1 << e;
   pc.goff = (unsigned)wB + (((((unsigned)y >> 2) * (unsigned)blk.tw + (unsigned)gtx) << 4) + (((unsigned)y & 3u) << 2)) * 4u;
-  const unsigned lds = (j * G::WS + rr * RS + 4u + 4u * tx - (unsigned)ox) * 4u;
+  const unsigned lds = (k * G::WS + rr * RS + 4u + 4u * tx - (unsigned)ox) * 4u;
   pc.lds = mine ? lds : (unsigned)(QB * G::WS * 4);
   return pc;
 }
@@ -233,30 +242,30 @@ __device__ __forceinline__ void store_out(float* p, float v) {
   else *p = v;
 }
 
-template <int R, bool STAMP, int STORE = 0>
+template <int R, int QB, bool STAMP, int STORE = 0>
 __device__ __forceinline__ void corr_lookup_fwd_body(
     const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out,
     int Q, const PyrLayout& P, unsigned long long* stamps) {
-  using G = Geo<R>;
+  using G = Geo<R, QB>;
   constexpr int N1 = G::N1, NP = G::NP, NRD = G::NRD;
   __shared__ __attribute__((aligned(16))) float s_win[G::LDS_FLOATS];
 
-  unsigned long long* st = stamp_begin<STAMP>(stamps, N1, threadIdx.y);
+  unsigned long long* st = stamp_begin<STAMP>(stamps, G::NW, threadIdx.y);
   stamp<STAMP>(st, 1, false);
-  Block<R> blk;
+  Block<R, QB> blk;
   blk.init(coords, Q, P);
   const float* slab0 = scalar_ptr(pyr + ((size_t)blk.b_img * Q + blk.q0) * P.slab);  // SGPR base of every piece
   stamp<STAMP>(st, 2, true);  // coords landed
 
-  // ---- Phase A: stage the windows of queries wv*NWIN .. +NWIN-1, 64 pieces per wave-instruction ----
-  if (blk.wv * G::NWIN < QB) {
+  // ---- Phase A: stage the block's windows, 64 pieces per wave-instruction ----
+  if (blk.wv * NP * 64 < QB * G::PIECES) {
     f32x4 v[NP];
     unsigned dst[NP];
     int wB[NP], wXY[NP];
-    fetch_window_params<R>(blk, wB, wXY);
+    fetch_window_params<R, QB>(blk, wB, wXY);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const Piece pc = make_piece<R>(blk, i, wB[i], wXY[i]);
+      const Piece pc = make_piece<R, QB>(blk, i, wB[i], wXY[i]);
       dst[i] = pc.lds;
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // pieces outside the level are zeros (reference: zero padding)
       load_piece_masked(v[i], slab0, pc.goff, __builtin_amdgcn_ballot_w64(pc.need()));
@@ -276,10 +285,12 @@ __device__ __forceinline__ void corr_lookup_fwd_body(
   stamp<STAMP>(st, 6, false);  // barrier passed
 
   // ---- Phase B: thread (query, b) blends the 2r+1 taps of window row b ---------------------
-  const int j = blk.lane, b = blk.wv;
+  const int j = blk.j, b = blk.wv * G::RPW + blk.lane / QB;
+  const bool has_row = G::RPW * G::NW == N1 || b < N1;
   const float fx = blk.o.fx, fy = blk.o.fy;
-  const float4* row0 = reinterpret_cast<const float4*>(&s_win[j * G::WS + b * RS + 4]);
-  const float4* row1 = reinterpret_cast<const float4*>(&s_win[j * G::WS + (b + 1) * RS + 4]);
+  const int br = has_row ? b : 0;  // lanes beyond the last tap row (QB = 32, odd 2r+1) read row 0 and store nothing
+  const float4* row0 = reinterpret_cast<const float4*>(&s_win[j * G::WS + br * RS + 4]);
+  const float4* row1 = reinterpret_cast<const float4*>(&s_win[j * G::WS + (br + 1) * RS + 4]);
   float t0[NRD * 4], t1[NRD * 4];
 #pragma unroll
   for (int i = 0; i < NRD; ++i) {
@@ -299,7 +310,7 @@ __device__ __forceinline__ void corr_lookup_fwd_body(
     for (int a = 0; a < N1; ++a) asm volatile("" : "+v"(res[a]));
   }
   stamp<STAMP>(st, 7, false);  // blended
-  if (blk.live) {
+  if (blk.live && has_row) {
 #pragma unroll
     for (int a = 0; a < N1; ++a) store_out<STORE>(o + (size_t)a * N1 * Q, res[a]);
   }
@@ -308,31 +319,31 @@ __device__ __forceinline__ void corr_lookup_fwd_body(
   stamp_end<STAMP>(st);
 }
 
-template <int R, bool STAMP>
+template <int R, int QB, bool STAMP>
 __device__ __forceinline__ void corr_lookup_bwd_body(
     float* __restrict__ dpyr, const float* __restrict__ coords, const float* __restrict__ grad_out,
     int Q, const PyrLayout& P, unsigned long long* stamps) {
-  using G = Geo<R>;
+  using G = Geo<R, QB>;
   constexpr int N1 = G::N1, WIN = G::WIN, NP = G::NP, NRD = G::NRD;
   __shared__ __attribute__((aligned(16))) float s_win[G::LDS_FLOATS];
 
-  unsigned long long* st = stamp_begin<STAMP>(stamps, N1, threadIdx.y);
+  unsigned long long* st = stamp_begin<STAMP>(stamps, G::NW, threadIdx.y);
   stamp<STAMP>(st, 1, false);
-  Block<R> blk;
+  Block<R, QB> blk;
   blk.init(coords, Q, P);
   float* slab0 = scalar_ptr(dpyr + ((size_t)blk.b_img * Q + blk.q0) * P.slab);
   stamp<STAMP>(st, 2, true);  // coords landed
 
   // ---- the read half of the read-modify-write goes out first, next to the tap-gradient loads ----
-  const bool stager = blk.wv * G::NWIN < QB;
+  const bool stager = blk.wv * NP * 64 < QB * G::PIECES;
   f32x4 v[NP];
   Piece pc[NP];
   if (stager) {
     int wB[NP], wXY[NP];
-    fetch_window_params<R>(blk, wB, wXY);
+    fetch_window_params<R, QB>(blk, wB, wXY);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      pc[i] = make_piece<R>(blk, i, wB[i], wXY[i]);
+      pc[i] = make_piece<R, QB>(blk, i, wB[i], wXY[i]);
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       load_piece_masked(v[i], slab0, pc[i].goff, __builtin_amdgcn_ballot_w64(pc[i].need()));
     }
@@ -341,15 +352,15 @@ __device__ __forceinline__ void corr_lookup_bwd_body(
 
   // ---- Phase A': thread (query, row) builds row `row` of the window's gradient image ----------------
   // d window[r][c] = w00 g[c][r] + w01 g[c-1][r] + w10 g[c][r-1] + w11 g[c-1][r-1]   (g = 0 outside 0..2r)
-  {
-    const int j = blk.lane;
+  const int row = blk.wv * G::RPW + blk.lane / QB;
+  if (G::RPW * G::NW == N1 || row < N1) {
+    const int j = blk.j;
     const float fx = blk.o.fx, fy = blk.o.fy;
     const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
     const float w10 = (1.f - fx) * fy, w11 = fx * fy;
     const int C = P.L * N1 * N1;
     const float* g = grad_out + ((size_t)blk.b_img * C + (size_t)blk.level * N1 * N1) * Q + blk.q0 + j;
     float gc[N1], gp[N1];  // tap gradients of window row `row` and of the row above, along a
-    const int row = blk.wv;
 #pragma unroll
     for (int a = 0; a < N1; ++a) {
       gc[a] = blk.live ? g[(size_t)(a * N1 + row) * Q] : 0.f;
@@ -368,7 +379,7 @@ __device__ __forceinline__ void corr_lookup_bwd_body(
     }
 #pragma unroll
     for (int i = 0; i < NRD; ++i) dst0[i] = make_float4(d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]);
-    if (row == N1 - 1) {  // the last wave also owns the window's last row (only the row above contributes)
+    if (row == N1 - 1) {  // the owner of the last tap row also builds the window's last row (only the row above contributes)
       float4* dst1 = reinterpret_cast<float4*>(&s_win[j * G::WS + (WIN - 1) * RS + 4]);
 #pragma unroll
       for (int c = 0; c < NRD * 4; ++c) {
@@ -414,17 +425,17 @@ __device__ __forceinline__ void corr_lookup_bwd_body(
 // LDS-limited occupancy (2 workgroups x 9 waves -> 5 waves/SIMD) and INFLATES the kernel descriptor's VGPR
 // count to cap the hardware at it (next_free_vgpr 81 for 36 live registers); a 9-wave workgroup then no longer
 // fits twice on a CU and the second half of the grid waits for the first (tools/dev/census.hip, measured).
-template <int R>
+template <int R, int QB = PCFA_LOOKUP_QB>
 __global__ __launch_bounds__(1024) void corr_lookup_fwd_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out, int Q, PyrLayout P) {
-  corr_lookup_fwd_body<R, false, PCFA_LOOKUP_STORE>(pyr, coords, out, Q, P, nullptr);
+  corr_lookup_fwd_body<R, QB, false, PCFA_LOOKUP_STORE>(pyr, coords, out, Q, P, nullptr);
 }
 
-template <int R>
+template <int R, int QB = PCFA_LOOKUP_QB>
 __global__ __launch_bounds__(1024) void corr_lookup_bwd_kernel(
     float* __restrict__ dpyr, const float* __restrict__ coords, const float* __restrict__ grad_out, int Q,
     PyrLayout P) {
-  corr_lookup_bwd_body<R, false>(dpyr, coords, grad_out, Q, P, nullptr);
+  corr_lookup_bwd_body<R, QB, false>(dpyr, coords, grad_out, Q, P, nullptr);
 }
 
 #ifdef PCFA_LOOKUP_DEV
@@ -432,25 +443,26 @@ template <int R>
 __global__ __launch_bounds__(1024) void corr_lookup_fwd_stamped_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out, int Q, PyrLayout P,
     unsigned long long* stamps) {
-  corr_lookup_fwd_body<R, true>(pyr, coords, out, Q, P, stamps);
+  corr_lookup_fwd_body<R, PCFA_LOOKUP_QB, true>(pyr, coords, out, Q, P, stamps);
 }
 template <int STORE>
 __global__ __launch_bounds__(1024) void corr_lookup_fwd_store_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out, int Q, PyrLayout P) {
-  corr_lookup_fwd_body<4, false, STORE>(pyr, coords, out, Q, P, nullptr);
+  corr_lookup_fwd_body<4, PCFA_LOOKUP_QB, false, STORE>(pyr, coords, out, Q, P, nullptr);
 }
 template <int R>
 __global__ __launch_bounds__(1024) void corr_lookup_bwd_stamped_kernel(
     float* __restrict__ dpyr, const float* __restrict__ coords, const float* __restrict__ grad_out, int Q,
     PyrLayout P, unsigned long long* stamps) {
-  corr_lookup_bwd_body<R, true>(dpyr, coords, grad_out, Q, P, stamps);
+  corr_lookup_bwd_body<R, PCFA_LOOKUP_QB, true>(dpyr, coords, grad_out, Q, P, stamps);
 }
 #endif
 
 template <int R>
 int launch_fwd(const float* pyr, const float* coords, float* out, int B, int Q,
                const PyrLayout& P, hipStream_t s) {
-  dim3 grid(pcfa_cdiv(Q, QB), P.L, B), block(QB, 2 * R + 1, 1);
+  using G = Geo<R, PCFA_LOOKUP_QB>;
+  dim3 grid(pcfa_cdiv(Q, PCFA_LOOKUP_QB), P.L, B), block(64, G::NW, 1);
   pcfa_launch(corr_lookup_fwd_kernel<R>, grid, block, 0, s, pyr, coords, out, Q, P);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
@@ -458,7 +470,8 @@ int launch_fwd(const float* pyr, const float* coords, float* out, int B, int Q,
 template <int R>
 int launch_bwd(float* dpyr, const float* coords, const float* go, int B, int Q,
                const PyrLayout& P, hipStream_t s) {
-  dim3 grid(pcfa_cdiv(Q, QB), P.L, B), block(QB, 2 * R + 1, 1);
+  using G = Geo<R, PCFA_LOOKUP_QB>;
+  dim3 grid(pcfa_cdiv(Q, PCFA_LOOKUP_QB), P.L, B), block(64, G::NW, 1);
   pcfa_launch(corr_lookup_bwd_kernel<R>, grid, block, 0, s, dpyr, coords, go, Q, P);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;

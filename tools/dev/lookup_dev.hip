@@ -17,7 +17,7 @@ DEV_API int dev_lookup_fwd_stamped(const float* pyr, const float* coords, float*
   PyrLayout P;
   if (!pcfa_make_layout(P, H, W, num_levels)) return -1;
   const int Q = H * W;
-  dim3 grid(pcfa_cdiv(Q, QB), P.L, B), block(QB, 9, 1);
+  dim3 grid(pcfa_cdiv(Q, PCFA_LOOKUP_QB), P.L, B), block(64, Geo<4, PCFA_LOOKUP_QB>::NW, 1);
   hipLaunchKernelGGL(corr_lookup_fwd_stamped_kernel<4>, grid, block, 0, (hipStream_t)stream, pyr, coords, out, Q, P,
                      stamps);
   return (int)hipGetLastError();
@@ -28,7 +28,7 @@ DEV_API int dev_lookup_bwd_stamped(float* dpyr, const float* coords, const float
   PyrLayout P;
   if (!pcfa_make_layout(P, H, W, num_levels)) return -1;
   const int Q = H * W;
-  dim3 grid(pcfa_cdiv(Q, QB), P.L, B), block(QB, 9, 1);
+  dim3 grid(pcfa_cdiv(Q, PCFA_LOOKUP_QB), P.L, B), block(64, Geo<4, PCFA_LOOKUP_QB>::NW, 1);
   hipLaunchKernelGGL(corr_lookup_bwd_stamped_kernel<4>, grid, block, 0, (hipStream_t)stream, dpyr, coords, grad_out,
                      Q, P, stamps);
   return (int)hipGetLastError();
@@ -39,7 +39,7 @@ DEV_API int dev_lookup_fwd_store(int mode, const float* pyr, const float* coords
   PyrLayout P;
   if (!pcfa_make_layout(P, H, W, num_levels)) return -1;
   const int Q = H * W;
-  dim3 grid(pcfa_cdiv(Q, QB), P.L, B), block(QB, 9, 1);
+  dim3 grid(pcfa_cdiv(Q, PCFA_LOOKUP_QB), P.L, B), block(64, Geo<4, PCFA_LOOKUP_QB>::NW, 1);
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) hipLaunchKernelGGL(corr_lookup_fwd_store_kernel<0>, grid, block, 0, s, pyr, coords, out, Q, P);
   if (mode == 1) hipLaunchKernelGGL(corr_lookup_fwd_store_kernel<1>, grid, block, 0, s, pyr, coords, out, Q, P);
@@ -48,3 +48,5 @@ DEV_API int dev_lookup_fwd_store(int mode, const float* pyr, const float* coords
 }
 
 DEV_API int dev_stamp_slots() { return STAMP_SLOTS; }
+DEV_API int dev_waves() { return Geo<4, PCFA_LOOKUP_QB>::NW; }
+DEV_API int dev_qb() { return PCFA_LOOKUP_QB; }

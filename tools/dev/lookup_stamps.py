@@ -29,7 +29,7 @@ BWD = ["rt0", "start", "coords landed", "dpyr loads issued", "image rows written
 def report(s, names, nwg, Q, label):
     rt0, rt1 = s[:, :, 0], s[:, :, 11]
     t0 = rt0.min()
-    print("== %s: %d workgroups x 9 waves; s_memrealtime tick = 10 ns" % (label, nwg))
+    print("== %s: %d workgroups x %d waves; s_memrealtime tick = 10 ns" % (label, nwg, s.shape[1]))
     print("span first wave start -> last wave end: %.2f us" % ((rt1.max() - t0) / 100.0))
     st = (rt0.min(axis=1) - t0) / 100.0
     en = (rt1.max(axis=1) - t0) / 100.0
@@ -85,7 +85,7 @@ def main():
 
     if what == "stores":  # A/B of the forward kernel's store flavour (run under rocprofv3)
         mode = sys.argv[2]
-        lib = ctypes.CDLL(os.path.join(HERE, "liblookup_dev.so"))
+        lib = ctypes.CDLL(os.environ.get("PCFA_LOOKUP_DEV_LIB") or os.path.join(HERE, "liblookup_dev.so"))
         P = ctypes.c_void_p
         lib.dev_lookup_fwd_store.argtypes = [ctypes.c_int, P, P, P] + [ctypes.c_int] * 4 + [P]
         out = torch.empty_like(want)
@@ -125,13 +125,13 @@ def main():
         torch.cuda.synchronize()
         return
 
-    lib = ctypes.CDLL(os.path.join(HERE, "liblookup_dev.so"))
+    lib = ctypes.CDLL(os.environ.get("PCFA_LOOKUP_DEV_LIB") or os.path.join(HERE, "liblookup_dev.so"))
     P = ctypes.c_void_p
     lib.dev_lookup_fwd_stamped.argtypes = [P, P, P] + [ctypes.c_int] * 4 + [P, P]
     lib.dev_lookup_bwd_stamped.argtypes = [P, P, P] + [ctypes.c_int] * 4 + [P, P]
-    slots = lib.dev_stamp_slots()
-    nwg = (Q // 64) * 4
-    stamps = torch.zeros(nwg * 9 * slots, dtype=torch.int64, device=DEV)
+    slots, nw, qb = lib.dev_stamp_slots(), lib.dev_waves(), lib.dev_qb()
+    nwg = (Q // qb) * 4
+    stamps = torch.zeros(nwg * nw * slots, dtype=torch.int64, device=DEV)
     out = torch.empty_like(want)
     dref = torch.zeros_like(pyr)
     product_bwd(dref)
@@ -159,7 +159,7 @@ def main():
             err = float((got - ref).abs().max())
             print("stamped vs product: max |diff| %.3g (max |ref| %.3g)" % (err, float(ref.abs().max())))
             assert err <= 1e-5 * float(ref.abs().max()), "stamped build changed the result"
-            s = stamps.cpu().numpy().reshape(nwg, 9, slots).astype(np.int64)
+            s = stamps.cpu().numpy().reshape(nwg, nw, slots).astype(np.int64)
             report(s, FWD if direction == "fwd" else BWD, nwg, Q, "%s %s" % (direction, mode))
 
 
