@@ -207,9 +207,9 @@ def kernel_table(timings, hf, wf, hp, wp, dim=256, levels=4, radius=4):
 
 TRACED = {  # kernel-name fragment -> label of kernel_table()
     "corr_lookup_fwd_kernel": "corr_lookup_fwd", "corr_lookup_bwd_kernel": "corr_lookup_bwd",
-    "gemm_f32_mfma_kernel<true, true>": "corr_pyramid_gemm_fwd",
-    "gemm_f32_mfma_kernel<false, false>": "corr_pyramid_gemm_dfmap1",
-    "gemm_f32_mfma_kernel<false, true>": "corr_pyramid_gemm_df2ext",
+    "gemm_f32_mfma_kernel<true, true,": "corr_pyramid_gemm_fwd",
+    "gemm_f32_mfma_kernel<false, false,": "corr_pyramid_gemm_dfmap1",
+    "gemm_f32_mfma_kernel<false, true,": "corr_pyramid_gemm_df2ext",
     "box_fwd_kernel": "box_transform_fwd", "box_bwd_kernel": "box_transform_bwd",
     "gru_gates_fwd_kernel": "gru_gates_fwd", "gru_update_fwd_kernel": "gru_update_fwd",
 }

@@ -72,6 +72,43 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ X, long long
   }
 }
 
+// FAST staging (both dims % 4 == 0, 16-B aligned operands, K range % 4 == 0): every load is an unconditional
+// float4 from a clamped, always valid address -- no branch between a load and its use, so hipcc keeps the loads
+// of stage k+1 in flight across the MFMAs of stage k instead of draining them first (with the predicated loader
+// the loop waits with vmcnt(0) BEFORE the MFMA block); out-of-range pieces are zeroed when the registers are
+// written to LDS.
+template <bool KMAJ>
+__device__ __forceinline__ void tile_load_fast(const float* __restrict__ X, long long ld, int dim, int d0, int k0,
+                                               int kend, float4 (&r)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + 256 * i;
+    int k, d;
+    if (KMAJ) {
+      k = min(k0 + f / 32, kend - 1);
+      d = min(d0 + (f % 32) * 4, dim - 4);
+      r[i] = *reinterpret_cast<const float4*>(X + (long long)k * ld + d);
+    } else {
+      d = min(d0 + f / 4, dim - 1);
+      k = min(k0 + (f % 4) * 4, kend - 4);
+      r[i] = *reinterpret_cast<const float4*>(X + (long long)d * ld + k);
+    }
+  }
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ void tile_mask(int dim, int d0, int k0, int kend, float4 (&r)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + 256 * i;
+    const bool ok = KMAJ ? (k0 + f / 32 < kend && d0 + (f % 32) * 4 < dim)
+                         : (d0 + f / 4 < dim && k0 + (f % 4) * 4 < kend);
+    if (!ok) r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 template <bool KMAJ>
 __device__ __forceinline__ void tile_store(float* __restrict__ s, const float4 (&r)[2]) {
   const int tid = threadIdx.x;
@@ -93,7 +130,7 @@ __device__ __forceinline__ void tile_store(float* __restrict__ s, const float4 (
 
 // C[m][n] = (sum_k A(m,k) B(k,n)) / div   over k in this block's split.
 // grid = (ceil(N/128), ceil(M/128), batch*splits).
-template <bool A_KM, bool B_KN>
+template <bool A_KM, bool B_KN, bool FAST>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
     int N, int K, long long lda, long long ldb, long long ldc, long long bsA, long long bsB,
@@ -127,8 +164,15 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
   float4 ra[2], rb[2];
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
-    tile_load<A_KM>(A, lda, M, m0, kbeg, kend, vecA, ra);
-    tile_load<B_KN>(B, ldb, N, n0, kbeg, kend, vecB, rb);
+    if (FAST) {
+      tile_load_fast<A_KM>(A, lda, M, m0, kbeg, kend, ra);
+      tile_load_fast<B_KN>(B, ldb, N, n0, kbeg, kend, rb);
+      tile_mask<A_KM>(M, m0, kbeg, kend, ra);
+      tile_mask<B_KN>(N, n0, kbeg, kend, rb);
+    } else {
+      tile_load<A_KM>(A, lda, M, m0, kbeg, kend, vecA, ra);
+      tile_load<B_KN>(B, ldb, N, n0, kbeg, kend, vecB, rb);
+    }
     tile_store<A_KM>(sA[0], ra);
     tile_store<B_KN>(sB[0], rb);
   }
@@ -136,8 +180,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    if (more) {
-      const int k0 = kbeg + (kt + 1) * BK;
+    const int k0 = kbeg + (kt + 1) * BK;
+    if (FAST) {  // unconditional: the stage past the end re-reads the last one (clamped) and is never stored
+      tile_load_fast<A_KM>(A, lda, M, m0, min(k0, kend - 4), kend, ra);
+      tile_load_fast<B_KN>(B, ldb, N, n0, min(k0, kend - 4), kend, rb);
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads ABOVE the MFMA block (hipcc otherwise sinks them to their use)
+    } else if (more) {
       tile_load<A_KM>(A, lda, M, m0, k0, kend, vecA, ra);
       tile_load<B_KN>(B, ldb, N, n0, k0, kend, vecB, rb);
     }
@@ -152,7 +200,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if (more) {
+    if (FAST) {  // unconditional (also after the last stage, into the idle buffer): a store under `if (more)`
+                 // lets hipcc sink the loads into that branch, i.e. below the MFMAs
+      tile_mask<A_KM>(M, m0, k0, kend, ra);
+      tile_mask<B_KN>(N, n0, k0, kend, rb);
+      tile_store<A_KM>(sA[cur ^ 1], ra);
+      tile_store<B_KN>(sB[cur ^ 1], rb);
+    } else if (more) {
       tile_store<A_KM>(sA[cur ^ 1], ra);
       tile_store<B_KN>(sB[cur ^ 1], rb);
     }
@@ -161,6 +215,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
   }
 
   // Epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // The reference divides by sqrt(D); when that is a power of two (D = 256 -> 16) multiplying by its reciprocal
+  // is the same fp32 result and saves a division sequence per output element.
+  int dexp;
+  const bool pow2 = frexpf(div, &dexp) == 0.5f;
+  const float rdiv = 1.0f / div;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -170,7 +229,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < M) C[(long long)row * ldc + col] = acc[i][j][r] / div;
+        if (row < M) C[(long long)row * ldc + col] = pow2 ? acc[i][j][r] * rdiv : acc[i][j][r] / div;
       }
     }
 }
@@ -328,11 +387,13 @@ extern "C" int pcfa_corr_pyramid_fwd(const float* fmap1, const float* f2ext, flo
   const int vecA = (Q % 4 == 0) && aligned16(fmap1);
   const int vecB = aligned16(f2ext);  // slab % 16 == 0 by construction
   dim3 grid(pcfa_cdiv(S, BN), pcfa_cdiv(Q, BM), B);
-  pcfa_launch(gemm_f32_mfma_kernel<true, true>, grid, dim3(256), 0,
-                     (hipStream_t)stream, fmap1, f2ext, pyr, Q, S, D, (long long)Q,
-                     (long long)S, (long long)S, (long long)D * Q, (long long)D * S,
-                     (long long)Q * S, 1, ((D + BK - 1) / BK) * BK, 0LL, sqrtf((float)D), vecA,
-                     vecB);
+#define PCFA_GEMM_ARGS fmap1, f2ext, pyr, Q, S, D, (long long)Q, (long long)S, (long long)S, (long long)D * Q, \
+                       (long long)D * S, (long long)Q * S, 1, ((D + BK - 1) / BK) * BK, 0LL, sqrtf((float)D), vecA, vecB
+  if (vecA && vecB && D % 4 == 0 && Q >= 4)
+    pcfa_launch(gemm_f32_mfma_kernel<true, true, true>, grid, dim3(256), 0, (hipStream_t)stream, PCFA_GEMM_ARGS);
+  else
+    pcfa_launch(gemm_f32_mfma_kernel<true, true, false>, grid, dim3(256), 0, (hipStream_t)stream, PCFA_GEMM_ARGS);
+#undef PCFA_GEMM_ARGS
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -369,10 +430,14 @@ extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, cons
     const int kchunk = choose_kchunk(S, BWD_SPLITS);
     const int vec = aligned16(f2ext) && aligned16(dpyr);
     dim3 grid(pcfa_cdiv(Q, BN), pcfa_cdiv(D, BM), B * BWD_SPLITS);
-    pcfa_launch(gemm_f32_mfma_kernel<false, false>, grid, dim3(256), 0, s, f2ext, dpyr,
-                       part1, D, Q, S, (long long)S, (long long)S, (long long)Q,
-                       (long long)D * S, (long long)Q * S, (long long)D * Q, BWD_SPLITS, kchunk,
-                       (long long)B * D * Q, div, vec, vec);
+#define PCFA_GEMM_ARGS f2ext, dpyr, part1, D, Q, S, (long long)S, (long long)S, (long long)Q, (long long)D * S, \
+                       (long long)Q * S, (long long)D * Q, BWD_SPLITS, kchunk, (long long)B * D * Q, div, vec, vec
+    // FAST: k (= slab index) is the contiguous axis of both operands; slab % 16 == 0 and kchunk % 16 == 0
+    if (vec)
+      pcfa_launch(gemm_f32_mfma_kernel<false, false, true>, grid, dim3(256), 0, s, PCFA_GEMM_ARGS);
+    else
+      pcfa_launch(gemm_f32_mfma_kernel<false, false, false>, grid, dim3(256), 0, s, PCFA_GEMM_ARGS);
+#undef PCFA_GEMM_ARGS
     PCFA_LAUNCH_CHECK();
     const long long n = (long long)B * D * Q;
     pcfa_launch(splitk_reduce_kernel, dim3(min(pcfa_cdiv(n, 256), 2048)), dim3(256), 0, s,
@@ -385,10 +450,13 @@ extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, cons
     const int vecA = (Q % 4 == 0) && aligned16(fmap1);
     const int vecB = aligned16(dpyr);
     dim3 grid(pcfa_cdiv(S, BN), pcfa_cdiv(D, BM), B * BWD_SPLITS);
-    pcfa_launch(gemm_f32_mfma_kernel<false, true>, grid, dim3(256), 0, s, fmap1, dpyr,
-                       part2, D, S, Q, (long long)Q, (long long)S, (long long)S,
-                       (long long)D * Q, (long long)Q * S, (long long)D * S, BWD_SPLITS, kchunk,
-                       (long long)B * D * S, div, vecA, vecB);
+#define PCFA_GEMM_ARGS fmap1, dpyr, part2, D, S, Q, (long long)Q, (long long)S, (long long)S, (long long)D * Q, \
+                       (long long)Q * S, (long long)D * S, BWD_SPLITS, kchunk, (long long)B * D * S, div, vecA, vecB
+    if (vecA && vecB && Q >= 4)   // k = query index: contiguous in fmap1 (Q % 4 == 0), row index of dpyr
+      pcfa_launch(gemm_f32_mfma_kernel<false, true, true>, grid, dim3(256), 0, s, PCFA_GEMM_ARGS);
+    else
+      pcfa_launch(gemm_f32_mfma_kernel<false, true, false>, grid, dim3(256), 0, s, PCFA_GEMM_ARGS);
+#undef PCFA_GEMM_ARGS
     PCFA_LAUNCH_CHECK();
     const long long n = (long long)B * D * S;
     pcfa_launch(splitk_reduce_kernel, dim3(min(pcfa_cdiv(n, 256), 2048)), dim3(256), 0, s,
