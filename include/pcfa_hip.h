@@ -213,6 +213,10 @@ PCFA_API int pcfa_gru_gates_fwd(const float* zc, const float* rc, const float* h
                        float* rh, long long n, int plane, int channels, void* stream);
 PCFA_API int pcfa_gru_gates_bwd(const float* z, const float* r, const float* h, const float* dz, const float* drh,
                        float* dzc, float* drc, float* dh, long long n, void* stream);
+/* pcfa_gru_gates_bwd with dh = dh_in + drh * r: dh_in (nullable) is the gradient that reached h on another path
+ * (the (1 - z) * g term of pcfa_gru_update_bwd), folded in here instead of by a separate add kernel. */
+PCFA_API int pcfa_gru_gates_bwd_acc(const float* z, const float* r, const float* h, const float* dz, const float* drh,
+                           const float* dh_in, float* dzc, float* drc, float* dh, long long n, void* stream);
 PCFA_API int pcfa_gru_update_fwd(const float* z, const float* qc, const float* h, const float* bias_q,
                         const float* add_q, float* q, float* hnew, long long n, int plane, int channels,
                         void* stream);
@@ -239,6 +243,15 @@ PCFA_API int pcfa_sepconv5_pack_weights(const float* w, float* fwd_packed, float
                                void* stream);
 PCFA_API int pcfa_sepconv5_fwd(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,
                       float* out, int B, int Cout, int H, int W, int vertical, void* stream);
+
+/* pcfa_sepconv5_fwd with the output channels split over two tensors -- channels [0, Cout_a) to out_a
+ * [B,Cout_a,H,W], the rest to out_b [B,Cout-Cout_a,H,W] -- and optional accumulation (out += result) per tensor.
+ * Used for the data gradient: grad of [h | x] lands directly in grad_h and grad_x, summed in place with the
+ * gradients those tensors receive from their other consumers (SepConvGRU uses h three times and x four times per
+ * step, models/raft/update.py:45-60). */
+PCFA_API int pcfa_sepconv5_fwd_split(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,
+                            float* out_a, int Cout_a, int accumulate_a, float* out_b, int accumulate_b, int B,
+                            int Cout, int H, int W, int vertical, void* stream);
 
 /* out = relu(x + bias[c]) and its backward gx = grad_out * (out > 0): the "conv -> +bias -> ReLU" tail of the
  * motion encoder / flow head convolutions (models/raft/update.py:12-16,91-101) in one pass. */

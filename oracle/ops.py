@@ -238,6 +238,15 @@ def sepconv5(a, b, weight):
     return F.conv2d(x, weight, None, padding=(weight.shape[2] // 2, weight.shape[3] // 2))
 
 
+def gru_step(h, rest, halves):
+    """SepConvGRU update (models/raft/update.py:45-60) from the hoisted context parts, composed from the oracle's own
+    operators: halves = ((w_zr, p_zr, w_q, p_q), (w_zr, p_zr, w_q, p_q))."""
+    for w_zr, p_zr, w_q, p_q in halves:
+        z, rh = gru_gates_packed(sepconv5(h, rest, w_zr), h, None, p_zr)
+        h = gru_update(z, sepconv5(rh, rest, w_q), h, None, p_q)
+    return h
+
+
 def bias_relu(x, bias=None):
     """F.relu(conv(x)) with the convolution's bias split off (models/raft/update.py:12-16,91-101)."""
     return torch.relu(x + _cb(bias))

@@ -57,6 +57,9 @@ SIGNATURES = {
     "pcfa_gru_update_bwd": (c_int, [_P] * 7 + [c_longlong, _P]),
     "pcfa_sepconv5_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "pcfa_sepconv5_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_sepconv5_fwd_split": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, _P]),
+    "pcfa_gru_gates_bwd_acc": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, _P]),
     "pcfa_lbfgs_workspace_floats": (c_size_t, []),
     "pcfa_lbfgs_pair": (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_longlong, _P]),
     "pcfa_lbfgs_direction": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_longlong, c_longlong,

@@ -73,8 +73,10 @@ __global__ void gru_gates_fwd_kernel(const float* __restrict__ zc, const float* 
 // dzc = dz * (1 - z) * z ; dr = drh * h ; drc = dr * (1 - r) * r ; dh = drh * r
 __global__ void gru_gates_bwd_kernel(const float* __restrict__ z, const float* __restrict__ r,
                                      const float* __restrict__ h, const float* __restrict__ dz,
-                                     const float* __restrict__ drh, float* __restrict__ dzc,
-                                     float* __restrict__ drc, float* __restrict__ dh, long long n, int vec_ok) {
+                                     const float* __restrict__ drh, const float* dh_in,  // dh_in may alias dh
+                                     float* __restrict__ dzc,
+                                     float* __restrict__ drc, float* dh, long long n, int vec_ok) {
+  // dh_in (nullable): gradient that already reached h on another path; added here instead of by a separate kernel
   auto one = [](float z_, float r_, float h_, float dz_, float drh_, float& a, float& b, float& c) {
     a = dz_ * (1.f - z_) * z_;
     const float dr = drh_ * h_;
@@ -89,9 +91,15 @@ __global__ void gru_gates_bwd_kernel(const float* __restrict__ z, const float* _
       one(zz.y, rr.y, hh.y, gz.y, gr.y, a.y, b.y, c.y);
       one(zz.z, rr.z, hh.z, gz.z, gr.z, a.z, b.z, c.z);
       one(zz.w, rr.w, hh.w, gz.w, gr.w, a.w, b.w, c.w);
+      if (dh_in) {
+        const float4 p = LD4(dh_in, i);
+        c.x += p.x; c.y += p.y; c.z += p.z; c.w += p.w;
+      }
       ST4(dzc, i, a); ST4(drc, i, b); ST4(dh, i, c);
     } else {
-      one(z[i], r[i], h[i], dz[i], drh[i], dzc[i], drc[i], dh[i]);
+      float c;
+      one(z[i], r[i], h[i], dz[i], drh[i], dzc[i], drc[i], c);
+      dh[i] = dh_in ? c + dh_in[i] : c;
     }
   });
 }
@@ -200,15 +208,22 @@ extern "C" int pcfa_gru_gates_fwd(const float* zc, const float* rc, const float*
   return PCFA_OK;
 }
 
+extern "C" int pcfa_gru_gates_bwd_acc(const float* z, const float* r, const float* h, const float* dz,
+                                      const float* drh, const float* dh_in, float* dzc, float* drc, float* dh,
+                                      long long n, void* stream) {
+  if (!z || !r || !h || !dz || !drh || !dzc || !drc || !dh || n < 1) return PCFA_ERR_INVALID_ARG;
+  const int vec_ok = al16(z) && al16(r) && al16(h) && al16(dz) && al16(drh) && al16(dzc) && al16(drc) && al16(dh) &&
+                     al16(dh_in);
+  pcfa_launch(gru_gates_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, r,
+                     h, dz, drh, dh_in, dzc, drc, dh, n, vec_ok);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
 extern "C" int pcfa_gru_gates_bwd(const float* z, const float* r, const float* h, const float* dz,
                                   const float* drh, float* dzc, float* drc, float* dh, long long n,
                                   void* stream) {
-  if (!z || !r || !h || !dz || !drh || !dzc || !drc || !dh || n < 1) return PCFA_ERR_INVALID_ARG;
-  const int vec_ok = al16(z) && al16(r) && al16(h) && al16(dz) && al16(drh) && al16(dzc) && al16(drc) && al16(dh);
-  pcfa_launch(gru_gates_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, r,
-                     h, dz, drh, dzc, drc, dh, n, vec_ok);
-  PCFA_LAUNCH_CHECK();
-  return PCFA_OK;
+  return pcfa_gru_gates_bwd_acc(z, r, h, dz, drh, nullptr, dzc, drc, dh, n, stream);
 }
 
 extern "C" int pcfa_gru_update_fwd(const float* z, const float* qc, const float* h, const float* bias_q,

@@ -43,6 +43,16 @@ struct Operand {
   int Ca, Cin;
 };
 
+// Output channels [0, Ca) go to `a`, the rest to `b` (b may be null when Ca == Cout); acc_*: add to what is there
+// (the data gradient of a convolution whose input feeds several consumers accumulates in place instead of being
+// summed by separate elementwise kernels).
+struct OutSplit {
+  float* a;
+  float* b;
+  int Ca;
+  int acc_a, acc_b;
+};
+
 __device__ __forceinline__ const float* channel_plane(const Operand& in, int ci, long long plane) {
   return ci < in.Ca ? in.a + ci * plane : in.b + (ci - in.Ca) * plane;
 }
@@ -71,7 +81,7 @@ __device__ __forceinline__ f32x4 keep_if(bool ok, f32x4 v) {
 // stages.  The generic variant keeps predicated element-wise loads for ragged shapes.
 template <bool VERT, bool FAST>
 __global__ __launch_bounds__(256) void sepconv5_kernel(Operand in, const float* __restrict__ wp,
-                                                       float* __restrict__ out, int Cout, int H, int W,
+                                                       OutSplit out, int Cout, int H, int W,
                                                        int tiles_x, int vec_w, int vec_x) {
   __shared__ __attribute__((aligned(16))) float sA[2][A_TILE];
   __shared__ __attribute__((aligned(16))) float sB[2][VERT ? B_TILE_V : B_TILE_H];
@@ -82,7 +92,8 @@ __global__ __launch_bounds__(256) void sepconv5_kernel(Operand in, const float* 
   const int m0 = blockIdx.y * TM;
   in.a += (long long)blockIdx.z * in.Ca * plane;
   if (in.b) in.b += (long long)blockIdx.z * (in.Cin - in.Ca) * plane;
-  out += (long long)blockIdx.z * Cout * plane;
+  out.a += (long long)blockIdx.z * out.Ca * plane;
+  if (out.b) out.b += (long long)blockIdx.z * (Cout - out.Ca) * plane;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -249,11 +260,35 @@ __global__ __launch_bounds__(256) void sepconv5_kernel(Operand in, const float* 
   // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   const int x = x0 + wc * 32 + l31;
   if (x < W) {
-    float* o = out + (long long)y * W + x;
+    const long long pix = (long long)y * W + x;
+    const int mw = m0 + wr * 32;  // first output channel of this wave's 32x32 tile
+    if ((out.Ca & 31) == 0 || out.b == nullptr) {
+      // the wave's 32 channels lie on one side of the split: destination and accumulate flag are wave-uniform
+      const bool first = out.b == nullptr || mw < out.Ca;
+      float* base = (first ? out.a + (long long)mw * plane : out.b + (long long)(mw - out.Ca) * plane) + pix;
+      if (first ? out.acc_a : out.acc_b) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m < Cout) o[m * plane] = acc[r];
+        for (int r = 0; r < 16; ++r) {
+          const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (mw + ml < Cout) base[ml * plane] += acc[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (mw + ml < Cout) base[ml * plane] = acc[r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < Cout) {
+          const bool first = m < out.Ca;
+          float* o = (first ? out.a + (long long)m * plane : out.b + (long long)(m - out.Ca) * plane) + pix;
+          *o = (first ? out.acc_a : out.acc_b) ? *o + acc[r] : acc[r];
+        }
+      }
     }
   }
 }
@@ -289,10 +324,29 @@ extern "C" int pcfa_sepconv5_pack_weights(const float* w, float* fwd_packed, flo
   return PCFA_OK;
 }
 
+static int sepconv5_launch(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,
+                           OutSplit out, int B, int Cout, int H, int W, int vertical, void* stream);
+
 extern "C" int pcfa_sepconv5_fwd(const float* in_a, int Ca, const float* in_b, int Cb,
                                  const float* w_packed, float* out, int B, int Cout, int H, int W,
                                  int vertical, void* stream) {
-  if (!in_a || !w_packed || !out || Ca < 1 || Cb < 0 || (Cb > 0 && !in_b) || B < 1 || Cout < 1 ||
+  if (!out) return PCFA_ERR_INVALID_ARG;
+  return sepconv5_launch(in_a, Ca, in_b, Cb, w_packed, OutSplit{out, nullptr, Cout, 0, 0}, B, Cout, H, W, vertical,
+                         stream);
+}
+
+extern "C" int pcfa_sepconv5_fwd_split(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,
+                                       float* out_a, int Cout_a, int accumulate_a, float* out_b, int accumulate_b,
+                                       int B, int Cout, int H, int W, int vertical, void* stream) {
+  if (!out_a || Cout_a < 1 || Cout_a > Cout || (Cout_a < Cout && !out_b)) return PCFA_ERR_INVALID_ARG;
+  return sepconv5_launch(in_a, Ca, in_b, Cb, w_packed,
+                         OutSplit{out_a, Cout_a < Cout ? out_b : nullptr, Cout_a, accumulate_a != 0, accumulate_b != 0},
+                         B, Cout, H, W, vertical, stream);
+}
+
+static int sepconv5_launch(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,
+                           OutSplit out, int B, int Cout, int H, int W, int vertical, void* stream) {
+  if (!in_a || !w_packed || Ca < 1 || Cb < 0 || (Cb > 0 && !in_b) || B < 1 || Cout < 1 ||
       H < 1 || W < 1)
     return PCFA_ERR_INVALID_ARG;
   const int tiles_x = pcfa_cdiv(W, TN);

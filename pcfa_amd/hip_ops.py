@@ -515,6 +515,88 @@ class _SepConv5(torch.autograd.Function):
         return gin[:, :Ca], (gin[:, Ca:] if Cb else None), None
 
 
+class _GruStep(torch.autograd.Function):
+    """One SepConvGRU update (both half-steps, models/raft/update.py:45-60) as ONE autograd node with a hand-ordered
+    backward.  Forward = the same kernel sequence as composing sepconv5 / gru_gates_packed / gru_update.  In the
+    backward every gradient that autograd would sum with separate elementwise kernels -- h is used three times per
+    half-step, the motion features four times per step -- is accumulated in place by the kernel that produces it
+    (pcfa_sepconv5_fwd_split with accumulate flags, pcfa_gru_gates_bwd_acc): 7 add launches less per refinement
+    iteration.  Arguments: h, rest, then per half-step (w_zr, p_zr, w_q, p_q) with p_* = the pre-activation
+    contribution of the constant context features (bias included)."""
+
+    @staticmethod
+    def forward(ctx, h, rest, w_zr1, p_zr1, w_q1, p_q1, w_zr2, p_zr2, w_q2, p_q2):
+        _dev(h, rest, w_zr1, p_zr1, w_q1, p_q1, w_zr2, p_zr2, w_q2, p_q2)
+        h, rest = h.contiguous(), rest.contiguous()
+        B, C, H, W = h.shape
+        Cr = rest.shape[1]
+        n, plane = C * H * W, H * W
+        new = lambda c: torch.empty((B, c, H, W), device=h.device, dtype=torch.float32)  # noqa: E731
+        saved, packs = [], []
+        for w_zr, p_zr, w_q, p_q in ((w_zr1, p_zr1, w_q1, p_q1), (w_zr2, p_zr2, w_q2, p_q2)):
+            if tuple(w_zr.shape[:2]) != (2 * C, C + Cr) or tuple(w_q.shape[:2]) != (C, C + Cr):
+                raise ValueError("gru_step: weights %s / %s do not fit h %s, rest %s"
+                                 % (tuple(w_zr.shape), tuple(w_q.shape), tuple(h.shape), tuple(rest.shape)))
+            vertical = int(w_zr.shape[2] == 5)
+            f_zr, b_zr = _sepconv5_packed(w_zr)
+            f_q, b_q = _sepconv5_packed(w_q)
+            p_zr, p_q = p_zr.contiguous(), p_q.contiguous()
+            zr, z, r, rh, qc, q, hnew = new(2 * C), new(C), new(C), new(C), new(C), new(C), new(C)
+            _call("pcfa_sepconv5_fwd", _ptr(h), C, _ptr(rest), Cr, _ptr(f_zr), _ptr(zr), B, 2 * C, H, W, vertical)
+            for b in range(B):  # per batch item the z and r halves of zr are contiguous blocks
+                o, oz = b * n, b * 2 * n
+                _call("pcfa_gru_gates_fwd", _ptr_off(zr, oz), _ptr_off(zr, oz + n), _ptr_off(h, o), None, None,
+                      _ptr_off(p_zr, oz), _ptr_off(p_zr, oz + n), _ptr_off(z, o), _ptr_off(r, o), _ptr_off(rh, o),
+                      n, plane, C)
+            _call("pcfa_sepconv5_fwd", _ptr(rh), C, _ptr(rest), Cr, _ptr(f_q), _ptr(qc), B, C, H, W, vertical)
+            _call("pcfa_gru_update_fwd", _ptr(z), _ptr(qc), _ptr(h), None, _ptr(p_q), _ptr(q), _ptr(hnew),
+                  z.numel(), plane, C)
+            saved += [z, r, q, h]
+            packs.append((b_zr, b_q, vertical))
+            h = hnew
+        ctx.save_for_backward(*saved)
+        ctx.packs, ctx.dims = packs, (B, C, Cr, H, W)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        if any(ctx.needs_input_grad[i] for i in (2, 4, 6, 8)):
+            raise RuntimeError("gru_step is the frozen-weight path: no weight gradient")
+        B, C, Cr, H, W = ctx.dims
+        n = C * H * W
+        new = lambda c: torch.empty((B, c, H, W), device=g.device, dtype=torch.float32)  # noqa: E731
+        g = g.contiguous()
+        d_rest = new(Cr)
+        grads_p = [None, None, None, None]  # p_zr1, p_q1, p_zr2, p_q2
+        rest_started = 0
+        for half in (1, 0):
+            z, r, q, h = ctx.saved_tensors[4 * half: 4 * half + 4]
+            b_zr, b_q, vertical = ctx.packs[half]
+            dz, dqc, dh, drh, dzr = new(C), new(C), new(C), new(C), new(2 * C)
+            _call("pcfa_gru_update_bwd", _ptr(z), _ptr(q), _ptr(h), _ptr(g), _ptr(dz), _ptr(dqc), _ptr(dh), z.numel())
+            # d[rh | rest] of the q convolution: rh part fresh, rest part into the step's running sum
+            _call("pcfa_sepconv5_fwd_split", _ptr(dqc), C, None, 0, _ptr(b_q), _ptr(drh), C, 0, _ptr(d_rest),
+                  rest_started, B, C + Cr, H, W, vertical)
+            rest_started = 1
+            for b in range(B):
+                o, oz = b * n, b * 2 * n
+                _call("pcfa_gru_gates_bwd_acc", _ptr_off(z, o), _ptr_off(r, o), _ptr_off(h, o), _ptr_off(dz, o),
+                      _ptr_off(drh, o), _ptr_off(dh, o), _ptr_off(dzr, oz), _ptr_off(dzr, oz + n), _ptr_off(dh, o), n)
+            # d[h | rest] of the stacked z|r convolution: both parts accumulate
+            _call("pcfa_sepconv5_fwd_split", _ptr(dzr), 2 * C, None, 0, _ptr(b_zr), _ptr(dh), C, 1, _ptr(d_rest), 1,
+                  B, C + Cr, H, W, vertical)
+            grads_p[2 * half], grads_p[2 * half + 1] = dzr, dqc
+            g = dh
+        return g, d_rest, None, grads_p[0], None, grads_p[1], None, grads_p[2], None, grads_p[3]
+
+
+def gru_step(h, rest, halves):
+    """SepConvGRU update from precomputed context parts: halves = ((w_zr, p_zr, w_q, p_q) for the 1x5 half-step,
+    (..) for the 5x1 half-step); see _GruStep."""
+    (a, b, c, d), (e, f, g_, i_) = halves
+    return _GruStep.apply(h, rest, a, b, c, d, e, f, g_, i_)
+
+
 def sepconv5(a, b, weight):
     """conv2d(cat([a, b], 1), weight, bias=None, padding='same') for a frozen (1,5) or (5,1) `weight`
     (SepConvGRU gate convolutions, models/raft/update.py:36-60); `b` may be None."""

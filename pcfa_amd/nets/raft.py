@@ -230,14 +230,9 @@ class SepConvGRU(nn.Module):
 
     def step(self, h, ctx, rest):
         """One GRU update given precompute()'s context; `rest` = the per-iteration part of x (motion features)."""
-        o = ops.get()
-        for zr, q in (("zr1", "q1"), ("zr2", "q2")):
-            w_zr, p_zr = ctx[zr]
-            w_q, p_q = ctx[q]
-            # sepconv5 reads [h | rest] in place: no torch.cat, no im2col
-            z, rh = o.gru_gates_packed(o.sepconv5(h, rest, w_zr), h, None, p_zr)
-            h = o.gru_update(z, o.sepconv5(rh, rest, w_q), h, None, p_q)
-        return h
+        # one autograd node per update: sepconv5 reads [h | rest] in place (no torch.cat, no im2col) and the
+        # backward accumulates the gradients of h and rest inside the kernels that produce them
+        return ops.get().gru_step(h, rest, tuple(ctx[zr] + ctx[q] for zr, q in (("zr1", "q1"), ("zr2", "q2"))))
 
 
 class BasicMotionEncoder(nn.Module):

@@ -269,6 +269,34 @@ def test_sepconv5_vs_oracle(oracle_ops, shape, vertical):
         assert rel_l2(gb.grad, cb.grad) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 128, 128, 55, 128), (2, 8, 12, 9, 70), (1, 128, 256, 16, 24)])
+def test_gru_step_vs_oracle(oracle_ops, shape):
+    """The fused SepConvGRU update (one autograd node, gradients of h / motion features accumulated inside the
+    kernels) against the oracle's composition of the same operators under autograd: values and every gradient
+    (h, rest, the four hoisted context parts) to 5e-6 relative L2 -- only the order of a few additions differs."""
+    B, C, Cr, H, W = shape
+    gen = torch.Generator().manual_seed(7 + C + W)
+    rnd = lambda *s: torch.randn(*s, generator=gen)  # noqa: E731
+    h, rest = torch.tanh(rnd(B, C, H, W)), rnd(B, Cr, H, W)
+    halves = []
+    for k in ((1, 5), (5, 1)):
+        sc = (5 * (C + Cr)) ** -.5
+        halves.append((rnd(2 * C, C + Cr, *k) * sc, rnd(B, 2 * C, H, W), rnd(C, C + Cr, *k) * sc, rnd(B, C, H, W)))
+    go = rnd(B, C, H, W)
+
+    def run(ops_mod, dev):
+        leaf = lambda t, g: t.detach().clone().to(dev).requires_grad_(g)  # noqa: E731
+        hh, rr = leaf(h, True), leaf(rest, True)
+        hv = [tuple(leaf(t, i % 2 == 1) for i, t in enumerate(hf)) for hf in halves]
+        out = ops_mod.gru_step(hh, rr, tuple(hv))
+        out.backward(go.to(dev))
+        return [out, hh.grad, rr.grad] + [hf[i].grad for hf in hv for i in (1, 3)]
+
+    want, got = run(oracle_ops, "cpu"), run(hip_ops, DEV)
+    for w_, g_ in zip(want, got):
+        assert rel_l2(g_, w_) < 5e-6
+
+
 def test_sepconv5_rejects_bad_operands():
     w = torch.zeros(4, 3, 1, 5, device=DEV)
     with pytest.raises(ValueError):
