@@ -72,8 +72,10 @@ def _conv_norm(conv, norm, x, relu, cache, tag):
         return conv._conv_forward(x, w, b)
     if (frozen and isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats):
         y = norm(conv._conv_forward(x, conv.weight, None))
-    else:
-        y = norm(conv(x))
+        # out of place: instance_norm returns a VIEW of its batch-norm output, and an in-place op on a view makes
+        # autograd rebase it (CopySlices), which clones a full activation-sized gradient in the backward
+        return F.relu(y) if relu else y
+    y = norm(conv(x))
     return F.relu(y, inplace=True) if relu else y
 
 
