@@ -63,6 +63,43 @@ class Attention(nn.Module):
         return sim.softmax(dim=-1)
 
 
+class _SharedAttnGrad:
+    """Book-keeping for one attention matrix that several _AttnTimesValue nodes multiply (once per refinement
+    iteration): its gradient is accumulated in ONE buffer by the GEMMs themselves (beta = 1) and handed to autograd
+    by whichever node runs last, instead of six [N, N] temporaries summed by five elementwise kernels of 3 x 198 MB
+    traffic each (N = 7040 at 436x1024)."""
+
+    def __init__(self):
+        self.pending = 0
+        self.buf = None
+
+
+class _AttnTimesValue(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attn, v, shared):
+        ctx.save_for_backward(attn, v)
+        ctx.shared = shared
+        shared.pending += 1
+        return torch.matmul(attn, v)
+
+    @staticmethod
+    def backward(ctx, g):
+        attn, v = ctx.saved_tensors
+        sh = ctx.shared
+        dv = torch.matmul(attn.transpose(-1, -2), g) if ctx.needs_input_grad[1] else None
+        d_attn = None
+        if ctx.needs_input_grad[0]:
+            n, d = attn.shape[-1], v.shape[-1]
+            if sh.buf is None:
+                sh.buf = torch.matmul(g, v.transpose(-1, -2))
+            else:
+                sh.buf.view(-1, n, n).baddbmm_(g.reshape(-1, n, d), v.reshape(-1, n, d).transpose(-1, -2))
+            sh.pending -= 1
+            if sh.pending == 0:
+                d_attn, sh.buf = sh.buf, None
+        return d_attn, dv, None
+
+
 class Aggregate(nn.Module):
     def __init__(self, args, dim, heads=4, dim_head=128):
         super().__init__()
@@ -74,11 +111,14 @@ class Aggregate(nn.Module):
         self.gamma = nn.Parameter(torch.zeros(1))
         self.project = nn.Conv2d(inner_dim, dim, 1, bias=False) if dim != inner_dim else None
 
-    def forward(self, attn, fmap):
+    def forward(self, attn, fmap, shared=None):
         b, c, h, w = fmap.shape
         heads = self.heads
         v = self.to_v(fmap).reshape(b, heads, -1, h * w).transpose(-1, -2)  # b h (x y) d
-        out = torch.matmul(attn, v)                                          # b h (x y) d
+        if shared is not None and torch.is_grad_enabled() and attn.requires_grad:
+            out = _AttnTimesValue.apply(attn, v.contiguous(), shared)        # b h (x y) d
+        else:
+            out = torch.matmul(attn, v)
         out = out.transpose(-1, -2).reshape(b, -1, h, w)                     # b (h d) x y
         if self.project is not None:
             out = self.project(out)
@@ -95,9 +135,9 @@ class GMAUpdateBlock(nn.Module):
         self.mask = _mask_head()
         self.aggregator = Aggregate(args=args, dim=128, dim_head=128, heads=args.num_heads)
 
-    def forward(self, net, inp, corr, flow, attention, want_mask=True, gru_ctx=None):
+    def forward(self, net, inp, corr, flow, attention, want_mask=True, gru_ctx=None, attn_grad=None):
         motion_features = self.encoder(flow, corr)
-        motion_features_global = self.aggregator(attention, motion_features)
+        motion_features_global = self.aggregator(attention, motion_features, attn_grad)
         if gru_ctx is not None:
             net = self.gru.step(net, gru_ctx, torch.cat([motion_features, motion_features_global], dim=1))
         else:
@@ -149,13 +189,14 @@ class RAFTGMA(nn.Module):
         gru_ctx = gru.precompute(inp) if gru.frozen() else None
         flow_predictions = []
         flow_up = None
+        attn_grad = _SharedAttnGrad()  # one accumulation buffer for the gradient of `attention` (used `iters` times)
         for itr in range(iters):
             coords1 = coords1.detach()
             corr = corr_fn(coords1)
             flow = coords1 - coords0
             need_up = (not test_mode) or itr == iters - 1
             net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, attention, want_mask=need_up,
-                                                         gru_ctx=gru_ctx)
+                                                         gru_ctx=gru_ctx, attn_grad=attn_grad)
             coords1 = coords1 + delta_flow
             if need_up:
                 flow_up = convex_upsample(coords1 - coords0, up_mask)
