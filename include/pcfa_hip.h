@@ -253,6 +253,19 @@ PCFA_API int pcfa_sepconv5_fwd_split(const float* in_a, int Ca, const float* in_
                             float* out_a, int Cout_a, int accumulate_a, float* out_b, int accumulate_b, int B,
                             int Cout, int H, int W, int vertical, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution (the update-block convolutions, models/raft/update.py:6-16,79-101) as Winograd
+ * F(2x2,3x3) on the fp32 matrix cores, bias and ReLU fused:  out[b,n] = act(bias[n] + sum_k w[n,k] (*) x[b,k]).
+ * pcfa_conv3x3_pack_weights: w [Cout][Cin][3][3] -> fwd_packed [16][Cin][pad64(Cout)] = G w G^T and/or
+ * bwd_packed [16][Cout][pad64(Cin)] (flipped, transposed: the data gradient is pcfa_conv3x3_fwd(grad_out, bwd_packed,
+ * NULL, grad_in, B, K = Cout, N = Cin, ...)); each needs pcfa_conv3x3_packed_floats(K, N) floats, 16-B aligned.
+ * pcfa_conv3x3_fwd: x [B][K][H][W], out [B][N][H][W], bias [N] or NULL, relu != 0 applies max(., 0).
+ * No weight gradient (the attack freezes the network). */
+PCFA_API long long pcfa_conv3x3_packed_floats(int K, int N);
+PCFA_API int pcfa_conv3x3_pack_weights(const float* w, float* fwd_packed, float* bwd_packed, int Cout, int Cin,
+                              void* stream);
+PCFA_API int pcfa_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K, int N,
+                     int H, int W, int relu, void* stream);
+
 /* out = relu(x + bias[c]) and its backward gx = grad_out * (out > 0): the "conv -> +bias -> ReLU" tail of the
  * motion encoder / flow head convolutions (models/raft/update.py:12-16,91-101) in one pass. */
 PCFA_API int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out, long long n, int plane, int channels,

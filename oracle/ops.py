@@ -238,6 +238,12 @@ def sepconv5(a, b, weight):
     return F.conv2d(x, weight, None, padding=(weight.shape[2] // 2, weight.shape[3] // 2))
 
 
+def conv3x3(x, weight, bias=None, relu=False):
+    """3x3 / stride 1 / pad 1 convolution (+ bias, + ReLU) of the update block (models/raft/update.py:6-16,79-101)."""
+    y = F.conv2d(x, weight, bias, stride=1, padding=1)
+    return F.relu(y) if relu else y
+
+
 def gru_step(h, rest, halves):
     """SepConvGRU update (models/raft/update.py:45-60) from the hoisted context parts, composed from the oracle's own
     operators: halves = ((w_zr, p_zr, w_q, p_q), (w_zr, p_zr, w_q, p_q))."""

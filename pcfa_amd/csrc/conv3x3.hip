@@ -1,0 +1,309 @@
+// 3x3 / stride 1 / pad 1 convolution, forward and data gradient, as Winograd F(2x2, 3x3) on the fp32 matrix cores of
+// gfx950.
+//
+// Replaces, for the frozen-weight attack, the 3x3 convolutions of the RAFT/GMA update block (reference
+// models/raft/update.py:6-16 FlowHead, :79-101 BasicMotionEncoder; models/gma/update.py likewise), which the library
+// path runs as a VALU Winograd kernel at 85-98 effective TFLOP/s.
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 4x4 input tile d -> 2x2 output tile Y
+// The 16 element-wise products over (tiles x Cin x Cout) are 16 independent GEMMs
+//   M_xi [tiles x Cout] = V_xi [tiles x Cin] . U_xi [Cin x Cout],   xi = 0..15,
+// and run on v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation): 2.25x fewer multiplies than the direct
+// form at the matrix-pipe rate.  U = G g G^T is computed once per weight tensor (pcfa_conv3x3_pack_weights); the data
+// gradient is the same operator on grad_out with the flipped / transposed weights (second packing).
+//
+// Workgroup = 4 waves: 32 tiles (4 tile rows x 8 tile columns = 8 x 16 output pixels) x 64 output channels.
+// Per chunk of 8 input channels: the 10 x 18 input patch goes global -> registers -> LDS, thread (tile, channel)
+// transforms its 4x4 patch to V[16][8][32] in LDS, wave w multiplies xi = 4w..4w+3 (4 MFMAs per xi and 32-channel
+// half: 32 per wave and chunk, 128 accumulator registers), the next chunk's patch and U slice (32 KB) prefetched in
+// registers meanwhile.  Epilogue: accumulators -> LDS in four passes of 16 channels, thread (channel, tile) applies
+// A^T . A, adds the bias, optionally ReLU, stores 2x2 pixels.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TR = 4, TC = 8, TB = TR * TC;      // tiles per workgroup
+constexpr int PR = 2 * TR + 2, PC = 2 * TC + 2;  // input patch rows / columns (10 x 18)
+constexpr int PCP = 20;                          // padded patch row stride
+constexpr int KC = 8;                            // input channels per chunk
+constexpr int CB = 64;                           // output channels per workgroup
+constexpr int RAW = KC * PR * PCP;               // 1600 floats
+constexpr int RAW_LOADS = (KC * PR * PC + 255) / 256;  // 6 scalar loads per thread and chunk
+constexpr int U_F4 = 16 * KC * CB / 4 / 256;     // 8 float4 per thread and chunk
+constexpr int MS = 33;                           // epilogue image: [16][16 channels][MS]
+
+// U[xi][k][n_pad] = (G g G^T)[xi] with g = w[n][k] (forward) or the flipped w[k][n] (data gradient);
+// columns n >= N are zero.
+__global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin,
+                                    int backward, int K, int N, int Npad) {
+  const long long total = (long long)K * Npad;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / Npad), n = (int)(e - (long long)k * Npad);
+    float g[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float v = 0.f;
+        if (n < N) v = backward ? w[(((long long)k * Cin + n) * 3 + (2 - i)) * 3 + (2 - j)]
+                                : w[(((long long)n * Cin + k) * 3 + i) * 3 + j];
+        g[i][j] = v;
+      }
+    float t[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      t[0][j] = g[0][j];
+      t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+      t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+      t[3][j] = g[2][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]),
+                  u3 = t[i][2];
+      U[((long long)(4 * i + 0) * K + k) * Npad + n] = u0;
+      U[((long long)(4 * i + 1) * K + k) * Npad + n] = u1;
+      U[((long long)(4 * i + 2) * K + k) * Npad + n] = u2;
+      U[((long long)(4 * i + 3) * K + k) * Npad + n] = u3;
+    }
+  }
+}
+
+// x [B][K][H][W], U [16][K][Npad], out [B][N][H][W]; grid = (tile blocks, Npad / CB, B).
+template <bool RELU>
+__global__ __launch_bounds__(256) void conv3x3_winograd_kernel(
+    const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
+    float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x) {
+  __shared__ __attribute__((aligned(16))) float smem[RAW + 16 * KC * TB + 16 * KC * CB];  // 54.4 KB: 2 blocks / CU
+  float* sRaw = smem;
+  float* sV = smem + RAW;
+  float* sU = sV + 16 * KC * TB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int by = blockIdx.x / blocks_x, bx = blockIdx.x - by * blocks_x;
+  const int y0 = by * (2 * TR), x0 = bx * (2 * TC);  // first output pixel of the block
+  const int n0 = blockIdx.y * CB;
+  const long long plane = (long long)H * W;
+  x += (long long)blockIdx.z * K * plane;
+  out += (long long)blockIdx.z * N * plane;
+
+  // ---- per-thread constants of the staging loads (chunk-invariant) ----
+  long long roff[RAW_LOADS];   // offset of the patch element inside a channel plane (clamped)
+  int rdst[RAW_LOADS];         // sRaw index, -1 = no element
+  int rch[RAW_LOADS];
+  bool rok[RAW_LOADS];
+#pragma unroll
+  for (int i = 0; i < RAW_LOADS; ++i) {
+    const int e = tid + 256 * i;
+    const int ch = e / (PR * PC), rem = e - ch * (PR * PC);
+    const int r = rem / PC, c = rem - r * PC;
+    const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+    rch[i] = min(ch, KC - 1);
+    rdst[i] = e < KC * PR * PC ? (ch * PR + r) * PCP + c : -1;
+    rok[i] = e < KC * PR * PC && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    roff[i] = (long long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+  }
+  const float* Ub = U + n0;  // this block's 64 columns
+
+  float rraw[RAW_LOADS];
+  float4 ru[U_F4];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < RAW_LOADS; ++i) {
+      const int ch = min(c0 + rch[i], K - 1);  // clamped: channels >= K are zeroed at the LDS write
+      rraw[i] = x[(long long)ch * plane + roff[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < U_F4; ++i) {
+      const int f = tid + 256 * i;            // float4 index inside [16][KC][CB/4]
+      const int xi = f / (KC * CB / 4), rem = f - xi * (KC * CB / 4);
+      const int k = rem / (CB / 4), n4 = rem - k * (CB / 4);
+      const int kk = min(c0 + k, K - 1);
+      ru[i] = *reinterpret_cast<const float4*>(Ub + ((long long)xi * K + kk) * Npad + n4 * 4);
+    }
+  };
+  auto store_chunk = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < RAW_LOADS; ++i)
+      if (rdst[i] >= 0) sRaw[rdst[i]] = (rok[i] && c0 + rch[i] < K) ? rraw[i] : 0.f;
+#pragma unroll
+    for (int i = 0; i < U_F4; ++i) {
+      const int f = tid + 256 * i;
+      const int xi = f / (KC * CB / 4), rem = f - xi * (KC * CB / 4);
+      const int k = rem / (CB / 4);
+      float4 v = ru[i];
+      if (c0 + k >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&sU[f * 4]) = v;
+    }
+  };
+  // thread (tile, channel) of the input transform
+  const int t_tile = tid & 31, t_ch = tid >> 5;
+  const int t_tr = t_tile >> 3, t_tc = t_tile & 7;
+  auto transform = [&]() {
+    const float* p = &sRaw[(t_ch * PR + 2 * t_tr) * PCP + 2 * t_tc];
+    float d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i][j] = p[i * PCP + j];
+    float t[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = d[0][j] - d[2][j];
+      t[1][j] = d[1][j] + d[2][j];
+      t[2][j] = d[2][j] - d[1][j];
+      t[3][j] = d[1][j] - d[3][j];
+    }
+    float* v = &sV[t_ch * TB + t_tile];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[(4 * i + 0) * (KC * TB)] = t[i][0] - t[i][2];
+      v[(4 * i + 1) * (KC * TB)] = t[i][1] + t[i][2];
+      v[(4 * i + 2) * (KC * TB)] = t[i][2] - t[i][1];
+      v[(4 * i + 3) * (KC * TB)] = t[i][1] - t[i][3];
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunk = (K + KC - 1) / KC;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  transform();
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    // the loads of chunk c+1 are unconditional (the one past the end re-reads the last chunk and is never used)
+    load_chunk(min(c + 1, nchunk - 1) * KC);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- MFMA phase: wave w owns xi = 4w .. 4w+3 ----
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int xi = wave * 4 + a;
+      const float* vp = &sV[(xi * KC + lh) * TB + l31];
+      const float* up = &sU[(xi * KC + lh) * CB + l31];
+#pragma unroll
+      for (int kp = 0; kp < KC; kp += 2) {
+        const float av = vp[kp * TB];
+        const float b0 = up[kp * CB], b1 = up[kp * CB + 32];
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[a][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();               // everyone is done with sV / sU / sRaw of chunk c
+    if (c + 1 < nchunk) {
+      store_chunk((c + 1) * KC);
+      __syncthreads();
+      transform();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: four passes of 16 output channels through LDS (the image reuses sV + sU) ----
+  static_assert(16 * 16 * MS <= 16 * KC * TB + 16 * KC * CB, "epilogue image must fit");
+  float* sM = sV;  // [16 xi][16 channels][MS]
+  const int e_tile = tid & 31, e_cl = tid >> 5;  // thread (tile, channel) and channel + 8
+  const int e_tr = e_tile >> 3, e_tc = e_tile & 7;
+  const int oy = y0 + 2 * e_tr, ox = x0 + 2 * e_tc;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int nb = pass >> 1, half = pass & 1;
+    if ((l31 >> 4) == half) {
+      const int cl = l31 & 15;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        float* m = &sM[((wave * 4 + a) * 16 + cl) * MS];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[(r & 3) + 8 * (r >> 2) + 4 * lh] = acc[a][nb][r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int cl = e_cl + 8 * q;
+      const int n = n0 + pass * 16 + cl;
+      float m[16];
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) m[xi] = sM[(xi * 16 + cl) * MS + e_tile];
+      // T = A^T M (2 x 4), Y = T A (2 x 2)
+      float t0[4], t1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t0[j] = m[j] + m[4 + j] + m[8 + j];
+        t1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+      }
+      const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+      float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
+      float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
+      if (RELU) {
+        y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
+      }
+      if (n < N && oy < H && ox < W) {
+        float* o = out + (long long)n * plane + (long long)oy * W + ox;
+        o[0] = y00;
+        if (ox + 1 < W) o[1] = y01;
+        if (oy + 1 < H) {
+          o[W] = y10;
+          if (ox + 1 < W) o[W + 1] = y11;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" long long pcfa_conv3x3_packed_floats(int K, int N) {
+  if (K < 1 || N < 1) return -1;
+  return 16LL * K * (((long long)N + CB - 1) / CB * CB);
+}
+
+extern "C" int pcfa_conv3x3_pack_weights(const float* w, float* fwd_packed, float* bwd_packed, int Cout, int Cin,
+                                         void* stream) {
+  if (!w || (!fwd_packed && !bwd_packed) || Cout < 1 || Cin < 1) return PCFA_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (fwd_packed) {
+    const int K = Cin, N = Cout, Npad = (N + CB - 1) / CB * CB;
+    pcfa_launch(conv3x3_pack_kernel, dim3((unsigned)min(((long long)K * Npad + 255) / 256, 4096LL)), dim3(256), 0, s, w,
+                fwd_packed, Cout, Cin, 0, K, N, Npad);
+    PCFA_LAUNCH_CHECK();
+  }
+  if (bwd_packed) {
+    const int K = Cout, N = Cin, Npad = (N + CB - 1) / CB * CB;
+    pcfa_launch(conv3x3_pack_kernel, dim3((unsigned)min(((long long)K * Npad + 255) / 256, 4096LL)), dim3(256), 0, s, w,
+                bwd_packed, Cout, Cin, 1, K, N, Npad);
+    PCFA_LAUNCH_CHECK();
+  }
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K,
+                                int N, int H, int W, int relu, void* stream) {
+  if (!x || !packed || !out || B < 1 || K < 1 || N < 1 || H < 1 || W < 1 || !aligned16(packed))
+    return PCFA_ERR_INVALID_ARG;
+  const int Npad = (N + CB - 1) / CB * CB;
+  const int blocks_x = pcfa_cdiv(W, 2 * TC), blocks_y = pcfa_cdiv(H, 2 * TR);
+  const long long gx = (long long)blocks_x * blocks_y;
+  if (gx > 0x7fffffffLL || B > 65535 || Npad / CB > 65535) return PCFA_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)gx, Npad / CB, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (relu)
+    pcfa_launch(conv3x3_winograd_kernel<true>, grid, block, 0, s, x, packed, bias, out, K, N, Npad, H, W, blocks_x);
+  else
+    pcfa_launch(conv3x3_winograd_kernel<false>, grid, block, 0, s, x, packed, bias, out, K, N, Npad, H, W, blocks_x);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}

@@ -515,6 +515,67 @@ class _SepConv5(torch.autograd.Function):
         return gin[:, :Ca], (gin[:, Ca:] if Cb else None), None
 
 
+_conv3_packs = {}  # id(weight) -> (weakref, version, fwd_packed, bwd_packed)
+
+
+def _conv3x3_packed(weight):
+    """pcfa_conv3x3_pack_weights of a frozen 3x3 Conv2d weight (Winograd-transformed, both directions), cached per
+    tensor version."""
+    key = id(weight)
+    hit = _conv3_packs.get(key)
+    if hit is None or hit[0]() is not weight or hit[1] != weight._version:
+        cout, cin = weight.shape[:2]
+        lib = _hip.load()
+        w = weight.detach().contiguous()
+        fwd = torch.empty(int(lib.pcfa_conv3x3_packed_floats(cin, cout)), device=w.device, dtype=torch.float32)
+        bwd = torch.empty(int(lib.pcfa_conv3x3_packed_floats(cout, cin)), device=w.device, dtype=torch.float32)
+        _call("pcfa_conv3x3_pack_weights", _ptr(w), _ptr(fwd), _ptr(bwd), cout, cin)
+        hit = (weakref.ref(weight, lambda _r, k=key: _conv3_packs.pop(k, None)), weight._version, fwd, bwd)
+        _conv3_packs[key] = hit
+    return hit[2], hit[3]
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        _dev(x, weight, bias)
+        if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.dtype != torch.float32:
+            raise ValueError("conv3x3 expects a float32 3x3 Conv2d weight, got %s" % (tuple(weight.shape),))
+        x = x.contiguous()
+        B, K, H, W = x.shape
+        N = weight.shape[0]
+        if weight.shape[1] != K:
+            raise ValueError("conv3x3: input %s does not match weight %s" % (tuple(x.shape), tuple(weight.shape)))
+        fwd, bwd = _conv3x3_packed(weight)
+        out = torch.empty((B, N, H, W), device=x.device, dtype=torch.float32)
+        _call("pcfa_conv3x3_fwd", _ptr(x), _ptr(fwd), _ptr(bias), _ptr(out), B, K, N, H, W, int(bool(relu)))
+        ctx.bwd, ctx.dims, ctx.relu = bwd, (B, K, N, H, W), bool(relu)
+        if relu:
+            ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise RuntimeError("conv3x3 is the frozen-weight path: no weight / bias gradient")
+        B, K, N, H, W = ctx.dims
+        g = g.contiguous()
+        if ctx.relu:
+            (out,) = ctx.saved_tensors
+            gm = torch.empty_like(g)
+            _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), g.numel())
+            g = gm
+        gin = torch.empty((B, K, H, W), device=g.device, dtype=torch.float32)
+        _call("pcfa_conv3x3_fwd", _ptr(g), _ptr(ctx.bwd), None, _ptr(gin), B, N, K, H, W, 0)
+        return gin, None, None, None
+
+
+def conv3x3(x, weight, bias=None, relu=False):
+    """act(conv2d(x, weight, bias, stride=1, padding=1)) for a frozen 3x3 weight: Winograd F(2x2,3x3) on the fp32
+    matrix cores with bias and ReLU fused into the epilogue; the data gradient runs the same kernel."""
+    return _Conv3x3.apply(x, weight, bias, relu)
+
+
 class _GruStep(torch.autograd.Function):
     """One SepConvGRU update (both half-steps, models/raft/update.py:45-60) as ONE autograd node with a hand-ordered
     backward.  Forward = the same kernel sequence as composing sepconv5 / gru_gates_packed / gru_update.  In the

@@ -297,6 +297,31 @@ def test_gru_step_vs_oracle(oracle_ops, shape):
         assert rel_l2(g_, w_) < 5e-6
 
 
+@pytest.mark.parametrize("shape", [
+    # (B, Cin, Cout, H, W): update-block convolutions at the BASELINE feature size, then ragged everything
+    (1, 256, 192, 55, 128), (1, 256, 126, 55, 128), (1, 128, 256, 55, 128), (1, 128, 64, 55, 128),
+    (2, 5, 7, 9, 21), (1, 12, 70, 3, 5), (1, 3, 2, 1, 1), (2, 64, 64, 40, 48)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv3x3_winograd_vs_oracle(oracle_ops, shape, relu):
+    """Winograd F(2x2,3x3) on fp32 MFMA against conv2d: forward (+bias, +ReLU) and data gradient.  Winograd's
+    transforms add a few roundings per product: 5e-6 relative L2."""
+    B, Cin, Cout, H, W = shape
+    gen = torch.Generator().manual_seed(3 + Cin + W)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (9 * Cin) ** .5
+    b = torch.randn(Cout, generator=gen)
+    go = torch.randn(B, Cout, H, W, generator=gen)
+    cx = x.clone().requires_grad_(True)
+    want = oracle_ops.conv3x3(cx, w, b, relu)
+    want.backward(go)
+    gx = x.clone().to(DEV).requires_grad_(True)
+    got = hip_ops.conv3x3(gx, w.to(DEV), b.to(DEV), relu)
+    assert got.shape == want.shape
+    assert rel_l2(got, want) < 5e-6
+    got.backward(go.to(DEV))
+    assert rel_l2(gx.grad, cx.grad) < 5e-6
+
+
 def test_sepconv5_rejects_bad_operands():
     w = torch.zeros(4, 3, 1, 5, device=DEV)
     with pytest.raises(ValueError):
