@@ -19,6 +19,7 @@
 // registers meanwhile.  Epilogue: accumulators -> LDS in four passes of 16 channels, thread (channel, tile) applies
 // A^T . A, adds the bias, optionally ReLU, stores 2x2 pixels.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -28,10 +29,9 @@ constexpr int TR = 4, TC = 8, TB = TR * TC;      // tiles per workgroup
 constexpr int PR = 2 * TR + 2, PC = 2 * TC + 2;  // input patch rows / columns (10 x 18)
 constexpr int PCP = 20;                          // padded patch row stride
 constexpr int KC = 8;                            // input channels per chunk
-constexpr int CB = 64;                           // output channels per workgroup
+constexpr int CB = 64;                           // packing granularity of the output channels (U row padding)
 constexpr int RAW = KC * PR * PCP;               // 1600 floats
 constexpr int RAW_LOADS = (KC * PR * PC + 255) / 256;  // 6 scalar loads per thread and chunk
-constexpr int U_F4 = 16 * KC * CB / 4 / 256;     // 8 float4 per thread and chunk
 constexpr int MS = 33;                           // epilogue image: [16][16 channels][MS]
 
 // U[xi][k][n_pad] = (G g G^T)[xi] with g = w[n][k] (forward) or the flipped w[k][n] (data gradient);
@@ -73,20 +73,25 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
 }
 
 // x [B][K][H][W], U [16][K][Npad], out [B][N][H][W]; grid = (tile blocks, Npad / CB, B).
-template <bool RELU>
+// CBT = output channels per workgroup: 64 (128 accumulator registers per lane, one block per CU) or 32 (64
+// accumulators, 76.8 KB LDS: two blocks per CU overlap each other's staging / transform / barrier phases).
+template <bool RELU, int CBT>
 __global__ __launch_bounds__(256) void conv3x3_winograd_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
     float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x) {
-  __shared__ __attribute__((aligned(16))) float smem[RAW + 16 * KC * TB + 16 * KC * CB];  // 54.4 KB: 2 blocks / CU
-  float* sRaw = smem;
-  float* sV = smem + RAW;
-  float* sU = sV + 16 * KC * TB;
+  // double-buffered staging: 2 x (patch 6.4 KB + V 16 KB + U 32 KB) = 108.8 KB, one block per CU, software-pipelined
+  constexpr int VSZ = 16 * KC * TB, USZ = 16 * KC * CBT, NB = CBT / 32, U_F4 = 16 * KC * CBT / 4 / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (RAW + VSZ + USZ)];
+  float* sRaw = smem;               // [2][RAW]
+  float* sV = smem + 2 * RAW;       // [2][VSZ]
+  float* sU = sV + 2 * VSZ;         // [2][USZ]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int by = blockIdx.x / blocks_x, bx = blockIdx.x - by * blocks_x;
   const int y0 = by * (2 * TR), x0 = bx * (2 * TC);  // first output pixel of the block
-  const int n0 = blockIdx.y * CB;
+  const int n0 = blockIdx.y * CBT;
+  if (n0 >= N) return;  // (the packing pads N to 64: a 32-channel block may lie entirely in the padding)
   const long long plane = (long long)H * W;
   x += (long long)blockIdx.z * K * plane;
   out += (long long)blockIdx.z * N * plane;
@@ -119,22 +124,24 @@ __global__ __launch_bounds__(256) void conv3x3_winograd_kernel(
     }
 #pragma unroll
     for (int i = 0; i < U_F4; ++i) {
-      const int f = tid + 256 * i;            // float4 index inside [16][KC][CB/4]
-      const int xi = f / (KC * CB / 4), rem = f - xi * (KC * CB / 4);
-      const int k = rem / (CB / 4), n4 = rem - k * (CB / 4);
+      const int f = tid + 256 * i;            // float4 index inside [16][KC][CBT/4]
+      const int xi = f / (KC * CBT / 4), rem = f - xi * (KC * CBT / 4);
+      const int k = rem / (CBT / 4), n4 = rem - k * (CBT / 4);
       const int kk = min(c0 + k, K - 1);
       ru[i] = *reinterpret_cast<const float4*>(Ub + ((long long)xi * K + kk) * Npad + n4 * 4);
     }
   };
-  auto store_chunk = [&](int c0) {
+  auto store_chunk = [&](int c0, int buf) {
+    float* sRaw = smem + buf * RAW;
+    float* sU = smem + 2 * RAW + 2 * VSZ + buf * USZ;
 #pragma unroll
     for (int i = 0; i < RAW_LOADS; ++i)
       if (rdst[i] >= 0) sRaw[rdst[i]] = (rok[i] && c0 + rch[i] < K) ? rraw[i] : 0.f;
 #pragma unroll
     for (int i = 0; i < U_F4; ++i) {
       const int f = tid + 256 * i;
-      const int xi = f / (KC * CB / 4), rem = f - xi * (KC * CB / 4);
-      const int k = rem / (CB / 4);
+      const int xi = f / (KC * CBT / 4), rem = f - xi * (KC * CBT / 4);
+      const int k = rem / (CBT / 4);
       float4 v = ru[i];
       if (c0 + k >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4*>(&sU[f * 4]) = v;
@@ -143,8 +150,8 @@ __global__ __launch_bounds__(256) void conv3x3_winograd_kernel(
   // thread (tile, channel) of the input transform
   const int t_tile = tid & 31, t_ch = tid >> 5;
   const int t_tr = t_tile >> 3, t_tc = t_tile & 7;
-  auto transform = [&]() {
-    const float* p = &sRaw[(t_ch * PR + 2 * t_tr) * PCP + 2 * t_tc];
+  auto transform = [&](int buf) {
+    const float* p = &sRaw[buf * RAW + (t_ch * PR + 2 * t_tr) * PCP + 2 * t_tc];
     float d[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void conv3x3_winograd_kernel(
       t[2][j] = d[2][j] - d[1][j];
       t[3][j] = d[1][j] - d[3][j];
     }
-    float* v = &sV[t_ch * TB + t_tile];
+    float* v = &sV[buf * VSZ + t_ch * TB + t_tile];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       v[(4 * i + 0) * (KC * TB)] = t[i][0] - t[i][2];
@@ -168,55 +175,61 @@ __global__ __launch_bounds__(256) void conv3x3_winograd_kernel(
     }
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][NB];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  // MFMAs of chunk `buf` for the xi-quarter a of this wave (8 MFMAs, two accumulator chains)
+  auto mfma_quarter = [&](int buf, int a) {
+    const int xi = wave * 4 + a;
+    const float* vp = &sV[buf * VSZ + (xi * KC + lh) * TB + l31];
+    const float* up = &sU[buf * USZ + (xi * KC + lh) * CBT + l31];
+#pragma unroll
+    for (int kp = 0; kp < KC; kp += 2) {
+      const float av = vp[kp * TB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, up[kp * CBT + 32 * b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  // Pipeline: while the matrix pipe works on chunk c (V, U in buffer c&1), the same waves write chunk c+1 to the
+  // other buffer, transform it, and have chunk c+2 in flight from global memory.  MFMAs are issued on both sides of
+  // the first barrier so that the barrier wait overlaps matrix work.
   const int nchunk = (K + KC - 1) / KC;
   load_chunk(0);
-  store_chunk(0);
+  store_chunk(0, 0);
+  load_chunk(min(1, nchunk - 1) * KC);
   __syncthreads();
-  transform();
+  transform(0);
   __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
-    // the loads of chunk c+1 are unconditional (the one past the end re-reads the last chunk and is never used)
-    load_chunk(min(c + 1, nchunk - 1) * KC);
+    const int cur = c & 1, nxt = cur ^ 1;
+    const bool more = c + 1 < nchunk;
+    store_chunk((c + 1) * KC, nxt);  // registers hold chunk c+1 (past the end: zeros, never multiplied)
+    load_chunk(min(c + 2, nchunk - 1) * KC);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- MFMA phase: wave w owns xi = 4w .. 4w+3 ----
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int xi = wave * 4 + a;
-      const float* vp = &sV[(xi * KC + lh) * TB + l31];
-      const float* up = &sU[(xi * KC + lh) * CB + l31];
-#pragma unroll
-      for (int kp = 0; kp < KC; kp += 2) {
-        const float av = vp[kp * TB];
-        const float b0 = up[kp * CB], b1 = up[kp * CB + 32];
-        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[a][0], 0, 0, 0);
-        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[a][1], 0, 0, 0);
-      }
-    }
-    __syncthreads();               // everyone is done with sV / sU / sRaw of chunk c
-    if (c + 1 < nchunk) {
-      store_chunk((c + 1) * KC);
-      __syncthreads();
-      transform();
-      __syncthreads();
-    }
+    mfma_quarter(cur, 0);
+    mfma_quarter(cur, 1);
+    __syncthreads();                 // patch c+1 is in LDS
+    if (more) transform(nxt);
+    mfma_quarter(cur, 2);
+    mfma_quarter(cur, 3);
+    __syncthreads();                 // V of chunk c+1 complete; everyone done with the buffers of chunk c
   }
 
   // ---- epilogue: four passes of 16 output channels through LDS (the image reuses sV + sU) ----
-  static_assert(16 * 16 * MS <= 16 * KC * TB + 16 * KC * CB, "epilogue image must fit");
+  static_assert(16 * 16 * MS <= 2 * (VSZ + USZ), "epilogue image must fit");  // sV and sU are contiguous
   float* sM = sV;  // [16 xi][16 channels][MS]
   const int e_tile = tid & 31, e_cl = tid >> 5;  // thread (tile, channel) and channel + 8
   const int e_tr = e_tile >> 3, e_tc = e_tile & 7;
   const int oy = y0 + 2 * e_tr, ox = x0 + 2 * e_tc;
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
+  for (int pass = 0; pass < CBT / 16; ++pass) {
     const int nb = pass >> 1, half = pass & 1;
     if ((l31 >> 4) == half) {
       const int cl = l31 & 15;
@@ -300,10 +313,20 @@ extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float
   if (gx > 0x7fffffffLL || B > 65535 || Npad / CB > 65535) return PCFA_ERR_UNSUPPORTED;
   dim3 grid((unsigned)gx, Npad / CB, B), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (relu)
-    pcfa_launch(conv3x3_winograd_kernel<true>, grid, block, 0, s, x, packed, bias, out, K, N, Npad, H, W, blocks_x);
-  else
-    pcfa_launch(conv3x3_winograd_kernel<false>, grid, block, 0, s, x, packed, bias, out, K, N, Npad, H, W, blocks_x);
+  // 64-channel blocks only when there are enough of them to fill the chip twice over; otherwise 32-channel blocks
+  // (twice the workgroups, two resident per CU)
+  int cb = (gx * (Npad / CB) * B >= 1024) ? 64 : 32;
+  if (const char* e = getenv("PCFA_CONV3X3_CB")) cb = atoi(e) == 64 ? 64 : 32;  // A/B switch for tools/dev
+  if (cb == 32) grid.y = Npad / 32;
+#define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, out, K, N, Npad, H, W, blocks_x
+  if (cb == 64) {
+    if (relu) pcfa_launch(conv3x3_winograd_kernel<true, 64>, PCFA_C3_ARGS);
+    else pcfa_launch(conv3x3_winograd_kernel<false, 64>, PCFA_C3_ARGS);
+  } else {
+    if (relu) pcfa_launch(conv3x3_winograd_kernel<true, 32>, PCFA_C3_ARGS);
+    else pcfa_launch(conv3x3_winograd_kernel<false, 32>, PCFA_C3_ARGS);
+  }
+#undef PCFA_C3_ARGS
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }

@@ -67,11 +67,14 @@ def _conv_norm(conv, norm, x, relu, cache, tag):
     if (frozen and isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats
             and not (norm.affine and (norm.weight.requires_grad or norm.bias.requires_grad))):
         w, b = _fold_batchnorm(conv, norm, cache, tag)
+        if _is_plain3x3(conv):
+            return ops.get().conv3x3(x, w, b, relu)
         if relu:
             return ops.get().bias_relu(conv._conv_forward(x, w, None), b)
         return conv._conv_forward(x, w, b)
     if (frozen and isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats):
-        y = norm(conv._conv_forward(x, conv.weight, None))
+        y = norm(ops.get().conv3x3(x, conv.weight, None, False) if _is_plain3x3(conv)
+                 else conv._conv_forward(x, conv.weight, None))
         # out of place: instance_norm returns a VIEW of its batch-norm output, and an in-place op on a view makes
         # autograd rebase it (CopySlices), which clones a full activation-sized gradient in the backward
         return F.relu(y) if relu else y
@@ -150,8 +153,20 @@ def _conv_nobias(conv, x):
     return conv._conv_forward(x, conv.weight, None)
 
 
+def _is_plain3x3(conv, min_out=16):
+    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and conv.out_channels >= min_out)
+
+
+def _frozen_conv(conv):
+    return not (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad))
+
+
 def _conv_relu(conv, x):
-    """relu(conv(x)): convolution on MIOpen, bias + ReLU in one fused pass."""
+    """relu(conv(x)).  Frozen 3x3 / stride 1 convolutions run as Winograd F(2x2,3x3) on the fp32 matrix cores with bias
+    and ReLU in the epilogue (ops.conv3x3); everything else: library convolution, bias + ReLU in one fused pass."""
+    if _is_plain3x3(conv) and _frozen_conv(conv):
+        return ops.get().conv3x3(x, conv.weight, conv.bias, True)
     return ops.get().bias_relu(_conv_nobias(conv, x), conv.bias)
 
 
