@@ -25,14 +25,11 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TR = 4, TC = 8, TB = TR * TC;      // tiles per workgroup
-constexpr int PR = 2 * TR + 2, PC = 2 * TC + 2;  // input patch rows / columns (10 x 18)
+constexpr int TC = 8;                            // tile columns per workgroup (16 output columns)
+constexpr int PC = 2 * TC + 2;                   // input patch columns (18)
 constexpr int PCP = 20;                          // padded patch row stride
 constexpr int KC = 8;                            // input channels per chunk
 constexpr int CB = 64;                           // packing granularity of the output channels (U row padding)
-constexpr int RAW = KC * PR * PCP;               // 1600 floats
-constexpr int RAW_LOADS = (KC * PR * PC + 255) / 256;  // 6 scalar loads per thread and chunk
-constexpr int MS = 33;                           // epilogue image: [16][16 channels][MS]
 
 // U[xi][k][n_pad] = (G g G^T)[xi] with g = w[n][k] (forward) or the flipped w[k][n] (data gradient);
 // columns n >= N are zero.
@@ -75,18 +72,28 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
 // x [B][K][H][W], U [16][K][Npad], out [B][N][H][W]; grid = (tile blocks, Npad / CB, B).
 // CBT = output channels per workgroup: 64 (128 accumulator registers per lane, one block per CU) or 32 (64
 // accumulators, 76.8 KB LDS: two blocks per CU overlap each other's staging / transform / barrier phases).
-template <bool RELU, int CBT>
-__global__ __launch_bounds__(256) void conv3x3_winograd_kernel(
+// MT = 32-tile groups per workgroup (4 waves each): MT = 2 -> 64 tiles (16 x 16 output pixels), 8 waves sharing one
+// U slice, i.e. half the L2 -> LDS weight traffic per multiply.
+// KFULL: K % 8 == 0 -- the staging loop then carries no channel bookkeeping at all (per-thread base pointers plus
+// one scalar chunk offset; the generic variant clamps and masks the channel index of every element).
+template <bool RELU, int CBT, int MT, bool KFULL>
+__global__ __launch_bounds__(256 * MT) void conv3x3_winograd_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
     float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x) {
-  // double-buffered staging: 2 x (patch 6.4 KB + V 16 KB + U 32 KB) = 108.8 KB, one block per CU, software-pipelined
-  constexpr int VSZ = 16 * KC * TB, USZ = 16 * KC * CBT, NB = CBT / 32, U_F4 = 16 * KC * CBT / 4 / 256;
+  constexpr int NT = 256 * MT;                         // threads
+  constexpr int TR = 4 * MT, TB = TR * TC;             // tile rows / tiles per workgroup
+  constexpr int PR = 2 * TR + 2;                       // input patch rows
+  constexpr int RAW = KC * PR * PCP;
+  constexpr int RAW_LOADS = (KC * PR * PC + NT - 1) / NT;
+  constexpr int MS = TB + 1;                           // epilogue image: [16][16 channels][MS]
+  // double-buffered staging (patch, V, U), software-pipelined
+  constexpr int VSZ = 16 * KC * TB, USZ = 16 * KC * CBT, NB = CBT / 32, U_F4 = 16 * KC * CBT / 4 / NT;
   __shared__ __attribute__((aligned(16))) float smem[2 * (RAW + VSZ + USZ)];
   float* sRaw = smem;               // [2][RAW]
   float* sV = smem + 2 * RAW;       // [2][VSZ]
   float* sU = sV + 2 * VSZ;         // [2][USZ]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, mt = tid >> 8;  // wave: xi group, mt: tile group
   const int l31 = lane & 31, lh = lane >> 5;
   const int by = blockIdx.x / blocks_x, bx = blockIdx.x - by * blocks_x;
   const int y0 = by * (2 * TR), x0 = bx * (2 * TC);  // first output pixel of the block
@@ -97,58 +104,67 @@ __global__ __launch_bounds__(256) void conv3x3_winograd_kernel(
   out += (long long)blockIdx.z * N * plane;
 
   // ---- per-thread constants of the staging loads (chunk-invariant) ----
-  long long roff[RAW_LOADS];   // offset of the patch element inside a channel plane (clamped)
-  int rdst[RAW_LOADS];         // sRaw index, -1 = no element
+  const float* praw[RAW_LOADS];  // chunk 0 source of the patch element (clamped into the image)
+  int rdst[RAW_LOADS];           // sRaw index, -1 = no element
   int rch[RAW_LOADS];
   bool rok[RAW_LOADS];
 #pragma unroll
   for (int i = 0; i < RAW_LOADS; ++i) {
-    const int e = tid + 256 * i;
+    const int e = tid + NT * i;
     const int ch = e / (PR * PC), rem = e - ch * (PR * PC);
     const int r = rem / PC, c = rem - r * PC;
     const int yy = y0 - 1 + r, xx = x0 - 1 + c;
     rch[i] = min(ch, KC - 1);
     rdst[i] = e < KC * PR * PC ? (ch * PR + r) * PCP + c : -1;
     rok[i] = e < KC * PR * PC && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    roff[i] = (long long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+    praw[i] = x + (long long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1) + (KFULL ? rch[i] * plane : 0);
   }
-  const float* Ub = U + n0;  // this block's 64 columns
+  const float* pu[U_F4];         // chunk 0 source of the U float4
+  int uk[U_F4];                  // its channel inside the chunk
+#pragma unroll
+  for (int i = 0; i < U_F4; ++i) {
+    const int f = tid + NT * i;               // float4 index inside [16][KC][CBT/4]
+    const int xi = f / (KC * CBT / 4), rem = f - xi * (KC * CBT / 4);
+    const int k = rem / (CBT / 4), n4 = rem - k * (CBT / 4);
+    uk[i] = k;
+    pu[i] = U + n0 + ((long long)xi * K + (KFULL ? k : 0)) * Npad + n4 * 4;
+  }
 
-  float rraw[RAW_LOADS];
-  float4 ru[U_F4];
-  auto load_chunk = [&](int c0) {
+  // register ring: the global loads of a chunk are issued NRING-1 chunks before its MFMAs
+  constexpr int NRING = 3;
+  float ring_raw[NRING][RAW_LOADS];
+  float4 ring_u[NRING][U_F4];
+  auto load_chunk = [&](int c0, float (&rraw)[RAW_LOADS], float4 (&ru)[U_F4]) {
+    if (KFULL) {
+      const long long xo = (long long)c0 * plane, uo = (long long)c0 * Npad;  // wave-uniform chunk offsets
 #pragma unroll
-    for (int i = 0; i < RAW_LOADS; ++i) {
-      const int ch = min(c0 + rch[i], K - 1);  // clamped: channels >= K are zeroed at the LDS write
-      rraw[i] = x[(long long)ch * plane + roff[i]];
-    }
+      for (int i = 0; i < RAW_LOADS; ++i) rraw[i] = praw[i][xo];
 #pragma unroll
-    for (int i = 0; i < U_F4; ++i) {
-      const int f = tid + 256 * i;            // float4 index inside [16][KC][CBT/4]
-      const int xi = f / (KC * CBT / 4), rem = f - xi * (KC * CBT / 4);
-      const int k = rem / (CBT / 4), n4 = rem - k * (CBT / 4);
-      const int kk = min(c0 + k, K - 1);
-      ru[i] = *reinterpret_cast<const float4*>(Ub + ((long long)xi * K + kk) * Npad + n4 * 4);
+      for (int i = 0; i < U_F4; ++i) ru[i] = *reinterpret_cast<const float4*>(pu[i] + uo);
+    } else {
+#pragma unroll
+      for (int i = 0; i < RAW_LOADS; ++i)
+        rraw[i] = praw[i][(long long)min(c0 + rch[i], K - 1) * plane];  // channels >= K are zeroed at the LDS write
+#pragma unroll
+      for (int i = 0; i < U_F4; ++i)
+        ru[i] = *reinterpret_cast<const float4*>(pu[i] + (long long)min(c0 + uk[i], K - 1) * Npad);
     }
   };
-  auto store_chunk = [&](int c0, int buf) {
+  auto store_chunk = [&](int c0, int buf, const float (&rraw)[RAW_LOADS], const float4 (&ru)[U_F4]) {
     float* sRaw = smem + buf * RAW;
     float* sU = smem + 2 * RAW + 2 * VSZ + buf * USZ;
 #pragma unroll
     for (int i = 0; i < RAW_LOADS; ++i)
-      if (rdst[i] >= 0) sRaw[rdst[i]] = (rok[i] && c0 + rch[i] < K) ? rraw[i] : 0.f;
+      if (rdst[i] >= 0) sRaw[rdst[i]] = (rok[i] && (KFULL || c0 + rch[i] < K)) ? rraw[i] : 0.f;
 #pragma unroll
     for (int i = 0; i < U_F4; ++i) {
-      const int f = tid + 256 * i;
-      const int xi = f / (KC * CBT / 4), rem = f - xi * (KC * CBT / 4);
-      const int k = rem / (CBT / 4);
       float4 v = ru[i];
-      if (c0 + k >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(&sU[f * 4]) = v;
+      if (!KFULL && c0 + uk[i] >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&sU[(tid + NT * i) * 4]) = v;
     }
   };
   // thread (tile, channel) of the input transform
-  const int t_tile = tid & 31, t_ch = tid >> 5;
+  const int t_tile = tid % TB, t_ch = tid / TB;
   const int t_tr = t_tile >> 3, t_tc = t_tile & 7;
   auto transform = [&](int buf) {
     const float* p = &sRaw[buf * RAW + (t_ch * PR + 2 * t_tr) * PCP + 2 * t_tc];
@@ -186,7 +202,7 @@ __global__ __launch_bounds__(256) void conv3x3_winograd_kernel(
   // MFMAs of chunk `buf` for the xi-quarter a of this wave (8 MFMAs, two accumulator chains)
   auto mfma_quarter = [&](int buf, int a) {
     const int xi = wave * 4 + a;
-    const float* vp = &sV[buf * VSZ + (xi * KC + lh) * TB + l31];
+    const float* vp = &sV[buf * VSZ + (xi * KC + lh) * TB + mt * 32 + l31];
     const float* up = &sU[buf * USZ + (xi * KC + lh) * CBT + l31];
 #pragma unroll
     for (int kp = 0; kp < KC; kp += 2) {
@@ -201,31 +217,38 @@ __global__ __launch_bounds__(256) void conv3x3_winograd_kernel(
   // other buffer, transform it, and have chunk c+2 in flight from global memory.  MFMAs are issued on both sides of
   // the first barrier so that the barrier wait overlaps matrix work.
   const int nchunk = (K + KC - 1) / KC;
-  load_chunk(0);
-  store_chunk(0, 0);
-  load_chunk(min(1, nchunk - 1) * KC);
+  const int lastc = (nchunk - 1) * KC;
+#pragma unroll
+  for (int j = 0; j < NRING; ++j) load_chunk(min(j * KC, lastc), ring_raw[j], ring_u[j]);
+  store_chunk(0, 0, ring_raw[0], ring_u[0]);
   __syncthreads();
   transform(0);
   __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const int cur = c & 1, nxt = cur ^ 1;
-    const bool more = c + 1 < nchunk;
-    store_chunk((c + 1) * KC, nxt);  // registers hold chunk c+1 (past the end: zeros, never multiplied)
-    load_chunk(min(c + 2, nchunk - 1) * KC);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_quarter(cur, 0);
-    mfma_quarter(cur, 1);
-    __syncthreads();                 // patch c+1 is in LDS
-    if (more) transform(nxt);
-    mfma_quarter(cur, 2);
-    mfma_quarter(cur, 3);
-    __syncthreads();                 // V of chunk c+1 complete; everyone done with the buffers of chunk c
+  for (int cbase = 0; cbase < nchunk; cbase += NRING) {
+#pragma unroll
+    for (int j = 0; j < NRING; ++j) {
+      const int c = cbase + j;
+      if (c < nchunk) {
+        const int cur = c & 1, nxt = cur ^ 1;
+        // registers of slot (j+1)%NRING hold chunk c+1 (past the end: a clamped re-read, zeroed, never multiplied)
+        store_chunk((c + 1) * KC, nxt, ring_raw[(j + 1) % NRING], ring_u[(j + 1) % NRING]);
+        load_chunk(min((c + NRING) * KC, lastc), ring_raw[j], ring_u[j]);  // slot j (chunk c) is free again
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quarter(cur, 0);
+        mfma_quarter(cur, 1);
+        __syncthreads();                 // patch c+1 is in LDS
+        if (c + 1 < nchunk) transform(nxt);
+        mfma_quarter(cur, 2);
+        mfma_quarter(cur, 3);
+        __syncthreads();                 // V of chunk c+1 complete; everyone done with the buffers of chunk c
+      }
+    }
   }
 
   // ---- epilogue: four passes of 16 output channels through LDS (the image reuses sV + sU) ----
   static_assert(16 * 16 * MS <= 2 * (VSZ + USZ), "epilogue image must fit");  // sV and sU are contiguous
   float* sM = sV;  // [16 xi][16 channels][MS]
-  const int e_tile = tid & 31, e_cl = tid >> 5;  // thread (tile, channel) and channel + 8
+  const int e_tile = tid % TB, e_cl = tid / TB;  // thread (tile, channel) and channel + 8
   const int e_tr = e_tile >> 3, e_tc = e_tile & 7;
   const int oy = y0 + 2 * e_tr, ox = x0 + 2 * e_tc;
 #pragma unroll
@@ -237,7 +260,7 @@ __global__ __launch_bounds__(256) void conv3x3_winograd_kernel(
       for (int a = 0; a < 4; ++a) {
         float* m = &sM[((wave * 4 + a) * 16 + cl) * MS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m[(r & 3) + 8 * (r >> 2) + 4 * lh] = acc[a][nb][r];
+        for (int r = 0; r < 16; ++r) m[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc[a][nb][r];
       }
     }
     __syncthreads();
@@ -308,24 +331,34 @@ extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float
   if (!x || !packed || !out || B < 1 || K < 1 || N < 1 || H < 1 || W < 1 || !aligned16(packed))
     return PCFA_ERR_INVALID_ARG;
   const int Npad = (N + CB - 1) / CB * CB;
-  const int blocks_x = pcfa_cdiv(W, 2 * TC), blocks_y = pcfa_cdiv(H, 2 * TR);
+  const int blocks_x = pcfa_cdiv(W, 2 * TC), blocks_y = pcfa_cdiv(H, 8);
   const long long gx = (long long)blocks_x * blocks_y;
   if (gx > 0x7fffffffLL || B > 65535 || Npad / CB > 65535) return PCFA_ERR_UNSUPPORTED;
   dim3 grid((unsigned)gx, Npad / CB, B), block(256);
   hipStream_t s = (hipStream_t)stream;
   // 64-channel blocks only when there are enough of them to fill the chip twice over; otherwise 32-channel blocks
   // (twice the workgroups, two resident per CU)
-  int cb = (gx * (Npad / CB) * B >= 1024) ? 64 : 32;
-  if (const char* e = getenv("PCFA_CONV3X3_CB")) cb = atoi(e) == 64 ? 64 : 32;  // A/B switch for tools/dev
-  if (cb == 32) grid.y = Npad / 32;
-#define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, out, K, N, Npad, H, W, blocks_x
-  if (cb == 64) {
-    if (relu) pcfa_launch(conv3x3_winograd_kernel<true, 64>, PCFA_C3_ARGS);
-    else pcfa_launch(conv3x3_winograd_kernel<false, 64>, PCFA_C3_ARGS);
-  } else {
-    if (relu) pcfa_launch(conv3x3_winograd_kernel<true, 32>, PCFA_C3_ARGS);
-    else pcfa_launch(conv3x3_winograd_kernel<false, 32>, PCFA_C3_ARGS);
+  int mt = 1;
+  if (const char* e = getenv("PCFA_CONV3X3_MT")) mt = atoi(e) == 2 ? 2 : 1;  // A/B switch for tools/dev
+  if (mt == 2) {
+    const int by2 = pcfa_cdiv(H, 16);
+    grid.x = (unsigned)(blocks_x * by2);
+    block.x = 512;
   }
+  grid.y = Npad / 32;
+#define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, out, K, N, Npad, H, W, blocks_x
+#define PCFA_C3_LAUNCH(MT_, KF_)                                                                   \
+  do {                                                                                             \
+    if (relu) pcfa_launch(conv3x3_winograd_kernel<true, 32, MT_, KF_>, PCFA_C3_ARGS);              \
+    else pcfa_launch(conv3x3_winograd_kernel<false, 32, MT_, KF_>, PCFA_C3_ARGS);                  \
+  } while (0)
+  const bool kfull = K % KC == 0;
+  if (mt == 2) {
+    if (kfull) PCFA_C3_LAUNCH(2, true); else PCFA_C3_LAUNCH(2, false);
+  } else {
+    if (kfull) PCFA_C3_LAUNCH(1, true); else PCFA_C3_LAUNCH(1, false);
+  }
+#undef PCFA_C3_LAUNCH
 #undef PCFA_C3_ARGS
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
