@@ -77,7 +77,7 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
 // KFULL: K % 8 == 0 -- the staging loop then carries no channel bookkeeping at all (per-thread base pointers plus
 // one scalar chunk offset; the generic variant clamps and masks the channel index of every element).
 template <bool RELU, int CBT, int MT, bool KFULL>
-__global__ __launch_bounds__(256 * MT) void conv3x3_winograd_kernel(
+__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3 : 2))) void conv3x3_winograd_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
     float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x) {
   constexpr int NT = 256 * MT;                         // threads
@@ -86,12 +86,14 @@ __global__ __launch_bounds__(256 * MT) void conv3x3_winograd_kernel(
   constexpr int RAW = KC * PR * PCP;
   constexpr int RAW_LOADS = (KC * PR * PC + NT - 1) / NT;
   constexpr int MS = TB + 1;                           // epilogue image: [16][16 channels][MS]
-  // double-buffered staging (patch, V, U), software-pipelined
-  constexpr int VSZ = 16 * KC * TB, USZ = 16 * KC * CBT, NB = CBT / 32, U_F4 = 16 * KC * CBT / 4 / NT;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (RAW + VSZ + USZ)];
+  // double-buffered staging of the patch and of V; the U operands go from L2 straight into registers (every U
+  // element is consumed by exactly one wave -- xi = 4w..4w+3 -- so an LDS round trip buys nothing)
+  constexpr int VSZ = 16 * KC * TB, NB = CBT / 32, NU = 4 * (KC / 2) * NB;  // U dwords per lane and chunk
+  constexpr int EPI = 16 * 16 * (TB + 1);                                   // epilogue image
+  constexpr int LDSF = 2 * (RAW + VSZ) > 2 * RAW + EPI ? 2 * (RAW + VSZ) : 2 * RAW + EPI;
+  __shared__ __attribute__((aligned(16))) float smem[LDSF];
   float* sRaw = smem;               // [2][RAW]
   float* sV = smem + 2 * RAW;       // [2][VSZ]
-  float* sU = sV + 2 * VSZ;         // [2][USZ]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, mt = tid >> 8;  // wave: xi group, mt: tile group
   const int l31 = lane & 31, lh = lane >> 5;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256 * MT) void conv3x3_winograd_kernel(
   out += (long long)blockIdx.z * N * plane;
 
   // ---- per-thread constants of the staging loads (chunk-invariant) ----
-  const float* praw[RAW_LOADS];  // chunk 0 source of the patch element (clamped into the image)
+  unsigned praw[RAW_LOADS];      // chunk 0 source of the patch element (clamped into the image), floats from x
   int rdst[RAW_LOADS];           // sRaw index, -1 = no element
   int rch[RAW_LOADS];
   bool rok[RAW_LOADS];
@@ -117,51 +119,47 @@ __global__ __launch_bounds__(256 * MT) void conv3x3_winograd_kernel(
     rch[i] = min(ch, KC - 1);
     rdst[i] = e < KC * PR * PC ? (ch * PR + r) * PCP + c : -1;
     rok[i] = e < KC * PR * PC && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    praw[i] = x + (long long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1) + (KFULL ? rch[i] * plane : 0);
+    praw[i] = (unsigned)(min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1) + (KFULL ? rch[i] * (int)plane : 0));
   }
-  const float* pu[U_F4];         // chunk 0 source of the U float4
-  int uk[U_F4];                  // its channel inside the chunk
+  // U operand of MFMA (a, kp, b): U[xi = 4*wave + a][k = c0 + kp + lh][n0 + 32 b + l31]
+  unsigned pu[4];  // floats from U
 #pragma unroll
-  for (int i = 0; i < U_F4; ++i) {
-    const int f = tid + NT * i;               // float4 index inside [16][KC][CBT/4]
-    const int xi = f / (KC * CBT / 4), rem = f - xi * (KC * CBT / 4);
-    const int k = rem / (CBT / 4), n4 = rem - k * (CBT / 4);
-    uk[i] = k;
-    pu[i] = U + n0 + ((long long)xi * K + (KFULL ? k : 0)) * Npad + n4 * 4;
-  }
+  for (int a = 0; a < 4; ++a) pu[a] = (unsigned)(((4 * wave + a) * K + lh) * Npad + n0 + l31);
 
   // register ring: the global loads of a chunk are issued NRING-1 chunks before its MFMAs
-  constexpr int NRING = 3;
+  constexpr int NRING = 2;
   float ring_raw[NRING][RAW_LOADS];
-  float4 ring_u[NRING][U_F4];
-  auto load_chunk = [&](int c0, float (&rraw)[RAW_LOADS], float4 (&ru)[U_F4]) {
+  float ring_u[NRING][NU];
+  auto load_chunk = [&](int c0, float (&rraw)[RAW_LOADS], float (&ru)[NU]) {
     if (KFULL) {
-      const long long xo = (long long)c0 * plane, uo = (long long)c0 * Npad;  // wave-uniform chunk offsets
+      const unsigned xo = (unsigned)(c0 * (int)plane), uo = (unsigned)(c0 * Npad);  // wave-uniform chunk offsets
 #pragma unroll
-      for (int i = 0; i < RAW_LOADS; ++i) rraw[i] = praw[i][xo];
+      for (int i = 0; i < RAW_LOADS; ++i) rraw[i] = x[praw[i] + xo];
 #pragma unroll
-      for (int i = 0; i < U_F4; ++i) ru[i] = *reinterpret_cast<const float4*>(pu[i] + uo);
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int kp = 0; kp < KC; kp += 2)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) ru[(a * (KC / 2) + kp / 2) * NB + b] = U[pu[a] + uo + (unsigned)(kp * Npad + 32 * b)];
     } else {
 #pragma unroll
       for (int i = 0; i < RAW_LOADS; ++i)
-        rraw[i] = praw[i][(long long)min(c0 + rch[i], K - 1) * plane];  // channels >= K are zeroed at the LDS write
+        rraw[i] = x[praw[i] + (unsigned)(min(c0 + rch[i], K - 1) * (int)plane)];  // channels >= K: zeroed at the LDS write
+      // rows k >= K: any finite value will do (their V operand is zero); clamp the row index
 #pragma unroll
-      for (int i = 0; i < U_F4; ++i)
-        ru[i] = *reinterpret_cast<const float4*>(pu[i] + (long long)min(c0 + uk[i], K - 1) * Npad);
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int kp = 0; kp < KC; kp += 2)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            ru[(a * (KC / 2) + kp / 2) * NB + b] = U[pu[a] + (unsigned)((min(c0 + kp + lh, K - 1) - lh) * Npad + 32 * b)];
     }
   };
-  auto store_chunk = [&](int c0, int buf, const float (&rraw)[RAW_LOADS], const float4 (&ru)[U_F4]) {
+  auto store_chunk = [&](int c0, int buf, const float (&rraw)[RAW_LOADS]) {
     float* sRaw = smem + buf * RAW;
-    float* sU = smem + 2 * RAW + 2 * VSZ + buf * USZ;
 #pragma unroll
     for (int i = 0; i < RAW_LOADS; ++i)
       if (rdst[i] >= 0) sRaw[rdst[i]] = (rok[i] && (KFULL || c0 + rch[i] < K)) ? rraw[i] : 0.f;
-#pragma unroll
-    for (int i = 0; i < U_F4; ++i) {
-      float4 v = ru[i];
-      if (!KFULL && c0 + uk[i] >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(&sU[(tid + NT * i) * 4]) = v;
-    }
   };
   // thread (tile, channel) of the input transform
   const int t_tile = tid % TB, t_ch = tid / TB;
@@ -199,28 +197,29 @@ __global__ __launch_bounds__(256 * MT) void conv3x3_winograd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // MFMAs of chunk `buf` for the xi-quarter a of this wave (8 MFMAs, two accumulator chains)
-  auto mfma_quarter = [&](int buf, int a) {
+  // MFMAs of the chunk staged in `buf` for the xi-quarter a of this wave; ru = the chunk's U operands
+  auto mfma_quarter = [&](int buf, int a, const float (&ru)[NU]) {
     const int xi = wave * 4 + a;
     const float* vp = &sV[buf * VSZ + (xi * KC + lh) * TB + mt * 32 + l31];
-    const float* up = &sU[buf * USZ + (xi * KC + lh) * CBT + l31];
 #pragma unroll
     for (int kp = 0; kp < KC; kp += 2) {
       const float av = vp[kp * TB];
 #pragma unroll
       for (int b = 0; b < NB; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, up[kp * CBT + 32 * b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ru[(a * (KC / 2) + kp / 2) * NB + b], acc[a][b], 0, 0, 0);
     }
   };
 
   // Pipeline: while the matrix pipe works on chunk c (V, U in buffer c&1), the same waves write chunk c+1 to the
   // other buffer, transform it, and have chunk c+2 in flight from global memory.  MFMAs are issued on both sides of
   // the first barrier so that the barrier wait overlaps matrix work.
+  // Ring slot c % NRING holds chunk c: its patch is written to LDS one iteration before its MFMAs, its U operands
+  // stay in registers until the MFMAs have consumed them; the slot is reloaded (chunk c + NRING) right after.
   const int nchunk = (K + KC - 1) / KC;
   const int lastc = (nchunk - 1) * KC;
 #pragma unroll
   for (int j = 0; j < NRING; ++j) load_chunk(min(j * KC, lastc), ring_raw[j], ring_u[j]);
-  store_chunk(0, 0, ring_raw[0], ring_u[0]);
+  store_chunk(0, 0, ring_raw[0]);
   __syncthreads();
   transform(0);
   __syncthreads();
@@ -230,23 +229,22 @@ __global__ __launch_bounds__(256 * MT) void conv3x3_winograd_kernel(
       const int c = cbase + j;
       if (c < nchunk) {
         const int cur = c & 1, nxt = cur ^ 1;
-        // registers of slot (j+1)%NRING hold chunk c+1 (past the end: a clamped re-read, zeroed, never multiplied)
-        store_chunk((c + 1) * KC, nxt, ring_raw[(j + 1) % NRING], ring_u[(j + 1) % NRING]);
-        load_chunk(min((c + NRING) * KC, lastc), ring_raw[j], ring_u[j]);  // slot j (chunk c) is free again
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_quarter(cur, 0);
-        mfma_quarter(cur, 1);
+        store_chunk((c + 1) * KC, nxt, ring_raw[(j + 1) % NRING]);  // patch of chunk c+1 (past the end: zeros)
+        mfma_quarter(cur, 0, ring_u[j]);
+        mfma_quarter(cur, 1, ring_u[j]);
         __syncthreads();                 // patch c+1 is in LDS
         if (c + 1 < nchunk) transform(nxt);
-        mfma_quarter(cur, 2);
-        mfma_quarter(cur, 3);
+        mfma_quarter(cur, 2, ring_u[j]);
+        mfma_quarter(cur, 3, ring_u[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(min((c + NRING) * KC, lastc), ring_raw[j], ring_u[j]);  // slot j is free again
         __syncthreads();                 // V of chunk c+1 complete; everyone done with the buffers of chunk c
       }
     }
   }
 
   // ---- epilogue: four passes of 16 output channels through LDS (the image reuses sV + sU) ----
-  static_assert(16 * 16 * MS <= 2 * (VSZ + USZ), "epilogue image must fit");  // sV and sU are contiguous
+  static_assert(EPI == 16 * 16 * MS, "epilogue image size");
   float* sM = sV;  // [16 xi][16 channels][MS]
   const int e_tile = tid % TB, e_cl = tid / TB;  // thread (tile, channel) and channel + 8
   const int e_tr = e_tile >> 3, e_tc = e_tile & 7;
@@ -333,7 +331,10 @@ extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float
   const int Npad = (N + CB - 1) / CB * CB;
   const int blocks_x = pcfa_cdiv(W, 2 * TC), blocks_y = pcfa_cdiv(H, 8);
   const long long gx = (long long)blocks_x * blocks_y;
-  if (gx > 0x7fffffffLL || B > 65535 || Npad / CB > 65535) return PCFA_ERR_UNSUPPORTED;
+  // 32-bit element offsets inside one image and inside the packed weights
+  if (gx > 0x7fffffffLL || B > 65535 || Npad / CB > 65535 || (long long)K * H * W > 0x7fffffffLL ||
+      16LL * K * Npad > 0x7fffffffLL)
+    return PCFA_ERR_UNSUPPORTED;
   dim3 grid((unsigned)gx, Npad / CB, B), block(256);
   hipStream_t s = (hipStream_t)stream;
   // 64-channel blocks only when there are enough of them to fill the chip twice over; otherwise 32-channel blocks
