@@ -12,12 +12,12 @@
 // form at the matrix-pipe rate.  U = G g G^T is computed once per weight tensor (pcfa_conv3x3_pack_weights); the data
 // gradient is the same operator on grad_out with the flipped / transposed weights (second packing).
 //
-// Workgroup = 4 waves: 32 tiles (4 tile rows x 8 tile columns = 8 x 16 output pixels) x 64 output channels.
-// Per chunk of 8 input channels: the 10 x 18 input patch goes global -> registers -> LDS, thread (tile, channel)
-// transforms its 4x4 patch to V[16][8][32] in LDS, wave w multiplies xi = 4w..4w+3 (4 MFMAs per xi and 32-channel
-// half: 32 per wave and chunk, 128 accumulator registers), the next chunk's patch and U slice (32 KB) prefetched in
-// registers meanwhile.  Epilogue: accumulators -> LDS in four passes of 16 channels, thread (channel, tile) applies
-// A^T . A, adds the bias, optionally ReLU, stores 2x2 pixels.
+// Workgroup = 4 waves: 32 tiles (4 tile rows x 8 tile columns = 8 x 16 output pixels) x 32 output channels.
+// Per chunk of 8 input channels the 10 x 18 input patch goes global -> registers -> LDS; wave w owns xi = 4w..4w+3
+// (row w of the transform) and every lane builds the A operands of its own MFMAs from two patch rows, the U
+// operands come from L2 straight into registers; 16 MFMAs per wave and chunk, one barrier per chunk.
+// Epilogue: accumulators -> LDS in passes of 16 channels, thread (channel, tile) applies A^T . A, adds the bias,
+// optionally ReLU, stores 2x2 pixels.
 #include "common.hpp"
 #include <cstdlib>
 
@@ -76,8 +76,10 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
 // U slice, i.e. half the L2 -> LDS weight traffic per multiply.
 // KFULL: K % 8 == 0 -- the staging loop then carries no channel bookkeeping at all (per-thread base pointers plus
 // one scalar chunk offset; the generic variant clamps and masks the channel index of every element).
-template <bool RELU, int CBT, int MT, bool KFULL>
-__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3 : 2))) void conv3x3_winograd_kernel(
+// NRING: depth of the register ring (2: <= 168 registers, 3 waves per SIMD -- large grids; 3: loads two chunks
+// ahead, 2 waves per SIMD -- small grids, where a CU holds one or two workgroups anyway and latency is all).
+template <bool RELU, int CBT, int MT, bool KFULL, int NRING>
+__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 1 && NRING == 2 ? 3 : 2))) void conv3x3_winograd_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
     float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x) {
   constexpr int NT = 256 * MT;                         // threads
@@ -86,14 +88,15 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   constexpr int RAW = KC * PR * PCP;
   constexpr int RAW_LOADS = (KC * PR * PC + NT - 1) / NT;
   constexpr int MS = TB + 1;                           // epilogue image: [16][16 channels][MS]
-  // double-buffered staging of the patch and of V; the U operands go from L2 straight into registers (every U
-  // element is consumed by exactly one wave -- xi = 4w..4w+3 -- so an LDS round trip buys nothing)
-  constexpr int VSZ = 16 * KC * TB, NB = CBT / 32, NU = 4 * (KC / 2) * NB;  // U dwords per lane and chunk
-  constexpr int EPI = 16 * 16 * (TB + 1);                                   // epilogue image
-  constexpr int LDSF = 2 * (RAW + VSZ) > 2 * RAW + EPI ? 2 * (RAW + VSZ) : 2 * RAW + EPI;
+  // Only the raw input patch lives in LDS (double-buffered).  Wave w owns xi = 4w..4w+3, i.e. ROW w of the 4x4
+  // transform: every lane builds the A operands of its own MFMAs -- V[w][0..3] of (tile l31, channel kp + lh) --
+  // from two patch rows (8 LDS reads, 8 adds), so there is no V image, no transform phase and ONE barrier per chunk.
+  // The U operands go from L2 straight into registers (every U element is consumed by exactly one wave).
+  constexpr int NB = CBT / 32, NU = 4 * (KC / 2) * NB;  // U dwords per lane and chunk
+  constexpr int EPI = 16 * 16 * (TB + 1);               // epilogue image
+  constexpr int LDSF = 2 * RAW > EPI ? 2 * RAW : EPI;
   __shared__ __attribute__((aligned(16))) float smem[LDSF];
   float* sRaw = smem;               // [2][RAW]
-  float* sV = smem + 2 * RAW;       // [2][VSZ]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, mt = tid >> 8;  // wave: xi group, mt: tile group
   const int l31 = lane & 31, lh = lane >> 5;
@@ -127,20 +130,29 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   for (int a = 0; a < 4; ++a) pu[a] = (unsigned)(((4 * wave + a) * K + lh) * Npad + n0 + l31);
 
   // register ring: the global loads of a chunk are issued NRING-1 chunks before its MFMAs
-  constexpr int NRING = 2;
   float ring_raw[NRING][RAW_LOADS];
   float ring_u[NRING][NU];
   auto load_chunk = [&](int c0, float (&rraw)[RAW_LOADS], float (&ru)[NU]) {
     if (KFULL) {
       const unsigned xo = (unsigned)(c0 * (int)plane), uo = (unsigned)(c0 * Npad);  // wave-uniform chunk offsets
 #pragma unroll
-      for (int i = 0; i < RAW_LOADS; ++i) rraw[i] = x[praw[i] + xo];
+      for (int i = 0; i < RAW_LOADS; ++i)
+#ifdef PCFA_C3_TIMING_NO_RAW  // timing-only build (tools/dev)
+        rraw[i] = (float)(praw[i] + xo);
+#else
+        rraw[i] = x[praw[i] + xo];
+#endif
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int kp = 0; kp < KC; kp += 2)
 #pragma unroll
-          for (int b = 0; b < NB; ++b) ru[(a * (KC / 2) + kp / 2) * NB + b] = U[pu[a] + uo + (unsigned)(kp * Npad + 32 * b)];
+          for (int b = 0; b < NB; ++b)
+#ifdef PCFA_C3_TIMING_NO_U   // timing-only build (tools/dev): what the loop costs without the U operand loads
+            ru[(a * (KC / 2) + kp / 2) * NB + b] = (float)(pu[a] + uo);
+#else
+            ru[(a * (KC / 2) + kp / 2) * NB + b] = U[pu[a] + uo + (unsigned)(kp * Npad + 32 * b)];
+#endif
     } else {
 #pragma unroll
       for (int i = 0; i < RAW_LOADS; ++i)
@@ -161,34 +173,6 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     for (int i = 0; i < RAW_LOADS; ++i)
       if (rdst[i] >= 0) sRaw[rdst[i]] = (rok[i] && (KFULL || c0 + rch[i] < K)) ? rraw[i] : 0.f;
   };
-  // thread (tile, channel) of the input transform
-  const int t_tile = tid % TB, t_ch = tid / TB;
-  const int t_tr = t_tile >> 3, t_tc = t_tile & 7;
-  auto transform = [&](int buf) {
-    const float* p = &sRaw[buf * RAW + (t_ch * PR + 2 * t_tr) * PCP + 2 * t_tc];
-    float d[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[i][j] = p[i * PCP + j];
-    float t[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      t[0][j] = d[0][j] - d[2][j];
-      t[1][j] = d[1][j] + d[2][j];
-      t[2][j] = d[2][j] - d[1][j];
-      t[3][j] = d[1][j] - d[3][j];
-    }
-    float* v = &sV[buf * VSZ + t_ch * TB + t_tile];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[(4 * i + 0) * (KC * TB)] = t[i][0] - t[i][2];
-      v[(4 * i + 1) * (KC * TB)] = t[i][1] + t[i][2];
-      v[(4 * i + 2) * (KC * TB)] = t[i][2] - t[i][1];
-      v[(4 * i + 3) * (KC * TB)] = t[i][1] - t[i][3];
-    }
-  };
-
   f32x16 acc[4][NB];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -197,22 +181,29 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // MFMAs of the chunk staged in `buf` for the xi-quarter a of this wave; ru = the chunk's U operands
-  auto mfma_quarter = [&](int buf, int a, const float (&ru)[NU]) {
-    const int xi = wave * 4 + a;
-    const float* vp = &sV[buf * VSZ + (xi * KC + lh) * TB + mt * 32 + l31];
+  // MFMAs of the chunk whose patch sits in sRaw[buf]; ru = the chunk's U operands.
+  // Row w of B^T d uses patch rows (ra, rb) with signs (sa, sb): 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3.
+  const int ra = wave == 0 ? 0 : 1, rb = wave == 3 ? 3 : 2;
+  const float sa = wave == 2 ? -1.f : 1.f, sb = (wave == 1 || wave == 2) ? 1.f : -1.f;
+  const int m_tile = mt * 32 + l31;
+  const float* prow = sRaw + (lh * PR + 2 * (m_tile >> 3)) * PCP + 2 * (m_tile & 7);
+  auto mfma_chunk = [&](int buf, const float (&ru)[NU]) {
 #pragma unroll
     for (int kp = 0; kp < KC; kp += 2) {
-      const float av = vp[kp * TB];
+      const float* p = prow + buf * RAW + kp * (PR * PCP);
+      const float2 a0 = *reinterpret_cast<const float2*>(p + ra * PCP), a1 = *reinterpret_cast<const float2*>(p + ra * PCP + 2);
+      const float2 b0 = *reinterpret_cast<const float2*>(p + rb * PCP), b1 = *reinterpret_cast<const float2*>(p + rb * PCP + 2);
+      const float t0 = fmaf(sb, b0.x, sa * a0.x), t1 = fmaf(sb, b0.y, sa * a0.y);
+      const float t2 = fmaf(sb, b1.x, sa * a1.x), t3 = fmaf(sb, b1.y, sa * a1.y);
+      const float av[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ru[(a * (KC / 2) + kp / 2) * NB + b], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], ru[(a * (KC / 2) + kp / 2) * NB + b], acc[a][b], 0, 0, 0);
     }
   };
 
-  // Pipeline: while the matrix pipe works on chunk c (V, U in buffer c&1), the same waves write chunk c+1 to the
-  // other buffer, transform it, and have chunk c+2 in flight from global memory.  MFMAs are issued on both sides of
-  // the first barrier so that the barrier wait overlaps matrix work.
   // Ring slot c % NRING holds chunk c: its patch is written to LDS one iteration before its MFMAs, its U operands
   // stay in registers until the MFMAs have consumed them; the slot is reloaded (chunk c + NRING) right after.
   const int nchunk = (K + KC - 1) / KC;
@@ -221,31 +212,27 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   for (int j = 0; j < NRING; ++j) load_chunk(min(j * KC, lastc), ring_raw[j], ring_u[j]);
   store_chunk(0, 0, ring_raw[0]);
   __syncthreads();
-  transform(0);
-  __syncthreads();
   for (int cbase = 0; cbase < nchunk; cbase += NRING) {
 #pragma unroll
     for (int j = 0; j < NRING; ++j) {
       const int c = cbase + j;
       if (c < nchunk) {
         const int cur = c & 1, nxt = cur ^ 1;
-        store_chunk((c + 1) * KC, nxt, ring_raw[(j + 1) % NRING]);  // patch of chunk c+1 (past the end: zeros)
-        mfma_quarter(cur, 0, ring_u[j]);
-        mfma_quarter(cur, 1, ring_u[j]);
-        __syncthreads();                 // patch c+1 is in LDS
-        if (c + 1 < nchunk) transform(nxt);
-        mfma_quarter(cur, 2, ring_u[j]);
-        mfma_quarter(cur, 3, ring_u[j]);
+        mfma_chunk(cur, ring_u[j]);
         __builtin_amdgcn_sched_barrier(0);
+        // the patch of chunk c+1 was requested at the end of the previous iteration: it had this iteration's MFMA
+        // phase to arrive (stored FIRST it stalled every iteration for the full load latency); its LDS buffer is
+        // the one chunk c-1 used, free since the last barrier
+        store_chunk((c + 1) * KC, nxt, ring_raw[(j + 1) % NRING]);  // (past the end: zeros, never read)
         load_chunk(min((c + NRING) * KC, lastc), ring_raw[j], ring_u[j]);  // slot j is free again
-        __syncthreads();                 // V of chunk c+1 complete; everyone done with the buffers of chunk c
+        __syncthreads();  // patch c+1 visible; everyone done with the patch of chunk c
       }
     }
   }
 
   // ---- epilogue: four passes of 16 output channels through LDS (the image reuses sV + sU) ----
   static_assert(EPI == 16 * 16 * MS, "epilogue image size");
-  float* sM = sV;  // [16 xi][16 channels][MS]
+  float* sM = smem;  // [16 xi][16 channels][MS]
   const int e_tile = tid % TB, e_cl = tid / TB;  // thread (tile, channel) and channel + 8
   const int e_tr = e_tile >> 3, e_tc = e_tile & 7;
   const int oy = y0 + 2 * e_tr, ox = x0 + 2 * e_tc;
@@ -348,16 +335,20 @@ extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float
   }
   grid.y = Npad / 32;
 #define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, out, K, N, Npad, H, W, blocks_x
-#define PCFA_C3_LAUNCH(MT_, KF_)                                                                   \
+#define PCFA_C3_LAUNCH(MT_, KF_, NR_)                                                              \
   do {                                                                                             \
-    if (relu) pcfa_launch(conv3x3_winograd_kernel<true, 32, MT_, KF_>, PCFA_C3_ARGS);              \
-    else pcfa_launch(conv3x3_winograd_kernel<false, 32, MT_, KF_>, PCFA_C3_ARGS);                  \
+    if (relu) pcfa_launch(conv3x3_winograd_kernel<true, 32, MT_, KF_, NR_>, PCFA_C3_ARGS);         \
+    else pcfa_launch(conv3x3_winograd_kernel<false, 32, MT_, KF_, NR_>, PCFA_C3_ARGS);             \
   } while (0)
   const bool kfull = K % KC == 0;
+  int deep = 0;  // measured: the 3-deep ring (2 waves per SIMD) is never faster, also not on small grids
+  if (const char* e = getenv("PCFA_CONV3X3_RING")) deep = atoi(e) == 3;  // A/B switch for tools/dev
   if (mt == 2) {
-    if (kfull) PCFA_C3_LAUNCH(2, true); else PCFA_C3_LAUNCH(2, false);
+    if (kfull) PCFA_C3_LAUNCH(2, true, 2); else PCFA_C3_LAUNCH(2, false, 2);
+  } else if (deep) {
+    if (kfull) PCFA_C3_LAUNCH(1, true, 3); else PCFA_C3_LAUNCH(1, false, 3);
   } else {
-    if (kfull) PCFA_C3_LAUNCH(1, true); else PCFA_C3_LAUNCH(1, false);
+    if (kfull) PCFA_C3_LAUNCH(1, true, 2); else PCFA_C3_LAUNCH(1, false, 2);
   }
 #undef PCFA_C3_LAUNCH
 #undef PCFA_C3_ARGS
