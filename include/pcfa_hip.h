@@ -265,6 +265,12 @@ PCFA_API int pcfa_conv3x3_pack_weights(const float* w, float* fwd_packed, float*
                               void* stream);
 PCFA_API int pcfa_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K, int N,
                      int H, int W, int relu, void* stream);
+/* The same with a choice of activation: act 0 = none, 1 = ReLU, 2 = LeakyReLU(slope) (PWC-Net's conv(),
+ * models/PWCNet/PWCNet.py:29-35); pcfa_leaky_relu_bwd: grad_x = grad_out * (out > 0 ? 1 : slope). */
+PCFA_API int pcfa_conv3x3_act_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K,
+                         int N, int H, int W, int act, float slope, void* stream);
+PCFA_API int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, float* grad_x, float slope, long long n,
+                        void* stream);
 
 /* out = relu(x + bias[c]) and its backward gx = grad_out * (out > 0): the "conv -> +bias -> ReLU" tail of the
  * motion encoder / flow head convolutions (models/raft/update.py:12-16,91-101) in one pass. */

@@ -238,9 +238,12 @@ def sepconv5(a, b, weight):
     return F.conv2d(x, weight, None, padding=(weight.shape[2] // 2, weight.shape[3] // 2))
 
 
-def conv3x3(x, weight, bias=None, relu=False):
-    """3x3 / stride 1 / pad 1 convolution (+ bias, + ReLU) of the update block (models/raft/update.py:6-16,79-101)."""
+def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None):
+    """3x3 / stride 1 / pad 1 convolution (+ bias, + ReLU or LeakyReLU): models/raft/update.py:6-16,79-101,
+    models/PWCNet/PWCNet.py:29-35."""
     y = F.conv2d(x, weight, bias, stride=1, padding=1)
+    if leaky_slope is not None:
+        return F.leaky_relu(y, leaky_slope)
     return F.relu(y) if relu else y
 
 

@@ -78,10 +78,10 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
 // one scalar chunk offset; the generic variant clamps and masks the channel index of every element).
 // NRING: depth of the register ring (2: <= 168 registers, 3 waves per SIMD -- large grids; 3: loads two chunks
 // ahead, 2 waves per SIMD -- small grids, where a CU holds one or two workgroups anyway and latency is all).
-template <bool RELU, int CBT, int MT, bool KFULL, int NRING>
+template <int ACT, int CBT, int MT, bool KFULL, int NRING>  // ACT: 0 none, 1 ReLU, 2 LeakyReLU(slope)
 __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 1 && NRING == 2 ? 3 : 2))) void conv3x3_winograd_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
-    float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x) {
+    float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x, float slope) {
   constexpr int NT = 256 * MT;                         // threads
   constexpr int TR = 4 * MT, TB = TR * TC;             // tile rows / tiles per workgroup
   constexpr int PR = 2 * TR + 2;                       // input patch rows
@@ -266,8 +266,11 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
       const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
       float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
       float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
-      if (RELU) {
+      if (ACT == 1) {
         y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
+      } else if (ACT == 2) {  // torch: x > 0 ? x : x * negative_slope
+        y00 = y00 > 0.f ? y00 : y00 * slope; y01 = y01 > 0.f ? y01 : y01 * slope;
+        y10 = y10 > 0.f ? y10 : y10 * slope; y11 = y11 > 0.f ? y11 : y11 * slope;
       }
       if (n < N && oy < H && ox < W) {
         float* o = out + (long long)n * plane + (long long)oy * W + ox;
@@ -311,8 +314,30 @@ extern "C" int pcfa_conv3x3_pack_weights(const float* w, float* fwd_packed, floa
   return PCFA_OK;
 }
 
+// dx = dy * (out > 0 ? 1 : slope): backward of LeakyReLU from its OUTPUT (same sign as the input for slope > 0)
+__global__ void leaky_relu_bwd_kernel(const float* __restrict__ out, const float* __restrict__ g, float* __restrict__ gx,
+                                      float slope, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    gx[i] = out[i] > 0.f ? g[i] : g[i] * slope;
+}
+
+extern "C" int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, float* grad_x, float slope, long long n,
+                                   void* stream) {
+  if (!out || !grad_out || !grad_x || n < 1) return PCFA_ERR_INVALID_ARG;
+  pcfa_launch(leaky_relu_bwd_kernel, dim3((unsigned)min((n + 255) / 256, 4096LL)), dim3(256), 0, (hipStream_t)stream,
+              out, grad_out, grad_x, slope, n);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
 extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K,
                                 int N, int H, int W, int relu, void* stream) {
+  return pcfa_conv3x3_act_fwd(x, packed, bias, out, B, K, N, H, W, relu ? 1 : 0, 0.f, stream);
+}
+
+extern "C" int pcfa_conv3x3_act_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K,
+                                    int N, int H, int W, int act, float slope, void* stream) {
+  if (act < 0 || act > 2) return PCFA_ERR_INVALID_ARG;
   if (!x || !packed || !out || B < 1 || K < 1 || N < 1 || H < 1 || W < 1 || !aligned16(packed))
     return PCFA_ERR_INVALID_ARG;
   const int Npad = (N + CB - 1) / CB * CB;
@@ -334,11 +359,12 @@ extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float
     block.x = 512;
   }
   grid.y = Npad / 32;
-#define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, out, K, N, Npad, H, W, blocks_x
+#define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, out, K, N, Npad, H, W, blocks_x, slope
 #define PCFA_C3_LAUNCH(MT_, KF_, NR_)                                                              \
   do {                                                                                             \
-    if (relu) pcfa_launch(conv3x3_winograd_kernel<true, 32, MT_, KF_, NR_>, PCFA_C3_ARGS);         \
-    else pcfa_launch(conv3x3_winograd_kernel<false, 32, MT_, KF_, NR_>, PCFA_C3_ARGS);             \
+    if (act == 1) pcfa_launch(conv3x3_winograd_kernel<1, 32, MT_, KF_, NR_>, PCFA_C3_ARGS);        \
+    else if (act == 2) pcfa_launch(conv3x3_winograd_kernel<2, 32, MT_, KF_, NR_>, PCFA_C3_ARGS);   \
+    else pcfa_launch(conv3x3_winograd_kernel<0, 32, MT_, KF_, NR_>, PCFA_C3_ARGS);                 \
   } while (0)
   const bool kfull = K % KC == 0;
   int deep = 0;  // measured: the 3-deep ring (2 waves per SIMD) is never faster, also not on small grids

@@ -537,7 +537,7 @@ def _conv3x3_packed(weight):
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, slope=None):
         _dev(x, weight, bias)
         if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.dtype != torch.float32:
             raise ValueError("conv3x3 expects a float32 3x3 Conv2d weight, got %s" % (tuple(weight.shape),))
@@ -548,9 +548,11 @@ class _Conv3x3(torch.autograd.Function):
             raise ValueError("conv3x3: input %s does not match weight %s" % (tuple(x.shape), tuple(weight.shape)))
         fwd, bwd = _conv3x3_packed(weight)
         out = torch.empty((B, N, H, W), device=x.device, dtype=torch.float32)
-        _call("pcfa_conv3x3_fwd", _ptr(x), _ptr(fwd), _ptr(bias), _ptr(out), B, K, N, H, W, int(bool(relu)))
-        ctx.bwd, ctx.dims, ctx.relu = bwd, (B, K, N, H, W), bool(relu)
-        if relu:
+        act = 2 if slope is not None else int(bool(relu))
+        _call("pcfa_conv3x3_act_fwd", _ptr(x), _ptr(fwd), _ptr(bias), _ptr(out), B, K, N, H, W, act,
+              float(slope or 0.))
+        ctx.bwd, ctx.dims, ctx.act, ctx.slope = bwd, (B, K, N, H, W), act, float(slope or 0.)
+        if act:
             ctx.save_for_backward(out)
         return out
 
@@ -560,20 +562,24 @@ class _Conv3x3(torch.autograd.Function):
             raise RuntimeError("conv3x3 is the frozen-weight path: no weight / bias gradient")
         B, K, N, H, W = ctx.dims
         g = g.contiguous()
-        if ctx.relu:
+        if ctx.act:
             (out,) = ctx.saved_tensors
             gm = torch.empty_like(g)
-            _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), g.numel())
+            if ctx.act == 1:
+                _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), g.numel())
+            else:
+                _call("pcfa_leaky_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), ctx.slope, g.numel())
             g = gm
         gin = torch.empty((B, K, H, W), device=g.device, dtype=torch.float32)
         _call("pcfa_conv3x3_fwd", _ptr(g), _ptr(ctx.bwd), None, _ptr(gin), B, N, K, H, W, 0)
-        return gin, None, None, None
+        return gin, None, None, None, None
 
 
-def conv3x3(x, weight, bias=None, relu=False):
+def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None):
     """act(conv2d(x, weight, bias, stride=1, padding=1)) for a frozen 3x3 weight: Winograd F(2x2,3x3) on the fp32
-    matrix cores with bias and ReLU fused into the epilogue; the data gradient runs the same kernel."""
-    return _Conv3x3.apply(x, weight, bias, relu)
+    matrix cores with bias and ReLU (or LeakyReLU(leaky_slope)) fused into the epilogue; the data gradient runs the
+    same kernel."""
+    return _Conv3x3.apply(x, weight, bias, relu, leaky_slope)
 
 
 class _GruStep(torch.autograd.Function):

@@ -17,8 +17,22 @@ import torch.nn as nn
 from .. import ops
 
 
+class _ConvLeaky(nn.Sequential):
+    """conv() of the reference (PWCNet.py:29-35): Conv2d + LeakyReLU(0.1); same parameter names ("0.weight", "0.bias").
+    Frozen 3x3 / stride 1 / pad 1 instances run as ops.conv3x3 (Winograd on the fp32 matrix cores, bias and
+    LeakyReLU in the epilogue); strided and dilated ones stay on the library convolution."""
+
+    def forward(self, x):
+        c = self[0]
+        if (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
+                and c.out_channels >= 16 and not c.weight.requires_grad
+                and not (c.bias is not None and c.bias.requires_grad)):
+            return ops.get().conv3x3(x, c.weight, c.bias, False, self[1].negative_slope)
+        return super().forward(x)
+
+
 def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
-    return nn.Sequential(
+    return _ConvLeaky(
         nn.Conv2d(int(in_planes), int(out_planes), kernel_size=kernel_size, stride=stride, padding=padding,
                   dilation=dilation, bias=True),
         nn.LeakyReLU(0.1))

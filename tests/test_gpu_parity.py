@@ -301,7 +301,7 @@ def test_gru_step_vs_oracle(oracle_ops, shape):
     # (B, Cin, Cout, H, W): update-block convolutions at the BASELINE feature size, then ragged everything
     (1, 256, 192, 55, 128), (1, 256, 126, 55, 128), (1, 128, 256, 55, 128), (1, 128, 64, 55, 128),
     (2, 5, 7, 9, 21), (1, 12, 70, 3, 5), (1, 3, 2, 1, 1), (2, 64, 64, 40, 48)])
-@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("relu", [False, True, 0.1])
 def test_conv3x3_winograd_vs_oracle(oracle_ops, shape, relu):
     """Winograd F(2x2,3x3) on fp32 MFMA against conv2d: forward (+bias, +ReLU) and data gradient.  Winograd's
     transforms add a few roundings per product: 5e-6 relative L2."""
@@ -312,10 +312,11 @@ def test_conv3x3_winograd_vs_oracle(oracle_ops, shape, relu):
     b = torch.randn(Cout, generator=gen)
     go = torch.randn(B, Cout, H, W, generator=gen)
     cx = x.clone().requires_grad_(True)
-    want = oracle_ops.conv3x3(cx, w, b, relu)
+    act = dict(relu=False, leaky_slope=relu) if isinstance(relu, float) else dict(relu=relu)   # 0.1: PWC-Net's LeakyReLU
+    want = oracle_ops.conv3x3(cx, w, b, **act)
     want.backward(go)
     gx = x.clone().to(DEV).requires_grad_(True)
-    got = hip_ops.conv3x3(gx, w.to(DEV), b.to(DEV), relu)
+    got = hip_ops.conv3x3(gx, w.to(DEV), b.to(DEV), **act)
     assert got.shape == want.shape
     assert rel_l2(got, want) < 5e-6
     got.backward(go.to(DEV))
