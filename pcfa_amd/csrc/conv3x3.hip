@@ -31,45 +31,64 @@ constexpr int PCP = 20;                          // padded patch row stride
 constexpr int KC = 8;                            // input channels per chunk
 constexpr int CB = 64;                           // packing granularity of the output channels (U row padding)
 
-// U[xi][k][n_pad] = (G g G^T)[xi] with g = w[n][k] (forward) or the flipped w[k][n] (data gradient);
-// columns n >= N are zero.
-__global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin,
-                                    int backward, int K, int N, int Npad) {
-  const long long total = (long long)K * Npad;
+// Packed weights: U = G g G^T with g = w[n][k] (forward) or the flipped w[k][n] (data gradient), laid out in the
+// order the kernel consumes it -- [32-channel block nb][8-channel chunk c][wave w][lane][16]: the 16 floats of a
+// lane are its B operands of one chunk, U[xi = 4w + a][k = 8c + 2kpi + (lane >> 5)][n = 32nb + (lane & 31)] at
+// position 4a + kpi, so a wave fetches them with four coalesced 16-B loads per lane instead of sixteen dword loads
+// (load issue was 21-31 % of the loop, tools/dev/conv3x3_stamps.py).  Rows k >= K and columns n >= N are zero.
+__global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ P, int Cout, int Cin,
+                                    int backward, int K, int N, int nchunk, long long total) {
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(e / Npad), n = (int)(e - (long long)k * Npad);
+    const int pos = (int)(e & 15), lane = (int)((e >> 4) & 63), wv = (int)((e >> 10) & 3);
+    const long long blk = e >> 12;  // nb * nchunk + c
+    const int c = (int)(blk % nchunk), nb = (int)(blk / nchunk);
+    const int a = pos >> 2, kpi = pos & 3;
+    const int i = wv, j = a;  // xi = 4 i + j
+    const int k = 8 * c + 2 * kpi + (lane >> 5), n = 32 * nb + (lane & 31);
     float g[3][3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int q = 0; q < 3; ++q) {
         float v = 0.f;
-        if (n < N) v = backward ? w[(((long long)k * Cin + n) * 3 + (2 - i)) * 3 + (2 - j)]
-                                : w[(((long long)n * Cin + k) * 3 + i) * 3 + j];
-        g[i][j] = v;
+        if (n < N && k < K) v = backward ? w[(((long long)k * Cin + n) * 3 + (2 - p)) * 3 + (2 - q)]
+                                         : w[(((long long)n * Cin + k) * 3 + p) * 3 + q];
+        g[p][q] = v;
       }
-    float t[4][3];
+    // row i of G g (1 x 3), then column j of (.) G^T
+    float r[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      t[0][j] = g[0][j];
-      t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
-      t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
-      t[3][j] = g[2][j];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]),
-                  u3 = t[i][2];
-      U[((long long)(4 * i + 0) * K + k) * Npad + n] = u0;
-      U[((long long)(4 * i + 1) * K + k) * Npad + n] = u1;
-      U[((long long)(4 * i + 2) * K + k) * Npad + n] = u2;
-      U[((long long)(4 * i + 3) * K + k) * Npad + n] = u3;
-    }
+    for (int q = 0; q < 3; ++q)
+      r[q] = i == 0 ? g[0][q] : i == 1 ? 0.5f * (g[0][q] + g[1][q] + g[2][q])
+                              : i == 2 ? 0.5f * (g[0][q] - g[1][q] + g[2][q]) : g[2][q];
+    P[e] = j == 0 ? r[0] : j == 1 ? 0.5f * (r[0] + r[1] + r[2]) : j == 2 ? 0.5f * (r[0] - r[1] + r[2]) : r[2];
   }
 }
 
-// x [B][K][H][W], U [16][K][Npad], out [B][N][H][W]; grid = (tile blocks, Npad / CB, B).
+// Diagnostic stamps (tools/dev, -DPCFA_C3_STAMPS): per workgroup and wave, sums of the s_memtime deltas between the
+// five points of a loop iteration, written to the floats just past the output tensor's end is NOT acceptable, so
+// they go to a __device__ buffer of their own that a dev tool copies back.  Compiled out of the product build.
+#ifdef PCFA_C3_STAMPS
+__device__ unsigned long long c3_stamp_sums[8];
+__device__ __forceinline__ unsigned long long c3_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define C3_STAMP(k)                                                                              \
+  do {                                                                                           \
+    const unsigned long long now_ = c3_now();                                                    \
+    if (k != 0) stamp_acc[k] += now_ - stamp_prev;                                               \
+    stamp_prev = now_;                                                                           \
+  } while (0)
+#else
+#define C3_STAMP(k) do {} while (0)
+#endif
+
+// x [B][K][H][W], U = packed weights (above), out [B][N][H][W]; grid = (tile blocks, Npad / 32, B).
 // CBT = output channels per workgroup: 64 (128 accumulator registers per lane, one block per CU) or 32 (64
 // accumulators, 76.8 KB LDS: two blocks per CU overlap each other's staging / transform / barrier phases).
 // MT = 32-tile groups per workgroup (4 waves each): MT = 2 -> 64 tiles (16 x 16 output pixels), 8 waves sharing one
@@ -79,7 +98,7 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
 // NRING: depth of the register ring (2: <= 168 registers, 3 waves per SIMD -- large grids; 3: loads two chunks
 // ahead, 2 waves per SIMD -- small grids, where a CU holds one or two workgroups anyway and latency is all).
 template <int ACT, int CBT, int MT, bool KFULL, int NRING>  // ACT: 0 none, 1 ReLU, 2 LeakyReLU(slope)
-__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 1 && NRING == 2 ? 3 : 2))) void conv3x3_winograd_kernel(
+__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 1 && NRING == 2 && CBT == 32 ? 3 : (CBT == 64 ? 1 : 2)))) void conv3x3_winograd_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
     float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x, float slope) {
   constexpr int NT = 256 * MT;                         // threads
@@ -92,7 +111,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   // transform: every lane builds the A operands of its own MFMAs -- V[w][0..3] of (tile l31, channel kp + lh) --
   // from two patch rows (8 LDS reads, 8 adds), so there is no V image, no transform phase and ONE barrier per chunk.
   // The U operands go from L2 straight into registers (every U element is consumed by exactly one wave).
-  constexpr int NB = CBT / 32, NU = 4 * (KC / 2) * NB;  // U dwords per lane and chunk
+  constexpr int NB = CBT / 32;
   constexpr int EPI = 16 * 16 * (TB + 1);               // epilogue image
   constexpr int LDSF = 2 * RAW > EPI ? 2 * RAW : EPI;
   __shared__ __attribute__((aligned(16))) float smem[LDSF];
@@ -124,17 +143,20 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     rok[i] = e < KC * PR * PC && yy >= 0 && yy < H && xx >= 0 && xx < W;
     praw[i] = (unsigned)(min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1) + (KFULL ? rch[i] * (int)plane : 0));
   }
-  // U operand of MFMA (a, kp, b): U[xi = 4*wave + a][k = c0 + kp + lh][n0 + 32 b + l31]
-  unsigned pu[4];  // floats from U
-#pragma unroll
-  for (int a = 0; a < 4; ++a) pu[a] = (unsigned)(((4 * wave + a) * K + lh) * Npad + n0 + l31);
+  // this lane's 16 B operands of chunk c: packed[((nb * nchunk + c) * 4 + wave) * 64 + lane][16]
+  static_assert(CBT == 32, "the packed weight layout is per 32-channel block");
+  const int nchunk = (K + KC - 1) / KC;
+  const float* pu = U + (((long long)blockIdx.y * nchunk * 4 + wave) * 64 + lane) * 16;
 
   // register ring: the global loads of a chunk are issued NRING-1 chunks before its MFMAs
   float ring_raw[NRING][RAW_LOADS];
-  float ring_u[NRING][NU];
-  auto load_chunk = [&](int c0, float (&rraw)[RAW_LOADS], float (&ru)[NU]) {
+  float4 ring_u[NRING][4];
+  auto load_chunk = [&](int c0, float (&rraw)[RAW_LOADS], float4 (&ru)[4]) {
+    const float4* q = reinterpret_cast<const float4*>(pu + (long long)(c0 / KC) * (4 * 64 * 16));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ru[i] = q[i];
     if (KFULL) {
-      const unsigned xo = (unsigned)(c0 * (int)plane), uo = (unsigned)(c0 * Npad);  // wave-uniform chunk offsets
+      const unsigned xo = (unsigned)(c0 * (int)plane);  // wave-uniform chunk offset
 #pragma unroll
       for (int i = 0; i < RAW_LOADS; ++i)
 #ifdef PCFA_C3_TIMING_NO_RAW  // timing-only build (tools/dev)
@@ -142,29 +164,10 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
 #else
         rraw[i] = x[praw[i] + xo];
 #endif
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int kp = 0; kp < KC; kp += 2)
-#pragma unroll
-          for (int b = 0; b < NB; ++b)
-#ifdef PCFA_C3_TIMING_NO_U   // timing-only build (tools/dev): what the loop costs without the U operand loads
-            ru[(a * (KC / 2) + kp / 2) * NB + b] = (float)(pu[a] + uo);
-#else
-            ru[(a * (KC / 2) + kp / 2) * NB + b] = U[pu[a] + uo + (unsigned)(kp * Npad + 32 * b)];
-#endif
     } else {
 #pragma unroll
       for (int i = 0; i < RAW_LOADS; ++i)
         rraw[i] = x[praw[i] + (unsigned)(min(c0 + rch[i], K - 1) * (int)plane)];  // channels >= K: zeroed at the LDS write
-      // rows k >= K: any finite value will do (their V operand is zero); clamp the row index
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int kp = 0; kp < KC; kp += 2)
-#pragma unroll
-          for (int b = 0; b < NB; ++b)
-            ru[(a * (KC / 2) + kp / 2) * NB + b] = U[pu[a] + (unsigned)((min(c0 + kp + lh, K - 1) - lh) * Npad + 32 * b)];
     }
   };
   auto store_chunk = [&](int c0, int buf, const float (&rraw)[RAW_LOADS]) {
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   const float sa = wave == 2 ? -1.f : 1.f, sb = (wave == 1 || wave == 2) ? 1.f : -1.f;
   const int m_tile = mt * 32 + l31;
   const float* prow = sRaw + (lh * PR + 2 * (m_tile >> 3)) * PCP + 2 * (m_tile & 7);
-  auto mfma_chunk = [&](int buf, const float (&ru)[NU]) {
+  auto mfma_chunk = [&](int buf, const float4 (&ru)[4]) {
 #pragma unroll
     for (int kp = 0; kp < KC; kp += 2) {
       const float* p = prow + buf * RAW + kp * (PR * PCP);
@@ -197,17 +200,19 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
       const float t2 = fmaf(sb, b1.x, sa * a1.x), t3 = fmaf(sb, b1.y, sa * a1.y);
       const float av[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], ru[(a * (KC / 2) + kp / 2) * NB + b], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < 4; ++a) {
+        const float bv = kp == 0 ? ru[a].x : kp == 2 ? ru[a].y : kp == 4 ? ru[a].z : ru[a].w;
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv, acc[a][0], 0, 0, 0);
+      }
     }
   };
 
   // Ring slot c % NRING holds chunk c: its patch is written to LDS one iteration before its MFMAs, its U operands
   // stay in registers until the MFMAs have consumed them; the slot is reloaded (chunk c + NRING) right after.
-  const int nchunk = (K + KC - 1) / KC;
   const int lastc = (nchunk - 1) * KC;
+#ifdef PCFA_C3_STAMPS
+  unsigned long long stamp_prev = 0, stamp_acc[5] = {0, 0, 0, 0, 0};
+#endif
 #pragma unroll
   for (int j = 0; j < NRING; ++j) load_chunk(min(j * KC, lastc), ring_raw[j], ring_u[j]);
   store_chunk(0, 0, ring_raw[0]);
@@ -218,19 +223,30 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
       const int c = cbase + j;
       if (c < nchunk) {
         const int cur = c & 1, nxt = cur ^ 1;
+        C3_STAMP(0);
         mfma_chunk(cur, ring_u[j]);
         __builtin_amdgcn_sched_barrier(0);
+        C3_STAMP(1);
         // the patch of chunk c+1 was requested at the end of the previous iteration: it had this iteration's MFMA
         // phase to arrive (stored FIRST it stalled every iteration for the full load latency); its LDS buffer is
         // the one chunk c-1 used, free since the last barrier
         store_chunk((c + 1) * KC, nxt, ring_raw[(j + 1) % NRING]);  // (past the end: zeros, never read)
+        C3_STAMP(2);
         load_chunk(min((c + NRING) * KC, lastc), ring_raw[j], ring_u[j]);  // slot j is free again
+        C3_STAMP(3);
         __syncthreads();  // patch c+1 visible; everyone done with the patch of chunk c
+        C3_STAMP(4);
       }
     }
   }
 
-  // ---- epilogue: four passes of 16 output channels through LDS (the image reuses sV + sU) ----
+#ifdef PCFA_C3_STAMPS
+  if (lane == 0 && wave == 0) {
+    for (int k = 1; k < 5; ++k) atomicAdd(&c3_stamp_sums[k], stamp_acc[k]);
+    atomicAdd(&c3_stamp_sums[0], (unsigned long long)nchunk);
+  }
+#endif
+  // ---- epilogue: passes of 16 output channels through LDS (the image reuses the patch buffers) ----
   static_assert(EPI == 16 * 16 * MS, "epilogue image size");
   float* sM = smem;  // [16 xi][16 channels][MS]
   const int e_tile = tid % TB, e_cl = tid / TB;  // thread (tile, channel) and channel + 8
@@ -292,23 +308,21 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 extern "C" long long pcfa_conv3x3_packed_floats(int K, int N) {
   if (K < 1 || N < 1) return -1;
-  return 16LL * K * (((long long)N + CB - 1) / CB * CB);
+  return 16LL * (((long long)K + KC - 1) / KC * KC) * (((long long)N + CB - 1) / CB * CB);
 }
 
 extern "C" int pcfa_conv3x3_pack_weights(const float* w, float* fwd_packed, float* bwd_packed, int Cout, int Cin,
                                          void* stream) {
   if (!w || (!fwd_packed && !bwd_packed) || Cout < 1 || Cin < 1) return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (fwd_packed) {
-    const int K = Cin, N = Cout, Npad = (N + CB - 1) / CB * CB;
-    pcfa_launch(conv3x3_pack_kernel, dim3((unsigned)min(((long long)K * Npad + 255) / 256, 4096LL)), dim3(256), 0, s, w,
-                fwd_packed, Cout, Cin, 0, K, N, Npad);
-    PCFA_LAUNCH_CHECK();
-  }
-  if (bwd_packed) {
-    const int K = Cout, N = Cin, Npad = (N + CB - 1) / CB * CB;
-    pcfa_launch(conv3x3_pack_kernel, dim3((unsigned)min(((long long)K * Npad + 255) / 256, 4096LL)), dim3(256), 0, s, w,
-                bwd_packed, Cout, Cin, 1, K, N, Npad);
+  for (int dir = 0; dir < 2; ++dir) {
+    float* dst = dir == 0 ? fwd_packed : bwd_packed;
+    if (!dst) continue;
+    const int K = dir == 0 ? Cin : Cout, N = dir == 0 ? Cout : Cin;
+    const int nchunk = (K + KC - 1) / KC;
+    const long long total = pcfa_conv3x3_packed_floats(K, N);
+    pcfa_launch(conv3x3_pack_kernel, dim3((unsigned)min((total + 255) / 256, 8192LL)), dim3(256), 0, s, w, dst, Cout,
+                Cin, dir, K, N, nchunk, total);
     PCFA_LAUNCH_CHECK();
   }
   return PCFA_OK;
@@ -320,6 +334,17 @@ __global__ void leaky_relu_bwd_kernel(const float* __restrict__ out, const float
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     gx[i] = out[i] > 0.f ? g[i] : g[i] * slope;
 }
+
+#ifdef PCFA_C3_STAMPS
+extern "C" __attribute__((visibility("default"))) int dev_c3_stamps(unsigned long long* host8, int reset) {
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(c3_stamp_sums), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c3_stamp_sums), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 extern "C" int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, float* grad_x, float slope, long long n,
                                    void* stream) {
@@ -345,7 +370,7 @@ extern "C" int pcfa_conv3x3_act_fwd(const float* x, const float* packed, const f
   const long long gx = (long long)blocks_x * blocks_y;
   // 32-bit element offsets inside one image and inside the packed weights
   if (gx > 0x7fffffffLL || B > 65535 || Npad / CB > 65535 || (long long)K * H * W > 0x7fffffffLL ||
-      16LL * K * Npad > 0x7fffffffLL)
+      pcfa_conv3x3_packed_floats(K, N) > 0x7fffffffLL)
     return PCFA_ERR_UNSUPPORTED;
   dim3 grid((unsigned)gx, Npad / CB, B), block(256);
   hipStream_t s = (hipStream_t)stream;
