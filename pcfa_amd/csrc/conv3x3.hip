@@ -191,11 +191,23 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   const int m_tile = mt * 32 + l31;
   const float* prow = sRaw + (lh * PR + 2 * (m_tile >> 3)) * PCP + 2 * (m_tile & 7);
   auto mfma_chunk = [&](int buf, const float4 (&ru)[4]) {
+    // the patch rows of channel pair kp+2 are requested BEFORE the MFMAs of pair kp are issued: an in-order wave
+    // otherwise starts the LDS reads only after its fourth MFMA has left the issue stage and the matrix pipe
+    // idles for the LDS latency in every pair (stamps: 2000 cycles for 1024 cycles of MFMA work)
+    const float* p0 = prow + buf * RAW;
+    float2 a0 = *reinterpret_cast<const float2*>(p0 + ra * PCP), a1 = *reinterpret_cast<const float2*>(p0 + ra * PCP + 2);
+    float2 b0 = *reinterpret_cast<const float2*>(p0 + rb * PCP), b1 = *reinterpret_cast<const float2*>(p0 + rb * PCP + 2);
 #pragma unroll
     for (int kp = 0; kp < KC; kp += 2) {
-      const float* p = prow + buf * RAW + kp * (PR * PCP);
-      const float2 a0 = *reinterpret_cast<const float2*>(p + ra * PCP), a1 = *reinterpret_cast<const float2*>(p + ra * PCP + 2);
-      const float2 b0 = *reinterpret_cast<const float2*>(p + rb * PCP), b1 = *reinterpret_cast<const float2*>(p + rb * PCP + 2);
+      float2 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+      if (kp + 2 < KC) {
+        const float* p = p0 + (kp + 2) * (PR * PCP);
+        na0 = *reinterpret_cast<const float2*>(p + ra * PCP);
+        na1 = *reinterpret_cast<const float2*>(p + ra * PCP + 2);
+        nb0 = *reinterpret_cast<const float2*>(p + rb * PCP);
+        nb1 = *reinterpret_cast<const float2*>(p + rb * PCP + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       const float t0 = fmaf(sb, b0.x, sa * a0.x), t1 = fmaf(sb, b0.y, sa * a0.y);
       const float t2 = fmaf(sb, b1.x, sa * a1.x), t3 = fmaf(sb, b1.y, sa * a1.y);
       const float av[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
@@ -204,6 +216,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
         const float bv = kp == 0 ? ru[a].x : kp == 2 ? ru[a].y : kp == 4 ? ru[a].z : ru[a].w;
         acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv, acc[a][0], 0, 0, 0);
       }
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
   };
 
