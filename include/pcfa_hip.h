@@ -142,6 +142,57 @@ PCFA_API int pcfa_spatial_corr_bwd(const float* in1, const float* in2, const flo
                           int dil_patchH, int dil_patchW, int dH, int dW, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * FlowNet2's native operators (CUDA-only extensions in the
+ * reference, no CPU build exists there).
+ *
+ * Correlation -- replaces correlation_cuda.forward / .backward
+ * (models/FlowNet/correlation_package/correlation_cuda.cc:10-87,89-167; kernels
+ * correlation_cuda_kernel.cu:74-147,150-333; Python side correlation.py:10-67).
+ * Same five integers in the same order (corr_multiply is ignored by the reference
+ * kernels and has no counterpart).  in1,in2: [B][C][H][W];
+ * out / grad_out: [B][D*D][oH][oW], D = 2*(max_displacement/stride2)+1,
+ * oH = ceil((H + 2*pad_size - 2*((kernel_size-1)/2 + max_displacement)) / stride1):
+ *   out[b][tj*D+ti][y][x] = 1/(k*k*C) * sum_{j,i,c} P1[c][y*s1+md+j][x*s1+md+i]
+ *                                                 * P2[c][y*s1+md+(tj-D/2)*s2+j][x*s1+md+(ti-D/2)*s2+i]
+ * with P = input zero-padded by pad_size.  The reference materialises P1/P2 as
+ * channels-last copies (rbot1/rbot2, caller-provided and resize_d); here padding is
+ * a load predicate and the two scratch tensors do not exist.  Outputs are fully
+ * overwritten (no pre-zeroing).  Backward: stride1 == 1 only (PCFA_ERR_UNSUPPORTED
+ * otherwise; FlowNetC.py:31-35 is the only call site and uses 20,1,20,1,2).
+ *
+ * Resample2d -- replaces resample2d_cuda.forward / .backward
+ * (resample2d_package/resample2d_cuda.cc:6-24, resample2d_kernel.cu:16-72,75-201).
+ * in1: [B][C][iH][iW]; flow: [B][2][H][W] (x, y displacement in pixels);
+ * out / grad_out: [B][C][H][W].  kernel_size must be 1 (the value FlowNet2 uses;
+ * larger values read past the border in the reference) and H <= iH, W <= iW.
+ * pcfa_resample2d_bwd zeroes grad_in1 itself (hipMemsetAsync on `stream`) and
+ * scatters with hardware fp32 atomics like the reference's atomicAdd, so the last
+ * bits of grad_in1 depend on the order of arrival; grad_flow is a gather.
+ *
+ * ChannelNorm -- replaces channelnorm_cuda.forward / .backward
+ * (channelnorm_package/channelnorm_cuda.cc:6-25, channelnorm_kernel.cu:18-60,63-96).
+ * in: [B][C][plane]; out: [B][1][plane] = sqrt(sum_c in^2);
+ * grad_in = grad_out * in / (out + 1e-9).  norm_deg must be 2 (the reference ignores it).
+ * ------------------------------------------------------------------------- */
+PCFA_API int pcfa_flownet_corr_out_size(int H, int W, int pad_size, int kernel_size, int max_displacement,
+                                        int stride1, int stride2, int* out_channels, int* oH, int* oW);
+PCFA_API int pcfa_flownet_corr_fwd(const float* in1, const float* in2, float* out, int B, int C, int H, int W,
+                                   int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                   void* stream);
+PCFA_API int pcfa_flownet_corr_bwd(const float* in1, const float* in2, const float* grad_out, float* grad_in1,
+                                   float* grad_in2, int B, int C, int H, int W, int pad_size, int kernel_size,
+                                   int max_displacement, int stride1, int stride2, void* stream);
+PCFA_API int pcfa_resample2d_fwd(const float* in1, const float* flow, float* out, int B, int C, int iH, int iW,
+                                 int H, int W, int kernel_size, int bilinear, void* stream);
+PCFA_API int pcfa_resample2d_bwd(const float* in1, const float* flow, const float* grad_out, float* grad_in1,
+                                 float* grad_flow, int B, int C, int iH, int iW, int H, int W, int kernel_size,
+                                 int bilinear, void* stream);
+PCFA_API int pcfa_channelnorm_fwd(const float* in, float* out, int B, int C, long long plane, int norm_deg,
+                                  void* stream);
+PCFA_API int pcfa_channelnorm_bwd(const float* in, const float* out, const float* grad_out, float* grad_in, int B,
+                                  int C, long long plane, int norm_deg, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Attack math (fused elementwise + reductions).
  * ------------------------------------------------------------------------- */
 

@@ -199,6 +199,235 @@ def spatial_correlation_shift_sum(input1, input2, patch_size=9):
 
 
 # --------------------------------------------------------------------------- #
+# FlowNet2's native operators.  The reference has them as CUDA extensions only (no CPU build, nothing to run
+# here): the functions below restate the CUDA kernels operation by operation.  PARITY UNPINNED for Resample2d and
+# ChannelNorm (no reference output exists on this machine); the correlation is cross-pinned against the
+# reference's own C++ sampler (patch 21, dilation_patch 2, k = 1), tests/test_oracle_cpu.py.
+# --------------------------------------------------------------------------- #
+def _shift2d(t, dy, dx):
+    """out[..., y, x] = t[..., y + dy, x + dx], zero outside."""
+    H, W = t.shape[-2:]
+    out = torch.zeros_like(t)
+    ys, ye = max(0, -dy), min(H, H - dy)
+    xs, xe = max(0, -dx), min(W, W - dx)
+    if ys < ye and xs < xe:
+        out[..., ys:ye, xs:xe] = t[..., ys + dy:ye + dy, xs + dx:xe + dx]
+    return out
+
+
+def _fcorr_geometry(H, W, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """correlation_cuda.cc:25-35."""
+    kr = (kernel_size - 1) // 2
+    border = kr + max_displacement
+    oH = math.ceil(float(H + 2 * pad_size - 2 * border) / float(stride1))
+    oW = math.ceil(float(W + 2 * pad_size - 2 * border) / float(stride1))
+    drad = max_displacement // stride2
+    return kr, oH, oW, drad, 2 * drad + 1
+
+
+def flownet_corr_forward(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """correlation_cuda_kernel.cu:74-147: products over the zero-padded inputs, divided by k*k*C."""
+    B, C, H, W = input1.shape
+    kr, oH, oW, drad, D = _fcorr_geometry(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    m = pad_size + kr + drad * stride2  # generous zero margin; index = padded index + (m - pad_size)
+    P1 = F.pad(input1, (m, m, m, m))
+    P2 = F.pad(input2, (m, m, m, m))
+    off = m - pad_size
+    out = torch.zeros((B, D * D, oH, oW), dtype=input1.dtype)
+    ys = max_displacement + off
+    for tj in range(-drad, drad + 1):
+        for ti in range(-drad, drad + 1):
+            acc = torch.zeros((B, oH, oW), dtype=input1.dtype)
+            for j in range(-kr, kr + 1):
+                for i in range(-kr, kr + 1):
+                    a = P1[:, :, ys + j:ys + j + (oH - 1) * stride1 + 1:stride1,
+                           ys + i:ys + i + (oW - 1) * stride1 + 1:stride1]
+                    y2, x2 = ys + tj * stride2 + j, ys + ti * stride2 + i
+                    b = P2[:, :, y2:y2 + (oH - 1) * stride1 + 1:stride1, x2:x2 + (oW - 1) * stride1 + 1:stride1]
+                    acc = acc + (a * b).sum(1)
+            out[:, (tj + drad) * D + (ti + drad)] = acc / float(kernel_size * kernel_size * C)
+    return out
+
+
+def flownet_corr_backward(input1, input2, grad_output, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """correlation_cuda_kernel.cu:150-241 (input1), :243-333 (input2); stride1 = 1."""
+    assert stride1 == 1
+    B, C, H, W = input1.shape
+    kr, oH, oW, drad, D = _fcorr_geometry(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    nelems = float(kernel_size * kernel_size * C)
+    off = pad_size - max_displacement
+    # S[tc][y][x] = sum of grad_output[tc] over the window [y+off-kr, y+off+kr] x [x+off-kr, x+off+kr],
+    # clipped to the output (the xmin/xmax/ymin/ymax logic of :173-193)
+    Lp = max(0, kr - off)
+    Rh = max(0, H - 1 + off + kr - (oH - 1))
+    Rw = max(0, W - 1 + off + kr - (oW - 1))
+    gp = F.pad(grad_output, (Lp, Rw, Lp, Rh))
+    box = F.avg_pool2d(gp, kernel_size, stride=1) * float(kernel_size * kernel_size) if kernel_size > 1 else gp
+    s0 = off - kr + Lp
+    S = box[:, :, s0:s0 + H, s0:s0 + W]
+    g1 = torch.zeros_like(input1)
+    g2 = torch.zeros_like(input2)
+    for tc in range(D * D):
+        i2 = (tc % D - drad) * stride2
+        j2 = (tc // D - drad) * stride2
+        w = S[:, tc:tc + 1]
+        g1 = g1 + w * _shift2d(input2, j2, i2)
+        g2 = g2 + _shift2d(w * input1, -j2, -i2)
+    return g1 / nelems, g2 / nelems
+
+
+class _FlownetCorr(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input1, input2, *geom):
+        ctx.save_for_backward(input1, input2)
+        ctx.geom = geom
+        return flownet_corr_forward(input1, input2, *geom)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        g1, g2 = flownet_corr_backward(*ctx.saved_tensors, grad_output, *ctx.geom)
+        return g1, g2, None, None, None, None, None
+
+
+def flownet_correlation(input1, input2, pad_size=0, kernel_size=0, max_displacement=0, stride1=1, stride2=2,
+                        corr_multiply=1):
+    """correlation_package/correlation.py:53-67 (corr_multiply is ignored by the reference kernels)."""
+    return _FlownetCorr.apply(input1.contiguous(), input2.contiguous(), pad_size, kernel_size, max_displacement,
+                              stride1, stride2)
+
+
+def _rs_taps(xf, yf, h, w):
+    """resample2d_kernel.cu:50-53: the four neighbour indices, each clamped on its own."""
+    fx, fy = torch.floor(xf), torch.floor(yf)
+    xL = fx.long().clamp(0, w - 1)
+    xR = (fx + 1).long().clamp(0, w - 1)
+    yT = fy.long().clamp(0, h - 1)
+    yB = (fy + 1).long().clamp(0, h - 1)
+    return xL, xR, yT, yB, xf - fx, yf - fy
+
+
+def _rs_positions(flow):
+    B, _, H, W = flow.shape
+    xs = torch.arange(W, dtype=torch.float32).view(1, 1, W)
+    ys = torch.arange(H, dtype=torch.float32).view(1, H, 1)
+    return xs + flow[:, 0], ys + flow[:, 1]
+
+
+def _rs_gather(img, yy, xx):
+    """img [B,C,iH,iW], yy/xx [B,H,W] long -> [B,C,H,W]."""
+    B, C, iH, iW = img.shape
+    lin = (yy * iW + xx).view(B, 1, -1).expand(B, C, -1)
+    return img.reshape(B, C, -1).gather(2, lin).view(B, C, *yy.shape[1:])
+
+
+def resample2d_forward(input1, flow, kernel_size=1, bilinear=True):
+    """resample2d_kernel.cu:16-72 (kernel_size 1)."""
+    assert kernel_size == 1
+    B, C, iH, iW = input1.shape
+    H, W = flow.shape[-2:]
+    xf, yf = _rs_positions(flow)
+    if not bilinear:
+        xN = torch.floor(xf + 0.5).long().clamp(0, W - 1)
+        yN = torch.floor(yf + 0.5).long().clamp(0, H - 1)
+        return _rs_gather(input1, yN, xN)
+    xL, xR, yT, yB, alpha, beta = _rs_taps(xf, yf, H, W)
+    a, b = alpha.double().unsqueeze(1), beta.double().unsqueeze(1)
+    img = input1.double()
+    val = torch.zeros((B, C, H, W), dtype=torch.float32)
+    val = val + ((1. - a) * (1. - b) * _rs_gather(img, yT, xL)).float()
+    val = val + (a * (1. - b) * _rs_gather(img, yT, xR)).float()
+    val = val + ((1. - a) * b * _rs_gather(img, yB, xL)).float()
+    val = val + (a * b * _rs_gather(img, yB, xR)).float()
+    return val
+
+
+def resample2d_backward(input1, flow, grad_output):
+    """resample2d_kernel.cu:75-123 (input1, scatter-add) and :125-201 (flow)."""
+    B, C, iH, iW = input1.shape
+    H, W = flow.shape[-2:]
+    xf, yf = _rs_positions(flow)
+    g = grad_output
+    # input1: weights from truncation (xf - int(xf), :103-104), indices clamped against the input size
+    xL, xR, yT, yB, _, _ = _rs_taps(xf, yf, iH, iW)
+    a = (xf - torch.trunc(xf)).unsqueeze(1)
+    b = (yf - torch.trunc(yf)).unsqueeze(1)
+    g1 = torch.zeros((B, C, iH * iW), dtype=torch.float32)
+    for yy, xx, wgt in ((yT, xL, (1 - a) * (1 - b)), (yT, xR, a * (1 - b)), (yB, xL, (1 - a) * b),
+                        (yB, xR, a * b)):
+        lin = (yy * iW + xx).view(B, 1, -1).expand(B, C, -1)
+        g1.scatter_add_(2, lin, (wgt * g).reshape(B, C, -1))
+    g1 = g1.view(B, C, iH, iW)
+    # flow: indices clamped against the flow size, gamma = 1 - fraction (:159-197)
+    xL, xR, yT, yB, alpha, beta = _rs_taps(xf, yf, H, W)
+    iTL, iTR = _rs_gather(input1, yT, xL), _rs_gather(input1, yT, xR)
+    iBL, iBR = _rs_gather(input1, yB, xL), _rs_gather(input1, yB, xR)
+    gx_, gy_ = (1 - beta).unsqueeze(1), (1 - alpha).unsqueeze(1)  # gamma of channel 0 (dx) / channel 1 (dy)
+    gdx = torch.zeros((B, H, W), dtype=torch.float32)
+    gdy = torch.zeros((B, H, W), dtype=torch.float32)
+    for c in range(C):
+        gv = g[:, c]
+        gdx = gdx + gx_[:, 0] * gv * iTR[:, c]
+        gdx = gdx - gx_[:, 0] * gv * iTL[:, c]
+        gdx = gdx + (1 - gx_[:, 0]) * gv * iBR[:, c]
+        gdx = gdx - (1 - gx_[:, 0]) * gv * iBL[:, c]
+        gdy = gdy + gy_[:, 0] * gv * iBL[:, c]
+        gdy = gdy - gy_[:, 0] * gv * iTL[:, c]
+        gdy = gdy + (1 - gy_[:, 0]) * gv * iBR[:, c]
+        gdy = gdy - (1 - gy_[:, 0]) * gv * iTR[:, c]
+    return g1, torch.stack((gdx, gdy), 1)
+
+
+class _Resample2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input1, flow, kernel_size, bilinear):
+        ctx.save_for_backward(input1, flow)
+        return resample2d_forward(input1, flow, kernel_size, bilinear)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        g1, g2 = resample2d_backward(*ctx.saved_tensors, grad_output)
+        return g1, g2, None, None
+
+
+def resample2d(input1, input2, kernel_size=1, bilinear=True):
+    """resample2d_package/resample2d.py:45-56."""
+    return _Resample2d.apply(input1.contiguous(), input2.contiguous(), kernel_size, bilinear)
+
+
+def channelnorm_forward(input1):
+    """channelnorm_kernel.cu:18-60: sqrt of the sum of squares over channels, accumulated in channel order."""
+    r = torch.zeros_like(input1[:, 0])
+    for c in range(input1.shape[1]):
+        r = r + input1[:, c] * input1[:, c]
+    return torch.sqrt(r).unsqueeze(1)
+
+
+def channelnorm_backward(input1, out, grad_output):
+    """channelnorm_kernel.cu:63-96: float product / (double(norm) + 1e-9)."""
+    return ((grad_output * input1).double() / (out.double() + 1e-9)).float()
+
+
+class _ChannelNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input1):
+        out = channelnorm_forward(input1)
+        ctx.save_for_backward(input1, out)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        return channelnorm_backward(*ctx.saved_tensors, grad_output)
+
+
+def channelnorm(input1, norm_deg=2):
+    """channelnorm_package/channelnorm.py:38-45 (the kernels ignore norm_deg)."""
+    return _ChannelNorm.apply(input1.contiguous())
+
+
+# --------------------------------------------------------------------------- #
 # SepConvGRU gate arithmetic
 # --------------------------------------------------------------------------- #
 def _cb(bias):

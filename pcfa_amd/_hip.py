@@ -40,6 +40,13 @@ SIGNATURES = {
     "pcfa_spatial_corr_out_size": (c_int, [c_int] * 10 + [POINTER(c_int), POINTER(c_int)]),
     "pcfa_spatial_corr_fwd": (c_int, [_P, _P, _P] + [c_int] * 16 + [_P]),
     "pcfa_spatial_corr_bwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 16 + [_P]),
+    "pcfa_flownet_corr_out_size": (c_int, [c_int] * 7 + [POINTER(c_int)] * 3),
+    "pcfa_flownet_corr_fwd": (c_int, [_P, _P, _P] + [c_int] * 9 + [_P]),
+    "pcfa_flownet_corr_bwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
+    "pcfa_resample2d_fwd": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P]),
+    "pcfa_resample2d_bwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    "pcfa_channelnorm_fwd": (c_int, [_P, _P, c_int, c_int, c_longlong, c_int, _P]),
+    "pcfa_channelnorm_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_longlong, c_int, _P]),
     "pcfa_box_transform_fwd": (c_int, [_P, _P, _P, c_int, c_longlong, c_int, c_double, c_float, _P]),
     "pcfa_box_transform_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_longlong, c_int, c_double, c_float, _P]),
     "pcfa_extract_deltas_fwd": (c_int, [_P, _P, _P, c_longlong, c_int, c_double, _P]),

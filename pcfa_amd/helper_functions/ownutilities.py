@@ -99,8 +99,12 @@ def build_network(net, weights="pretrained", device=torch.device("cpu")):
                 for p in model.parameters():
                     p.data.normal_(0.0, 0.02)
         elif net == 'FlowNet2':
-            raise NotImplementedError(
-                "FlowNet2 needs the correlation/resample2d/channelnorm trio (SURVEY.md section 8f, next)")
+            from ..nets.flownet2 import FlowNet2
+            # configuration hard-coded by the reference: fp16=False, rgb_max=255, div_flow=20, batchNorm=False
+            model = FlowNet2(rgb_max=255.0, div_flow=20.)
+            if seed is None:
+                state = torch.load(os.path.join(wdir, 'FlowNet2_checkpoint.pth.tar'), map_location=device)
+                model.load_state_dict(state['state_dict'])
         else:
             raise RuntimeWarning('The network %s is not a valid model option for import_and_load(network). '
                                  'No model was loaded. Use "RAFT", "GMA", "FlowNetC", "PWCNet" or "SpyNet" instead.'
@@ -167,7 +171,12 @@ def compute_flow(model, network, x1, x2, test_mode=True, **kwargs):
     elif network == 'GMA':
         _, flow = model(x1, x2, iters=6, test_mode=test_mode, **kwargs)
     elif network[:7] == 'FlowNet':
-        raise NotImplementedError("FlowNet variants are not part of this build (SURVEY.md section 8f)")
+        # [B, 3, 2, H, W]; FlowNet2 takes [0,255] images and removes the mean itself (FlowNet2.py:116-118)
+        x = torch.stack((x1, x2), dim=-3)
+        if not network[:8] == 'FlowNet2':
+            rgb_mean = x.contiguous().view(x.size()[:2] + (-1,)).mean(dim=-1).view(x.size()[:2] + (1, 1, 1,)).detach()
+            x = x - rgb_mean
+        flow = model(x)
     else:  # PWCNet, SpyNet
         flow = model(x1, x2, **kwargs)
     return flow

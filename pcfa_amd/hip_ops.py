@@ -8,6 +8,7 @@ the surrounding MIOpen/hipBLASLt work and can be captured into a hipGraph.
 Operator boundaries mirrored (reference file:line):
   CorrBlock                      models/raft/corr.py:12-60 (== models/gma/corr.py:15-63)
   spatial_correlation_sample     .../spatial_correlation_sampler/spatial_correlation_sampler.py:9-91
+  flownet_correlation, resample2d, channelnorm   models/FlowNet/{correlation,resample2d,channelnorm}_package/*.py
   box_transform                  helper_functions/own_models.py:62-85
   extract_deltas(_joint)         attack_PCFA.py:20-37
   loss_delta_constraint, avg_epe, two_norm_*   helper_functions/losses.py
@@ -87,6 +88,12 @@ class DispatchTimer:
         "pcfa_corr_f2ext_fwd": [("corr_f2ext_fwd", 0)],
         "pcfa_spatial_corr_fwd": [("spatial_corr_fwd", 0)],
         "pcfa_spatial_corr_bwd": [("spatial_corr_bwd_in1", 0), ("spatial_corr_bwd_in2", 1)],
+        "pcfa_flownet_corr_fwd": [("flownet_corr_fwd", 0)],
+        "pcfa_flownet_corr_bwd": [("flownet_corr_bwd_in1", 0), ("flownet_corr_bwd_in2", 1)],
+        "pcfa_resample2d_fwd": [("resample2d_fwd", 0)],
+        "pcfa_resample2d_bwd": [("resample2d_bwd", 0)],
+        "pcfa_channelnorm_fwd": [("channelnorm_fwd", 0)],
+        "pcfa_channelnorm_bwd": [("channelnorm_bwd", 0)],
         "pcfa_box_transform_fwd": [("box_transform_fwd", 0)],
         "pcfa_box_transform_bwd": [("box_transform_bwd", 0)],
         "pcfa_flow_loss_fwd": [("flow_loss_partial", 0)],
@@ -344,6 +351,110 @@ def spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=1, stri
                                dilation_patch=1):
     return SpatialCorrelationSamplerFunction.apply(input1, input2, kernel_size, patch_size, stride, padding,
                                                    dilation, dilation_patch)
+
+
+# --------------------------------------------------------------------------- #
+# FlowNet2's native operators (models/FlowNet/{correlation,resample2d,channelnorm}_package)
+# --------------------------------------------------------------------------- #
+class CorrelationFunction(torch.autograd.Function):
+    """correlation_package/correlation.py:10-51 on pcfa_flownet_corr_fwd/bwd (no rbot1/rbot2 scratch copies)."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, pad_size=3, kernel_size=3, max_displacement=20, stride1=1, stride2=2,
+                corr_multiply=1):
+        _dev(input1, input2)
+        input1, input2 = input1.contiguous(), input2.contiguous()
+        if input1.shape != input2.shape or input1.dim() != 4:
+            raise RuntimeError("Correlation: inputs must be two [B,C,H,W] tensors of the same shape")
+        lib = _hip.load()
+        B, C, H, W = input1.shape
+        ctx.params = (B, C, H, W, int(pad_size), int(kernel_size), int(max_displacement), int(stride1), int(stride2))
+        oc, oH, oW = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _hip.check(lib.pcfa_flownet_corr_out_size(H, W, *ctx.params[4:], ctypes.byref(oc), ctypes.byref(oH),
+                                                  ctypes.byref(oW)), "pcfa_flownet_corr_out_size")
+        out = torch.empty((B, oc.value, oH.value, oW.value), device=input1.device, dtype=torch.float32)
+        _call("pcfa_flownet_corr_fwd", _ptr(input1), _ptr(input2), _ptr(out), *ctx.params)
+        ctx.save_for_backward(input1, input2)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        input1, input2 = ctx.saved_tensors
+        g = grad_output.contiguous()
+        g1, g2 = torch.empty_like(input1), torch.empty_like(input2)
+        _call("pcfa_flownet_corr_bwd", _ptr(input1), _ptr(input2), _ptr(g), _ptr(g1), _ptr(g2), *ctx.params)
+        return g1, g2, None, None, None, None, None, None
+
+
+def flownet_correlation(input1, input2, pad_size=0, kernel_size=0, max_displacement=0, stride1=1, stride2=2,
+                        corr_multiply=1):
+    """Correlation.forward (correlation_package/correlation.py:53-67)."""
+    return CorrelationFunction.apply(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2,
+                                     corr_multiply)
+
+
+class Resample2dFunction(torch.autograd.Function):
+    """resample2d_package/resample2d.py:12-43."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, kernel_size=1, bilinear=True):
+        _dev(input1, input2)
+        if not (input1.is_contiguous() and input2.is_contiguous()):
+            raise AssertionError("Resample2d: inputs must be contiguous")  # the reference asserts (resample2d.py:16-17)
+        B, C, iH, iW = input1.shape
+        b, two, H, W = input2.shape
+        if b != B or two != 2:
+            raise RuntimeError("Resample2d: flow must be [B,2,H,W] with the batch size of input1")
+        out = torch.empty((B, C, H, W), device=input1.device, dtype=torch.float32)
+        ctx.params = (B, C, iH, iW, H, W, int(kernel_size), int(bool(bilinear)))
+        _call("pcfa_resample2d_fwd", _ptr(input1), _ptr(input2), _ptr(out), *ctx.params)
+        ctx.save_for_backward(input1, input2)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        input1, input2 = ctx.saved_tensors
+        g = grad_output.contiguous()
+        g1, g2 = torch.empty_like(input1), torch.empty_like(input2)
+        _call("pcfa_resample2d_bwd", _ptr(input1), _ptr(input2), _ptr(g), _ptr(g1), _ptr(g2), *ctx.params)
+        return g1, g2, None, None
+
+
+def resample2d(input1, input2, kernel_size=1, bilinear=True):
+    """Resample2d.forward (resample2d_package/resample2d.py:45-56)."""
+    return Resample2dFunction.apply(input1.contiguous(), input2, kernel_size, bilinear)
+
+
+class ChannelNormFunction(torch.autograd.Function):
+    """channelnorm_package/channelnorm.py:11-36."""
+
+    @staticmethod
+    def forward(ctx, input1, norm_deg=2):
+        _dev(input1)
+        if not input1.is_contiguous():
+            raise AssertionError("ChannelNorm: input must be contiguous")  # channelnorm.py:15
+        B, C, H, W = input1.shape
+        out = torch.empty((B, 1, H, W), device=input1.device, dtype=torch.float32)
+        ctx.params = (B, C, H * W, int(norm_deg))
+        _call("pcfa_channelnorm_fwd", _ptr(input1), _ptr(out), *ctx.params)
+        ctx.save_for_backward(input1, out)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        input1, out = ctx.saved_tensors
+        g = grad_output.contiguous()
+        g1 = torch.empty_like(input1)
+        _call("pcfa_channelnorm_bwd", _ptr(input1), _ptr(out), _ptr(g), _ptr(g1), *ctx.params)
+        return g1, None
+
+
+def channelnorm(input1, norm_deg=2):
+    """ChannelNorm.forward (channelnorm_package/channelnorm.py:38-45)."""
+    return ChannelNormFunction.apply(input1, norm_deg)
 
 
 # --------------------------------------------------------------------------- #

@@ -20,6 +20,14 @@ Fixtures:
   attack_math.npz         losses / extract_deltas / ScaledInputModel prologue
   closure_<net>.npz       one PCFA closure: flow, loss, d loss / d nw_input  (128x160 or 128x192)
   trajectory_raft.npz     5-step pcfa_attack, at 8 and at 3 CPU threads (noise floor)
+  closure_flownet2.npz    one PCFA closure of FlowNet2 (128x192).  WIRING ONLY: the reference's Python model code
+                          (models/FlowNet/FlowNet2.py, FlowNetC/S/SD/Fusion.py, submodules.py and the three
+                          autograd Functions correlation.py / resample2d.py / channelnorm.py) runs for real, but its
+                          CUDA-only extension modules correlation_cuda / resample2d_cuda / channelnorm_cuda cannot be
+                          built here (no CUDA), so those three module names are bound to the oracle restatement
+                          (oracle/ops.py).  The fixture therefore pins layer wiring, parameter names, pre-/post-
+                          processing and autograd plumbing -- NOT the arithmetic of the three operators, which stays
+                          "parity unpinned" (cross-checked against the pinned C++ sampler instead).
 """
 import importlib
 import os
@@ -68,6 +76,49 @@ def install_stubs():
     torch.Tensor.cuda = lambda self, *a, **k: self  # models/PWCNet/PWCNet.py:194
 
 
+def install_flownet_extension_bindings():
+    """Bind the names of the reference's three CUDA-only extension modules to the oracle (see module docstring:
+    wiring-only fixture).  Signatures: correlation_cuda.cc:10-16,89-96; resample2d_cuda.cc:6-24;
+    channelnorm_cuda.cc:6-25 -- caller-allocated outputs that the callee resizes / fills."""
+    from oracle import ops as O
+
+    def corr_fwd(i1, i2, rbot1, rbot2, output, pad, k, md, s1, s2, mult):
+        res = O.flownet_corr_forward(i1, i2, pad, k, md, s1, s2)
+        output.resize_(res.shape).copy_(res)
+        return 1
+
+    def corr_bwd(i1, i2, rbot1, rbot2, gout, g1, g2, pad, k, md, s1, s2, mult):
+        a, b = O.flownet_corr_backward(i1, i2, gout, pad, k, md, s1, s2)
+        g1.resize_(a.shape).copy_(a)
+        g2.resize_(b.shape).copy_(b)
+        return 1
+
+    def rs_fwd(i1, i2, output, kernel_size, bilinear):
+        output.copy_(O.resample2d_forward(i1, i2, kernel_size, bilinear))
+        return 1
+
+    def rs_bwd(i1, i2, gout, g1, g2, kernel_size, bilinear):
+        a, b = O.resample2d_backward(i1, i2, gout)
+        g1.copy_(a)
+        g2.copy_(b)
+        return 1
+
+    def cn_fwd(i1, output, norm_deg):
+        output.copy_(O.channelnorm_forward(i1))
+        return 1
+
+    def cn_bwd(i1, output, gout, g1, norm_deg):
+        g1.copy_(O.channelnorm_backward(i1, output, gout))
+        return 1
+
+    for name, fwd, bwd in (("correlation_cuda", corr_fwd, corr_bwd), ("resample2d_cuda", rs_fwd, rs_bwd),
+                           ("channelnorm_cuda", cn_fwd, cn_bwd)):
+        m = types.ModuleType(name)
+        m.forward, m.backward = fwd, bwd
+        sys.modules[name] = m
+    # correlation.py:23 wraps the call in `torch.cuda.device_of(tensor)`, a no-op context for CPU tensors
+
+
 def product_state(net):
     from pcfa_amd.helper_functions import ownutilities as own
     model = own.build_network(net, weights="random:%d" % WEIGHT_SEED)
@@ -85,7 +136,7 @@ class patched_torch_load:
         path = str(path)
         if self.net in ("RAFT", "GMA"):
             return {"module." + k_: v for k_, v in self.state.items()}
-        if self.net == "PWCNet":
+        if self.net in ("PWCNet", "FlowNet2"):
             return {"state_dict": self.state}
         # SpyNet: .../modelL{level+1}_F-{conv+1}-{weight|bias}.pth.tar   (models/SpyNet/SpyNet.py:77-81)
         base = os.path.basename(path)
@@ -300,6 +351,11 @@ def golden_closures():
     save("closure_spynet", **closure_case("SpyNet", 100, 150, "change_of_variables", False, "zero", "mse", 4))
 
 
+def golden_flownet2():
+    install_flownet_extension_bindings()
+    save("closure_flownet2", **closure_case("FlowNet2", 128, 192, "change_of_variables", False, "zero", "aee", 5))
+
+
 def golden_trajectory():
     import attack_PCFA
     from argparse import Namespace
@@ -323,7 +379,7 @@ def golden_trajectory():
 if __name__ == "__main__":
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["corr", "scorr", "math", "closures", "trajectory"]
+    which = sys.argv[1:] or ["corr", "scorr", "math", "closures", "trajectory", "flownet2"]
     if "corr" in which:
         golden_corr_block()
     if "scorr" in which:
@@ -334,3 +390,5 @@ if __name__ == "__main__":
         golden_closures()
     if "trajectory" in which:
         golden_trajectory()
+    if "flownet2" in which:
+        golden_flownet2()

@@ -53,6 +53,15 @@ def test_host_only_entry_points():
     oh, ow = ctypes.c_int(), ctypes.c_int()
     assert lib.pcfa_spatial_corr_out_size(11, 9, 3, 3, 1, 1, 1, 1, 2, 2, ctypes.byref(oh), ctypes.byref(ow)) == 0
     assert (oh.value, ow.value) == (6, 5)
+    oc = ctypes.c_int()
+    # FlowNetC's layer at 448x1024 / 8 (correlation_cuda.cc:25-35): 441 x 56 x 128
+    assert lib.pcfa_flownet_corr_out_size(56, 128, 20, 1, 20, 1, 2, ctypes.byref(oc), ctypes.byref(oh),
+                                          ctypes.byref(ow)) == 0
+    assert (oc.value, oh.value, ow.value) == (441, 56, 128)
+    assert lib.pcfa_flownet_corr_out_size(10, 12, 2, 1, 4, 1, 2, ctypes.byref(oc), ctypes.byref(oh),
+                                          ctypes.byref(ow)) == 0
+    assert (oc.value, oh.value, ow.value) == (25, 6, 8)
+    assert lib.pcfa_flownet_corr_out_size(10, 12, 0, 2, 4, 1, 2, None, None, None) == -1  # even kernel_size
     assert lib.pcfa_status_string(-2).decode().startswith("unsupported")
     # argument validation happens before any launch
     assert lib.pcfa_corr_lookup_fwd(None, None, None, 1, 8, 8, 4, 4, None) == -1

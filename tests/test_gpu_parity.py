@@ -196,6 +196,105 @@ def test_spatial_corr_pwc_levels_vs_oracle(oracle_ops, shape):
     assert torch.equal(ag2.grad, ag.grad) and torch.equal(bg2.grad, bg.grad)
 
 
+# --------------------------------------------------------------------------- FlowNet2's three operators
+# Oracle = restatement of the CUDA kernels (no reference output exists: CUDA-only extensions), correlation
+# cross-pinned against the reference's C++ sampler in tests/test_oracle_cpu.py.  Tolerances: correlation
+# 2e-6 * C * max|out| (summation order over C), gradients 1e-5 relative L2; Resample2d forward 1e-6 * max|img|
+# (same operation order, fma contraction aside), backward 1e-5 relative L2 (atomic arrival order); ChannelNorm 2e-7.
+@pytest.mark.parametrize("shape", [(1, 32, 24, 40), (2, 19, 13, 37), (1, 8, 8, 32), (1, 256, 56, 128)])
+def test_flownet_corr_fast_path_vs_oracle(oracle_ops, shape):
+    """FlowNetC's configuration (FlowNetC.py:31-35): ragged tiles, odd width (scalar stores), channel tail, and
+    the full 448x1024 shape (256 x 56 x 128)."""
+    gen = torch.Generator().manual_seed(shape[1] + shape[3])
+    a = torch.randn(*shape, generator=gen).requires_grad_(True)
+    b = torch.randn(*shape, generator=gen).requires_grad_(True)
+    want = oracle_ops.flownet_correlation(a, b, 20, 1, 20, 1, 2)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    ag, bg = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.flownet_correlation(ag, bg, pad_size=20, kernel_size=1, max_displacement=20, stride1=1, stride2=2)
+    assert got.shape == want.shape
+    assert max_abs(got, want) <= 2e-6 * shape[1] * float(want.detach().abs().max())
+    got.backward(go.to(DEV))
+    assert rel_l2(ag.grad, a.grad) < 1e-5 and rel_l2(bg.grad, b.grad) < 1e-5
+    ag2, bg2 = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    got2 = hip_ops.flownet_correlation(ag2, bg2, 20, 1, 20, 1, 2)
+    got2.backward(go.to(DEV))
+    assert torch.equal(got2, got) and torch.equal(ag2.grad, ag.grad) and torch.equal(bg2.grad, bg.grad)
+
+
+@pytest.mark.parametrize("params", [(4, 1, 4, 1, 2), (5, 3, 4, 1, 2), (3, 3, 2, 1, 1), (2, 1, 4, 1, 2),
+                                    (6, 1, 4, 1, 2), (20, 1, 20, 1, 4)])
+def test_flownet_corr_generic_path_vs_oracle(oracle_ops, params):
+    gen = torch.Generator().manual_seed(sum(params))
+    a = torch.randn(2, 6, 12, 14, generator=gen).requires_grad_(True)
+    b = torch.randn(2, 6, 12, 14, generator=gen).requires_grad_(True)
+    want = oracle_ops.flownet_correlation(a, b, *params)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    ag, bg = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.flownet_correlation(ag, bg, *params)
+    assert got.shape == want.shape
+    assert max_abs(got, want) <= 2e-6 * 6 * 9 * float(want.detach().abs().max())
+    got.backward(go.to(DEV))
+    assert rel_l2(ag.grad, a.grad) < 1e-5 and rel_l2(bg.grad, b.grad) < 1e-5
+
+
+def test_flownet_corr_argument_errors():
+    x = torch.randn(1, 4, 8, 8, device=DEV)
+    with pytest.raises(RuntimeError):
+        hip_ops.flownet_correlation(x, x, 0, 2, 4, 1, 2)        # even kernel_size
+    with pytest.raises(RuntimeError):
+        hip_ops.flownet_correlation(x, x, 0, 1, 20, 1, 2)       # empty output
+    y = hip_ops.flownet_correlation(x.requires_grad_(True), x, 4, 1, 4, 2, 2)  # stride1 = 2: forward only
+    assert y.shape == (1, 25, 4, 4)
+    with pytest.raises(RuntimeError):
+        y.sum().backward()
+    with pytest.raises(RuntimeError):
+        hip_ops.flownet_correlation(x.cpu(), x.cpu(), 4, 1, 4, 1, 2)
+
+
+@pytest.mark.parametrize("shape,scale", [((2, 3, 9, 11), 4.0), ((1, 3, 64, 96), 8.0), ((1, 3, 448, 1024), 20.0),
+                                         ((1, 5, 17, 33), 0.4)])
+def test_resample2d_vs_oracle(oracle_ops, shape, scale):
+    gen = torch.Generator().manual_seed(shape[2])
+    B, C, H, W = shape
+    img = torch.randn(*shape, generator=gen).requires_grad_(True)
+    flow = (scale * torch.randn(B, 2, H, W, generator=gen)).requires_grad_(True)
+    want = oracle_ops.resample2d(img, flow)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    ig, fg = img.detach().to(DEV).requires_grad_(True), flow.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.resample2d(ig, fg)
+    assert max_abs(got, want) <= 1e-6 * float(img.detach().abs().max())
+    got.backward(go.to(DEV))
+    assert rel_l2(ig.grad, img.grad) < 1e-5 and rel_l2(fg.grad, flow.grad) < 1e-5
+    near = hip_ops.resample2d(ig.detach(), fg.detach(), 1, False)
+    assert torch.equal(near.cpu(), oracle_ops.resample2d(img.detach(), flow.detach(), 1, False))
+    # a zero flow is the identity, an integer shift is a clamped shift
+    assert torch.equal(hip_ops.resample2d(ig.detach(), torch.zeros_like(fg)), ig.detach())
+    with pytest.raises(RuntimeError):
+        hip_ops.resample2d(ig.detach(), fg.detach(), 3, True)  # kernel_size > 1 is out of bounds in the reference
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (1, 2, 448, 1024), (1, 3, 448, 1024)])
+def test_channelnorm_vs_oracle(oracle_ops, shape):
+    gen = torch.Generator().manual_seed(shape[3])
+    x = torch.randn(*shape, generator=gen)
+    x[0, :, 0, 0] = 0.
+    xc = x.clone().requires_grad_(True)
+    want = oracle_ops.channelnorm(xc)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    xg = x.to(DEV).requires_grad_(True)
+    got = hip_ops.channelnorm(xg)
+    assert got.shape == want.shape
+    assert max_abs(got, want) <= 2e-7 * float(want.detach().abs().max())
+    got.backward(go.to(DEV))
+    assert rel_l2(xg.grad, xc.grad) < 1e-6
+    assert float(xg.grad[0, :, 0, 0].abs().max()) == 0.0
+
+
 # --------------------------------------------------------------------------- attack math
 def test_attack_math_vs_reference_golden():
     g = load_golden("attack_math")
@@ -427,6 +526,9 @@ CASES = {
     "gma": ("GMA", 128, 160, "change_of_variables", False, "neg_flow", "aee", 2),
     "pwcnet": ("PWCNet", 120, 180, "clipping", True, "zero", "aee", 3),
     "spynet": ("SpyNet", 100, 150, "change_of_variables", False, "zero", "mse", 4),
+    # wiring-only fixture: the reference's model code with its CUDA-only extensions bound to the oracle
+    # (tests/golden/make_golden.py docstring)
+    "flownet2": ("FlowNet2", 128, 192, "change_of_variables", False, "zero", "aee", 5),
 }
 
 

@@ -21,6 +21,9 @@ CASES = {
     "gma": ("GMA", 128, 160, "change_of_variables", False, "neg_flow", "aee", 2),
     "pwcnet": ("PWCNet", 120, 180, "clipping", True, "zero", "aee", 3),
     "spynet": ("SpyNet", 100, 150, "change_of_variables", False, "zero", "mse", 4),
+    # wiring-only fixture: the reference's model code with its CUDA-only extensions bound to the oracle
+    # (tests/golden/make_golden.py docstring)
+    "flownet2": ("FlowNet2", 128, 192, "change_of_variables", False, "zero", "aee", 5),
 }
 
 
