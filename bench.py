@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--net", default="RAFT", choices=["RAFT", "GMA", "PWCNet", "SpyNet"])
+    ap.add_argument("--net", default="RAFT", choices=["RAFT", "GMA", "PWCNet", "SpyNet", "FlowNet2"])
     ap.add_argument("--size", default="436x1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC convolutions")

@@ -53,7 +53,8 @@ PCFA_API int pcfa_abi_version(void);
  * hipEventElapsedTime(start, stop) is the kernel's own duration -- the timestamps rocprofv3's kernel trace
  * reads -- without the two barrier packets an event bracket around a launch adds (about 7 us on MI355X).
  * Entry points that launch several kernels: pcfa_corr_pyramid_bwd = {GEMM dfmap1, reduce, GEMM df2ext, reduce,
- * pooling adjoint}, pcfa_flow_loss_fwd = {partials, final}, pcfa_spatial_corr_bwd = {grad_in1, grad_in2}.
+ * pooling adjoint}, pcfa_flow_loss_fwd = {partials, final}, pcfa_spatial_corr_bwd = {grad_in1, grad_in2},
+ * pcfa_flownet_corr_bwd = {grad_in1, grad_in2}, pcfa_resample2d_bwd = {clear grad_in1, scatter + flow gradient}.
  * nth < 0 drops every pair still queued (events of kernels that were never launched stay unrecorded). */
 PCFA_API int pcfa_timing_arm(void* start_event, void* stop_event, int nth);
 
@@ -165,8 +166,8 @@ PCFA_API int pcfa_spatial_corr_bwd(const float* in1, const float* in2, const flo
  * in1: [B][C][iH][iW]; flow: [B][2][H][W] (x, y displacement in pixels);
  * out / grad_out: [B][C][H][W].  kernel_size must be 1 (the value FlowNet2 uses;
  * larger values read past the border in the reference) and H <= iH, W <= iW.
- * pcfa_resample2d_bwd zeroes grad_in1 itself (hipMemsetAsync on `stream`) and
- * scatters with hardware fp32 atomics like the reference's atomicAdd, so the last
+ * pcfa_resample2d_bwd zeroes grad_in1 itself (a fill kernel on `stream`, then the
+ * scatter kernel) and scatters with hardware fp32 atomics like the reference's atomicAdd, so the last
  * bits of grad_in1 depend on the order of arrival; grad_flow is a gather.
  *
  * ChannelNorm -- replaces channelnorm_cuda.forward / .backward

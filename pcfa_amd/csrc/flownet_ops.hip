@@ -128,8 +128,9 @@ constexpr int FNT = 8 * FH * FTJ;    // 192 threads
 __global__ __launch_bounds__(FNT) void fcorr_fwd_fast_kernel(const float* __restrict__ in1,
                                                             const float* __restrict__ in2,
                                                             float* __restrict__ out, int C, int H, int W) {
-  __shared__ __attribute__((aligned(16))) float s1[FCC][FH][FW];    // row = [16 even | 16 odd]
-  __shared__ __attribute__((aligned(16))) float s2[FCC][FRH][FRW];  // row = [36 even | 36 odd]
+  // two stages: the next channel chunk is written while the current one is read (one barrier per chunk)
+  __shared__ __attribute__((aligned(16))) float s1[2][FCC][FH][FW];    // row = [16 even | 16 odd]
+  __shared__ __attribute__((aligned(16))) float s2[2][FCC][FRH][FRW];  // row = [36 even | 36 odd]
 
   const int ntx = (W + FW - 1) / FW;
   const int tile_x = blockIdx.x % ntx, g = blockIdx.x / ntx;  // g = displacement-row group
@@ -142,28 +143,32 @@ __global__ __launch_bounds__(FNT) void fcorr_fwd_fast_kernel(const float* __rest
   const float* p1 = in1 + (size_t)b * C * plane;
   const float* p2 = in2 + (size_t)b * C * plane;
   const int ry0 = y0 + 2 * (FTJ * g - FR);  // global row of in2 region row 0
-  const int rx0 = x0 - 2 * FR;              // global column of region column 0 (even)
+  const int rx0 = x0 - 2 * FR;              // global column of region column 0 (multiple of 4)
 
-  // Staging plan, fixed per thread: in1 tile = 256 positions (2 slots), in2 region = 864 positions (5 slots);
-  // a slot is loaded for the 8 channels of the chunk.
-  int o1[2], l1[2], o2[5], l2[5];
+  // Staging plan in 16-B pieces (W % 4 == 0 and 16-B aligned inputs are preconditions of this kernel, so a
+  // piece is either inside the image or outside): a chunk is FCC x (8 rows x 8 pieces) of in1 + FCC x (12 rows x
+  // 18 pieces) of in2 = 512 + 1728 pieces = 3 + 9 per thread.  Piece (x .. x+3) lands de-interleaved:
+  // (x, x+2) -> even half, (x+1, x+3) -> odd half, two 8-B LDS writes.
+  constexpr int N1 = FCC * FH * (FW / 4), N2 = FCC * FRH * (FRW / 4);
+  constexpr int S1 = (N1 + FNT - 1) / FNT, S2 = (N2 + FNT - 1) / FNT;
+  static_assert(N2 % FNT == 0, "in2 pieces must divide evenly");
+  int o1[S1], l1[S1], o2[S2], l2[S2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < S1; ++s) {
     const int e = tid + s * FNT;
-    const int r = e / FW, x = e % FW;
-    const int gy = y0 + r, gx = x0 + x;
-    const bool ok = e < FH * FW && gy < H && gx < W;
-    o1[s] = ok ? gy * W + gx : -1;
-    l1[s] = e < FH * FW ? r * FW + (x & 1) * (FW / 2) + (x >> 1) : -1;
+    const int c = e / (FH * (FW / 4)), r = (e / (FW / 4)) % FH, m = e % (FW / 4);
+    const int gy = y0 + r, gx = x0 + 4 * m;
+    const bool live = e < N1;
+    o1[s] = (live && gy < H && gx < W) ? (int)(c * plane) + gy * W + gx : -1;
+    l1[s] = live ? (c * FH + r) * FW + 2 * m : -1;
   }
 #pragma unroll
-  for (int s = 0; s < 5; ++s) {
+  for (int s = 0; s < S2; ++s) {
     const int e = tid + s * FNT;
-    const int r = e / FRW, x = e % FRW;
-    const int gy = ry0 + r, gx = rx0 + x;
-    const bool ok = e < FRH * FRW && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    o2[s] = ok ? gy * W + gx : -1;
-    l2[s] = e < FRH * FRW ? r * FRW + (x & 1) * (FRW / 2) + (x >> 1) : -1;
+    const int c = e / (FRH * (FRW / 4)), r = (e / (FRW / 4)) % FRH, m = e % (FRW / 4);
+    const int gy = ry0 + r, gx = rx0 + 4 * m;
+    o2[s] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (int)(c * plane) + gy * W + gx : -1;
+    l2[s] = (c * FRH + r) * FRW + 2 * m;
   }
 
   float acc[4][FD];
@@ -172,39 +177,54 @@ __global__ __launch_bounds__(FNT) void fcorr_fwd_fast_kernel(const float* __rest
 #pragma unroll
     for (int d = 0; d < FD; ++d) acc[p][d] = 0.f;
 
-  float r1[2][FCC], r2[5][FCC];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 r1[S1], r2[S2];
   auto fetch = [&](int c0) {
+    // branch-free: a dead piece reads offset 0 of the chunk (always mapped) and is zeroed afterwards; a channel
+    // tail (C % FCC) is dead through the offset limit
+    const float* b1 = p1 + (size_t)c0 * plane;
+    const float* b2 = p2 + (size_t)c0 * plane;
+    const int climit = (int)((size_t)(C - c0) * plane);  // offsets at or past this belong to channels >= C
 #pragma unroll
-    for (int c = 0; c < FCC; ++c) {
-      const bool cok = c0 + c < C;
-      const size_t co = (size_t)(c0 + c) * plane;
+    for (int s = 0; s < S1; ++s) {
+      const bool ok = o1[s] >= 0 && o1[s] < climit;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(b1 + (ok ? o1[s] : 0));
+      r1[s] = ok ? t : (f32x4)(0.f);
+    }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) r1[s][c] = (cok && o1[s] >= 0) ? p1[co + o1[s]] : 0.f;
-#pragma unroll
-      for (int s = 0; s < 5; ++s) r2[s][c] = (cok && o2[s] >= 0) ? p2[co + o2[s]] : 0.f;
+    for (int s = 0; s < S2; ++s) {
+      const bool ok = o2[s] >= 0 && o2[s] < climit;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(b2 + (ok ? o2[s] : 0));
+      r2[s] = ok ? t : (f32x4)(0.f);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int buf) {
+    float* d1 = &s1[buf][0][0][0];
+    float* d2 = &s2[buf][0][0][0];
 #pragma unroll
-    for (int c = 0; c < FCC; ++c) {
+    for (int s = 0; s < S1; ++s)
+      if (l1[s] >= 0) {
+        *reinterpret_cast<float2*>(d1 + l1[s]) = make_float2(r1[s].x, r1[s].z);
+        *reinterpret_cast<float2*>(d1 + l1[s] + FW / 2) = make_float2(r1[s].y, r1[s].w);
+      }
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        if (l1[s] >= 0) (&s1[c][0][0])[l1[s]] = r1[s][c];
-#pragma unroll
-      for (int s = 0; s < 5; ++s)
-        if (l2[s] >= 0) (&s2[c][0][0])[l2[s]] = r2[s][c];
+    for (int s = 0; s < S2; ++s) {
+      *reinterpret_cast<float2*>(d2 + l2[s]) = make_float2(r2[s].x, r2[s].z);
+      *reinterpret_cast<float2*>(d2 + l2[s] + FRW / 2) = make_float2(r2[s].y, r2[s].w);
     }
   };
 
   fetch(0);
+  commit(0);
+  __syncthreads();
+  int cur = 0;
   for (int c0 = 0; c0 < C; c0 += FCC) {
-    commit();
-    __syncthreads();
-    if (c0 + FCC < C) fetch(c0 + FCC);  // in flight across the FMA block below
-#pragma unroll
+    const bool more = c0 + FCC < C;
+    if (more) fetch(c0 + FCC);  // in flight across the FMA block below
+#pragma unroll 2
     for (int c = 0; c < FCC; ++c) {
-      const float4 a = *reinterpret_cast<const float4*>(&s1[c][ty][par * (FW / 2) + 4 * q]);
-      const float* row = &s2[c][ty + 2 * tz][par * (FRW / 2) + 4 * q];
+      const float4 a = *reinterpret_cast<const float4*>(&s1[cur][c][ty][par * (FW / 2) + 4 * q]);
+      const float* row = &s2[cur][c][ty + 2 * tz][par * (FRW / 2) + 4 * q];
       float v[24];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
@@ -217,48 +237,56 @@ __global__ __launch_bounds__(FNT) void fcorr_fwd_fast_kernel(const float* __rest
 #pragma unroll
         for (int d = 0; d < FD; ++d) acc[p][d] += av[p] * v[p + d];
     }
+    if (more) commit(cur ^ 1);
     __syncthreads();
+    cur ^= 1;
   }
 
   // Thread (par, q) holds pixels x0 + 8q + 2p + par.  Lane pairs (tx, tx^4) swap halves so that the even lane
   // stores x0+8q .. +3 and the odd lane x0+8q+4 .. +7 as one 16-B vector each.
+  // the reference divides by C (correlation_cuda_kernel.cu:143); for a power of two the reciprocal gives the same
+  // fp32 result and saves 84 division sequences per thread
   const float nelems = (float)C;
   const int gy = y0 + ty;
   const int tj = FTJ * g + tz;
   const int gx = x0 + 8 * q + 4 * par;
-  const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   float* ob = out + ((size_t)b * FD * FD + (size_t)tj * FD) * plane + (size_t)gy * W + gx;
+  if ((C & (C - 1)) == 0) {
+    const float rn = 1.0f / nelems;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int d = 0; d < FD; ++d) acc[p][d] *= rn;
+  } else {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int d = 0; d < FD; ++d) acc[p][d] /= nelems;
+  }
 #pragma unroll
   for (int d = 0; d < FD; ++d) {
-    const float m0 = acc[0][d] / nelems, m1 = acc[1][d] / nelems, m2 = acc[2][d] / nelems, m3 = acc[3][d] / nelems;
+    const float m0 = acc[0][d], m1 = acc[1][d], m2 = acc[2][d], m3 = acc[3][d];
     // even lane keeps (m0, m1) and needs the partner's (m0, m1); odd lane keeps (m2, m3), needs partner's (m2, m3)
     const float send0 = par ? m0 : m2, send1 = par ? m1 : m3;
     const float recv0 = __shfl_xor(send0, 4), recv1 = __shfl_xor(send1, 4);
     const float4 o = par ? make_float4(recv0, m2, recv1, m3) : make_float4(m0, recv0, m1, recv1);
-    if (gy < H) {
-      float* od = ob + (size_t)d * plane;
-      if (vec && gx + 3 < W) {
-        *reinterpret_cast<float4*>(od) = o;
-      } else {
-        const float ov[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-          if (gx + p < W) od[p] = ov[p];
-      }
-    }
+    if (gy < H && gx < W) *reinterpret_cast<float4*>(ob + (size_t)d * plane) = o;
   }
 }
 
 constexpr int BRH = FH + 4 * FR;  // 48 halo rows
-constexpr int BRS = FRW + 1;      // row stride 73: rows land in different banks
 
 // gin[c][p] = 1/C * sum_d G(d) * X[c][p + SIGN*2d]:  SIGN=+1: G = g[d][p], X = in2 (grad in1)
 //                                                    SIGN=-1: G = g[d][p-2d], X = in1 (grad in2)
+// LDS image of X: [2 channel halves][48 rows][72 columns][4 channels] -- the 8 channels of one tap are two 16-B
+// reads, consecutive lanes 16 B apart (conflict-free).
 template <int SIGN>
 __global__ __launch_bounds__(FH* FW) void fcorr_bwd_fast_kernel(const float* __restrict__ X,
                                                                 const float* __restrict__ gout,
                                                                 float* __restrict__ gin, int C, int H, int W) {
-  extern __shared__ float sx[];  // [FCC][BRH][BRS]
+  static_assert(FCC == 8, "two float4 per tap");
+  extern __shared__ __attribute__((aligned(16))) float sx[];  // [2][BRH][FRW][4]
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int ngroups = (C + FCC - 1) / FCC;
   const int b = blockIdx.z / ngroups;
   const int c0 = (blockIdx.z - b * ngroups) * FCC;
@@ -269,12 +297,33 @@ __global__ __launch_bounds__(FH* FW) void fcorr_bwd_fast_kernel(const float* __r
   const bool inside = gy < H && gx < W;
   const size_t plane = (size_t)H * W;
   const float* px = X + ((size_t)b * C + c0) * plane;
-  for (int e = tid; e < FCC * BRH * FRW; e += FH * FW) {
-    const int c = e / (BRH * FRW), r = (e / FRW) % BRH, x = e % FRW;
-    const int yy = y0 + r - 2 * FR, xx = x0 + x - 2 * FR;
-    float v = 0.f;
-    if (c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W) v = px[(size_t)c * plane + (size_t)yy * W + xx];
-    sx[(c * BRH + r) * BRS + x] = v;
+  // staging in 16-B pieces (W % 4 == 0, 16-B aligned X: preconditions): 8 ch x 48 rows x 18 pieces = 27 per thread
+  constexpr int NP = FCC * BRH * (FRW / 4);
+  static_assert(NP % (FH * FW) == 0, "pieces must divide evenly");
+  constexpr int BATCH = 9;  // pieces in flight per thread: all loads of a batch are issued before its LDS writes
+  static_assert(NP % (FH * FW * BATCH) == 0, "batches must divide evenly");
+#pragma unroll 1
+  for (int e0 = tid; e0 < NP; e0 += FH * FW * BATCH) {
+    f32x4 t[BATCH];
+    bool ok[BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int e = e0 + k * FH * FW;
+      const int c = e / (BRH * (FRW / 4)), r = (e / (FRW / 4)) % BRH, m = e % (FRW / 4);
+      const int yy = y0 + r - 2 * FR, xx = x0 + 4 * m - 2 * FR;
+      ok[k] = c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      t[k] = *reinterpret_cast<const f32x4*>(px + (ok[k] ? (size_t)c * plane + (size_t)yy * W + xx : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int e = e0 + k * FH * FW;
+      const int c = e / (BRH * (FRW / 4)), r = (e / (FRW / 4)) % BRH, m = e % (FRW / 4);
+      float* d = sx + (((c >> 2) * BRH + r) * FRW + 4 * m) * 4 + (c & 3);
+      d[0] = ok[k] ? t[k].x : 0.f;
+      d[4] = ok[k] ? t[k].y : 0.f;
+      d[8] = ok[k] ? t[k].z : 0.f;
+      d[12] = ok[k] ? t[k].w : 0.f;
+    }
   }
   __syncthreads();
 
@@ -282,22 +331,39 @@ __global__ __launch_bounds__(FH* FW) void fcorr_bwd_fast_kernel(const float* __r
 #pragma unroll
   for (int c = 0; c < FCC; ++c) acc[c] = 0.f;
   const float* gb = gout + (size_t)b * FD * FD * plane;
-  for (int tj = 0; tj < FD; ++tj) {
+  const int cy = min(gy, H - 1), cx = min(gx, W - 1);  // threads past the edge compute a clamped pixel, never store
+  // The 21 gradient taps of displacement row tj+1 are requested before the FMAs of row tj (one wave per SIMD:
+  // nothing else hides the load latency).
+  auto load_row = [&](int tj, float (&gv)[FD]) {
     const int dy = 2 * (tj - FR);
-    const int sy = (SIGN > 0) ? gy : gy - dy;  // pixel whose gradient row is read
-    const bool rowok = inside && sy >= 0 && sy < H;
+    const int sy = (SIGN > 0) ? cy : cy - dy;  // pixel whose gradient row is read
+    const bool rowok = sy >= 0 && sy < H;
+    const float* grow = gb + (size_t)(tj * FD) * plane + (size_t)(rowok ? sy : 0) * W;
+#pragma unroll
+    for (int ti = 0; ti < FD; ++ti) {  // branch-free: clamped address, zeroed afterwards
+      const int sxp = (SIGN > 0) ? cx : cx - 2 * (ti - FR);
+      const bool ok = rowok && sxp >= 0 && sxp < W;
+      const float t = grow[(size_t)ti * plane + (ok ? sxp : 0)];
+      gv[ti] = ok ? t : 0.f;
+    }
+  };
+  float gcur[FD], gnext[FD];
+  load_row(0, gcur);
+#pragma unroll 1
+  for (int tj = 0; tj < FD; ++tj) {
+    load_row(min(tj + 1, FD - 1), gnext);
     const int lr = (SIGN > 0) ? ly + 2 * tj : ly + 4 * FR - 2 * tj;
 #pragma unroll
     for (int ti = 0; ti < FD; ++ti) {
-      const int dx = 2 * (ti - FR);
-      const int sxp = (SIGN > 0) ? gx : gx - dx;
-      float gv = 0.f;
-      if (rowok && sxp >= 0 && sxp < W) gv = gb[(size_t)(tj * FD + ti) * plane + (size_t)sy * W + sxp];
       const int lc = (SIGN > 0) ? lx + 2 * ti : lx + 4 * FR - 2 * ti;
-      const float* col = sx + lr * BRS + lc;
-#pragma unroll
-      for (int c = 0; c < FCC; ++c) acc[c] += gv * col[c * BRH * BRS];
+      const f32x4* tap = reinterpret_cast<const f32x4*>(sx + (lr * FRW + lc) * 4);
+      const f32x4 u0 = tap[0], u1 = tap[BRH * FRW];
+      const float gvt = gcur[ti];
+      acc[0] += gvt * u0.x; acc[1] += gvt * u0.y; acc[2] += gvt * u0.z; acc[3] += gvt * u0.w;
+      acc[4] += gvt * u1.x; acc[5] += gvt * u1.y; acc[6] += gvt * u1.z; acc[7] += gvt * u1.w;
     }
+#pragma unroll
+    for (int ti = 0; ti < FD; ++ti) gcur[ti] = gnext[ti];
   }
   if (inside) {
     const float nelems = (float)C;
@@ -439,6 +505,19 @@ __global__ void channelnorm_bwd_kernel(const float* __restrict__ in, const float
   gin[idx] = (float)((double)(gout[b * plane + p] * in[idx]) / ((double)out[b * plane + p] + 1e-9));
 }
 
+// grad_in1 of Resample2d is cleared by a kernel, not hipMemsetAsync: inside torch's stream capture the memset node
+// was not replayed with the graph (stale gradients accumulated from replay to replay), a kernel node is.
+__global__ void zero_fill_kernel(float* __restrict__ p, long long n) {
+  const long long step = (long long)gridDim.x * blockDim.x * 4;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += step) {
+    if (i + 3 < n && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+      *reinterpret_cast<float4*>(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (long long k = i; k < n && k < i + 4; ++k) p[k] = 0.f;
+    }
+  }
+}
+
 int blocks_for(long long total, int threads) {
   const long long n = (total + threads - 1) / threads;
   return (int)(n < 65535LL * 32 ? n : 65535LL * 32);
@@ -465,7 +544,9 @@ extern "C" int pcfa_flownet_corr_fwd(const float* in1, const float* in2, float* 
       !fc_make_params(p, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2))
     return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (fc_is_flownetc(p)) {
+  const bool aligned = W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2) |
+                                        reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (fc_is_flownetc(p) && aligned) {
     dim3 grid(pcfa_cdiv(W, FW) * (FD / FTJ), pcfa_cdiv(H, FH), B), block(8, FH, FTJ);
     pcfa_launch(fcorr_fwd_fast_kernel, grid, block, 0, s, in1, in2, out, C, H, W);
   } else {
@@ -485,16 +566,17 @@ extern "C" int pcfa_flownet_corr_bwd(const float* in1, const float* in2, const f
     return PCFA_ERR_INVALID_ARG;
   if (stride1 != 1) return PCFA_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (fc_is_flownetc(p)) {
+  const bool aligned = W % 4 == 0 && ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
+  if (fc_is_flownetc(p) && aligned) {
     static const bool attr_ok = [] {
-      const int bytes = FCC * BRH * BRS * (int)sizeof(float);
+      const int bytes = FCC * BRH * FRW * (int)sizeof(float);
       return hipFuncSetAttribute((const void*)fcorr_bwd_fast_kernel<+1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  bytes) == hipSuccess &&
              hipFuncSetAttribute((const void*)fcorr_bwd_fast_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  bytes) == hipSuccess;
     }();
     if (!attr_ok) return PCFA_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)FCC * BRH * BRS * sizeof(float);
+    const size_t lds = (size_t)FCC * BRH * FRW * sizeof(float);
     dim3 grid(pcfa_cdiv(W, FW), pcfa_cdiv(H, FH), B * pcfa_cdiv(C, FCC)), block(FW, FH, 1);
     pcfa_launch(fcorr_bwd_fast_kernel<+1>, grid, block, lds, s, in2, grad_out, grad_in1, C, H, W);
     PCFA_LAUNCH_CHECK();
@@ -532,8 +614,9 @@ extern "C" int pcfa_resample2d_bwd(const float* in1, const float* flow, const fl
     return PCFA_ERR_INVALID_ARG;
   if (kernel_size != 1 || H > iH || W > iW) return PCFA_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_in1, 0, (size_t)B * C * iH * iW * sizeof(float), s);
-  if (e != hipSuccess) return (int)e;
+  const long long n1 = (long long)B * C * iH * iW;
+  pcfa_launch(zero_fill_kernel, dim3(blocks_for((n1 + 3) / 4, 256)), dim3(256), 0, s, grad_in1, n1);
+  PCFA_LAUNCH_CHECK();
   const long long total = (long long)B * H * W;
   pcfa_launch(resample2d_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, in1, flow, grad_out,
               grad_in1, grad_flow, B, C, iH, iW, H, W);

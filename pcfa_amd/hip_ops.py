@@ -91,7 +91,7 @@ class DispatchTimer:
         "pcfa_flownet_corr_fwd": [("flownet_corr_fwd", 0)],
         "pcfa_flownet_corr_bwd": [("flownet_corr_bwd_in1", 0), ("flownet_corr_bwd_in2", 1)],
         "pcfa_resample2d_fwd": [("resample2d_fwd", 0)],
-        "pcfa_resample2d_bwd": [("resample2d_bwd", 0)],
+        "pcfa_resample2d_bwd": [("resample2d_bwd", 1)],  # kernel 0 clears grad_in1
         "pcfa_channelnorm_fwd": [("channelnorm_fwd", 0)],
         "pcfa_channelnorm_bwd": [("channelnorm_bwd", 0)],
         "pcfa_box_transform_fwd": [("box_transform_fwd", 0)],

@@ -584,13 +584,13 @@ def _cli_args(**kw):
 
 
 @pytest.mark.parametrize("net,joint,box", [("SpyNet", False, "change_of_variables"), ("PWCNet", True, "clipping"),
-                                           ("RAFT", False, "clipping")])
+                                           ("RAFT", False, "clipping"), ("FlowNet2", False, "change_of_variables")])
 def test_attack_l2_end_to_end_on_gpu_vs_cpu_port(oracle_ops, net, joint, box):
     """The whole driver (dataset -> model -> pcfa_attack per pair -> averages) on the GPU vs the same host code with
     the oracle operators on CPU: 2 pairs x 1 step (10 closures; longer runs amplify fp32 noise chaotically --
     SURVEY.md D10 -- and are covered by the trajectory test against the reference's own noise floor)."""
     from pcfa_amd import attack_PCFA
-    size = "128x160" if net == "RAFT" else "64x96"
+    size = {"RAFT": "128x160", "FlowNet2": "64x128"}.get(net, "64x96")
     a = _cli_args(net=net, joint_perturbation=joint, boxconstraint=box, synthetic_size=size, steps=1)
     got = attack_PCFA.attack_l2(a)
     import os
@@ -609,9 +609,11 @@ def test_attack_l2_end_to_end_on_gpu_vs_cpu_port(oracle_ops, net, joint, box):
     assert got["pairs"] == want["pairs"] == 2
     keys = ("aee_avg_pred-tgt", "aee_avg_predadv-tgt", "aee_avg_pred-predadv", "l2_avg_delta12",
             "aee_avg_predadv-tgt_min", "l2_avg_delta12_min")
-    if net == "SpyNet":
+    if net in ("SpyNet", "FlowNet2"):
         # with these seeded weights one SpyNet pair sits on a knife edge: the CPU port ALONE lands on
         # l2 = 0.0025 (3 threads) or 0.28 (8 threads) after 10 closures, so only the deterministic part is compared
+        # (FlowNet2: 162 M random weights and three warps with a piecewise gradient amplify fp32 noise the same way;
+        # the closure itself is pinned by test_closure_on_gpu_vs_reference_golden[flownet2])
         keys = ("aee_avg_pred-tgt",)
         assert all(np.isfinite(got[k]) for k in got if isinstance(got[k], float) and "gt" not in k)
     for k in keys:
@@ -626,13 +628,15 @@ def test_universal_attack_runs_on_gpu():
     assert len(res["history"]) == 1 and np.isfinite(res["history"][0]["aee_predadv-tgt"])
 
 
-def test_graphed_closure_matches_eager():
-    """The hipGraph replay of a RAFT closure reproduces the eager launch: same kernels in the same order; the loss
+@pytest.mark.parametrize("net,size", [("RAFT", (128, 160)), ("FlowNet2", (64, 128))])
+def test_graphed_closure_matches_eager(net, size):
+    """The hipGraph replay of a closure reproduces the eager launch: same kernels in the same order; the loss
     agrees to 1e-6 and the gradient to 1e-5 relative L2 (a few MIOpen backward kernels accumulate with atomics,
-    so even two eager launches differ in the last bits)."""
+    so even two eager launches differ in the last bits).  FlowNet2: regression test for the Resample2d backward,
+    whose hipMemsetAsync of grad_in1 was not replayed with the graph (gradients grew from replay to replay)."""
     import bench
     torch.backends.cudnn.benchmark = False
-    st = bench.AttackStepper("RAFT", 128, 160, torch.device(DEV), seed=3)
+    st = bench.AttackStepper(net, size[0], size[1], torch.device(DEV), seed=3)
     st.optimizer.zero_grad()
     l_eager = float(st._closure_body())   # keep no autograd node alive: a live AccumulateGrad of nw1/nw2 would
                                           # pin the default stream into the capture (see graphed.py)
@@ -645,9 +649,11 @@ def test_graphed_closure_matches_eager():
         st.nw1.sub_(0.01)
     l_graph = float(st.closure())
     assert abs(l_graph - l_eager) <= 1e-6 * abs(l_eager) and abs(l_graph_moved - l_eager) > 1e-6 * abs(l_eager)
-    assert rel_l2(st.nw1.grad, g_eager[0]) < 1e-5 and rel_l2(st.nw2.grad, g_eager[1]) < 1e-5
+    tol = 1e-5 if net == "RAFT" else 1e-4  # FlowNet2: fp32 atomics in the warp's scatter and in MIOpen's deconvolutions
+    assert rel_l2(st.nw1.grad, g_eager[0]) < tol and rel_l2(st.nw2.grad, g_eager[1]) < tol
     l_again = float(st.closure())
     assert abs(l_again - l_graph) <= 1e-6 * abs(l_graph)
+    assert rel_l2(st.nw1.grad, g_eager[0]) < tol and rel_l2(st.nw2.grad, g_eager[1]) < tol
 
 
 # --------------------------------------------------------------------------- #
