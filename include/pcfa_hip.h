@@ -54,7 +54,8 @@ PCFA_API int pcfa_abi_version(void);
  * reads -- without the two barrier packets an event bracket around a launch adds (about 7 us on MI355X).
  * Entry points that launch several kernels: pcfa_corr_pyramid_bwd = {GEMM dfmap1, reduce, GEMM df2ext, reduce,
  * pooling adjoint}, pcfa_flow_loss_fwd = {partials, final}, pcfa_spatial_corr_bwd = {grad_in1, grad_in2},
- * pcfa_flownet_corr_bwd = {grad_in1, grad_in2}, pcfa_resample2d_bwd = {clear grad_in1, scatter + flow gradient}.
+ * pcfa_flownet_corr_bwd = {grad_in1, grad_in2}, pcfa_resample2d_bwd = {clear grad_in1, scatter + flow gradient},
+ * pcfa_instnorm_fwd / _bwd = {partial sums, apply}.
  * nth < 0 drops every pair still queued (events of kernels that were never launched stay unrecorded). */
 PCFA_API int pcfa_timing_arm(void* start_event, void* stop_event, int nth);
 
@@ -329,6 +330,23 @@ PCFA_API int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, float*
 PCFA_API int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out, long long n, int plane, int channels,
                        void* stream);
 PCFA_API int pcfa_relu_bwd(const float* out, const float* grad_out, float* grad_x, long long n, void* stream);
+
+/* InstanceNorm2d without affine parameters on batch statistics, fused with the ReLU that follows it: every
+ * `relu(norm(conv(x)))` / `norm(conv(x))` of the feature encoder (models/raft/extractor.py:23-58 with
+ * norm_fn='instance', :118-157; nn.InstanceNorm2d defaults: eps 1e-5, biased variance).
+ *   x, y, grad_out, grad_x: [planes][plane] (planes = B*C, plane = H*W);  mean_rstd: [planes][2] written by the
+ *   forward, read by the backward;  workspace: pcfa_instnorm_workspace_bytes(planes, plane) bytes, 16-B aligned.
+ *   forward : y = relu?((x - mean) * rstd), rstd = 1/sqrt(var + eps)
+ *   backward: grad_x = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = grad_out * (xhat > 0) if relu else grad_out
+ * Two launches each {partial sums, apply}; sums are accumulated in fp64 and combined in index order (bitwise
+ * reproducible).  pcfa_add_relu_fwd: out = relu(a + b), the block output of ResidualBlock.forward
+ * (extractor.py:50-58); its backward for both operands is pcfa_relu_bwd(out, grad_out, ...). */
+PCFA_API size_t pcfa_instnorm_workspace_bytes(int planes, long long plane);
+PCFA_API int pcfa_instnorm_fwd(const float* x, float* y, float* mean_rstd, void* workspace, int planes,
+                               long long plane, float eps, int relu, void* stream);
+PCFA_API int pcfa_instnorm_bwd(const float* x, const float* mean_rstd, const float* grad_out, float* grad_x,
+                               void* workspace, int planes, long long plane, int relu, void* stream);
+PCFA_API int pcfa_add_relu_fwd(const float* a, const float* b, float* out, long long n, void* stream);
 
 /* Metric helpers (helper_functions/losses.py:3-30,129-142): out[0] = sum over
  * pixels of sqrt(du^2+dv^2) / (B*H*W);  pcfa_sum_squares: out[0] = sum x^2. */

@@ -485,6 +485,17 @@ def gru_step(h, rest, halves):
     return h
 
 
+def instance_norm_relu(x, eps=1e-5, relu=False):
+    """models/raft/extractor.py:23-58: nn.InstanceNorm2d (no affine, batch statistics) then the optional ReLU."""
+    y = F.instance_norm(x, eps=eps)
+    return F.relu(y) if relu else y
+
+
+def add_relu(a, b):
+    """models/raft/extractor.py:50-58: relu(x + y)."""
+    return F.relu(a + b)
+
+
 def bias_relu(x, bias=None):
     """F.relu(conv(x)) with the convolution's bias split off (models/raft/update.py:12-16,91-101)."""
     return torch.relu(x + _cb(bias))

@@ -101,6 +101,9 @@ class DispatchTimer:
         "pcfa_gru_gates_bwd": [("gru_gates_bwd", 0)],
         "pcfa_gru_update_fwd": [("gru_update_fwd", 0)],
         "pcfa_gru_update_bwd": [("gru_update_bwd", 0)],
+        "pcfa_instnorm_fwd": [("instnorm_stats_fwd", 0), ("instnorm_apply_fwd", 1)],
+        "pcfa_instnorm_bwd": [("instnorm_stats_bwd", 0), ("instnorm_apply_bwd", 1)],
+        "pcfa_add_relu_fwd": [("add_relu_fwd", 0)],
         "pcfa_bias_relu_fwd": [("bias_relu_fwd", 0)],
         "pcfa_relu_bwd": [("relu_bwd", 0)],
     }
@@ -576,6 +579,71 @@ class _BiasRelu(torch.autograd.Function):
 
 
 _sepconv_packs = {}  # id(weight) -> (weakref, version, fwd_packed, bwd_packed)
+
+
+class _InstNormRelu(torch.autograd.Function):
+    """relu?(F.instance_norm(x, eps=eps)) on pcfa_instnorm_fwd/bwd (two streaming launches per direction)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, relu):
+        _dev(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        planes, plane = B * C, H * W
+        lib = _hip.load()
+        ws = torch.empty((int(lib.pcfa_instnorm_workspace_bytes(planes, plane)) + 3) // 4, device=x.device,
+                         dtype=torch.float32)
+        y = torch.empty_like(x)
+        stats = torch.empty((planes, 2), device=x.device, dtype=torch.float32)
+        _call("pcfa_instnorm_fwd", _ptr(x), _ptr(y), _ptr(stats), _ptr(ws), planes, plane, float(eps), int(bool(relu)))
+        ctx.save_for_backward(x, stats)
+        ctx.dims = (planes, plane, int(bool(relu)))
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, stats = ctx.saved_tensors
+        planes, plane, relu = ctx.dims
+        g = g.contiguous()
+        lib = _hip.load()
+        ws = torch.empty((int(lib.pcfa_instnorm_workspace_bytes(planes, plane)) + 3) // 4, device=x.device,
+                         dtype=torch.float32)
+        gx = torch.empty_like(x)
+        _call("pcfa_instnorm_bwd", _ptr(x), _ptr(stats), _ptr(g), _ptr(gx), _ptr(ws), planes, plane, relu)
+        return gx, None, None
+
+
+def instance_norm_relu(x, eps=1e-5, relu=False):
+    """relu?(InstanceNorm2d(affine=False, track_running_stats=False)(x)) -- models/raft/extractor.py:23-58."""
+    return _InstNormRelu.apply(x, eps, relu)
+
+
+class _AddRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _dev(a, b)
+        if a.shape != b.shape:
+            raise ValueError("add_relu: shapes differ: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        _call("pcfa_add_relu_fwd", _ptr(a), _ptr(b), _ptr(out), a.numel())
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = g.contiguous()
+        gm = torch.empty_like(g)
+        _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), g.numel())
+        return gm, gm
+
+
+def add_relu(a, b):
+    """relu(a + b): the output of ResidualBlock.forward (models/raft/extractor.py:50-58)."""
+    return _AddRelu.apply(a, b)
 
 
 def _sepconv5_packed(weight):

@@ -295,6 +295,44 @@ def test_channelnorm_vs_oracle(oracle_ops, shape):
     assert float(xg.grad[0, :, 0, 0].abs().max()) == 0.0
 
 
+# --------------------------------------------------------------------------- encoder normalisation
+@pytest.mark.parametrize("shape,relu", [((2, 64, 220, 512), True), ((2, 96, 110, 256), False), ((2, 128, 55, 128), True),
+                                        ((1, 5, 7, 9), True), ((3, 2, 33, 21), False), ((1, 3, 1, 6), True)])
+def test_instance_norm_relu_vs_oracle(oracle_ops, shape, relu):
+    """relu?(InstanceNorm2d(x)) vs torch's own instance_norm on the CPU (what the reference runs): the three
+    feature-encoder stages at 440x1024 with both images batched, odd planes (scalar path), tiny planes.
+    Statistics are accumulated in fp64 here, in fp32 (Welford) there: 3e-6 absolute on O(1) outputs; gradients 2e-5."""
+    gen = torch.Generator().manual_seed(shape[1] * shape[2])
+    x = (torch.randn(*shape, generator=gen) * 1.7 + 0.4).requires_grad_(True)
+    want = oracle_ops.instance_norm_relu(x, 1e-5, relu)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.instance_norm_relu(xg, 1e-5, relu)
+    assert max_abs(got, want) <= 3e-6 * max(1.0, float(want.detach().abs().max()))
+    got.backward(go.to(DEV))
+    assert rel_l2(xg.grad, x.grad) < 2e-5
+    xg2 = x.detach().to(DEV).requires_grad_(True)
+    got2 = hip_ops.instance_norm_relu(xg2, 1e-5, relu)
+    got2.backward(go.to(DEV))
+    assert torch.equal(got2, got) and torch.equal(xg2.grad, xg.grad)  # fixed summation order
+
+
+def test_add_relu_vs_oracle(oracle_ops):
+    gen = torch.Generator().manual_seed(77)
+    for shape in ((2, 64, 55, 128), (1, 3, 5, 7)):
+        a = torch.randn(*shape, generator=gen).requires_grad_(True)
+        b = torch.randn(*shape, generator=gen).requires_grad_(True)
+        want = oracle_ops.add_relu(a, b)
+        go = torch.randn(want.shape, generator=gen)
+        want.backward(go)
+        ag, bg = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+        got = hip_ops.add_relu(ag, bg)
+        assert torch.equal(got.cpu(), want.detach())
+        got.backward(go.to(DEV))
+        assert torch.equal(ag.grad.cpu(), a.grad) and torch.equal(bg.grad.cpu(), b.grad)
+
+
 # --------------------------------------------------------------------------- attack math
 def test_attack_math_vs_reference_golden():
     g = load_golden("attack_math")
