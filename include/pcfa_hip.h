@@ -331,6 +331,16 @@ PCFA_API int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out, l
                        void* stream);
 PCFA_API int pcfa_relu_bwd(const float* out, const float* grad_out, float* grad_x, long long n, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution with N <= 4 output channels and its data gradient (frozen weights): the
+ * flow-prediction layers -- FlowHead.conv2 of RAFT / GMA (models/raft/update.py:6-14), predict_flow of PWC-Net
+ * (models/PWCNet/PWCNet.py:37-38) and FlowNet2 (models/FlowNet/submodules.py:33-34).  A stream over the input
+ * (HBM-bound), not matrix-core work.  x / grad_x: [B][K][H][W]; w: [N][K][3][3] as nn.Conv2d stores it;
+ * bias: [N] or NULL; out / grad_out: [B][N][H][W].  Fixed summation order (bitwise reproducible). */
+PCFA_API int pcfa_conv3x3_fewout_fwd(const float* x, const float* w, const float* bias, float* out, int B, int K,
+                                     int N, int H, int W, void* stream);
+PCFA_API int pcfa_conv3x3_fewout_bwd(const float* grad_out, const float* w, float* grad_x, int B, int K, int N, int H,
+                                     int W, void* stream);
+
 /* InstanceNorm2d without affine parameters on batch statistics, fused with the ReLU that follows it: every
  * `relu(norm(conv(x)))` / `norm(conv(x))` of the feature encoder (models/raft/extractor.py:23-58 with
  * norm_fn='instance', :118-157; nn.InstanceNorm2d defaults: eps 1e-5, biased variance).

@@ -485,6 +485,11 @@ def gru_step(h, rest, halves):
     return h
 
 
+def conv3x3_fewout(x, weight, bias=None):
+    """The flow-prediction convolutions (models/raft/update.py:6-14, PWCNet.py:37-38, FlowNet/submodules.py:33-34)."""
+    return F.conv2d(x, weight, bias, stride=1, padding=1)
+
+
 def instance_norm_relu(x, eps=1e-5, relu=False):
     """models/raft/extractor.py:23-58: nn.InstanceNorm2d (no affine, batch statistics) then the optional ReLU."""
     y = F.instance_norm(x, eps=eps)

@@ -1,0 +1,179 @@
+// 3x3 / stride 1 / pad 1 convolution with 1..4 OUTPUT channels (frozen weights), forward and data gradient.
+//
+// Replaces the library convolution for the flow-prediction layers: FlowHead.conv2 of RAFT / GMA
+// (models/raft/update.py:6-14, Conv2d(256, 2, 3, padding=1): 24 launches per closure, 31 us each as a Winograd
+// kernel padded to a 32-channel output tile), predict_flow of PWC-Net (models/PWCNet/PWCNet.py:37-38) and of
+// FlowNet2 (models/FlowNet/submodules.py:33-34).  With two output channels the layer is a stream over its input:
+// 7.2 MB in, 56 KB out at 256 x 55 x 128 -- HBM-bound, 0.9 us at 8 TB/s; the matrix cores have nothing to do.
+//   forward : workgroup = 64 consecutive pixels x 16 waves; wave w reduces channels w, w+16, ... with the nine taps
+//             of its pixel in registers and WAVE-UNIFORM weights (scalar loads), partial sums meet in LDS and are
+//             added in wave order (bitwise reproducible), + bias.
+//   backward: grad_x[c][p] = sum_{o,ky,kx} w[o][c][ky][kx] * grad_out[o][p + (1-ky, 1-kx)]: a lane keeps the 9*N
+//             gradient taps of its pixel in registers, a wave walks its channels with scalar weights and streams
+//             grad_x out (64 consecutive floats per store instruction).
+#include "common.hpp"
+
+namespace {
+
+constexpr int FO_PX = 64;     // pixels per workgroup (one per lane)
+constexpr int FO_WAVES = 8;   // channel groups per workgroup (backward)
+constexpr int FO_FWD_WAVES = 16;  // forward: 16 waves x 8 channels in flight = 72 loads per lane
+
+template <int N>
+__global__ __launch_bounds__(FO_PX* FO_FWD_WAVES) void conv3x3_fewout_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int K, int H, int W) {
+  __shared__ float red[FO_FWD_WAVES][N][FO_PX];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  const long long plane = (long long)H * W;
+  const long long p = (long long)blockIdx.x * FO_PX + lane;
+  const bool live = p < plane;
+  const int y = live ? (int)(p / W) : 0, xx = live ? (int)(p % W) : 0;
+  // tap offsets and validity of this lane's 3x3 neighbourhood
+  int off[9];
+  bool ok[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = y + ky - 1, xq = xx + kx - 1;
+      ok[ky * 3 + kx] = live && yy >= 0 && yy < H && xq >= 0 && xq < W;
+      off[ky * 3 + kx] = ok[ky * 3 + kx] ? yy * W + xq : 0;
+    }
+  float acc[N];
+#pragma unroll
+  for (int o = 0; o < N; ++o) acc[o] = 0.f;
+  const float* xb = x + (size_t)b * K * plane;
+  constexpr int U = 8;  // channels in flight per wave: 72 loads per lane (the loop is a latency chain otherwise)
+  for (int c0 = wave; c0 < K; c0 += U * FO_FWD_WAVES) {
+    float v[U][9];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * FO_FWD_WAVES;  // wave-uniform
+      const float* xc = xb + (size_t)(c < K ? c : c0) * plane;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float t = xc[off[k]];
+        v[u][k] = ok[k] ? t : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * FO_FWD_WAVES;
+      if (c < K) {  // uniform branch
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+          const float* wc = w + ((size_t)o * K + c) * 9;  // wave-uniform address: scalar loads
+#pragma unroll
+          for (int k = 0; k < 9; ++k) acc[o] += wc[k] * v[u][k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < N; ++o) red[wave][o][lane] = acc[o];
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * FO_PX; e += FO_PX * FO_FWD_WAVES) {
+    const int o = e / FO_PX, l = e % FO_PX;
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < FO_FWD_WAVES; ++g) s += red[g][o][l];
+    const long long q = (long long)blockIdx.x * FO_PX + l;
+    if (q < plane) out[((size_t)b * N + o) * plane + q] = s + (bias ? bias[o] : 0.f);
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(FO_PX* FO_WAVES) void conv3x3_fewout_bwd_kernel(
+    const float* __restrict__ gout, const float* __restrict__ w, float* __restrict__ gx, int K, int H, int W,
+    int csplit) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y / csplit, part = blockIdx.y % csplit;
+  const long long plane = (long long)H * W;
+  const long long p = (long long)blockIdx.x * FO_PX + lane;
+  const bool live = p < plane;
+  const int y = live ? (int)(p / W) : 0, xx = live ? (int)(p % W) : 0;
+  // g[o][ky*3+kx] = grad_out[o][y + 1 - ky][x + 1 - kx]
+  float g[N][9];
+  const float* gb = gout + (size_t)b * N * plane;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = y + 1 - ky, xq = xx + 1 - kx;
+      const bool ok = live && yy >= 0 && yy < H && xq >= 0 && xq < W;
+      const int o_ = ok ? yy * W + xq : 0;
+#pragma unroll
+      for (int o = 0; o < N; ++o) {
+        const float t = gb[(size_t)o * plane + o_];
+        g[o][ky * 3 + kx] = ok ? t : 0.f;
+      }
+    }
+  float* xb = gx + (size_t)b * K * plane;
+  constexpr int U = 4;
+  const int cstep = FO_WAVES * csplit;
+  for (int c0 = part * FO_WAVES + wave; c0 < K; c0 += U * cstep) {
+    float s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * cstep;  // wave-uniform
+      s[u] = 0.f;
+      if (c < K) {
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+          const float* wc = w + ((size_t)o * K + c) * 9;  // wave-uniform address: scalar loads
+#pragma unroll
+          for (int k = 0; k < 9; ++k) s[u] += wc[k] * g[o][k];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * cstep;
+      if (c < K && live) xb[(size_t)c * plane + p] = s[u];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pcfa_conv3x3_fewout_fwd(const float* x, const float* w, const float* bias, float* out, int B, int K,
+                                       int N, int H, int W, void* stream) {
+  if (!x || !w || !out || B < 1 || K < 1 || H < 1 || W < 1) return PCFA_ERR_INVALID_ARG;
+  if (N < 1 || N > 4) return PCFA_ERR_UNSUPPORTED;
+  const long long plane = (long long)H * W;
+  dim3 grid(pcfa_cdiv(plane, FO_PX), B), block(FO_PX * FO_FWD_WAVES);
+  hipStream_t s = (hipStream_t)stream;
+  switch (N) {
+    case 1: pcfa_launch(conv3x3_fewout_fwd_kernel<1>, grid, block, 0, s, x, w, bias, out, K, H, W); break;
+    case 2: pcfa_launch(conv3x3_fewout_fwd_kernel<2>, grid, block, 0, s, x, w, bias, out, K, H, W); break;
+    case 3: pcfa_launch(conv3x3_fewout_fwd_kernel<3>, grid, block, 0, s, x, w, bias, out, K, H, W); break;
+    default: pcfa_launch(conv3x3_fewout_fwd_kernel<4>, grid, block, 0, s, x, w, bias, out, K, H, W); break;
+  }
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_conv3x3_fewout_bwd(const float* grad_out, const float* w, float* grad_x, int B, int K, int N,
+                                       int H, int W, void* stream) {
+  if (!grad_out || !w || !grad_x || B < 1 || K < 1 || H < 1 || W < 1) return PCFA_ERR_INVALID_ARG;
+  if (N < 1 || N > 4) return PCFA_ERR_UNSUPPORTED;
+  const long long plane = (long long)H * W;
+  // channels are independent in the data gradient: split them over blockIdx.y until the grid fills the chip
+  const int tiles = pcfa_cdiv(plane, FO_PX) * B;
+  int csplit = 1;
+  while (tiles * csplit < 512 && FO_WAVES * csplit * 2 <= K) csplit *= 2;
+  dim3 grid(pcfa_cdiv(plane, FO_PX), B * csplit), block(FO_PX * FO_WAVES);
+  hipStream_t s = (hipStream_t)stream;
+  switch (N) {
+    case 1: pcfa_launch(conv3x3_fewout_bwd_kernel<1>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
+    case 2: pcfa_launch(conv3x3_fewout_bwd_kernel<2>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
+    case 3: pcfa_launch(conv3x3_fewout_bwd_kernel<3>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
+    default: pcfa_launch(conv3x3_fewout_bwd_kernel<4>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
+  }
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}

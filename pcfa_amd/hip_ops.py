@@ -101,6 +101,8 @@ class DispatchTimer:
         "pcfa_gru_gates_bwd": [("gru_gates_bwd", 0)],
         "pcfa_gru_update_fwd": [("gru_update_fwd", 0)],
         "pcfa_gru_update_bwd": [("gru_update_bwd", 0)],
+        "pcfa_conv3x3_fewout_fwd": [("conv3x3_fewout_fwd", 0)],
+        "pcfa_conv3x3_fewout_bwd": [("conv3x3_fewout_bwd", 0)],
         "pcfa_instnorm_fwd": [("instnorm_stats_fwd", 0), ("instnorm_apply_fwd", 1)],
         "pcfa_instnorm_bwd": [("instnorm_stats_bwd", 0), ("instnorm_apply_bwd", 1)],
         "pcfa_add_relu_fwd": [("add_relu_fwd", 0)],
@@ -579,6 +581,43 @@ class _BiasRelu(torch.autograd.Function):
 
 
 _sepconv_packs = {}  # id(weight) -> (weakref, version, fwd_packed, bwd_packed)
+
+
+class _Conv3x3FewOut(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _dev(x, weight, bias)
+        if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or not 1 <= weight.shape[0] <= 4:
+            raise ValueError("conv3x3_fewout expects a [N<=4, K, 3, 3] weight, got %s" % (tuple(weight.shape),))
+        x = x.contiguous()
+        B, K, H, W = x.shape
+        N = weight.shape[0]
+        if weight.shape[1] != K:
+            raise ValueError("conv3x3_fewout: input %s does not match weight %s" % (tuple(x.shape), tuple(weight.shape)))
+        w = weight.detach().contiguous()
+        out = torch.empty((B, N, H, W), device=x.device, dtype=torch.float32)
+        _call("pcfa_conv3x3_fewout_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(out), B, K, N, H, W)
+        ctx.save_for_backward(w)
+        ctx.dims = (B, K, N, H, W)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise RuntimeError("conv3x3_fewout is the frozen-weight path: no weight / bias gradient")
+        (w,) = ctx.saved_tensors
+        B, K, N, H, W = ctx.dims
+        g = g.contiguous()
+        gx = torch.empty((B, K, H, W), device=g.device, dtype=torch.float32)
+        _call("pcfa_conv3x3_fewout_bwd", _ptr(g), _ptr(w), _ptr(gx), B, K, N, H, W)
+        return gx, None, None
+
+
+def conv3x3_fewout(x, weight, bias=None):
+    """conv2d(x, weight, bias, stride=1, padding=1) for a frozen 3x3 weight with at most 4 output channels (the
+    flow-prediction layers): a streaming kernel instead of a padded matrix-core tile."""
+    return _Conv3x3FewOut.apply(x, weight, bias)
 
 
 class _InstNormRelu(torch.autograd.Function):

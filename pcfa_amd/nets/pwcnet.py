@@ -38,8 +38,18 @@ def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
         nn.LeakyReLU(0.1))
 
 
+class _PredictFlow(nn.Conv2d):
+    """A 3x3 flow-prediction layer (2 output channels).  Frozen weights stream through ops.conv3x3_fewout (an
+    HBM-bound kernel) instead of a library convolution padded to a matrix-core tile; parameter names unchanged."""
+
+    def forward(self, x):
+        if not (self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad)):
+            return ops.get().conv3x3_fewout(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def predict_flow(in_planes):
-    return nn.Conv2d(int(in_planes), 2, kernel_size=3, stride=1, padding=1, bias=True)
+    return _PredictFlow(int(in_planes), 2, kernel_size=3, stride=1, padding=1, bias=True)
 
 
 def deconv(in_planes, out_planes, kernel_size=4, stride=2, padding=1):

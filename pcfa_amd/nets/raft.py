@@ -175,6 +175,15 @@ def _conv_relu(conv, x):
     return ops.get().bias_relu(_conv_nobias(conv, x), conv.bias)
 
 
+def _predict_flow(conv, x):
+    """conv(x) for a flow-prediction layer (3x3, <= 4 output channels): frozen weights stream through
+    ops.conv3x3_fewout instead of a library convolution padded to a matrix-core tile."""
+    if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and conv.out_channels <= 4 and _frozen_conv(conv)):
+        return ops.get().conv3x3_fewout(x, conv.weight, conv.bias)
+    return conv(x)
+
+
 class FlowHead(nn.Module):
     def __init__(self, input_dim=128, hidden_dim=256):
         super().__init__()
@@ -183,7 +192,7 @@ class FlowHead(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return self.conv2(_conv_relu(self.conv1, x))
+        return _predict_flow(self.conv2, _conv_relu(self.conv1, x))
 
 
 class SepConvGRU(nn.Module):

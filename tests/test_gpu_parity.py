@@ -295,6 +295,34 @@ def test_channelnorm_vs_oracle(oracle_ops, shape):
     assert float(xg.grad[0, :, 0, 0].abs().max()) == 0.0
 
 
+# --------------------------------------------------------------------------- flow-prediction convolutions
+@pytest.mark.parametrize("shape,n", [((1, 256, 55, 128), 2), ((2, 37, 9, 13), 2), ((1, 1026, 14, 32), 2),
+                                     ((1, 5, 3, 70), 1), ((2, 16, 17, 5), 3), ((1, 64, 24, 40), 4)])
+def test_conv3x3_fewout_vs_oracle(oracle_ops, shape, n):
+    """FlowHead.conv2 at 440x1024 / 8, FlowNet2's predict_flow5 shape, ragged sizes, 1..4 output channels, with
+    and without bias.  Tolerance: summation order over K*9 products (2e-6 * sqrt(9K) * max|out|)."""
+    gen = torch.Generator().manual_seed(shape[1] + n)
+    B, K, H, W = shape
+    x = torch.randn(*shape, generator=gen).requires_grad_(True)
+    w = torch.randn(n, K, 3, 3, generator=gen) / (3 * K ** 0.5)
+    bias = torch.randn(n, generator=gen) if K % 2 else None
+    want = oracle_ops.conv3x3_fewout(x, w, bias)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.conv3x3_fewout(xg, w.to(DEV), None if bias is None else bias.to(DEV))
+    assert got.shape == want.shape
+    assert max_abs(got, want) <= 2e-6 * (9 * K) ** 0.5 * float(want.detach().abs().max())
+    got.backward(go.to(DEV))
+    assert rel_l2(xg.grad, x.grad) < 1e-5
+    xg2 = x.detach().to(DEV).requires_grad_(True)
+    got2 = hip_ops.conv3x3_fewout(xg2, w.to(DEV), None if bias is None else bias.to(DEV))
+    got2.backward(go.to(DEV))
+    assert torch.equal(got2, got) and torch.equal(xg2.grad, xg.grad)
+    with pytest.raises(ValueError):
+        hip_ops.conv3x3_fewout(xg.detach(), torch.zeros(5, K, 3, 3, device=DEV))
+
+
 # --------------------------------------------------------------------------- encoder normalisation
 @pytest.mark.parametrize("shape,relu", [((2, 64, 220, 512), True), ((2, 96, 110, 256), False), ((2, 128, 55, 128), True),
                                         ((1, 5, 7, 9), True), ((3, 2, 33, 21), False), ((1, 3, 1, 6), True)])
