@@ -55,7 +55,7 @@ PCFA_API int pcfa_abi_version(void);
  * Entry points that launch several kernels: pcfa_corr_pyramid_bwd = {GEMM dfmap1, reduce, GEMM df2ext, reduce,
  * pooling adjoint}, pcfa_flow_loss_fwd = {partials, final}, pcfa_spatial_corr_bwd = {grad_in1, grad_in2},
  * pcfa_flownet_corr_bwd = {grad_in1, grad_in2}, pcfa_resample2d_bwd = {clear grad_in1, scatter + flow gradient},
- * pcfa_instnorm_fwd / _bwd = {partial sums, apply}.
+ * pcfa_instnorm_fwd / _bwd = {partial sums, apply}, pcfa_pwc_warp_bwd = {clear, scatter + flow gradient}.
  * nth < 0 drops every pair still queued (events of kernels that were never launched stay unrecorded). */
 PCFA_API int pcfa_timing_arm(void* start_event, void* stop_event, int nth);
 
@@ -330,6 +330,17 @@ PCFA_API int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, float*
 PCFA_API int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out, long long n, int plane, int channels,
                        void* stream);
 PCFA_API int pcfa_relu_bwd(const float* out, const float* grad_out, float* grad_x, long long n, void* stream);
+
+/* PWC-Net's backward warp (models/PWCNet/PWCNet.py:166-206) as one pass per direction:
+ *   out = grid_sample(x, normalise(meshgrid + flo)) * (grid_sample(ones, ...) >= mask_threshold)
+ * bilinear, zero padding, align_corners = False, the reference's fp32 coordinate arithmetic (normalise by W-1, then
+ * grid_sample's un-normalisation by W).  x, out, grad_*: [B][C][H][W]; flo, grad_flo: [B][2][H][W].
+ * pcfa_pwc_warp_bwd = {clear grad_x and grad_flo, scatter (hardware fp32 atomics, like grid_sampler_2d_backward) +
+ * flow gradient}. */
+PCFA_API int pcfa_pwc_warp_fwd(const float* x, const float* flo, float* out, int B, int C, int H, int W,
+                               float mask_threshold, void* stream);
+PCFA_API int pcfa_pwc_warp_bwd(const float* x, const float* flo, const float* grad_out, float* grad_x,
+                               float* grad_flo, int B, int C, int H, int W, float mask_threshold, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution with N <= 4 output channels and its data gradient (frozen weights): the
  * flow-prediction layers -- FlowHead.conv2 of RAFT / GMA (models/raft/update.py:6-14), predict_flow of PWC-Net

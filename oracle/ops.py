@@ -485,6 +485,24 @@ def gru_step(h, rest, halves):
     return h
 
 
+def pwc_warp(x, flo, mask_threshold=0.0001):
+    """models/PWCNet/PWCNet.py:166-206, statement by statement."""
+    B, C, H, W = x.size()
+    xx = torch.arange(0, W).view(1, -1).repeat(H, 1)
+    yy = torch.arange(0, H).view(-1, 1).repeat(1, W)
+    xx = xx.view(1, 1, H, W).repeat(B, 1, 1, 1)
+    yy = yy.view(1, 1, H, W).repeat(B, 1, 1, 1)
+    grid = torch.cat((xx, yy), 1).float()
+    vgrid = grid + flo
+    vx = 2.0 * vgrid[:, 0, :, :] / max(W - 1, 1) - 1.0
+    vy = 2.0 * vgrid[:, 1, :, :] / max(H - 1, 1) - 1.0
+    vgrid = torch.stack((vx, vy), dim=3)
+    output = F.grid_sample(x, vgrid, align_corners=False)
+    mask = F.grid_sample(torch.ones(x.size()), vgrid, align_corners=False)
+    mask = (mask >= mask_threshold).float()
+    return output * mask
+
+
 def conv3x3_fewout(x, weight, bias=None):
     """The flow-prediction convolutions (models/raft/update.py:6-14, PWCNet.py:37-38, FlowNet/submodules.py:33-34)."""
     return F.conv2d(x, weight, bias, stride=1, padding=1)

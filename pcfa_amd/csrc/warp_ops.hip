@@ -1,0 +1,197 @@
+// PWC-Net's backward warp as ONE kernel per direction.
+//
+// Replaces the Python sequence of PWCDCNet.warp (reference models/PWCNet/PWCNet.py:166-206):
+//   vgrid = meshgrid + flo;  vx = 2*vgrid_x / max(W-1, 1) - 1;  vy likewise
+//   output = grid_sample(x, vgrid)            (bilinear, zero padding, align_corners = False)
+//   mask   = grid_sample(ones_like(x), vgrid) >= 0.0001
+//   return output * mask
+// which the library runs as ~14 launches forward (arange / repeat / cat / normalise, two grid_sampler_2d, compare,
+// cast, multiply) and two grid_sampler_2d_backward launches (221 us each at 32 x 96 x 320) plus elementwise
+// backward kernels.  Here: forward = one pass (read x where sampled, read flo, write out), backward = one pass that
+// scatters grad_x with hardware fp32 atomics (as grid_sampler_2d_backward does) and accumulates grad_flo.
+// The coordinate arithmetic repeats the reference's fp32 operation sequence: normalise (x2, /(W-1), -1), then
+// grid_sample's un-normalisation ((g + 1) * W - 1) / 2 -- the two do NOT cancel (align_corners mismatch of the
+// original PWC-Net code), the sample position is x * W / (W - 1) - 0.5.
+#include "common.hpp"
+
+namespace {
+
+struct WarpTaps {
+  int x0, y0;          // north-west tap
+  float wx1, wy1;      // weight of the east / south neighbour (ix - x0, iy - y0)
+  bool vx0, vx1, vy0, vy1;
+};
+
+__device__ __forceinline__ float warp_coord(float base, float flow, int size) {
+  float g = 2.0f * (base + flow);
+  g = g / (float)max(size - 1, 1);
+  g = g - 1.0f;
+  return ((g + 1.f) * (float)size - 1.f) / 2.f;  // grid_sampler_unnormalize, align_corners = false
+}
+
+__device__ __forceinline__ WarpTaps warp_taps(float ix, float iy, int H, int W) {
+  WarpTaps t;
+  const float fx = floorf(ix), fy = floorf(iy);
+  t.x0 = (int)fx;
+  t.y0 = (int)fy;
+  t.wx1 = ix - fx;
+  t.wy1 = iy - fy;
+  t.vx0 = t.x0 >= 0 && t.x0 < W;
+  t.vx1 = t.x0 + 1 >= 0 && t.x0 + 1 < W;
+  t.vy0 = t.y0 >= 0 && t.y0 < H;
+  t.vy1 = t.y0 + 1 >= 0 && t.y0 + 1 < H;
+  return t;
+}
+
+// grid = (pixel blocks, channel groups, B); thread = one pixel, channels c = group, group + G, ...
+__global__ __launch_bounds__(256) void pwc_warp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ flo,
+                                                          float* __restrict__ out, int C, int H, int W,
+                                                          float mask_thresh) {
+  const long long plane = (long long)H * W;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const int b = blockIdx.z, G = gridDim.y;
+  const int py = (int)(p / W), px = (int)(p % W);
+  const float* fb = flo + (size_t)b * 2 * plane;
+  const float ix = warp_coord((float)px, fb[p], W), iy = warp_coord((float)py, fb[plane + p], H);
+  const WarpTaps t = warp_taps(ix, iy, H, W);
+  // weights as grid_sampler_2d forms them: nw = (ix_se - ix) * (iy_se - iy), ...
+  const float ex = (float)(t.x0 + 1) - ix, ey = (float)(t.y0 + 1) - iy;  // ix_se - ix, iy_se - iy
+  const float nw = ex * ey, ne = t.wx1 * ey, sw = ex * t.wy1, se = t.wx1 * t.wy1;
+  const bool bnw = t.vx0 && t.vy0, bne = t.vx1 && t.vy0, bsw = t.vx0 && t.vy1, bse = t.vx1 && t.vy1;
+  float msum = 0.f;  // grid_sample(ones): the in-bounds weights, added in the kernel's tap order
+  if (bnw) msum += nw;
+  if (bne) msum += ne;
+  if (bsw) msum += sw;
+  if (bse) msum += se;
+  const float m = msum >= mask_thresh ? 1.f : 0.f;
+  const int onw = bnw ? t.y0 * W + t.x0 : 0, one = bne ? t.y0 * W + t.x0 + 1 : 0;
+  const int osw = bsw ? (t.y0 + 1) * W + t.x0 : 0, ose = bse ? (t.y0 + 1) * W + t.x0 + 1 : 0;
+  const float* xb = x + (size_t)b * C * plane;
+  float* ob = out + (size_t)b * C * plane + p;
+  for (int c = blockIdx.y; c < C; c += G) {
+    const float* xc = xb + (size_t)c * plane;
+    float v = 0.f;
+    const float a = xc[onw], bq = xc[one], cq = xc[osw], d = xc[ose];
+    if (bnw) v += a * nw;
+    if (bne) v += bq * ne;
+    if (bsw) v += cq * sw;
+    if (bse) v += d * se;
+    ob[(size_t)c * plane] = v * m;
+  }
+}
+
+// grad_x must be zero on entry (cleared by zero2_kernel below); grad_flo likewise when G > 1.
+__global__ __launch_bounds__(256) void pwc_warp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ flo,
+                                                          const float* __restrict__ gout, float* __restrict__ gx,
+                                                          float* __restrict__ gflo, int C, int H, int W,
+                                                          float mask_thresh) {
+  const long long plane = (long long)H * W;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const int b = blockIdx.z, G = gridDim.y;
+  const int py = (int)(p / W), px = (int)(p % W);
+  const float* fb = flo + (size_t)b * 2 * plane;
+  const float ix = warp_coord((float)px, fb[p], W), iy = warp_coord((float)py, fb[plane + p], H);
+  const WarpTaps t = warp_taps(ix, iy, H, W);
+  const float ex = (float)(t.x0 + 1) - ix, ey = (float)(t.y0 + 1) - iy;
+  const float nw = ex * ey, ne = t.wx1 * ey, sw = ex * t.wy1, se = t.wx1 * t.wy1;
+  const bool bnw = t.vx0 && t.vy0, bne = t.vx1 && t.vy0, bsw = t.vx0 && t.vy1, bse = t.vx1 && t.vy1;
+  float msum = 0.f;
+  if (bnw) msum += nw;
+  if (bne) msum += ne;
+  if (bsw) msum += sw;
+  if (bse) msum += se;
+  if (!(msum >= mask_thresh)) return;  // output * 0: no gradient to either input (buffers are zero)
+  const int onw = bnw ? t.y0 * W + t.x0 : 0, one = bne ? t.y0 * W + t.x0 + 1 : 0;
+  const int osw = bsw ? (t.y0 + 1) * W + t.x0 : 0, ose = bse ? (t.y0 + 1) * W + t.x0 + 1 : 0;
+  const float* xb = x + (size_t)b * C * plane;
+  float* gb = gx + (size_t)b * C * plane;
+  const float* go = gout + (size_t)b * C * plane + p;
+  float gix = 0.f, giy = 0.f;
+  for (int c = blockIdx.y; c < C; c += G) {
+    const float g = go[(size_t)c * plane];
+    const float* xc = xb + (size_t)c * plane;
+    float* gc = gb + (size_t)c * plane;
+    // grid_sampler_2d_backward: scatter into x, gather the grid gradient from the in-bounds taps
+    if (bnw) {
+      unsafeAtomicAdd(gc + onw, nw * g);
+      const float v = xc[onw];
+      gix -= v * ey * g;
+      giy -= v * ex * g;
+    }
+    if (bne) {
+      unsafeAtomicAdd(gc + one, ne * g);
+      const float v = xc[one];
+      gix += v * ey * g;
+      giy -= v * t.wx1 * g;
+    }
+    if (bsw) {
+      unsafeAtomicAdd(gc + osw, sw * g);
+      const float v = xc[osw];
+      gix -= v * t.wy1 * g;
+      giy += v * ex * g;
+    }
+    if (bse) {
+      unsafeAtomicAdd(gc + ose, se * g);
+      const float v = xc[ose];
+      gix += v * t.wy1 * g;
+      giy += v * t.wx1 * g;
+    }
+  }
+  // d ix / d grid = W / 2 (unnormalize), d grid / d flo = 2 / max(W - 1, 1) (the reference divides, then doubles)
+  const float dfx = 2.0f * ((0.5f * (float)W * gix) / (float)max(W - 1, 1));
+  const float dfy = 2.0f * ((0.5f * (float)H * giy) / (float)max(H - 1, 1));
+  float* gf = gflo + (size_t)b * 2 * plane;
+  if (G == 1) {
+    gf[p] = dfx;
+    gf[plane + p] = dfy;
+  } else {
+    unsafeAtomicAdd(gf + p, dfx);
+    unsafeAtomicAdd(gf + plane + p, dfy);
+  }
+}
+
+__global__ void zero2_kernel(float* __restrict__ a, long long na, float* __restrict__ b, long long nb) {
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += step) {
+    if (i < na) a[i] = 0.f;
+    else b[i - na] = 0.f;
+  }
+}
+
+int channel_groups(long long plane, int C) {
+  int g = 1;
+  while (plane * g < 65536 && 2 * g <= C / 4 && g < 32) g *= 2;
+  return g;
+}
+
+}  // namespace
+
+extern "C" int pcfa_pwc_warp_fwd(const float* x, const float* flo, float* out, int B, int C, int H, int W,
+                                 float mask_threshold, void* stream) {
+  if (!x || !flo || !out || B < 1 || C < 1 || H < 1 || W < 1) return PCFA_ERR_INVALID_ARG;
+  const long long plane = (long long)H * W;
+  dim3 grid(pcfa_cdiv(plane, 256), channel_groups(plane, C), B);
+  pcfa_launch(pwc_warp_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, flo, out, C, H, W, mask_threshold);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_pwc_warp_bwd(const float* x, const float* flo, const float* grad_out, float* grad_x,
+                                 float* grad_flo, int B, int C, int H, int W, float mask_threshold, void* stream) {
+  if (!x || !flo || !grad_out || !grad_x || !grad_flo || B < 1 || C < 1 || H < 1 || W < 1)
+    return PCFA_ERR_INVALID_ARG;
+  const long long plane = (long long)H * W;
+  hipStream_t s = (hipStream_t)stream;
+  const long long na = (long long)B * C * plane, nb = (long long)B * 2 * plane;
+  long long zb = (na + nb + 255) / 256;
+  if (zb > 4096) zb = 4096;
+  pcfa_launch(zero2_kernel, dim3((int)zb), dim3(256), 0, s, grad_x, na, grad_flo, nb);
+  PCFA_LAUNCH_CHECK();
+  dim3 grid(pcfa_cdiv(plane, 256), channel_groups(plane, C), B);
+  pcfa_launch(pwc_warp_bwd_kernel, grid, dim3(256), 0, s, x, flo, grad_out, grad_x, grad_flo, C, H, W,
+              mask_threshold);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}

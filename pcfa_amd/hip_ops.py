@@ -101,6 +101,8 @@ class DispatchTimer:
         "pcfa_gru_gates_bwd": [("gru_gates_bwd", 0)],
         "pcfa_gru_update_fwd": [("gru_update_fwd", 0)],
         "pcfa_gru_update_bwd": [("gru_update_bwd", 0)],
+        "pcfa_pwc_warp_fwd": [("pwc_warp_fwd", 0)],
+        "pcfa_pwc_warp_bwd": [("pwc_warp_bwd", 1)],
         "pcfa_conv3x3_fewout_fwd": [("conv3x3_fewout_fwd", 0)],
         "pcfa_conv3x3_fewout_bwd": [("conv3x3_fewout_bwd", 0)],
         "pcfa_instnorm_fwd": [("instnorm_stats_fwd", 0), ("instnorm_apply_fwd", 1)],
@@ -581,6 +583,37 @@ class _BiasRelu(torch.autograd.Function):
 
 
 _sepconv_packs = {}  # id(weight) -> (weakref, version, fwd_packed, bwd_packed)
+
+
+class _PwcWarp(torch.autograd.Function):
+    """PWCDCNet.warp (models/PWCNet/PWCNet.py:166-206) on pcfa_pwc_warp_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, x, flo, mask_threshold):
+        _dev(x, flo)
+        x, flo = x.contiguous(), flo.contiguous()
+        B, C, H, W = x.shape
+        if tuple(flo.shape) != (B, 2, H, W):
+            raise ValueError("pwc_warp: flow %s does not match features %s" % (tuple(flo.shape), tuple(x.shape)))
+        out = torch.empty_like(x)
+        ctx.params = (B, C, H, W, float(mask_threshold))
+        _call("pcfa_pwc_warp_fwd", _ptr(x), _ptr(flo), _ptr(out), *ctx.params)
+        ctx.save_for_backward(x, flo)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, flo = ctx.saved_tensors
+        g = g.contiguous()
+        gx, gf = torch.empty_like(x), torch.empty_like(flo)
+        _call("pcfa_pwc_warp_bwd", _ptr(x), _ptr(flo), _ptr(g), _ptr(gx), _ptr(gf), *ctx.params)
+        return gx, gf, None
+
+
+def pwc_warp(x, flo, mask_threshold=0.0001):
+    """Backward-warp x by flo with PWC-Net's validity mask: one launch forward, two backward."""
+    return _PwcWarp.apply(x, flo, mask_threshold)
 
 
 class _Conv3x3FewOut(torch.autograd.Function):

@@ -295,6 +295,30 @@ def test_channelnorm_vs_oracle(oracle_ops, shape):
     assert float(xg.grad[0, :, 0, 0].abs().max()) == 0.0
 
 
+# --------------------------------------------------------------------------- PWC-Net warp
+@pytest.mark.parametrize("shape,scale", [((1, 128, 12, 40), 1.5), ((1, 96, 24, 80), 3.0), ((2, 64, 48, 160), 6.0),
+                                         ((1, 32, 96, 320), 12.0), ((1, 5, 7, 9), 4.0)])
+def test_pwc_warp_vs_oracle(oracle_ops, shape, scale):
+    """PWCDCNet.warp at the four KITTI-size levels (+ a ragged shape) vs the reference's own statement sequence on
+    the CPU (grid_sample x2, mask, multiply).  Flows reach outside the image (zero padding, mask = 0).  Tolerance:
+    the coordinate arithmetic is the same fp32 sequence, products may be fused: 2e-6 * max|x|; gradients 2e-5."""
+    gen = torch.Generator().manual_seed(shape[2])
+    B, C, H, W = shape
+    x = torch.randn(*shape, generator=gen).requires_grad_(True)
+    flo = (scale * torch.randn(B, 2, H, W, generator=gen)).requires_grad_(True)
+    want = oracle_ops.pwc_warp(x, flo)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    xg, fg = x.detach().to(DEV).requires_grad_(True), flo.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.pwc_warp(xg, fg)
+    assert max_abs(got, want) <= 2e-6 * float(x.detach().abs().max())
+    got.backward(go.to(DEV))
+    assert rel_l2(xg.grad, x.grad) < 2e-5 and rel_l2(fg.grad, flo.grad) < 2e-5
+    # zero flow: the align_corners mismatch of the original code samples at x * W / (W - 1) - 0.5, not at x
+    ident = hip_ops.pwc_warp(xg.detach(), torch.zeros_like(fg))
+    assert max_abs(ident, oracle_ops.pwc_warp(x.detach(), torch.zeros_like(flo))) <= 2e-6 * float(x.detach().abs().max())
+
+
 # --------------------------------------------------------------------------- flow-prediction convolutions
 @pytest.mark.parametrize("shape,n", [((1, 256, 55, 128), 2), ((2, 37, 9, 13), 2), ((1, 1026, 14, 32), 2),
                                      ((1, 5, 3, 70), 1), ((2, 16, 17, 5), 3), ((1, 64, 24, 40), 4)])
