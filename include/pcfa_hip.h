@@ -346,9 +346,12 @@ PCFA_API int pcfa_pwc_warp_bwd(const float* x, const float* flo, const float* gr
  * flow-prediction layers -- FlowHead.conv2 of RAFT / GMA (models/raft/update.py:6-14), predict_flow of PWC-Net
  * (models/PWCNet/PWCNet.py:37-38) and FlowNet2 (models/FlowNet/submodules.py:33-34).  A stream over the input
  * (HBM-bound), not matrix-core work.  x / grad_x: [B][K][H][W]; w: [N][K][3][3] as nn.Conv2d stores it;
- * bias: [N] or NULL; out / grad_out: [B][N][H][W].  Fixed summation order (bitwise reproducible). */
-PCFA_API int pcfa_conv3x3_fewout_fwd(const float* x, const float* w, const float* bias, float* out, int B, int K,
-                                     int N, int H, int W, void* stream);
+ * bias: [N] or NULL; out / grad_out: [B][N][H][W]; workspace: pcfa_conv3x3_fewout_workspace_bytes() bytes (0 for
+ * large planes; small planes split the channel sum over workgroups: {partial sums, reduce}).  Fixed summation
+ * order (bitwise reproducible). */
+PCFA_API size_t pcfa_conv3x3_fewout_workspace_bytes(int B, int K, int N, int H, int W);
+PCFA_API int pcfa_conv3x3_fewout_fwd(const float* x, const float* w, const float* bias, float* out, void* workspace,
+                                     int B, int K, int N, int H, int W, void* stream);
 PCFA_API int pcfa_conv3x3_fewout_bwd(const float* grad_out, const float* w, float* grad_x, int B, int K, int N, int H,
                                      int W, void* stream);
 

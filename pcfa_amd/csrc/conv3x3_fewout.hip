@@ -22,11 +22,15 @@ constexpr int FO_FWD_WAVES = 16;  // forward: 16 waves x 8 channels in flight = 
 template <int N>
 __global__ __launch_bounds__(FO_PX* FO_FWD_WAVES) void conv3x3_fewout_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ out, int K, int H, int W) {
+    float* __restrict__ out, int K, int H, int W, int splits, int kper) {
   __shared__ float red[FO_FWD_WAVES][N][FO_PX];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.y;
+  // blockIdx.y = b * splits + split: with splits > 1 the workgroup reduces channels [kbeg, kend) only and `out` is
+  // the partial-sum workspace [splits][B][N][plane] (no bias), summed in split order by fewout_reduce_kernel
+  const int nb = gridDim.y / splits;
+  const int b = blockIdx.y / splits, split = blockIdx.y - b * splits;
+  const int kbeg = split * kper, kend = min(K, kbeg + kper);
   const long long plane = (long long)H * W;
   const long long p = (long long)blockIdx.x * FO_PX + lane;
   const bool live = p < plane;
@@ -47,12 +51,12 @@ __global__ __launch_bounds__(FO_PX* FO_FWD_WAVES) void conv3x3_fewout_fwd_kernel
   for (int o = 0; o < N; ++o) acc[o] = 0.f;
   const float* xb = x + (size_t)b * K * plane;
   constexpr int U = 8;  // channels in flight per wave: 72 loads per lane (the loop is a latency chain otherwise)
-  for (int c0 = wave; c0 < K; c0 += U * FO_FWD_WAVES) {
+  for (int c0 = kbeg + wave; c0 < kend; c0 += U * FO_FWD_WAVES) {
     float v[U][9];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int c = c0 + u * FO_FWD_WAVES;  // wave-uniform
-      const float* xc = xb + (size_t)(c < K ? c : c0) * plane;
+      const float* xc = xb + (size_t)(c < kend ? c : c0) * plane;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         const float t = xc[off[k]];
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(FO_PX* FO_FWD_WAVES) void conv3x3_fewout_fwd_kernel
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int c = c0 + u * FO_FWD_WAVES;
-      if (c < K) {  // uniform branch
+      if (c < kend) {  // uniform branch
 #pragma unroll
         for (int o = 0; o < N; ++o) {
           const float* wc = w + ((size_t)o * K + c) * 9;  // wave-uniform address: scalar loads
@@ -81,7 +85,21 @@ __global__ __launch_bounds__(FO_PX* FO_FWD_WAVES) void conv3x3_fewout_fwd_kernel
 #pragma unroll
     for (int g = 0; g < FO_FWD_WAVES; ++g) s += red[g][o][l];
     const long long q = (long long)blockIdx.x * FO_PX + l;
-    if (q < plane) out[((size_t)b * N + o) * plane + q] = s + (bias ? bias[o] : 0.f);
+    if (q < plane) {
+      if (splits > 1) out[(((size_t)split * nb + b) * N + o) * plane + q] = s;
+      else out[((size_t)b * N + o) * plane + q] = s + (bias ? bias[o] : 0.f);
+    }
+  }
+}
+
+// out[b][o][p] = bias[o] + sum over splits (in order) of part[split][b][o][p]
+__global__ void fewout_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                     float* __restrict__ out, long long n, long long plane, int N, int splits) {
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
+    out[i] = s + (bias ? bias[(i / plane) % N] : 0.f);
   }
 }
 
@@ -140,20 +158,51 @@ __global__ __launch_bounds__(FO_PX* FO_WAVES) void conv3x3_fewout_bwd_kernel(
 
 }  // namespace
 
-extern "C" int pcfa_conv3x3_fewout_fwd(const float* x, const float* w, const float* bias, float* out, int B, int K,
-                                       int N, int H, int W, void* stream) {
+// Channel splits of the forward: few pixels (coarse pyramid levels: 2 workgroups at 1024 x 7 x 16) cannot fill the
+// chip with one workgroup per 64 pixels, so the channel sum is split until ~256 workgroups exist (>= 64 channels each;
+// FlowNet2 closure: 920 -> 480 us over its 23 predict_flow layers).
+static int fewout_splits(int B, int K, long long plane) {
+  const long long tiles = (long long)pcfa_cdiv(plane, FO_PX) * B;
+  long long want = (256 + tiles - 1) / tiles;
+  const long long by_k = K / 64 > 0 ? K / 64 : 1;
+  if (want > by_k) want = by_k;
+  if (want > 64) want = 64;
+  return want < 4 ? 1 : (int)want;  // the reduce launch costs ~5 us: not worth it below a 4-fold split
+}
+
+extern "C" size_t pcfa_conv3x3_fewout_workspace_bytes(int B, int K, int N, int H, int W) {
+  if (B < 1 || K < 1 || N < 1 || N > 4 || H < 1 || W < 1) return 0;
+  const long long plane = (long long)H * W;
+  const int splits = fewout_splits(B, K, plane);
+  return splits > 1 ? (size_t)splits * B * N * plane * sizeof(float) : 0;
+}
+
+extern "C" int pcfa_conv3x3_fewout_fwd(const float* x, const float* w, const float* bias, float* out,
+                                       void* workspace, int B, int K, int N, int H, int W, void* stream) {
   if (!x || !w || !out || B < 1 || K < 1 || H < 1 || W < 1) return PCFA_ERR_INVALID_ARG;
   if (N < 1 || N > 4) return PCFA_ERR_UNSUPPORTED;
   const long long plane = (long long)H * W;
-  dim3 grid(pcfa_cdiv(plane, FO_PX), B), block(FO_PX * FO_FWD_WAVES);
+  const int splits = fewout_splits(B, K, plane);
+  if (splits > 1 && !workspace) return PCFA_ERR_WORKSPACE;
+  const int kper = ((K + splits - 1) / splits + FO_FWD_WAVES - 1) / FO_FWD_WAVES * FO_FWD_WAVES;
+  float* dst = splits > 1 ? (float*)workspace : out;
+  dim3 grid(pcfa_cdiv(plane, FO_PX), B * splits), block(FO_PX * FO_FWD_WAVES);
   hipStream_t s = (hipStream_t)stream;
   switch (N) {
-    case 1: pcfa_launch(conv3x3_fewout_fwd_kernel<1>, grid, block, 0, s, x, w, bias, out, K, H, W); break;
-    case 2: pcfa_launch(conv3x3_fewout_fwd_kernel<2>, grid, block, 0, s, x, w, bias, out, K, H, W); break;
-    case 3: pcfa_launch(conv3x3_fewout_fwd_kernel<3>, grid, block, 0, s, x, w, bias, out, K, H, W); break;
-    default: pcfa_launch(conv3x3_fewout_fwd_kernel<4>, grid, block, 0, s, x, w, bias, out, K, H, W); break;
+    case 1: pcfa_launch(conv3x3_fewout_fwd_kernel<1>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+    case 2: pcfa_launch(conv3x3_fewout_fwd_kernel<2>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+    case 3: pcfa_launch(conv3x3_fewout_fwd_kernel<3>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+    default: pcfa_launch(conv3x3_fewout_fwd_kernel<4>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
   }
   PCFA_LAUNCH_CHECK();
+  if (splits > 1) {
+    const long long n = (long long)B * N * plane;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    pcfa_launch(fewout_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)workspace, bias, out, n, plane,
+                N, splits);
+    PCFA_LAUNCH_CHECK();
+  }
   return PCFA_OK;
 }
 

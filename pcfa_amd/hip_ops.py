@@ -629,7 +629,9 @@ class _Conv3x3FewOut(torch.autograd.Function):
             raise ValueError("conv3x3_fewout: input %s does not match weight %s" % (tuple(x.shape), tuple(weight.shape)))
         w = weight.detach().contiguous()
         out = torch.empty((B, N, H, W), device=x.device, dtype=torch.float32)
-        _call("pcfa_conv3x3_fewout_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(out), B, K, N, H, W)
+        nws = int(_hip.load().pcfa_conv3x3_fewout_workspace_bytes(B, K, N, H, W))
+        ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32) if nws else None
+        _call("pcfa_conv3x3_fewout_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), B, K, N, H, W)
         ctx.save_for_backward(w)
         ctx.dims = (B, K, N, H, W)
         return out
