@@ -12,7 +12,8 @@
 // Fast path (what PWC-Net uses: k=1, stride 1, pad 0, patch PxP, dil_patch 1):
 //   forward : workgroup = 8x32 output pixels, wave z = patch row; a thread owns
 //             4 consecutive pixels x P shifts in registers and streams channel
-//             chunks of both feature maps through LDS (in2 tile carries the halo),
+//             chunks of both feature maps through LDS (in2 tile carries the halo;
+//             16-B pieces, next chunk prefetched into registers, two LDS stages),
 //             so every input byte is read from HBM once per tile and written
 //             outputs are 16-B vectors.
 //   backward: both gradients are gathers with the same shape,
@@ -27,8 +28,13 @@
 namespace {
 
 constexpr int TH = 8, TW = 32;  // output-pixel tile of the fast path
-constexpr int CC = 8;           // channels per LDS chunk
+constexpr int CC = 8;           // channels per LDS chunk (backward)
+constexpr int FC = 16;          // channels per LDS chunk (forward: half as many latency-bound round trips)
 
+// Preconditions (checked by the host): W % 4 == 0 and 16-B aligned in1 / in2, so the tiles are staged in 16-B
+// pieces that lie either inside or outside the image.  Two LDS stages: the next channel chunk is fetched into
+// registers before the FMAs of the current one and written to the other stage after them (one barrier per chunk;
+// the coarse pyramid levels are a single workgroup walking up to 25 chunks, i.e. a pure latency chain).
 template <int PS>
 __global__ __launch_bounds__(64 * PS) void scorr_fwd_fast_kernel(
     const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C,
@@ -36,9 +42,10 @@ __global__ __launch_bounds__(64 * PS) void scorr_fwd_fast_kernel(
   constexpr int R = (PS - 1) / 2;
   constexpr int HW2 = TW + 2 * R;  // in2 tile width  (40 for PS=9)
   constexpr int HH2 = TH + 2 * R;  // in2 tile height (16)
-  constexpr int S2 = (HW2 + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) float s1[CC][TH][TW];
-  __shared__ __attribute__((aligned(16))) float s2[CC][HH2][S2];
+  static_assert(R % 4 == 0 && HW2 % 4 == 0, "halo must keep the 16-B pieces aligned");
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float s1[2][FC][TH][TW];
+  __shared__ __attribute__((aligned(16))) float s2[2][FC][HH2][HW2];
 
   const int b = blockIdx.z;
   const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
@@ -49,51 +56,91 @@ __global__ __launch_bounds__(64 * PS) void scorr_fwd_fast_kernel(
   const float* p1 = in1 + (size_t)b * C * plane;
   const float* p2 = in2 + (size_t)b * C * plane;
 
+  // staging plan (fixed per thread): pieces of the in1 tile and of the in2 tile with its halo
+  constexpr int N1 = FC * TH * (TW / 4), N2 = FC * HH2 * (HW2 / 4);
+  constexpr int S1 = (N1 + NT - 1) / NT, S2 = (N2 + NT - 1) / NT;
+  int o1[S1], d1[S1], o2[S2], d2[S2];  // global offset inside the chunk (-1: outside), LDS float index (-1: none)
+#pragma unroll
+  for (int k = 0; k < S1; ++k) {
+    const int e = tid + k * NT;
+    const int c = e / (TH * (TW / 4)), r = (e / (TW / 4)) % TH, m = e % (TW / 4);
+    const int gy = y0 + r, gx = x0 + 4 * m;
+    o1[k] = (e < N1 && gy < H && gx < W) ? (int)(c * plane) + gy * W + gx : -1;
+    d1[k] = e < N1 ? (c * TH + r) * TW + 4 * m : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < S2; ++k) {
+    const int e = tid + k * NT;
+    const int c = e / (HH2 * (HW2 / 4)), r = (e / (HW2 / 4)) % HH2, m = e % (HW2 / 4);
+    const int gy = y0 + r - R, gx = x0 + 4 * m - R;
+    o2[k] = (e < N2 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (int)(c * plane) + gy * W + gx : -1;
+    d2[k] = e < N2 ? (c * HH2 + r) * HW2 + 4 * m : -1;
+  }
+
   float acc[4][PS];
 #pragma unroll
   for (int p = 0; p < 4; ++p)
 #pragma unroll
     for (int d = 0; d < PS; ++d) acc[p][d] = 0.f;
 
-  for (int c0 = 0; c0 < C; c0 += CC) {
-    // stage in1 tile
-    for (int e = tid; e < CC * TH * TW; e += NT) {
-      const int c = e / (TH * TW), r = (e / TW) % TH, x = e % TW;
-      const int gy = y0 + r, gx = x0 + x;
-      float v = 0.f;
-      if (c0 + c < C && gy < H && gx < W) v = p1[(size_t)(c0 + c) * plane + (size_t)gy * W + gx];
-      s1[c][r][x] = v;
-    }
-    // stage in2 tile with halo
-    for (int e = tid; e < CC * HH2 * HW2; e += NT) {
-      const int c = e / (HH2 * HW2), r = (e / HW2) % HH2, x = e % HW2;
-      const int gy = y0 + r - R, gx = x0 + x - R;
-      float v = 0.f;
-      if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W)
-        v = p2[(size_t)(c0 + c) * plane + (size_t)gy * W + gx];
-      s2[c][r][x] = v;
-    }
-    __syncthreads();
+  f32x4 r1[S1], r2[S2];
+  auto fetch = [&](int c0) {  // branch-free: a dead piece reads offset 0 of the chunk and is zeroed
+    const int climit = (int)((size_t)(C - c0) * plane);
+    const float* b1 = p1 + (size_t)c0 * plane;
+    const float* b2 = p2 + (size_t)c0 * plane;
 #pragma unroll
-    for (int c = 0; c < CC; ++c) {
-      const float4 a = *reinterpret_cast<const float4*>(&s1[c][ty][4 * tx]);
+    for (int k = 0; k < S1; ++k) {
+      const bool ok = o1[k] >= 0 && o1[k] < climit;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(b1 + (ok ? o1[k] : 0));
+      r1[k] = ok ? t : (f32x4)(0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < S2; ++k) {
+      const bool ok = o2[k] >= 0 && o2[k] < climit;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(b2 + (ok ? o2[k] : 0));
+      r2[k] = ok ? t : (f32x4)(0.f);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < S1; ++k)
+      if (d1[k] >= 0) *reinterpret_cast<f32x4*>(&s1[buf][0][0][0] + d1[k]) = r1[k];
+#pragma unroll
+    for (int k = 0; k < S2; ++k)
+      if (d2[k] >= 0) *reinterpret_cast<f32x4*>(&s2[buf][0][0][0] + d2[k]) = r2[k];
+  };
+
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  int cur = 0;
+  for (int c0 = 0; c0 < C; c0 += FC) {
+    const bool more = c0 + FC < C;
+    if (more) fetch(c0 + FC);
+#pragma unroll 2
+    for (int c = 0; c < FC; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(&s1[cur][c][ty][4 * tx]);
       float v2[4 + 2 * R];
 #pragma unroll
-      for (int k = 0; k < 4 + 2 * R; ++k) v2[k] = s2[c][ty + tz][4 * tx + k];
+      for (int k = 0; k < (4 + 2 * R) / 4; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(&s2[cur][c][ty + tz][4 * tx + 4 * k]);
+        v2[4 * k] = t.x; v2[4 * k + 1] = t.y; v2[4 * k + 2] = t.z; v2[4 * k + 3] = t.w;
+      }
       const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
       for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int d = 0; d < PS; ++d) acc[p][d] += av[p] * v2[p + d];
     }
+    if (more) commit(cur ^ 1);
     __syncthreads();
+    cur ^= 1;
   }
 
   const int gy = y0 + ty, gx = x0 + 4 * tx;
-  if (gy >= H) return;
+  if (gy >= H || gx >= W) return;
   float* o = out + (((size_t)b * PS + tz) * PS) * plane + (size_t)gy * W + gx;
-  const bool vec = (W % 4 == 0) && (gx + 3 < W) &&
-                   ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const bool vec = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
 #pragma unroll
   for (int d = 0; d < PS; ++d) {
     float* od = o + (size_t)d * plane;
@@ -101,8 +148,7 @@ __global__ __launch_bounds__(64 * PS) void scorr_fwd_fast_kernel(
       *reinterpret_cast<float4*>(od) = make_float4(acc[0][d], acc[1][d], acc[2][d], acc[3][d]);
     } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
-        if (gx + p < W) od[p] = acc[p][d];
+      for (int p = 0; p < 4; ++p) od[p] = acc[p][d];
     }
   }
 }
@@ -309,7 +355,8 @@ extern "C" int pcfa_spatial_corr_fwd(const float* in1, const float* in2, float* 
                    dil_patchW, dH, dW))
     return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (is_fast(p, 9)) {
+  const bool aligned = iW % 4 == 0 && ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
+  if (is_fast(p, 9) && aligned) {
     dim3 grid(pcfa_cdiv(iW, TW), pcfa_cdiv(iH, TH), B), block(8, 8, 9);
     pcfa_launch(scorr_fwd_fast_kernel<9>, grid, block, 0, s, in1, in2, out, C, iH, iW);
   } else {
