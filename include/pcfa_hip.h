@@ -331,6 +331,13 @@ PCFA_API int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out, l
                        void* stream);
 PCFA_API int pcfa_relu_bwd(const float* out, const float* grad_out, float* grad_x, long long n, void* stream);
 
+/* act(conv2d(x, w, bias, stride=1, padding=ksize/2)) for Cin <= 4 input channels, forward only: convf1 of the
+ * motion encoder (models/raft/update.py:79-101, Conv2d(2, 128, 7, padding=3) + ReLU on the detached flow).
+ * x: [B][Cin][H][W]; w: [N][Cin][k][k]; out: [B][N][H][W].  Supported (Cin, ksize): (2,7) (1,7) (2,5) (2,3);
+ * anything else returns PCFA_ERR_UNSUPPORTED (the caller keeps the library convolution). */
+PCFA_API int pcfa_conv_fewin_fwd(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int N,
+                                 int H, int W, int ksize, int relu, void* stream);
+
 /* PWC-Net's backward warp (models/PWCNet/PWCNet.py:166-206) as one pass per direction:
  *   out = grid_sample(x, normalise(meshgrid + flo)) * (grid_sample(ones, ...) >= mask_threshold)
  * bilinear, zero padding, align_corners = False, the reference's fp32 coordinate arithmetic (normalise by W-1, then

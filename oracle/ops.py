@@ -485,6 +485,15 @@ def gru_step(h, rest, halves):
     return h
 
 
+FEWIN_SHAPES = {(2, 7), (1, 7), (2, 5), (2, 3)}
+
+
+def conv_fewin(x, weight, bias=None, relu=False):
+    """models/raft/update.py:79-101: F.relu(self.convf1(flow)) (any k x k "same" convolution)."""
+    y = F.conv2d(x, weight, bias, stride=1, padding=weight.shape[-1] // 2)
+    return F.relu(y) if relu else y
+
+
 def pwc_warp(x, flo, mask_threshold=0.0001):
     """models/PWCNet/PWCNet.py:166-206, statement by statement."""
     B, C, H, W = x.size()

@@ -78,6 +78,7 @@ SIGNATURES = {
                                      _P]),
     "pcfa_bias_relu_fwd": (c_int, [_P, _P, _P, c_longlong, c_int, c_int, _P]),
     "pcfa_relu_bwd": (c_int, [_P, _P, _P, c_longlong, _P]),
+    "pcfa_conv_fewin_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_pwc_warp_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "pcfa_pwc_warp_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "pcfa_conv3x3_fewout_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -101,6 +101,7 @@ class DispatchTimer:
         "pcfa_gru_gates_bwd": [("gru_gates_bwd", 0)],
         "pcfa_gru_update_fwd": [("gru_update_fwd", 0)],
         "pcfa_gru_update_bwd": [("gru_update_bwd", 0)],
+        "pcfa_conv_fewin_fwd": [("conv_fewin_fwd", 0)],
         "pcfa_pwc_warp_fwd": [("pwc_warp_fwd", 0)],
         "pcfa_pwc_warp_bwd": [("pwc_warp_bwd", 1)],
         "pcfa_conv3x3_fewout_fwd": [("conv3x3_fewout_fwd", 0)],
@@ -583,6 +584,27 @@ class _BiasRelu(torch.autograd.Function):
 
 
 _sepconv_packs = {}  # id(weight) -> (weakref, version, fwd_packed, bwd_packed)
+
+
+FEWIN_SHAPES = {(2, 7), (1, 7), (2, 5), (2, 3)}  # (Cin, ksize) instances of pcfa_conv_fewin_fwd
+
+
+def conv_fewin(x, weight, bias=None, relu=False):
+    """act(conv2d(x, weight, bias, stride=1, padding=k//2)) for a frozen k x k weight with <= 4 input channels and an
+    input that needs no gradient (convf1 of the motion encoder on the detached flow): one streaming launch with bias
+    and ReLU fused.  Forward only."""
+    _dev(x, weight, bias)
+    if x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad):
+        raise RuntimeError("conv_fewin is forward-only: input and parameters must not require gradients")
+    N, Cin, kh, kw = weight.shape
+    if kh != kw or (Cin, kh) not in FEWIN_SHAPES or x.shape[1] != Cin:
+        raise ValueError("conv_fewin: unsupported weight %s for input %s" % (tuple(weight.shape), tuple(x.shape)))
+    x = x.contiguous()
+    B, _, H, W = x.shape
+    out = torch.empty((B, N, H, W), device=x.device, dtype=torch.float32)
+    _call("pcfa_conv_fewin_fwd", _ptr(x), _ptr(weight.contiguous()), _ptr(bias), _ptr(out), B, Cin, N, H, W, kh,
+          int(bool(relu)))
+    return out
 
 
 class _PwcWarp(torch.autograd.Function):

@@ -172,7 +172,14 @@ def _conv_relu(conv, x):
     and ReLU in the epilogue (ops.conv3x3); everything else: library convolution, bias + ReLU in one fused pass."""
     if _is_plain3x3(conv) and _frozen_conv(conv):
         return ops.get().conv3x3(x, conv.weight, conv.bias, True)
-    return ops.get().bias_relu(_conv_nobias(conv, x), conv.bias)
+    o = ops.get()
+    k = conv.kernel_size[0]
+    if (_frozen_conv(conv) and not x.requires_grad and conv.kernel_size == (k, k) and conv.stride == (1, 1)
+            and conv.padding == (k // 2, k // 2) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding_mode == "zeros" and (conv.in_channels, k) in o.FEWIN_SHAPES):
+        # convf1 on the detached flow: 2 input channels, no data gradient -- one streaming launch, bias + ReLU fused
+        return o.conv_fewin(x, conv.weight, conv.bias, True)
+    return o.bias_relu(_conv_nobias(conv, x), conv.bias)
 
 
 def _predict_flow(conv, x):

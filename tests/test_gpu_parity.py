@@ -347,6 +347,26 @@ def test_conv3x3_fewout_vs_oracle(oracle_ops, shape, n):
         hip_ops.conv3x3_fewout(xg.detach(), torch.zeros(5, K, 3, 3, device=DEV))
 
 
+@pytest.mark.parametrize("shape,n,k", [((1, 2, 55, 128), 128, 7), ((2, 2, 9, 13), 5, 7), ((1, 1, 7, 20), 16, 7),
+                                       ((1, 2, 11, 6), 9, 5), ((1, 2, 4, 3), 3, 3), ((1, 2, 3, 130), 64, 7)])
+def test_conv_fewin_vs_oracle(oracle_ops, shape, n, k):
+    """convf1 of the motion encoder (2 -> 128, 7x7 on 55x128) and ragged / tiny shapes (image narrower than the
+    kernel, rows wrapping inside a 64-pixel tile), with and without bias / ReLU.  2e-6 * sqrt(taps) * max|out|."""
+    gen = torch.Generator().manual_seed(n + k)
+    B, C, H, W = shape
+    x = 3 * torch.randn(*shape, generator=gen)
+    w = torch.randn(n, C, k, k, generator=gen) / k
+    for bias, relu in ((torch.randn(n, generator=gen), True), (None, False)):
+        want = oracle_ops.conv_fewin(x, w, bias, relu)
+        got = hip_ops.conv_fewin(x.to(DEV), w.to(DEV), None if bias is None else bias.to(DEV), relu)
+        assert got.shape == want.shape
+        assert max_abs(got, want) <= 2e-6 * (C * k * k) ** 0.5 * float(want.abs().max()) + 1e-6
+    with pytest.raises(RuntimeError):
+        hip_ops.conv_fewin(x.to(DEV).requires_grad_(True), w.to(DEV))
+    with pytest.raises(ValueError):
+        hip_ops.conv_fewin(torch.zeros(1, 3, 8, 8, device=DEV), torch.zeros(4, 3, 7, 7, device=DEV))
+
+
 # --------------------------------------------------------------------------- encoder normalisation
 @pytest.mark.parametrize("shape,relu", [((2, 64, 220, 512), True), ((2, 96, 110, 256), False), ((2, 128, 55, 128), True),
                                         ((1, 5, 7, 9), True), ((3, 2, 33, 21), False), ((1, 3, 1, 6), True)])
