@@ -21,9 +21,8 @@ __global__ __launch_bounds__(FI_PX* FI_WAVES) void conv_fewin_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, int N, int H, int W, int relu) {
   constexpr int R = KS / 2, T = CIN * KS * KS;  // taps per output
-  constexpr int TP = (T + 3) & ~3;              // padded to 16 B
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [N][TP] weights, then [CIN][span] inputs
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [N][T] weights (padded to 16 B), then [CIN][span] inputs
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y;
@@ -32,12 +31,27 @@ __global__ __launch_bounds__(FI_PX* FI_WAVES) void conv_fewin_fwd_kernel(
   const int halo = R * (W + 1);
   const int span = FI_PX + 2 * halo;
   float* wl = lds;
-  float* xl = lds + (size_t)N * TP;
+  float* xl = lds + (((size_t)N * T + 3) & ~(size_t)3);
 
-  // weights: w[o][c][ky][kx] is contiguous per output channel (T floats) -> wl[o][0..T), zero tail
-  for (int e = threadIdx.x; e < N * TP; e += FI_PX * FI_WAVES) {
-    const int o = e / TP, t = e - o * TP;
-    wl[e] = t < T ? w[(size_t)o * T + t] : 0.f;
+  // weights: a flat copy of w ([N][T] contiguous) in 16-B pieces, all loads of a batch issued before its LDS
+  // writes (a plain copy loop is one global round trip per element: 25 of them made the kernel 20 us)
+  {
+    constexpr int NTH = FI_PX * FI_WAVES, BATCH = 8;
+    const int n4 = (N * T) / 4;  // whole float4s (the pointer is 16-B aligned: checked by the host)
+    for (int e0 = threadIdx.x; e0 < n4; e0 += NTH * BATCH) {
+      f32x4 t[BATCH];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int e = e0 + k * NTH;
+        t[k] = reinterpret_cast<const f32x4*>(w)[e < n4 ? e : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int e = e0 + k * NTH;
+        if (e < n4) reinterpret_cast<f32x4*>(wl)[e] = t[k];
+      }
+    }
+    for (int e = 4 * n4 + threadIdx.x; e < N * T; e += NTH) wl[e] = w[e];
   }
   // inputs: flat range [p0 - halo, p0 + 63 + halo] of every channel, zero outside the image
   const float* xb = x + (size_t)b * CIN * plane;
@@ -50,9 +64,7 @@ __global__ __launch_bounds__(FI_PX* FI_WAVES) void conv_fewin_fwd_kernel(
 
   const long long p = p0 + lane;
   const int xx = (int)(p % W);  // (rows outside the image are zero in the flat range; columns wrap and are masked)
-  float v[TP];
-#pragma unroll
-  for (int t = T; t < TP; ++t) v[t] = 0.f;
+  float v[T];
 #pragma unroll
   for (int c = 0; c < CIN; ++c)
 #pragma unroll
@@ -67,16 +79,17 @@ __global__ __launch_bounds__(FI_PX* FI_WAVES) void conv_fewin_fwd_kernel(
   if (p >= plane) return;
   float* ob = out + (size_t)b * N * plane + p;
   for (int o = wave; o < N; o += FI_WAVES) {
-    const f32x4* wo = reinterpret_cast<const f32x4*>(wl + (size_t)o * TP);
+    const float* wo = wl + (size_t)o * T;  // broadcast reads (all lanes, same address)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four partial sums in a fixed pattern
 #pragma unroll
-    for (int i = 0; i < TP / 4; ++i) {
-      const f32x4 q = wo[i];
-      s0 += q.x * v[4 * i];
-      s1 += q.y * v[4 * i + 1];
-      s2 += q.z * v[4 * i + 2];
-      s3 += q.w * v[4 * i + 3];
+    for (int i = 0; i + 3 < T; i += 4) {
+      s0 += wo[i] * v[i];
+      s1 += wo[i + 1] * v[i + 1];
+      s2 += wo[i + 2] * v[i + 2];
+      s3 += wo[i + 3] * v[i + 3];
     }
+#pragma unroll
+    for (int i = T & ~3; i < T; ++i) s0 += wo[i] * v[i];
     float s = (s0 + s1) + (s2 + s3) + (bias ? bias[o] : 0.f);
     if (relu) s = fmaxf(s, 0.f);
     ob[(size_t)o * plane] = s;
@@ -86,10 +99,11 @@ __global__ __launch_bounds__(FI_PX* FI_WAVES) void conv_fewin_fwd_kernel(
 template <int CIN, int KS>
 int launch_fewin(const float* x, const float* w, const float* bias, float* out, int B, int N, int H, int W,
                  int relu, hipStream_t s) {
-  constexpr int T = CIN * KS * KS, TP = (T + 3) & ~3;
+  constexpr int T = CIN * KS * KS;
   const long long plane = (long long)H * W;
   const size_t span = FI_PX + 2 * (size_t)(KS / 2) * (W + 1);
-  const size_t bytes = ((size_t)N * TP + CIN * span) * sizeof(float);
+  const size_t bytes = ((((size_t)N * T + 3) & ~(size_t)3) + CIN * span) * sizeof(float);
+  if (reinterpret_cast<uintptr_t>(w) & 15) return PCFA_ERR_UNSUPPORTED;
   if (bytes > 150 * 1024) return PCFA_ERR_UNSUPPORTED;
   static size_t granted = 0;  // per template instance
   if (bytes > granted) {
