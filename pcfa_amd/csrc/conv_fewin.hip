@@ -6,104 +6,139 @@
 // iteration (raft.py:122-123), so no data gradient exists; the wrapper refuses inputs that require one.
 // With two input channels the layer is 98 multiplies per output: far too thin for the matrix cores, and writing the
 // 128-channel output (3.6 MB at 55 x 128) is the only real traffic -- an HBM-bound stream.
-//   workgroup = 64 consecutive pixels (one per lane) x 8 waves.  The flat input range the tile's taps can touch
-//   ([p0 - r(W+1), p0 + 63 + r(W+1)] per channel) and ALL weights go to LDS once; a lane gathers its Cin*k*k taps
-//   into registers (horizontal wrap-around masked), wave w then produces output channels w, w+8, ... with the
-//   weights as broadcast 16-B LDS reads and stores 64 consecutive floats per channel.
+//   workgroup = 64 consecutive pixels x 4 waves.  The flat input range the tile's taps can touch
+//   ([p0 - r(W+1), p0 + 63 + r(W+1)] per channel) and ALL weights go to LDS once; the layer then is the GEMM
+//   out[N x 64] = W[N x T] . V[T x 64] (T = Cin*k*k taps, V gathered from the flat range with the horizontal
+//   wrap-around masked) on v_mfma_f32_32x32x2_f32, wave w owning 32 output channels; bias + ReLU in the epilogue.
 #include "common.hpp"
 
 namespace {
 
-constexpr int FI_PX = 64, FI_WAVES = 8;  // 8 waves: the Cin*k*k taps of a lane live in registers (<= 256 VGPRs)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int FI_PX = 64;      // pixels per workgroup: two 32-wide MFMA column tiles
+constexpr int FI_THREADS = 256;  // 4 waves, wave w owns output rows 32w .. 32w+31 of a 128-row block
+
+// out[N x 64 pixels] = W[N x T] . V[T x 64], T = Cin*k*k taps -- an im2col-in-LDS GEMM on v_mfma_f32_32x32x2_f32
+// (exact fp32 products, fp32 accumulation).  The first version gave every lane the taps of its pixel in registers
+// and read the weights as wave-wide broadcasts; a broadcast read still costs the full LDS bandwidth and the kernel
+// sat at 19 us.  As MFMA operands both matrices are ordinary per-lane reads: A = W[32w + (lane & 31)][2s + (lane >> 5)],
+// B = tap (2s + (lane >> 5)) of pixel (32j + (lane & 31)).
 template <int CIN, int KS>
-__global__ __launch_bounds__(FI_PX* FI_WAVES) void conv_fewin_fwd_kernel(
+__global__ __launch_bounds__(FI_THREADS) void conv_fewin_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, int N, int H, int W, int relu) {
-  constexpr int R = KS / 2, T = CIN * KS * KS;  // taps per output
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [N][T] weights (padded to 16 B), then [CIN][span] inputs
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int R = KS / 2, T = CIN * KS * KS;
+  constexpr int STEPS = (T + 1) / 2;     // k pairs
+  constexpr int TS = (T + 1) | 1;        // odd row stride > T: conflict-free A reads, zero column at index T
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [npad][TS] weights, then [CIN][span] inputs
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.y;
   const long long plane = (long long)H * W;
   const long long p0 = (long long)blockIdx.x * FI_PX;
   const int halo = R * (W + 1);
   const int span = FI_PX + 2 * halo;
+  const int npad = (N + 127) & ~127;
   float* wl = lds;
-  float* xl = lds + (((size_t)N * T + 3) & ~(size_t)3);
+  float* xl = lds + (size_t)npad * TS;
 
-  // weights: a flat copy of w ([N][T] contiguous) in 16-B pieces, all loads of a batch issued before its LDS
-  // writes (a plain copy loop is one global round trip per element: 25 of them made the kernel 20 us)
+  // weights -> wl[o][t] (row stride TS); rows >= N and the stride padding stay zero.  The copy keeps 8 loads per
+  // thread in flight (a plain copy loop is one global round trip per element).
+  for (int e = threadIdx.x; e < (npad * TS + 3) / 4; e += FI_THREADS)
+    reinterpret_cast<f32x4*>(wl)[e] = (f32x4)(0.f);  // (the tail past npad*TS is the start of xl, written below)
+  __syncthreads();
   {
-    constexpr int NTH = FI_PX * FI_WAVES, BATCH = 8;
-    const int n4 = (N * T) / 4;  // whole float4s (the pointer is 16-B aligned: checked by the host)
-    for (int e0 = threadIdx.x; e0 < n4; e0 += NTH * BATCH) {
-      f32x4 t[BATCH];
+    constexpr int BATCH = 8;
+    const int total = N * T;
+    for (int f0 = threadIdx.x; f0 < total; f0 += FI_THREADS * BATCH) {
+      float t[BATCH];
 #pragma unroll
       for (int k = 0; k < BATCH; ++k) {
-        const int e = e0 + k * NTH;
-        t[k] = reinterpret_cast<const f32x4*>(w)[e < n4 ? e : 0];
+        const int f = f0 + k * FI_THREADS;
+        t[k] = w[f < total ? f : 0];
       }
 #pragma unroll
       for (int k = 0; k < BATCH; ++k) {
-        const int e = e0 + k * NTH;
-        if (e < n4) reinterpret_cast<f32x4*>(wl)[e] = t[k];
+        const int f = f0 + k * FI_THREADS;
+        if (f < total) wl[f + (f / T) * (TS - T)] = t[k];
       }
     }
-    for (int e = 4 * n4 + threadIdx.x; e < N * T; e += NTH) wl[e] = w[e];
   }
   // inputs: flat range [p0 - halo, p0 + 63 + halo] of every channel, zero outside the image
   const float* xb = x + (size_t)b * CIN * plane;
-  for (int e = threadIdx.x; e < CIN * span; e += FI_PX * FI_WAVES) {
+  for (int e = threadIdx.x; e < CIN * span; e += FI_THREADS) {
     const int c = e / span, i = e - c * span;
     const long long q = p0 - halo + i;
     xl[e] = (q >= 0 && q < plane) ? xb[(size_t)c * plane + q] : 0.f;
   }
   __syncthreads();
 
-  const long long p = p0 + lane;
-  const int xx = (int)(p % W);  // (rows outside the image are zero in the flat range; columns wrap and are masked)
-  float v[T];
+  // column validity of this lane's two pixels: bit kx set <=> 0 <= x + kx - R < W (rows outside the image read zeros
+  // from the flat range; columns wrap into the neighbouring row and are masked)
+  unsigned colmask[2];
 #pragma unroll
-  for (int c = 0; c < CIN; ++c)
+  for (int j = 0; j < 2; ++j) {
+    const int xx = (int)((p0 + 32 * j + l31) % W);
+    unsigned m = 0;
 #pragma unroll
-    for (int ky = 0; ky < KS; ++ky)
+    for (int kx = 0; kx < KS; ++kx)
+      if (xx + kx - R >= 0 && xx + kx - R < W) m |= 1u << kx;
+    colmask[j] = m;
+  }
+
+  for (int nb = 0; nb < npad; nb += 128) {
+    f32x16 acc[2];
 #pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
-        const int dx = kx - R;
-        const bool ok = xx + dx >= 0 && xx + dx < W;
-        const float t = xl[c * span + halo + lane + (ky - R) * W + dx];
-        v[(c * KS + ky) * KS + kx] = ok ? t : 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const float* arow = wl + (size_t)(nb + 32 * wave + l31) * TS + lh;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      // tap index of this half-wave: k = 2s + lh (compile-time per half)
+      const int k0 = 2 * s, k1 = 2 * s + 1;
+      const int c0 = k0 / (KS * KS), r0 = k0 % (KS * KS), c1 = k1 / (KS * KS), r1 = k1 % (KS * KS);
+      const int off0 = c0 * span + (r0 / KS - R) * W + (r0 % KS - R);
+      const int off1 = c1 * span + (r1 / KS - R) * W + (r1 % KS - R);
+      const bool live1 = k1 < T;  // odd T: the last odd tap does not exist
+      const int off = lh ? (live1 ? off1 : off0) : off0;
+      const int kx = lh ? (r1 % KS) : (r0 % KS);
+      const float a = arow[k0];  // + lh folded into arow; rows/columns beyond (N, T) are zero in LDS
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v = xl[halo + 32 * j + l31 + off];
+        if (!((colmask[j] >> kx) & 1u) || (lh && !live1)) v = 0.f;
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc[j], 0, 0, 0);
       }
-  if (p >= plane) return;
-  float* ob = out + (size_t)b * N * plane + p;
-  for (int o = wave; o < N; o += FI_WAVES) {
-    const float* wo = wl + (size_t)o * T;  // broadcast reads (all lanes, same address)
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four partial sums in a fixed pattern
-#pragma unroll
-    for (int i = 0; i + 3 < T; i += 4) {
-      s0 += wo[i] * v[i];
-      s1 += wo[i + 1] * v[i + 1];
-      s2 += wo[i + 2] * v[i + 2];
-      s3 += wo[i + 3] * v[i + 3];
     }
+    // C/D layout of the 32x32 tile: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int i = T & ~3; i < T; ++i) s0 += wo[i] * v[i];
-    float s = (s0 + s1) + (s2 + s3) + (bias ? bias[o] : 0.f);
-    if (relu) s = fmaxf(s, 0.f);
-    ob[(size_t)o * plane] = s;
+    for (int j = 0; j < 2; ++j) {
+      const long long p = p0 + 32 * j + l31;
+      if (p >= plane) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = nb + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (o < N) {
+          float v = acc[j][r] + (bias ? bias[o] : 0.f);
+          if (relu) v = fmaxf(v, 0.f);
+          out[((size_t)b * N + o) * plane + p] = v;
+        }
+      }
+    }
   }
 }
 
 template <int CIN, int KS>
 int launch_fewin(const float* x, const float* w, const float* bias, float* out, int B, int N, int H, int W,
                  int relu, hipStream_t s) {
-  constexpr int T = CIN * KS * KS;
+  constexpr int T = CIN * KS * KS, TS = (T + 1) | 1;
   const long long plane = (long long)H * W;
   const size_t span = FI_PX + 2 * (size_t)(KS / 2) * (W + 1);
-  const size_t bytes = ((((size_t)N * T + 3) & ~(size_t)3) + CIN * span) * sizeof(float);
-  if (reinterpret_cast<uintptr_t>(w) & 15) return PCFA_ERR_UNSUPPORTED;
+  const size_t npad = ((size_t)N + 127) & ~(size_t)127;
+  const size_t bytes = (npad * TS + CIN * span) * sizeof(float);
   if (bytes > 150 * 1024) return PCFA_ERR_UNSUPPORTED;
   static size_t granted = 0;  // per template instance
   if (bytes > granted) {
@@ -112,7 +147,7 @@ int launch_fewin(const float* x, const float* w, const float* bias, float* out, 
       return PCFA_ERR_UNSUPPORTED;
     granted = bytes;
   }
-  dim3 grid(pcfa_cdiv(plane, FI_PX), B), block(FI_PX * FI_WAVES);
+  dim3 grid(pcfa_cdiv(plane, FI_PX), B), block(FI_THREADS);
   pcfa_launch(conv_fewin_fwd_kernel<CIN, KS>, grid, block, bytes, s, x, w, bias, out, N, H, W, relu);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
