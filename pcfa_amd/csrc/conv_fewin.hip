@@ -44,35 +44,50 @@ __global__ __launch_bounds__(FI_THREADS) void conv_fewin_fwd_kernel(
   float* wl = lds;
   float* xl = lds + (size_t)npad * TS;
 
-  // weights -> wl[o][t] (row stride TS); rows >= N and the stride padding stay zero.  The copy keeps 8 loads per
-  // thread in flight (a plain copy loop is one global round trip per element).
+  // Staging.  Every global load of the workgroup (weights in 16-B pieces, inputs as dwords) is issued before the
+  // first LDS write: a copy loop that waits per element is one global round trip per iteration, and 14 of them were
+  // 3/4 of this kernel's time in its first versions.  Preconditions (host): w 16-B aligned.
+  constexpr int WQ = 16;   // 16-B weight pieces per thread in flight: covers N*T <= 16384 floats per pass
+  constexpr int XQ = 12;   // input dwords per thread in flight: covers Cin*span <= 3072 per pass
+  const int total = N * T, n4 = total / 4;
   for (int e = threadIdx.x; e < (npad * TS + 3) / 4; e += FI_THREADS)
-    reinterpret_cast<f32x4*>(wl)[e] = (f32x4)(0.f);  // (the tail past npad*TS is the start of xl, written below)
-  __syncthreads();
-  {
-    constexpr int BATCH = 8;
-    const int total = N * T;
-    for (int f0 = threadIdx.x; f0 < total; f0 += FI_THREADS * BATCH) {
-      float t[BATCH];
+    reinterpret_cast<f32x4*>(wl)[e] = (f32x4)(0.f);  // rows >= N and the stride padding stay zero
+  const float* xb = x + (size_t)b * CIN * plane;
+  for (int w0 = 0, x0 = 0; w0 < n4 || x0 < CIN * span; w0 += WQ * FI_THREADS, x0 += XQ * FI_THREADS) {
+    f32x4 tw[WQ];
+    float tx[XQ];
 #pragma unroll
-      for (int k = 0; k < BATCH; ++k) {
-        const int f = f0 + k * FI_THREADS;
-        t[k] = w[f < total ? f : 0];
-      }
+    for (int k = 0; k < WQ; ++k) {
+      const int e = w0 + threadIdx.x + k * FI_THREADS;
+      tw[k] = reinterpret_cast<const f32x4*>(w)[e < n4 ? e : 0];
+    }
 #pragma unroll
-      for (int k = 0; k < BATCH; ++k) {
-        const int f = f0 + k * FI_THREADS;
-        if (f < total) wl[f + (f / T) * (TS - T)] = t[k];
+    for (int k = 0; k < XQ; ++k) {
+      const int e = x0 + threadIdx.x + k * FI_THREADS;
+      const int c = e / span, i = e - c * span;
+      const long long q = p0 - halo + i;
+      const bool ok = e < CIN * span && q >= 0 && q < plane;
+      const float t = xb[ok ? (size_t)c * plane + q : 0];
+      tx[k] = ok ? t : 0.f;
+    }
+    __syncthreads();  // (first pass: the zero fill above is complete)
+#pragma unroll
+    for (int k = 0; k < WQ; ++k) {
+      const int e = w0 + threadIdx.x + k * FI_THREADS;
+      if (e < n4) {
+        const int f = 4 * e;
+        const float tv[4] = {tw[k].x, tw[k].y, tw[k].z, tw[k].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wl[f + u + ((f + u) / T) * (TS - T)] = tv[u];
       }
     }
+#pragma unroll
+    for (int k = 0; k < XQ; ++k) {
+      const int e = x0 + threadIdx.x + k * FI_THREADS;
+      if (e < CIN * span) xl[e] = tx[k];
+    }
   }
-  // inputs: flat range [p0 - halo, p0 + 63 + halo] of every channel, zero outside the image
-  const float* xb = x + (size_t)b * CIN * plane;
-  for (int e = threadIdx.x; e < CIN * span; e += FI_THREADS) {
-    const int c = e / span, i = e - c * span;
-    const long long q = p0 - halo + i;
-    xl[e] = (q >= 0 && q < plane) ? xb[(size_t)c * plane + q] : 0.f;
-  }
+  for (int f = 4 * n4 + threadIdx.x; f < total; f += FI_THREADS) wl[f + (f / T) * (TS - T)] = w[f];
   __syncthreads();
 
   // column validity of this lane's two pixels: bit kx set <=> 0 <= x + kx - R < W (rows outside the image read zeros
@@ -95,9 +110,9 @@ __global__ __launch_bounds__(FI_THREADS) void conv_fewin_fwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const float* arow = wl + (size_t)(nb + 32 * wave + l31) * TS + lh;
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      // tap index of this half-wave: k = 2s + lh (compile-time per half)
+    // operands of step s+1 are read before the MFMAs of step s (the compiler otherwise waits for each step's three
+    // LDS reads right in front of its two MFMAs)
+    auto operands = [&](int s, float& a, float (&v)[2]) {
       const int k0 = 2 * s, k1 = 2 * s + 1;
       const int c0 = k0 / (KS * KS), r0 = k0 % (KS * KS), c1 = k1 / (KS * KS), r1 = k1 % (KS * KS);
       const int off0 = c0 * span + (r0 / KS - R) * W + (r0 % KS - R);
@@ -105,13 +120,33 @@ __global__ __launch_bounds__(FI_THREADS) void conv_fewin_fwd_kernel(
       const bool live1 = k1 < T;  // odd T: the last odd tap does not exist
       const int off = lh ? (live1 ? off1 : off0) : off0;
       const int kx = lh ? (r1 % KS) : (r0 % KS);
-      const float a = arow[k0];  // + lh folded into arow; rows/columns beyond (N, T) are zero in LDS
+      a = arow[k0];  // + lh folded into arow; rows / columns beyond (N, T) are zero in LDS
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        float v = xl[halo + 32 * j + l31 + off];
-        if (!((colmask[j] >> kx) & 1u) || (lh && !live1)) v = 0.f;
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc[j], 0, 0, 0);
+        const float t = xl[halo + 32 * j + l31 + off];
+        v[j] = (!((colmask[j] >> kx) & 1u) || (lh && !live1)) ? 0.f : t;
       }
+    };
+    // bias of this lane's 16 output rows, requested before the MFMA loop (32 dependent loads in the epilogue, each
+    // waited for, cost more than the whole GEMM)
+    float brow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = nb + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float t = bias ? bias[o < N ? o : 0] : 0.f;
+      brow[r] = (bias && o < N) ? t : 0.f;
+    }
+    float a_cur, v_cur[2];
+    operands(0, a_cur, v_cur);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      float a_nxt = 0.f, v_nxt[2] = {0.f, 0.f};
+      if (s + 1 < STEPS) operands(s + 1, a_nxt, v_nxt);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, v_cur[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, v_cur[1], acc[1], 0, 0, 0);
+      a_cur = a_nxt;
+      v_cur[0] = v_nxt[0];
+      v_cur[1] = v_nxt[1];
     }
     // C/D layout of the 32x32 tile: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -122,7 +157,7 @@ __global__ __launch_bounds__(FI_THREADS) void conv_fewin_fwd_kernel(
       for (int r = 0; r < 16; ++r) {
         const int o = nb + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (o < N) {
-          float v = acc[j][r] + (bias ? bias[o] : 0.f);
+          float v = acc[j][r] + brow[r];
           if (relu) v = fmaxf(v, 0.f);
           out[((size_t)b * N + o) * plane + p] = v;
         }
