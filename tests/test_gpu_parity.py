@@ -321,7 +321,8 @@ def test_pwc_warp_vs_oracle(oracle_ops, shape, scale):
 
 # --------------------------------------------------------------------------- flow-prediction convolutions
 @pytest.mark.parametrize("shape,n", [((1, 256, 55, 128), 2), ((2, 37, 9, 13), 2), ((1, 1026, 14, 32), 2),
-                                     ((1, 5, 3, 70), 1), ((2, 16, 17, 5), 3), ((1, 64, 24, 40), 4)])
+                                     ((1, 5, 3, 70), 1), ((2, 16, 17, 5), 3), ((1, 64, 24, 40), 4),
+                                     ((1, 1024, 1, 2), 2), ((2, 9, 1, 1), 2), ((1, 8, 1, 3), 2), ((1, 6, 3, 1), 2)])
 def test_conv3x3_fewout_vs_oracle(oracle_ops, shape, n):
     """FlowHead.conv2 at 440x1024 / 8, FlowNet2's predict_flow5 shape, ragged sizes, 1..4 output channels, with
     and without bias.  Tolerance: summation order over K*9 products (2e-6 * sqrt(9K) * max|out|)."""
