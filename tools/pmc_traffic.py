@@ -11,7 +11,8 @@ import os
 import sys
 
 OURS = ("corr_lookup_fwd", "corr_lookup_bwd", "gemm_f32_mfma", "f2ext_", "scorr_", "loss_partial", "box_fwd",
-        "deltas_fwd")
+        "deltas_fwd", "instnorm_stats_kernel<false>", "instnorm_stats_kernel<true>", "instnorm_apply_kernel<false>",
+        "instnorm_apply_kernel<true>", "add_relu_kernel", "gru_gates_fwd", "gru_update_fwd")
 
 
 def collect(folder, counter):
