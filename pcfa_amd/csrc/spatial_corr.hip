@@ -35,38 +35,40 @@ constexpr int FC = 16;          // channels per LDS chunk (forward: half as many
 // pieces that lie either inside or outside the image.  Two LDS stages: the next channel chunk is fetched into
 // registers before the FMAs of the current one and written to the other stage after them (one barrier per chunk;
 // the coarse pyramid levels are a single workgroup walking up to 25 chunks, i.e. a pure latency chain).
-template <int PS>
-__global__ __launch_bounds__(64 * PS) void scorr_fwd_fast_kernel(
+// THT = tile rows: 8 for the fine levels; 2 for the coarse ones, where 8-row tiles leave 1-30 workgroups walking a
+// serial channel loop on as many CUs (LDS-read bound): four times as many, four times lighter workgroups.
+template <int PS, int THT>
+__global__ __launch_bounds__(8 * THT * PS) void scorr_fwd_fast_kernel(
     const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C,
     int H, int W) {
   constexpr int R = (PS - 1) / 2;
   constexpr int HW2 = TW + 2 * R;  // in2 tile width  (40 for PS=9)
-  constexpr int HH2 = TH + 2 * R;  // in2 tile height (16)
+  constexpr int HH2 = THT + 2 * R;  // in2 tile height (16)
   static_assert(R % 4 == 0 && HW2 % 4 == 0, "halo must keep the 16-B pieces aligned");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) float s1[2][FC][TH][TW];
+  __shared__ __attribute__((aligned(16))) float s1[2][FC][THT][TW];
   __shared__ __attribute__((aligned(16))) float s2[2][FC][HH2][HW2];
 
   const int b = blockIdx.z;
-  const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const int y0 = blockIdx.y * THT, x0 = blockIdx.x * TW;
   const int tx = threadIdx.x, ty = threadIdx.y, tz = threadIdx.z;  // quad, row, patch row
-  const int tid = tx + 8 * ty + 64 * tz;
-  constexpr int NT = 64 * PS;
+  const int tid = tx + 8 * ty + 8 * THT * tz;
+  constexpr int NT = 8 * THT * PS;
   const size_t plane = (size_t)H * W;
   const float* p1 = in1 + (size_t)b * C * plane;
   const float* p2 = in2 + (size_t)b * C * plane;
 
   // staging plan (fixed per thread): pieces of the in1 tile and of the in2 tile with its halo
-  constexpr int N1 = FC * TH * (TW / 4), N2 = FC * HH2 * (HW2 / 4);
+  constexpr int N1 = FC * THT * (TW / 4), N2 = FC * HH2 * (HW2 / 4);
   constexpr int S1 = (N1 + NT - 1) / NT, S2 = (N2 + NT - 1) / NT;
   int o1[S1], d1[S1], o2[S2], d2[S2];  // global offset inside the chunk (-1: outside), LDS float index (-1: none)
 #pragma unroll
   for (int k = 0; k < S1; ++k) {
     const int e = tid + k * NT;
-    const int c = e / (TH * (TW / 4)), r = (e / (TW / 4)) % TH, m = e % (TW / 4);
+    const int c = e / (THT * (TW / 4)), r = (e / (TW / 4)) % THT, m = e % (TW / 4);
     const int gy = y0 + r, gx = x0 + 4 * m;
     o1[k] = (e < N1 && gy < H && gx < W) ? (int)(c * plane) + gy * W + gx : -1;
-    d1[k] = e < N1 ? (c * TH + r) * TW + 4 * m : -1;
+    d1[k] = e < N1 ? (c * THT + r) * TW + 4 * m : -1;
   }
 #pragma unroll
   for (int k = 0; k < S2; ++k) {
@@ -357,8 +359,13 @@ extern "C" int pcfa_spatial_corr_fwd(const float* in1, const float* in2, float* 
   hipStream_t s = (hipStream_t)stream;
   const bool aligned = iW % 4 == 0 && ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
   if (is_fast(p, 9) && aligned) {
-    dim3 grid(pcfa_cdiv(iW, TW), pcfa_cdiv(iH, TH), B), block(8, 8, 9);
-    pcfa_launch(scorr_fwd_fast_kernel<9>, grid, block, 0, s, in1, in2, out, C, iH, iW);
+    if ((long long)iH * iW <= 48 * 160) {  // coarse levels: 2-row tiles
+      dim3 grid(pcfa_cdiv(iW, TW), pcfa_cdiv(iH, 2), B), block(8, 2, 9);
+      pcfa_launch(scorr_fwd_fast_kernel<9, 2>, grid, block, 0, s, in1, in2, out, C, iH, iW);
+    } else {
+      dim3 grid(pcfa_cdiv(iW, TW), pcfa_cdiv(iH, TH), B), block(8, 8, 9);
+      pcfa_launch(scorr_fwd_fast_kernel<9, TH>, grid, block, 0, s, in1, in2, out, C, iH, iW);
+    }
   } else {
     const long long total = (long long)B * patchH * patchW * p.oH * p.oW;
     const int blocks = (int)((total + 255) / 256 < 65535LL * 16 ? (total + 255) / 256 : 65535LL * 16);
