@@ -7,11 +7,12 @@ cd $R
 : > gpurun_out/${TAG}_bench_nets.jsonl
 for spec in "GMA 436x1024" "PWCNet 375x1242" "SpyNet 436x1024" "FlowNet2 436x1024"; do
   set -- $spec
-  timeout -k 10 400 python bench.py --net $1 --size $2 --steps 3 --warmup 1 --no-cpu-baseline >> gpurun_out/${TAG}_bench_nets.jsonl 2>> gpurun_out/${TAG}_bench_nets.err || exit 1
+  timeout -k 10 400 python bench.py --net $1 --size $2 --steps 3 --warmup 1 --cpu-closures 4 >> gpurun_out/${TAG}_bench_nets.jsonl 2>> gpurun_out/${TAG}_bench_nets.err || exit 1
 done
 python - <<PY
 import json
 for line in open("gpurun_out/${TAG}_bench_nets.jsonl"):
     d = json.loads(line)
-    print("%-70s %7.3f steps/s  %8.1f ms/step  closures/s %.1f" % (d["config"]["workload"][:70], d["value"], d["ms_per_step"], d["closure_evals_per_sec"]))
+    c = d.get("cpu_baseline") or {}
+    print("%-70s %7.3f steps/s  %8.1f ms/step  closures/s %.1f  cpu port %.4f steps/s on %s threads" % (d["config"]["workload"][:70], d["value"], d["ms_per_step"], d["closure_evals_per_sec"], c.get("value", float("nan")), c.get("cores", "?")))
 PY
