@@ -92,6 +92,110 @@ __global__ __launch_bounds__(FO_PX* FO_FWD_WAVES) void conv3x3_fewout_fwd_kernel
   }
 }
 
+// Same operator, rows staged through LDS (used when every channel plane is 16-B aligned: H*W % 4 == 0 and an aligned
+// x).  The nine taps of a pixel lie in three flat 66-float segments [p0 + dy*W - 1, p0 + dy*W + 64] of the channel
+// plane -- contiguous whatever the image width, because a 64-pixel tile is a flat pixel range and wrapped columns are
+// masked.  A wave fetches the three segments of one channel with ONE 16-B-per-lane load (54 lanes) instead of nine
+// dword loads: a wave-wide load costs ~16 cycles of address processing whatever its width, which is what bounded the
+// kernel above (15.5 us at 256 x 55 x 128).  Each wave stages its own channels in a private LDS slice (no barrier).
+constexpr int FO_SEG = 72;   // floats per staged segment (18 pieces)
+constexpr int FO_UL = 4;     // channels in flight per wave (8 measured slower)
+
+template <int N>
+__global__ __launch_bounds__(FO_PX* FO_FWD_WAVES) void conv3x3_fewout_fwd_lds_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int K, int H, int W, int splits, int kper) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[FO_FWD_WAVES][N][FO_PX];
+  __shared__ __attribute__((aligned(16))) float seg[FO_FWD_WAVES][FO_UL][3][FO_SEG];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nb = gridDim.y / splits;
+  const int b = blockIdx.y / splits, split = blockIdx.y - b * splits;
+  const int kbeg = split * kper, kend = min(K, kbeg + kper);
+  const long long plane = (long long)H * W;
+  const long long p0 = (long long)blockIdx.x * FO_PX;
+  const long long p = p0 + lane;
+  const bool live = p < plane;
+  const int y = live ? (int)(p / W) : 0, xx = live ? (int)(p % W) : 0;
+  bool ok[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = y + ky - 1, xq = xx + kx - 1;
+      ok[ky * 3 + kx] = live && yy >= 0 && yy < H && xq >= 0 && xq < W;
+    }
+  // this lane's piece of the staging load: segment r = lane / 18, piece m = lane % 18 (lanes >= 54 idle)
+  const int lr = lane / 18, lm = lane - lr * 18;
+  long long s4[3];
+  int dsh[3];  // wave-uniform: offset of the segment's first float inside its aligned 72-float window
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const long long st = p0 + (long long)(r - 1) * W - 1;
+    s4[r] = st & ~3LL;  // (two's complement: rounds towards -inf)
+    dsh[r] = (int)(st - s4[r]);
+  }
+  const long long myidx = (lr == 0 ? s4[0] : (lr == 1 ? s4[1] : s4[2])) + 4 * lm;
+  const bool myok = lane < 54 && myidx >= 0 && myidx + 3 < plane;
+  const long long myoff = myok ? myidx : 0;
+
+  float acc[N];
+#pragma unroll
+  for (int o = 0; o < N; ++o) acc[o] = 0.f;
+  const float* xb = x + (size_t)b * K * plane;
+  float* mine = &seg[wave][0][0][0];
+  for (int c0 = kbeg + wave; c0 < kend; c0 += FO_UL * FO_FWD_WAVES) {
+    f32x4 t[FO_UL];
+#pragma unroll
+    for (int u = 0; u < FO_UL; ++u) {
+      const int c = c0 + u * FO_FWD_WAVES;  // wave-uniform
+      const float* xc = xb + (size_t)(c < kend ? c : c0) * plane;
+      const f32x4 q = *reinterpret_cast<const f32x4*>(xc + myoff);
+      t[u] = myok ? q : (f32x4)(0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < FO_UL; ++u)
+      if (lane < 54) *reinterpret_cast<f32x4*>(mine + (u * 3 + lr) * FO_SEG + 4 * lm) = t[u];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < FO_UL; ++u) {
+      const int c = c0 + u * FO_FWD_WAVES;
+      if (c < kend) {  // uniform branch
+        float v[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float q = mine[(u * 3 + r) * FO_SEG + dsh[r] + lane + kx];
+            v[3 * r + kx] = ok[3 * r + kx] ? q : 0.f;
+          }
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+          const float* wc = w + ((size_t)o * K + c) * 9;  // wave-uniform address: scalar loads
+#pragma unroll
+          for (int k = 0; k < 9; ++k) acc[o] += wc[k] * v[k];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the slice is rewritten by the next batch
+  }
+#pragma unroll
+  for (int o = 0; o < N; ++o) red[wave][o][lane] = acc[o];
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * FO_PX; e += FO_PX * FO_FWD_WAVES) {
+    const int o = e / FO_PX, l = e % FO_PX;
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < FO_FWD_WAVES; ++g) sum += red[g][o][l];
+    const long long q = p0 + l;
+    if (q < plane) {
+      if (splits > 1) out[(((size_t)split * nb + b) * N + o) * plane + q] = sum;
+      else out[((size_t)b * N + o) * plane + q] = sum + (bias ? bias[o] : 0.f);
+    }
+  }
+}
+
 // out[b][o][p] = bias[o] + sum over splits (in order) of part[split][b][o][p]
 __global__ void fewout_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                      float* __restrict__ out, long long n, long long plane, int N, int splits) {
@@ -188,11 +292,21 @@ extern "C" int pcfa_conv3x3_fewout_fwd(const float* x, const float* w, const flo
   float* dst = splits > 1 ? (float*)workspace : out;
   dim3 grid(pcfa_cdiv(plane, FO_PX), B * splits), block(FO_PX * FO_FWD_WAVES);
   hipStream_t s = (hipStream_t)stream;
-  switch (N) {
-    case 1: pcfa_launch(conv3x3_fewout_fwd_kernel<1>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
-    case 2: pcfa_launch(conv3x3_fewout_fwd_kernel<2>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
-    case 3: pcfa_launch(conv3x3_fewout_fwd_kernel<3>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
-    default: pcfa_launch(conv3x3_fewout_fwd_kernel<4>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+  const bool wide = plane % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  if (wide) {
+    switch (N) {
+      case 1: pcfa_launch(conv3x3_fewout_fwd_lds_kernel<1>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+      case 2: pcfa_launch(conv3x3_fewout_fwd_lds_kernel<2>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+      case 3: pcfa_launch(conv3x3_fewout_fwd_lds_kernel<3>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+      default: pcfa_launch(conv3x3_fewout_fwd_lds_kernel<4>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+    }
+  } else {
+    switch (N) {
+      case 1: pcfa_launch(conv3x3_fewout_fwd_kernel<1>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+      case 2: pcfa_launch(conv3x3_fewout_fwd_kernel<2>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+      case 3: pcfa_launch(conv3x3_fewout_fwd_kernel<3>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+      default: pcfa_launch(conv3x3_fewout_fwd_kernel<4>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+    }
   }
   PCFA_LAUNCH_CHECK();
   if (splits > 1) {
