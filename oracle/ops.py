@@ -494,6 +494,13 @@ def conv_fewin(x, weight, bias=None, relu=False):
     return F.relu(y) if relu else y
 
 
+def dense_block(x, layers, slope=0.1):
+    """models/PWCNet/PWCNet.py:234-323: x = cat((conv_i(x), x), 1) for the five decoder convolutions of a level."""
+    for w, b in layers:
+        x = torch.cat((F.leaky_relu(F.conv2d(x, w, b, stride=1, padding=1), slope), x), 1)
+    return x
+
+
 def pwc_warp(x, flo, mask_threshold=0.0001):
     """models/PWCNet/PWCNet.py:166-206, statement by statement."""
     B, C, H, W = x.size()

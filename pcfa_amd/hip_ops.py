@@ -850,6 +850,67 @@ class _Conv3x3(torch.autograd.Function):
         return gin, None, None, None, None
 
 
+class _DenseBlock(torch.autograd.Function):
+    """x_{i+1} = cat(leaky_relu(conv3x3_i(x_i)), x_i) for i = 0..n-1 (PWC-Net's DenseNet decoders, PWCNet.py:234-323)
+    written into ONE pre-allocated buffer: every convolution reads the channel suffix it needs in place and writes
+    its output in front of it, so no torch.cat copies the growing tensor (5 copies of up to 69 MB per level).
+    Batch size 1 only (a channel suffix of an NCHW tensor is contiguous only then)."""
+
+    @staticmethod
+    def forward(ctx, x0, slope, *wb):
+        weights, biases = wb[0::2], wb[1::2]
+        _dev(x0, *weights)
+        x0 = x0.contiguous()
+        B, K0, H, W = x0.shape
+        if B != 1:
+            raise ValueError("dense_block: batch size 1 only")
+        widths = [w.shape[0] for w in weights]
+        total = K0 + sum(widths)
+        buf = torch.empty((1, total, H, W), device=x0.device, dtype=torch.float32)
+        plane = H * W
+        start = total - K0
+        buf[:, start:].copy_(x0)
+        packs = []
+        k = K0
+        for w, b, n in zip(weights, biases, widths):
+            if tuple(w.shape[1:]) != (k, 3, 3):
+                raise ValueError("dense_block: weight %s does not fit %d input channels" % (tuple(w.shape), k))
+            fwd, bwd = _conv3x3_packed(w)
+            _call("pcfa_conv3x3_act_fwd", _ptr_off(buf, start * plane), _ptr(fwd), _ptr(b),
+                  _ptr_off(buf, (start - n) * plane), 1, k, n, H, W, 2, float(slope))
+            packs.append((bwd, k, n, start))
+            start -= n
+            k += n
+        ctx.packs, ctx.dims, ctx.slope = packs, (total, K0, H, W), float(slope)
+        ctx.save_for_backward(buf)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        if any(ctx.needs_input_grad[2:]):
+            raise RuntimeError("dense_block is the frozen-weight path: no weight / bias gradient")
+        (buf,) = ctx.saved_tensors
+        total, K0, H, W = ctx.dims
+        plane = H * W
+        gb = g.contiguous().clone()  # running gradient of the buffer: every layer adds its input gradient to a suffix
+        for bwd, k, n, start in reversed(ctx.packs):
+            gm = torch.empty((1, n, H, W), device=g.device, dtype=torch.float32)
+            _call("pcfa_leaky_relu_bwd", _ptr_off(buf, (start - n) * plane), _ptr_off(gb, (start - n) * plane), _ptr(gm),
+                  ctx.slope, n * plane)
+            gin = torch.empty((1, k, H, W), device=g.device, dtype=torch.float32)
+            _call("pcfa_conv3x3_fwd", _ptr(gm), _ptr(bwd), None, _ptr(gin), 1, n, k, H, W, 0)
+            gb[:, start:].add_(gin)
+        return (gb[:, total - K0:], None) + (None,) * (2 * len(ctx.packs))
+
+
+def dense_block(x, layers, slope=0.1):
+    """layers = [(weight, bias), ...] of frozen 3x3 convolutions; returns cat(y_n-1, ..., y_0, x) along channels."""
+    flat = []
+    for w, b in layers:
+        flat += [w, b]
+    return _DenseBlock.apply(x, slope, *flat)
+
+
 def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None):
     """act(conv2d(x, weight, bias, stride=1, padding=1)) for a frozen 3x3 weight: Winograd F(2x2,3x3) on the fp32
     matrix cores with bias and ReLU (or LeakyReLU(leaky_slope)) fused into the epilogue; the data gradient runs the

@@ -111,8 +111,12 @@ class PWCDCNet(nn.Module):
         return ops.get().pwc_warp(x, flo, 0.0001)
 
     def _decode(self, lvl, x):
-        for i in range(5):
-            x = torch.cat((getattr(self, "conv%d_%d" % (lvl, i))(x), x), 1)
+        blocks = [getattr(self, "conv%d_%d" % (lvl, i)) for i in range(5)]
+        if x.shape[0] == 1 and not any(p.requires_grad for blk in blocks for p in blk.parameters()):
+            # one pre-allocated buffer: every convolution reads its channel suffix in place and writes in front of it
+            return ops.get().dense_block(x, [(blk[0].weight, blk[0].bias) for blk in blocks], blocks[0][1].negative_slope)
+        for blk in blocks:
+            x = torch.cat((blk(x), x), 1)
         return x
 
     def forward(self, im1, im2):

@@ -295,6 +295,31 @@ def test_channelnorm_vs_oracle(oracle_ops, shape):
     assert float(xg.grad[0, :, 0, 0].abs().max()) == 0.0
 
 
+# --------------------------------------------------------------------------- PWC-Net dense decoder block
+@pytest.mark.parametrize("shape", [(1, 115, 12, 40), (1, 81, 6, 20), (1, 21, 7, 9)])
+def test_dense_block_vs_oracle(oracle_ops, shape):
+    """x = cat(leaky(conv_i(x)), x) five times (PWCNet.py:234-323) in one pre-allocated buffer vs the torch.cat loop.
+    Winograd F(2x2,3x3) in fp32: 1e-5 relative on outputs, 1e-4 relative L2 on the input gradient."""
+    gen = torch.Generator().manual_seed(shape[1])
+    B, K, H, W = shape
+    x = torch.randn(*shape, generator=gen).requires_grad_(True)
+    layers, k = [], K
+    for n in (128, 128, 96, 64, 32):
+        layers.append((torch.randn(n, k, 3, 3, generator=gen) / (3 * k ** 0.5), 0.1 * torch.randn(n, generator=gen)))
+        k += n
+    want = oracle_ops.dense_block(x, layers, 0.1)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.dense_block(xg, [(w.to(DEV), b.to(DEV)) for w, b in layers], 0.1)
+    assert got.shape == want.shape
+    assert max_abs(got, want) <= 1e-5 * float(want.detach().abs().max())
+    got.backward(go.to(DEV))
+    assert rel_l2(xg.grad, x.grad) < 1e-4
+    with pytest.raises(ValueError):
+        hip_ops.dense_block(torch.cat([xg.detach(), xg.detach()]), [(w.to(DEV), b.to(DEV)) for w, b in layers], 0.1)
+
+
 # --------------------------------------------------------------------------- PWC-Net warp
 @pytest.mark.parametrize("shape,scale", [((1, 128, 12, 40), 1.5), ((1, 96, 24, 80), 3.0), ((2, 64, 48, 160), 6.0),
                                          ((1, 32, 96, 320), 12.0), ((1, 5, 7, 9), 4.0)])
