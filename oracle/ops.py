@@ -494,6 +494,11 @@ def conv_fewin(x, weight, bias=None, relu=False):
     return F.relu(y) if relu else y
 
 
+def conv3x3_cat(convs, tails=()):
+    """models/raft/update.py:91-101: torch.cat([relu(conv(x)) ...] + tails, dim=1)."""
+    return torch.cat([F.relu(F.conv2d(x, w, b, stride=1, padding=1)) for x, w, b in convs] + list(tails), dim=1)
+
+
 def dense_block(x, layers, slope=0.1):
     """models/PWCNet/PWCNet.py:234-323: x = cat((conv_i(x), x), 1) for the five decoder convolutions of a level."""
     for w, b in layers:

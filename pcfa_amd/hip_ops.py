@@ -850,6 +850,71 @@ class _Conv3x3(torch.autograd.Function):
         return gin, None, None, None, None
 
 
+class _Conv3x3Cat(torch.autograd.Function):
+    """cat([relu(conv3x3(x_i, w_i, b_i)) for i] + tails, dim=1) in one pre-allocated buffer (batch size 1): the
+    convolutions write their channel blocks in place, trailing tensors (e.g. the flow of the motion encoder,
+    models/raft/update.py:91-101) are copied behind them -- no torch.cat pass over the convolution outputs."""
+
+    @staticmethod
+    def forward(ctx, n_conv, *args):
+        xs, ws, bs = args[0:3 * n_conv:3], args[1:3 * n_conv:3], args[2:3 * n_conv:3]
+        tails = args[3 * n_conv:]
+        _dev(*xs, *ws, *tails)
+        xs = [x.contiguous() for x in xs]
+        B, _, H, W = xs[0].shape
+        if B != 1:
+            raise ValueError("conv3x3_cat: batch size 1 only")
+        plane = H * W
+        widths = [w.shape[0] for w in ws] + [t.shape[1] for t in tails]
+        buf = torch.empty((1, sum(widths), H, W), device=xs[0].device, dtype=torch.float32)
+        off, packs = 0, []
+        for x, w, b in zip(xs, ws, bs):
+            if tuple(x.shape) != (1, w.shape[1], H, W) or tuple(w.shape[2:]) != (3, 3):
+                raise ValueError("conv3x3_cat: input %s does not fit weight %s" % (tuple(x.shape), tuple(w.shape)))
+            fwd, bwd = _conv3x3_packed(w)
+            _call("pcfa_conv3x3_act_fwd", _ptr(x), _ptr(fwd), _ptr(b), _ptr_off(buf, off * plane), 1, w.shape[1],
+                  w.shape[0], H, W, 1, 0.)
+            packs.append((bwd, w.shape[1], w.shape[0], off))
+            off += w.shape[0]
+        for t in tails:
+            buf[:, off:off + t.shape[1]].copy_(t)
+            off += t.shape[1]
+        ctx.packs, ctx.dims, ctx.n_conv, ctx.tail_widths = packs, (H, W), n_conv, [t.shape[1] for t in tails]
+        ctx.save_for_backward(buf)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        (buf,) = ctx.saved_tensors
+        H, W = ctx.dims
+        plane = H * W
+        g = g.contiguous()
+        grads = [None]
+        for i, (bwd, k, n, off) in enumerate(ctx.packs):
+            if ctx.needs_input_grad[2 + 3 * i] or ctx.needs_input_grad[3 + 3 * i]:
+                raise RuntimeError("conv3x3_cat is the frozen-weight path: no weight / bias gradient")
+            gx = None
+            if ctx.needs_input_grad[1 + 3 * i]:
+                gm = torch.empty((1, n, H, W), device=g.device, dtype=torch.float32)
+                _call("pcfa_relu_bwd", _ptr_off(buf, off * plane), _ptr_off(g, off * plane), _ptr(gm), n * plane)
+                gx = torch.empty((1, k, H, W), device=g.device, dtype=torch.float32)
+                _call("pcfa_conv3x3_fwd", _ptr(gm), _ptr(bwd), None, _ptr(gx), 1, n, k, H, W, 0)
+            grads += [gx, None, None]
+        off = sum(p[2] for p in ctx.packs)
+        for j, tw in enumerate(ctx.tail_widths):
+            grads.append(g[:, off:off + tw] if ctx.needs_input_grad[1 + 3 * ctx.n_conv + j] else None)
+            off += tw
+        return tuple(grads)
+
+
+def conv3x3_cat(convs, tails=()):
+    """convs = [(x, weight, bias), ...] (frozen 3x3 / stride 1 / pad 1, ReLU), tails = tensors appended unchanged."""
+    flat = []
+    for x, w, b in convs:
+        flat += [x, w, b]
+    return _Conv3x3Cat.apply(len(convs), *flat, *tails)
+
+
 class _DenseBlock(torch.autograd.Function):
     """x_{i+1} = cat(leaky_relu(conv3x3_i(x_i)), x_i) for i = 0..n-1 (PWC-Net's DenseNet decoders, PWCNet.py:234-323)
     written into ONE pre-allocated buffer: every convolution reads the channel suffix it needs in place and writes

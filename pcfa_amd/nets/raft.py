@@ -284,6 +284,12 @@ class BasicMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
     def forward(self, flow, corr):
+        if flow.shape[0] == 1 and _all_frozen(self) and all(_is_plain3x3(c) for c in (self.convc2, self.convf2, self.conv)):
+            # the 3x3 convolutions write their channel blocks of the concatenated tensors in place (no torch.cat pass)
+            o = ops.get()
+            cor1, flo1 = _conv_relu(self.convc1, corr), _conv_relu(self.convf1, flow)
+            cf = o.conv3x3_cat([(cor1, self.convc2.weight, self.convc2.bias), (flo1, self.convf2.weight, self.convf2.bias)])
+            return o.conv3x3_cat([(cf, self.conv.weight, self.conv.bias)], (flow,))
         cor = _conv_relu(self.convc2, _conv_relu(self.convc1, corr))
         flo = _conv_relu(self.convf2, _conv_relu(self.convf1, flow))
         out = _conv_relu(self.conv, torch.cat([cor, flo], dim=1))

@@ -295,6 +295,32 @@ def test_channelnorm_vs_oracle(oracle_ops, shape):
     assert float(xg.grad[0, :, 0, 0].abs().max()) == 0.0
 
 
+def test_conv3x3_cat_vs_oracle(oracle_ops):
+    """The motion encoder's two concatenations (update.py:91-101): cat(relu(convc2(.)), relu(convf2(.))) and
+    cat(relu(conv(.)), flow) written in place by the convolutions."""
+    gen = torch.Generator().manual_seed(91)
+    H, W = 55, 128
+    a = torch.randn(1, 256, H, W, generator=gen).requires_grad_(True)
+    b = torch.randn(1, 128, H, W, generator=gen).requires_grad_(True)
+    flow = torch.randn(1, 2, H, W, generator=gen)
+    wa, ba = torch.randn(192, 256, 3, 3, generator=gen) / 48, 0.1 * torch.randn(192, generator=gen)
+    wb, bb = torch.randn(64, 128, 3, 3, generator=gen) / 34, 0.1 * torch.randn(64, generator=gen)
+    wc, bc = torch.randn(126, 256, 3, 3, generator=gen) / 48, 0.1 * torch.randn(126, generator=gen)
+    cf = oracle_ops.conv3x3_cat([(a, wa, ba), (b, wb, bb)])
+    want = oracle_ops.conv3x3_cat([(cf, wc, bc)], (flow,))
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    ag, bg = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    cfg = hip_ops.conv3x3_cat([(ag, d(wa), d(ba)), (bg, d(wb), d(bb))])
+    got = hip_ops.conv3x3_cat([(cfg, d(wc), d(bc))], (d(flow),))
+    assert got.shape == want.shape == (1, 128, H, W)
+    assert max_abs(got, want) <= 1e-5 * float(want.detach().abs().max())
+    assert torch.equal(got[:, 126:].cpu(), flow)
+    got.backward(go.to(DEV))
+    assert rel_l2(ag.grad, a.grad) < 1e-4 and rel_l2(bg.grad, b.grad) < 1e-4
+
+
 # --------------------------------------------------------------------------- PWC-Net dense decoder block
 @pytest.mark.parametrize("shape", [(1, 115, 12, 40), (1, 81, 6, 20), (1, 21, 7, 9)])
 def test_dense_block_vs_oracle(oracle_ops, shape):
