@@ -9,6 +9,10 @@ Operator boundaries mirrored (reference file:line):
   CorrBlock                      models/raft/corr.py:12-60 (== models/gma/corr.py:15-63)
   spatial_correlation_sample     .../spatial_correlation_sampler/spatial_correlation_sampler.py:9-91
   flownet_correlation, resample2d, channelnorm   models/FlowNet/{correlation,resample2d,channelnorm}_package/*.py
+  pwc_warp, dense_block          models/PWCNet/PWCNet.py:166-206, :234-323
+  conv3x3, conv3x3_fewout, conv3x3_cat, conv_fewin, sepconv5, gru_step, bias_relu
+                                 models/raft/update.py, models/raft/extractor.py, PWCNet.py:29-38, FlowNet/submodules.py
+  instance_norm_relu, add_relu   models/raft/extractor.py:23-58
   box_transform                  helper_functions/own_models.py:62-85
   extract_deltas(_joint)         attack_PCFA.py:20-37
   loss_delta_constraint, avg_epe, two_norm_*   helper_functions/losses.py
