@@ -178,23 +178,20 @@ __global__ __launch_bounds__(TH* TW) void scorr_bwd_fast_kernel(
   const bool inside = gy < H && gx < W;
   const size_t plane = (size_t)H * W;
 
+  // Every load below is branch-free (clamped address, value zeroed afterwards) and the staging loop issues a batch
+  // of loads before its LDS writes: with predicated loads the 81 gradient taps and the 20 staging iterations were
+  // each a dependent global round trip, and the kernel was a 17-20 us latency chain.
   float G[PS][PS];
   const float* gb = gout + (size_t)b * PS * PS * plane;
+  const int cgy = min(gy, H - 1), cgx = min(gx, W - 1);
 #pragma unroll
   for (int i = 0; i < PS; ++i)
 #pragma unroll
     for (int j = 0; j < PS; ++j) {
-      float v = 0.f;
-      if (inside) {
-        if (SIGN > 0) {
-          v = gb[(size_t)(i * PS + j) * plane + (size_t)gy * W + gx];
-        } else {
-          const int sy = gy - (i - R), sx_ = gx - (j - R);
-          if (sy >= 0 && sy < H && sx_ >= 0 && sx_ < W)
-            v = gb[(size_t)(i * PS + j) * plane + (size_t)sy * W + sx_];
-        }
-      }
-      G[i][j] = v;
+      const int sy = (SIGN > 0) ? cgy : cgy - (i - R), sx_ = (SIGN > 0) ? cgx : cgx - (j - R);
+      const bool ok = inside && sy >= 0 && sy < H && sx_ >= 0 && sx_ < W;
+      const float v = gb[(size_t)(i * PS + j) * plane + (ok ? (size_t)sy * W + sx_ : 0)];
+      G[i][j] = ok ? v : 0.f;
     }
 
   // The channels are independent in both gradients, so blockIdx.z also splits them: a workgroup stages
@@ -202,13 +199,26 @@ __global__ __launch_bounds__(TH* TW) void scorr_bwd_fast_kernel(
   const float* px = X + (size_t)b * C * plane;
   float* po = gin + (size_t)b * C * plane;
   {
-    for (int e = tid; e < CC * HH2 * HW2; e += NT) {
-      const int c = e / (HH2 * HW2), r = (e / HW2) % HH2, x = e % HW2;
-      const int yy = y0 + r - R, xx = x0 + x - R;
-      float v = 0.f;
-      if (c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W)
-        v = px[(size_t)(c0 + c) * plane + (size_t)yy * W + xx];
-      sx[c][r][x] = v;
+    constexpr int NE = CC * HH2 * HW2, BATCH = 10;
+    static_assert(NE % (NT * BATCH) == 0, "staging batches must divide evenly");
+#pragma unroll 1
+    for (int e0 = tid; e0 < NE; e0 += NT * BATCH) {
+      float t[BATCH];
+      bool ok[BATCH];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int e = e0 + k * NT;
+        const int c = e / (HH2 * HW2), r = (e / HW2) % HH2, x = e % HW2;
+        const int yy = y0 + r - R, xx = x0 + x - R;
+        ok[k] = c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        t[k] = px[ok[k] ? (size_t)(c0 + c) * plane + (size_t)yy * W + xx : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int e = e0 + k * NT;
+        const int c = e / (HH2 * HW2), r = (e / HW2) % HH2, x = e % HW2;
+        sx[c][r][x] = ok[k] ? t[k] : 0.f;
+      }
     }
     __syncthreads();
 #pragma unroll 1

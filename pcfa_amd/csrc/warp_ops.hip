@@ -113,30 +113,28 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_kernel(const float* __restri
     const float g = go[(size_t)c * plane];
     const float* xc = xb + (size_t)c * plane;
     float* gc = gb + (size_t)c * plane;
-    // grid_sampler_2d_backward: scatter into x, gather the grid gradient from the in-bounds taps
+    // grid_sampler_2d_backward: scatter into x, gather the grid gradient from the in-bounds taps.  The four tap
+    // loads are unconditional (clamped offsets) so that they are in flight together; only the atomics are predicated.
+    const float vnw = xc[onw], vne = xc[one], vsw = xc[osw], vse = xc[ose];
     if (bnw) {
       unsafeAtomicAdd(gc + onw, nw * g);
-      const float v = xc[onw];
-      gix -= v * ey * g;
-      giy -= v * ex * g;
+      gix -= vnw * ey * g;
+      giy -= vnw * ex * g;
     }
     if (bne) {
       unsafeAtomicAdd(gc + one, ne * g);
-      const float v = xc[one];
-      gix += v * ey * g;
-      giy -= v * t.wx1 * g;
+      gix += vne * ey * g;
+      giy -= vne * t.wx1 * g;
     }
     if (bsw) {
       unsafeAtomicAdd(gc + osw, sw * g);
-      const float v = xc[osw];
-      gix -= v * t.wy1 * g;
-      giy += v * ex * g;
+      gix -= vsw * t.wy1 * g;
+      giy += vsw * ex * g;
     }
     if (bse) {
       unsafeAtomicAdd(gc + ose, se * g);
-      const float v = xc[ose];
-      gix += v * t.wy1 * g;
-      giy += v * t.wx1 * g;
+      gix += vse * t.wy1 * g;
+      giy += vse * t.wx1 * g;
     }
   }
   // d ix / d grid = W / 2 (unnormalize), d grid / d flo = 2 / max(W - 1, 1) (the reference divides, then doubles)
