@@ -5,24 +5,35 @@
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one `--steps` iteration of pcfa_attack on one synthetic 436x1024 image pair with RAFT
-(seeded random weights -- no checkpoints exist offline): torch.optim.LBFGS(max_iter=10).step =
-10 closure evaluations (box transform -> RAFT forward -> AEE + L2 penalty -> backward) + 1 re-prediction
-forward + the step's metrics.  Inputs are resident in HBM before the timed region.
-Every rank attacks its own pair (disjoint perturbations, no data-path collective): weak scaling,
-value = N*K / max-over-ranks time.
+(seeded random weights -- no checkpoints exist offline): L-BFGS(max_iter=10).step = 10 closure evaluations
+(box transform -> RAFT forward -> AEE + L2 penalty -> backward) + 1 re-prediction forward + the step's metrics
+(SURVEY.md D3).  The timed object is `pcfa_amd.attack_PCFA.PairAttack.step` -- the body of pcfa_attack's own loop,
+not a restatement.  Inputs are resident in HBM before the timed region.  Every rank attacks its own pair
+(disjoint perturbations, no data-path collective): weak scaling, value = N*K / max-over-ranks time.
+
+    --universal   BASELINE config 5 instead: ONE perturbation pair shared by all images, data parallel over the
+                  batch (`--pairs-per-gpu` pairs on every rank), one RCCL all-reduce of [grad delta1 | grad delta2 |
+                  loss] per closure (`pcfa_amd.attack_PCFA.UniversalAttack.step`).  value = pair-steps/s =
+                  N * pairs-per-gpu * K / time (weak scaling: per-GPU work fixed).
+With N > 1 the default (per-pair) run also appends a short universal leg after the timed region
+(`"universal": {...}` in the JSON line) so that a multi-GPU run exercises the all-reduce path too.
 
 The JSON line also carries
-  roofline      the correlation-lookup forward kernel (the kernel BASELINE's north_star names):
-                algorithmic bytes/launch (20.44 MB at 55x128) / mean launch duration measured
-                with HIP events around every launch inside the timed steps, against 8 TB/s HBM;
-  cpu_baseline  this repo's CPU port (pcfa_amd host code + oracle operators, torch fp32 on all host cores)
-                timed on a bounded sample of the same workload, extrapolated to the 10+1 schedule.
+  roofline            the correlation-lookup forward kernel (the kernel BASELINE's north_star names): algorithmic
+                      bytes/launch (SURVEY 8d: 20.44 MB at 55x128) / mean launch duration, against 8 TB/s HBM;
+  kernels             the other hand-written kernels of the path with their own roofline rows (RAFT/GMA: pyramid GEMMs,
+                      lookup backward, ...; PWCNet: cost volume forward/backward, warp);
+  cpu_baseline        this repo's CPU port (pcfa_amd host code + oracle operators, torch fp32 on host cores) timed on
+                      a bounded sample of the same workload, extrapolated to the 10+1 schedule;
+  parity_vs_cpu_port  loss / gradient / flow of ONE closure of the same pair at the same (perturbed) variables on the
+                      GPU and on the CPU port (the cpu_baseline leg's warm-up closure) -- parity at the BASELINE size.
 """
 import argparse
 import json
 import os
 import sys
 import time
+from argparse import Namespace
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -31,6 +42,8 @@ if REPO not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+PARITY_SEED, PARITY_SIGMA = 7, 0.02
 
 
 def parse():
@@ -40,6 +53,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--net", default="RAFT", choices=["RAFT", "GMA", "PWCNet", "SpyNet", "FlowNet2"])
     ap.add_argument("--size", default="436x1024")
+    ap.add_argument("--universal", action="store_true", help="time the universal attack (config 5) instead")
+    ap.add_argument("--pairs-per-gpu", type=int, default=1, help="--universal: local batch size")
+    ap.add_argument("--no-universal-leg", action="store_true", help="N > 1: skip the short universal leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC convolutions")
     ap.add_argument("--no-graph", action="store_true", help="launch the closure eagerly instead of replaying "
@@ -54,89 +70,103 @@ def parse():
     return ap.parse_args()
 
 
-class AttackStepper:
-    """The body of pcfa_attack's step loop (attack_PCFA.py:155-247) on pre-resident tensors."""
+# --------------------------------------------------------------------------------------------------------------
+# the product objects under test
+# --------------------------------------------------------------------------------------------------------------
+def attack_args(net, boxconstraint="change_of_variables", joint=False, universal=False, steps=1):
+    """BASELINE config 2 flags (attack_PCFA.py CLI defaults): delta_bound 0.005, zero target, AEE."""
+    return Namespace(net=net, steps=steps, joint_perturbation=joint, universal_perturbation=universal,
+                     boxconstraint=boxconstraint, delta_bound=0.005, mu=-1., target="zero", custom_target_path="",
+                     loss="aee", save_frequency=1, small_save=False, no_save=True, unregistered_artifacts=True,
+                     weights="random:1234", batch_size=1, epochs=1)
 
-    def __init__(self, net, h, w, device, seed, boxconstraint="change_of_variables"):
-        from pcfa_amd import attack_PCFA
-        from pcfa_amd.helper_functions import datasets, losses, ownutilities, targets, logging as plog
-        self.A, self.losses, self.own, self.plog = attack_PCFA, losses, ownutilities, plog
-        self.net, self.device, self.box = net, device, boxconstraint
-        self.eps = attack_PCFA.EPS_BOX
-        cov = boxconstraint == "change_of_variables"
-        unit = ownutilities.model_takes_unit_input(net)
-        kw = {"eps_box": self.eps} if cov else {}
-        self.model = ownutilities.import_and_load(net, make_unit_input=not unit, variable_change=cov,
-                                                  make_scaled_input_model=True, device=device,
-                                                  weights="random:1234", **kw)
-        self.model.eval()
-        for p in self.model.parameters():
-            p.requires_grad = False
-        i1, i2, _ = datasets.synthetic_pair(seed, h, w)
-        i1, i2 = i1[None].to(device), i2[None].to(device)
-        if not unit:
-            i1, i2 = i1 / 255., i2 / 255.
-        self.padder, [self.image1, self.image2] = ownutilities.preprocess_img(net, i1, i2)
-        if cov:
-            self.nw1 = torch.atanh(2. * (1. - self.eps) * self.image1 - (1 - self.eps))
-            self.nw2 = torch.atanh(2. * (1. - self.eps) * self.image2 - (1 - self.eps))
-        else:
-            self.nw1, self.nw2 = self.image1.clone(), self.image2.clone()
-        self.nw1.requires_grad = True
-        self.nw2.requires_grad = True
-        from pcfa_amd import ops
-        self.optimizer = ops.get().LBFGS([self.nw1, self.nw2], max_iter=10)
-        self.delta_bound = 0.005
-        self.mu = 2500. / self.delta_bound
+
+def load_model(net, device, cov):
+    from pcfa_amd import attack_PCFA
+    from pcfa_amd.helper_functions import ownutilities
+    unit = ownutilities.model_takes_unit_input(net)
+    kw = {"eps_box": attack_PCFA.EPS_BOX} if cov else {}
+    model = ownutilities.import_and_load(net, make_unit_input=not unit, variable_change=cov,
+                                         make_scaled_input_model=True, device=device, weights="random:1234", **kw)
+    model.eval()
+    for p in model.parameters():
+        p.requires_grad = False
+    return model
+
+
+def AttackStepper(net, h, w, device, seed, boxconstraint="change_of_variables", use_graph=False, model=None):
+    """`pcfa_amd.attack_PCFA.PairAttack` on one synthetic pair (what pcfa_attack builds per pair), graph off unless
+    asked: call `.enable_graph()` -- exactly what pcfa_attack does on the GPU."""
+    from pcfa_amd import attack_PCFA
+    from pcfa_amd.helper_functions import datasets
+    cov = boxconstraint == "change_of_variables"
+    args = attack_args(net, boxconstraint)
+    if model is None:
+        model = load_model(net, device, cov)
+    i1, i2, _ = datasets.synthetic_pair(seed, h, w)
+    st = attack_PCFA.PairAttack(model, i1[None], i2[None], None, 0, attack_PCFA.EPS_BOX, device, False,
+                                attack_PCFA.default_mu(args), args, use_graph=use_graph)
+    st.nw1, st.nw2, st._closure_body = st.nw_input1, st.nw_input2, st.closure_body   # names the tools use
+    return st
+
+
+def UniversalStepper(net, h, w, device, seeds, use_graph=None, model=None):
+    """`pcfa_amd.attack_PCFA.UniversalAttack` with this rank's slice of one global batch loaded."""
+    from pcfa_amd import attack_PCFA
+    from pcfa_amd.helper_functions import datasets, ownutilities
+    args = attack_args(net, "clipping", universal=True)
+    if model is None:
+        model = load_model(net, device, False)
+    pairs = [datasets.synthetic_pair(s, h, w) for s in seeds]
+    im1 = torch.stack([p[0] for p in pairs])
+    im2 = torch.stack([p[1] for p in pairs])
+    _, [p1, p2] = ownutilities.preprocess_img(net, im1[:1], im2[:1])
+    ua = attack_PCFA.UniversalAttack(model, p1[0], p2[0], device, attack_PCFA.default_mu(args), args,
+                                     use_graph=use_graph)
+    ua.begin_batch(im1, im2)
+    return ua
+
+
+def parity_closure(st):
+    """loss, gradients and flow of ONE closure at the initial variables + PARITY_SIGMA * N(0,1) (seeded on the
+    host, so the GPU and the CPU port evaluate the same point); variables restored afterwards."""
+    g = torch.Generator().manual_seed(PARITY_SEED)
+    saved = [p.detach().clone() for p in st.params]
+    with torch.no_grad():
+        for p in st.params:
+            p.add_((PARITY_SIGMA * torch.randn(p.shape, generator=g)).to(p.device))
+    graphed, st.graphed = st.graphed, None        # eager: the graph path is covered by the timed region + its test
+    try:
+        loss = float(st.closure())
+        grads = torch.cat([p.grad.detach().flatten().cpu() for p in st.params])
         with torch.no_grad():
-            self.flow_init = self.predict().clone()
-        self.target = targets.get_target("zero", self.flow_init, device=device)
-        self.closures = 0
-        self.graphed = self.repredict = None
-
-    def enable_graph(self):
-        """Capture forward+loss+backward (and the re-prediction forward) once; later evaluations replay the
-        hipGraphs -- exactly what pcfa_attack does on the GPU."""
-        from pcfa_amd.graphed import GraphedClosure, GraphedForward
-        self.graphed = GraphedClosure(self._closure_body, [self.nw1, self.nw2])
-        self.repredict = GraphedForward(self._repredict_body, self.device)
-
-    def _repredict_body(self):
-        d1, d2 = self.A.extract_deltas(self.nw1, self.nw2, self.image1, self.image2, self.box, eps_box=self.eps)
-        return d1, d2, self.predict()
-
-    def predict(self):
-        out = self.own.compute_flow(self.model, "scaled_input_model", self.nw1, self.nw2, test_mode=True)
-        [out] = self.own.postprocess_flow(self.net, self.padder, out)
-        return out
-
-    def _closure_body(self):
-        flow = self.predict()
-        d1, d2 = self.A.extract_deltas(self.nw1, self.nw2, self.image1, self.image2, self.box, eps_box=self.eps)
-        loss = self.losses.loss_delta_constraint(flow, self.target, d1, d2, self.device,
-                                                 delta_bound=self.delta_bound, mu=self.mu, f_type="aee")
-        loss.backward()
-        return loss
-
-    def closure(self):
-        self.closures += 1
-        if self.graphed is not None:
-            return self.graphed()
-        self.optimizer.zero_grad()
-        return self._closure_body()
-
-    def step(self):
-        self.optimizer.step(self.closure)
-        if self.repredict is not None:
-            d1, d2, flow = self.repredict()
-        else:
-            with torch.no_grad():
-                d1, d2, flow = self._repredict_body()
-        aee_tgt, aee_init = self.plog.calc_metrics_adv(flow, self.target, self.flow_init)
-        l2 = self.plog.calc_delta_metrics(d1, d2)
-        return aee_tgt, aee_init, l2[2]
+            flow = st.predict().detach().cpu().clone()
+    finally:
+        st.graphed = graphed
+        st.closures -= 1
+        with torch.no_grad():
+            for p, s in zip(st.params, saved):
+                p.copy_(s)
+        for p in st.params:
+            p.grad = None
+    return {"loss": loss, "grads": grads, "flow": flow}
 
 
+def parity_record(gpu, cpu):
+    df = gpu["flow"] - cpu["flow"]
+    return {"loss_rel": abs(gpu["loss"] - cpu["loss"]) / abs(cpu["loss"]),
+            "grad_rel_l2": float((gpu["grads"] - cpu["grads"]).norm() / cpu["grads"].norm()),
+            "flow_aee": float(df.pow(2).sum(1).sqrt().mean()), "flow_max_abs": float(df.abs().max()),
+            "loss_gpu": gpu["loss"], "loss_cpu_port": cpu["loss"],
+            "point": "one closure at the initial variables + %g*N(0,1) (host seed %d), same pair, same weights"
+                     % (PARITY_SIGMA, PARITY_SEED),
+            "tolerance": "tests/test_gpu_parity.py::test_closure_at_baseline_size_vs_cpu_port: flow AEE <= 1e-3, "
+                         "loss 1e-4, gradient 1e-2 relative L2"}
+
+
+# --------------------------------------------------------------------------------------------------------------
+# per-kernel roofline rows
+# --------------------------------------------------------------------------------------------------------------
 def event_overhead_us(reps=200):
     """Mean interval of an event BRACKET (record, launch, record) around an empty kernel: what per-launch
     figures would carry if they were taken with bracketing events instead of dispatch-attached ones
@@ -167,12 +197,20 @@ def lookup_algorithmic_bytes(hf, wf, levels=4, radius=4):
     return q * levels * (2 * radius + 2) ** 2 * 4 + q * 2 * 4 + q * levels * n1 * n1 * 4
 
 
-MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+def _row(label, bound, work, us, n, note=None):
+    if bound == "hbm":
+        ach, peak, unit = work / (us * 1e-6) / 1e9, HBM_PEAK_GBS, "GB/s"
+    else:
+        ach, peak, unit = work / (us * 1e-6) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+    r = {"kernel": label, "bound": bound, "per_launch": work, "mean_launch_us": round(us, 2), "launches_timed": n,
+         "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4)}
+    if note:
+        r["note"] = note
+    return r
 
 
 def kernel_table(timings, hf, wf, hp, wp, dim=256, levels=4, radius=4):
-    """Per-kernel roofline rows for the RAFT/GMA path: algorithmic work per launch (SURVEY 8d figures, stated
-    in DESIGN.md section 4) / mean dispatch duration measured with hipEvents on the dispatch packets."""
+    """RAFT/GMA: algorithmic work per launch (SURVEY 8d figures, stated in DESIGN.md) / mean dispatch duration."""
     q = hf * wf
     n1 = 2 * radius + 1
     out_b = q * levels * n1 * n1 * 4
@@ -182,6 +220,7 @@ def kernel_table(timings, hf, wf, hp, wp, dim=256, levels=4, radius=4):
     work = {  # label -> (bound, algorithmic bytes or flop per launch)
         "corr_lookup_fwd": ("hbm", win_b + q * 8 + out_b),
         "corr_lookup_bwd": ("hbm", out_b + q * 8 + 2 * win_b),
+        "corr_lookup_convc1_fwd": ("hbm", win_b + q * 8 + q * 256 * 4),
         "corr_pyramid_gemm_fwd": ("mfma", gemm),
         "corr_pyramid_gemm_dfmap1": ("mfma", gemm),
         "corr_pyramid_gemm_df2ext": ("mfma", gemm),
@@ -190,28 +229,50 @@ def kernel_table(timings, hf, wf, hp, wp, dim=256, levels=4, radius=4):
         "gru_gates_fwd": ("hbm", 8 * q * 128 * 4),
         "gru_update_fwd": ("hbm", 6 * q * 128 * 4),
     }
+    return [_row(label, work[label][0], work[label][1], us, n) for label, (us, n) in sorted(timings.items())
+            if label in work]
+
+
+PWC_LEVEL_CHANNELS = {2: 32, 3: 64, 4: 96, 5: 128, 6: 196}  # models/PWCNet/PWCNet.py:76-93
+
+
+def pwc_kernel_table(timings, hp, wp):
+    """PWC-Net: the five cost volumes of one closure together (13.9 MB in + 13.3 MB out forward at
+    384x1280; backward reads grad_out + both maps and writes both gradients).  Rows are per CLOSURE: the five
+    launches (levels 6..2) have different sizes, so bytes and durations are summed over them."""
+    fwd = bwd = 0
+    for lvl, c in PWC_LEVEL_CHANNELS.items():
+        px = (hp >> lvl) * (wp >> lvl)
+        fwd += (2 * c + 81) * px * 4
+        bwd += (81 + 2 * c + 2 * c) * px * 4
     rows = []
-    for label, (us, n) in sorted(timings.items()):
-        if label not in work:
-            continue
-        bound, w = work[label]
-        if bound == "hbm":
-            ach, peak, unit = w / (us * 1e-6) / 1e9, HBM_PEAK_GBS, "GB/s"
-        else:
-            ach, peak, unit = w / (us * 1e-6) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-        rows.append({"kernel": label, "bound": bound, "per_launch": w, "mean_launch_us": round(us, 2),
-                     "launches_timed": n, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                     "frac": round(ach / peak, 4)})
+    if "spatial_corr_fwd" in timings:
+        us, n = timings["spatial_corr_fwd"]
+        rows.append(_row("spatial_corr_fwd (5 levels)", "hbm", fwd, us * 5, n // 5, "per closure: 5 launches summed"))
+    tb = [timings[k] for k in ("spatial_corr_bwd_in1", "spatial_corr_bwd_in2") if k in timings]
+    if tb:
+        tot = sum(us * n for us, n in tb)
+        closures = max(tb[0][1] // 5, 1)
+        rows.append(_row("spatial_corr_bwd (5 levels, both gradients)", "hbm", bwd, tot / closures, closures,
+                         "per closure: all backward launches summed"))
+    if "pwc_warp_fwd" in timings:
+        us, n = timings["pwc_warp_fwd"]
+        w = sum((2 * PWC_LEVEL_CHANNELS[l] + 2) * (hp >> l) * (wp >> l) * 4 for l in (2, 3, 4, 5))
+        rows.append(_row("pwc_warp_fwd (4 levels)", "hbm", w, us * 4, n // 4, "per forward: 4 launches summed"))
     return rows
 
 
-TRACED = {  # kernel-name fragment -> label of kernel_table()
+TRACED = {  # kernel-name fragment -> label
     "corr_lookup_fwd_kernel": "corr_lookup_fwd", "corr_lookup_bwd_kernel": "corr_lookup_bwd",
+    "corr_lookup_convc1_fwd_kernel": "corr_lookup_convc1_fwd",
     "gemm_f32_mfma_kernel<true, true,": "corr_pyramid_gemm_fwd",
     "gemm_f32_mfma_kernel<false, false,": "corr_pyramid_gemm_dfmap1",
     "gemm_f32_mfma_kernel<false, true,": "corr_pyramid_gemm_df2ext",
     "box_fwd_kernel": "box_transform_fwd", "box_bwd_kernel": "box_transform_bwd",
     "gru_gates_fwd_kernel": "gru_gates_fwd", "gru_update_fwd_kernel": "gru_update_fwd",
+    "scorr_fwd": "spatial_corr_fwd", "scorr_bwd_fast_kernel<9, 1>": "spatial_corr_bwd_in1",
+    "scorr_bwd_fast_kernel<9, -1>": "spatial_corr_bwd_in2", "scorr_bwd": "spatial_corr_bwd_in1",
+    "pwc_warp_fwd_kernel": "pwc_warp_fwd",
 }
 
 
@@ -238,24 +299,29 @@ def graph_replay_kernel_times(st):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items() if v[1]}
 
 
-def cpu_baseline(net, h, w, nclosures, threads=0):
-    """Time the CPU port (pcfa_amd host code + oracle operators) on a bounded sample of the workload."""
+# --------------------------------------------------------------------------------------------------------------
+# CPU baseline (+ the CPU side of the parity record)
+# --------------------------------------------------------------------------------------------------------------
+def cpu_baseline(net, h, w, nclosures, threads=0, boxconstraint="change_of_variables"):
+    """Time the CPU port (pcfa_amd host code + oracle operators) on a bounded sample of the workload.  Its warm-up
+    closure is evaluated at the parity point, so the same leg yields the CPU side of `parity_vs_cpu_port`."""
     from oracle import ops as oracle_ops
     from pcfa_amd import ops
     cores = threads if threads > 0 else min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     with ops.override_for_testing(oracle_ops):
-        st = AttackStepper(net, h, w, torch.device("cpu"), seed=0)
+        st = AttackStepper(net, h, w, torch.device("cpu"), seed=0, boxconstraint=boxconstraint)
         t0 = time.perf_counter()
         with torch.no_grad():
             st.predict()
         t_fwd = time.perf_counter() - t0  # forward only (includes first-touch warm-up)
+        parity = parity_closure(st)       # warm-up closure (excluded from the timing) at the parity point
         times = []
-        for _ in range(nclosures):
+        for _ in range(max(nclosures - 1, 1)):
             t0 = time.perf_counter()
             st.closure()
             times.append(time.perf_counter() - t0)
-    t_c = sum(times[1:]) / max(len(times) - 1, 1) if len(times) > 1 else times[0]  # first one warms up
+    t_c = sum(times) / len(times)
     step_s = 10 * t_c + t_fwd
     model_name = "?"
     try:
@@ -264,8 +330,46 @@ def cpu_baseline(net, h, w, nclosures, threads=0):
         pass
     return {"value": 1.0 / step_s, "unit": "attack_steps/s", "cores": cores, "kind": "port", "cpu": model_name,
             "host_cores_available": os.cpu_count(), "closure_s": t_c, "forward_s": t_fwd,
-            "sample": "%d closure evals + 1 forward of %s %dx%d on %d host threads, extrapolated to the "
-                      "10 closures + 1 forward of one step" % (nclosures, net, h, w, cores)}
+            "sample": "1 forward + 1 warm-up closure + %d timed closure evals of %s %dx%d on %d host threads, "
+                      "extrapolated to the 10 closures + 1 forward of one step" % (len(times), net, h, w, cores)
+            }, parity
+
+
+# --------------------------------------------------------------------------------------------------------------
+def timed_steps(st, steps, sharding):
+    torch.cuda.synchronize()
+    sharding.barrier()
+    c0 = st.closures
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = st.step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    return time.perf_counter() - t0, st.closures - c0, last
+
+
+def universal_leg(net, h, w, dev, rank, world, pairs_per_gpu, warmup, steps, sharding, cdev, model=None,
+                  use_graph=None):
+    """K steps of UniversalAttack on one global batch of world*pairs_per_gpu pairs (rank r holds pairs
+    r*b .. r*b+b-1); returns the timing record (rank 0 fills the JSON from it)."""
+    seeds = [100 + rank * pairs_per_gpu + i for i in range(pairs_per_gpu)]
+    t0 = time.perf_counter()
+    ua = UniversalStepper(net, h, w, dev, seeds, use_graph=use_graph, model=model)
+    setup = time.perf_counter() - t0
+    for _ in range(warmup):
+        ua.step()
+    col0 = ua.reducer.collectives if ua.reducer is not None else 0
+    elapsed, closures, last = timed_steps(ua, steps, sharding)
+    elapsed = sharding.max_scalar(elapsed, cdev)
+    cols = (ua.reducer.collectives if ua.reducer is not None else 0) - col0
+    flat = ua.reducer.flat.numel() * 4 if ua.reducer is not None else 0
+    return {"metric": "universal_pair_steps_per_sec", "value": world * pairs_per_gpu * steps / elapsed,
+            "unit": "pair-steps/s", "optimizer_steps_per_sec": steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
+            "steps": steps, "warmup": warmup, "global_batch": world * pairs_per_gpu, "pairs_per_gpu": pairs_per_gpu,
+            "closure_evals_per_step": closures / steps, "allreduces_per_closure": cols / max(closures, 1),
+            "allreduce_bytes": flat, "closure_launch": "hipGraph replay" if ua.graphed else "eager",
+            "setup_s": setup, "final": last}
 
 
 def main():
@@ -293,41 +397,55 @@ def main():
     rank = sharding.rank()
     if world != a.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
-    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the two scalar collectives live
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the scalar collectives live
     torch.backends.cudnn.benchmark = a.miopen_find
     h, w = (int(v) for v in a.size.lower().split("x"))
+    use_graph = not a.no_graph
 
+    if a.universal:
+        rec = universal_leg(a.net, h, w, dev, rank, world, a.pairs_per_gpu, a.warmup, a.steps, sharding, cdev,
+                            use_graph=use_graph)
+        if rank == 0:
+            out = {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "n_gpus": world,
+                   "steps": a.steps, "warmup": a.warmup, "ms_per_step": rec["ms_per_step"],
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                   "data": "synthetic",
+                   "config": {"workload": "%s universal perturbation (BASELINE config 5), %d synthetic %dx%d pair(s) "
+                                          "per GPU, clipping, delta_bound=0.005, zero target, L-BFGS max_iter=10, "
+                                          "one all-reduce of [grad delta1|grad delta2|loss] per closure"
+                                          % (a.net, a.pairs_per_gpu, h, w), "weights": "random:1234",
+                              "parallelism": "data parallel over the batch, %d rank(s)" % world},
+                   "universal": rec}
+            print(json.dumps(out), file=json_out, flush=True)
+        sharding.shutdown()
+        return
+
+    t0 = time.perf_counter()
     st = AttackStepper(a.net, h, w, dev, seed=rank)
     if a.channels_last:
         st.model = st.model.to(memory_format=torch.channels_last)
+    setup_eager = time.perf_counter() - t0
     from pcfa_amd import hip_ops
     corr_net = a.net in ("RAFT", "GMA")
+    gpu_parity = parity_closure(st) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
     # HIP events attached to every dispatch of the named kernel (on the stream it is launched on)
     prof = hip_ops.DispatchTimer() if corr_net else None
+    t0 = time.perf_counter()
+    if use_graph:
+        st.enable_graph()   # what pcfa_attack does per pair: 2 warm-up closures + capture, 1 warm-up + capture forward
+        torch.cuda.synchronize()
+    setup_graph = time.perf_counter() - t0
     for _ in range(a.warmup):
         st.step()
-    use_graph = not a.no_graph
-    if use_graph:
-        st.enable_graph()
-        st.step()  # one untimed step on the graph
-    torch.cuda.synchronize()
-    sharding.barrier()
     if not use_graph:
         hip_ops.set_dispatch_timer(prof)
-    c0 = st.closures
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(a.steps):
-        last = st.step()
-    torch.cuda.synchronize()
-    sharding.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, closures, last = timed_steps(st, a.steps, sharding)
     hip_ops.set_dispatch_timer(None)
     elapsed = sharding.max_scalar(elapsed, cdev)
-    closures = st.closures - c0
     traced = None
     # PCFA_BENCH_NO_TRACER=1: skip the in-process tracer (set when an external profiler already owns it)
-    if use_graph and corr_net and rank == 0 and os.environ.get("PCFA_BENCH_NO_TRACER", "0") != "1":
+    if use_graph and rank == 0 and os.environ.get("PCFA_BENCH_NO_TRACER", "0") != "1" and \
+            a.net in ("RAFT", "GMA", "PWCNet"):
         try:
             traced = graph_replay_kernel_times(st)
         except Exception as e:  # the tracer is an extra: fall back to the eager hipEvent figures
@@ -341,6 +459,14 @@ def main():
         torch.cuda.synchronize()
         hip_ops.set_dispatch_timer(None)
 
+    universal = None
+    if world > 1 and not a.no_universal_leg:
+        try:
+            universal = universal_leg(a.net, h, w, dev, rank, world, 1, 1, 2, sharding, cdev, model=st.model,
+                                      use_graph=use_graph)
+        except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure of the extra leg
+            universal = {"error": repr(e)}
+
     out = None
     if rank == 0:
         hp, wp = st.image1.shape[-2:]
@@ -353,10 +479,16 @@ def main():
                                    "change_of_variables, delta_bound=0.005, zero target, L-BFGS max_iter=10"
                                    % (a.net, h, w, hp, wp), "weights": "random:1234",
                        "closure_evals_per_step": closures / a.steps, "parallelism": "pairs sharded 1/GPU",
-                       "closure_launch": "hipGraph replay" if use_graph else "eager"},
+                       "closure_launch": "hipGraph replay" if use_graph else "eager",
+                       "timed_object": "pcfa_amd.attack_PCFA.PairAttack.step (the body of pcfa_attack's loop)"},
             "closure_evals_per_sec": world * closures / elapsed,
+            "per_pair_setup_s": {"upload_init_forward_target": setup_eager, "graph_warmup_and_capture": setup_graph,
+                                 "note": "paid once per image pair, outside the timed steps; a 20-step attack of "
+                                         "one pair = setup + 20 steps"},
             "final": {"aee_adv_tgt": last[0], "aee_adv_init": last[1], "l2_delta": last[2]},
         }
+        if universal is not None:
+            out["universal"] = universal
         if corr_net:
             timings = prof.summary()
             eager_us, eager_n = timings["corr_lookup_fwd"]
@@ -380,8 +512,20 @@ def main():
                                "eager_step_frac": nbytes / (eager_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                "event_bracket_overhead_us": event_overhead_us()}
             out["kernels_eager_step_hip_events"] = kernel_table(timings, hp // 8, wp // 8, hp, wp)
+        elif a.net == "PWCNet" and traced:
+            rows = pwc_kernel_table(traced, hp, wp)
+            out["kernels"] = rows
+            if rows:
+                r0 = rows[0]
+                out["roofline"] = {"kernel": "scorr_fwd (five cost volumes of one closure)", "bound": "hbm",
+                                   "achieved": r0["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": r0["frac"], "traffic": None, "bytes_per_launch": r0["per_launch"],
+                                   "mean_launch_us": r0["mean_launch_us"], "launches_timed": r0["launches_timed"],
+                                   "timing": "dispatch timestamps inside the hipGraph replays (HIP activity tracer)"}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.net, h, w, a.cpu_closures, a.cpu_threads)
+            out["cpu_baseline"], cpu_parity = cpu_baseline(a.net, h, w, a.cpu_closures, a.cpu_threads)
+            if gpu_parity is not None:
+                out["parity_vs_cpu_port"] = parity_record(gpu_parity, cpu_parity)
         print(json.dumps(out), file=json_out, flush=True)
     sharding.shutdown()
     return out

@@ -67,159 +67,221 @@ def _should_save(batch, args):
         and not args.no_save
 
 
-def pcfa_attack(model, image1, image2, flow, batch, distortion_folder, eps_box, device, has_gt, optim_mu, args,
-                statistics_in_every_step=True):
-    """Attack one image pair; returns the reference's 12-tuple (attack_PCFA.py:40-294)."""
-    curr_step = batch * args.steps
-    aee_gt = aee_gt_tgt = aee_adv_gt = 0.
-    aee_adv_tgt = aee_adv_pred = 0.
-    l2_delta1 = l2_delta2 = l2_delta12 = 0.
+def _graphs_enabled(device, args):
+    return torch.device(device).type == "cuda" and os.environ.get("PCFA_HIP_GRAPH", "1") == "1" and args.steps > 0
 
-    image1, image2 = image1.to(device), image2.to(device)
-    flow = flow.to(device)
-    if not ownutilities.model_takes_unit_input(args.net):
-        image1 = image1 / 255.
-        image2 = image2 / 255.
-    padder, [image1, image2] = ownutilities.preprocess_img(args.net, image1, image2)
-    image1.requires_grad = False
-    image2.requires_grad = False
-    images_max = torch.max(image1, image2).detach()
-    images_min = torch.min(image1, image2).detach()
 
-    delta1 = torch.zeros_like(image1)
-    delta2 = torch.zeros_like(image2)
-    nw_delta = None
-    cov = args.boxconstraint in ['change_of_variables']
+class PairAttack:
+    """Everything pcfa_attack holds for ONE image pair (attack_PCFA.py:40-247): the optimisation variables,
+    the optimiser, the target, the best-iterate bookkeeping -- and `step()`, the body of the `--steps` loop.
 
-    if args.joint_perturbation:
-        if cov:
-            raise ValueError("Training a --joint_perturbation with --boxconstraint=change_of_variables is not "
-                             "defined. Please use --boxconstraint=clipping.")
-        nw_delta = delta1
-        nw_delta.requires_grad = True
-        nw_input1, nw_input2 = image1, image2
-        optimizer = ops.get().LBFGS([nw_delta], max_iter=10)
-        fwd_kwargs = {"delta1": nw_delta}
-    else:
-        if cov:
-            nw_input1 = torch.atanh(2. * (1. - eps_box) * (image1 + delta1) - (1 - eps_box))
-            nw_input2 = torch.atanh(2. * (1. - eps_box) * (image2 + delta2) - (1 - eps_box))
+    `pcfa_attack` is `PairAttack(...)` + `args.steps` x `step()`; bench.py times `step()` of this class, so the
+    measured loop IS the product loop.  On the GPU the closure (static shapes, variables updated in place by
+    L-BFGS) and the re-prediction forward are captured once per pair into hipGraphs and replayed
+    (`use_graph=None`: on for CUDA devices unless PCFA_HIP_GRAPH=0; if capture fails the eager closure -- the same
+    kernels in the same order -- is used and a warning is logged)."""
+
+    def __init__(self, model, image1, image2, flow, batch, eps_box, device, has_gt, optim_mu, args, use_graph=None):
+        self.model, self.args, self.device, self.batch = model, args, device, batch
+        self.has_gt, self.optim_mu, self.eps_box = has_gt, optim_mu, eps_box
+        curr_step = batch * args.steps
+
+        image1, image2 = image1.to(device), image2.to(device)
+        self.flow_gt = flow.to(device) if flow is not None else None
+        if not ownutilities.model_takes_unit_input(args.net):
+            image1 = image1 / 255.
+            image2 = image2 / 255.
+        self.padder, [image1, image2] = ownutilities.preprocess_img(args.net, image1, image2)
+        image1.requires_grad = False
+        image2.requires_grad = False
+        self.image1, self.image2 = image1, image2
+        self.images_max = torch.max(image1, image2).detach()
+        self.images_min = torch.min(image1, image2).detach()
+
+        delta1 = torch.zeros_like(image1)
+        delta2 = torch.zeros_like(image2)
+        self.nw_delta = None
+        cov = args.boxconstraint in ['change_of_variables']
+        if args.joint_perturbation:
+            if cov:
+                raise ValueError("Training a --joint_perturbation with --boxconstraint=change_of_variables is not "
+                                 "defined. Please use --boxconstraint=clipping.")
+            self.nw_delta = delta1
+            self.nw_delta.requires_grad = True
+            self.nw_input1, self.nw_input2 = image1, image2
+            self.params = [self.nw_delta]
+            self.fwd_kwargs = {"delta1": self.nw_delta}
         else:
-            nw_input1 = image1 + delta1
-            nw_input2 = image2 + delta2
-        nw_input1.requires_grad = True
-        nw_input2.requires_grad = True
-        optimizer = ops.get().LBFGS([nw_input1, nw_input2], max_iter=10)
-        fwd_kwargs = {}
+            if cov:
+                self.nw_input1 = torch.atanh(2. * (1. - eps_box) * (image1 + delta1) - (1 - eps_box))
+                self.nw_input2 = torch.atanh(2. * (1. - eps_box) * (image2 + delta2) - (1 - eps_box))
+            else:
+                self.nw_input1 = image1 + delta1
+                self.nw_input2 = image2 + delta2
+            self.nw_input1.requires_grad = True
+            self.nw_input2.requires_grad = True
+            self.params = [self.nw_input1, self.nw_input2]
+            self.fwd_kwargs = {}
+        self.optimizer = ops.get().LBFGS(self.params, max_iter=10)
 
-    def predict():
-        out = ownutilities.compute_flow(model, "scaled_input_model", nw_input1, nw_input2, test_mode=True,
-                                        **fwd_kwargs)
-        [out] = ownutilities.postprocess_flow(args.net, padder, out)
+        with torch.no_grad():
+            self.flow_pred_init = self.predict().detach().clone()
+        self.target = targets.get_target(args.target, self.flow_pred_init,
+                                         custom_target_path=args.custom_target_path, device=device).to(device)
+        self.target.requires_grad = False
+
+        self.aee_tgt = logging.calc_metrics_const(self.target, self.flow_pred_init)
+        if has_gt:
+            self.aee_gt_tgt, self.aee_gt = logging.calc_metrics_const_gt(self.target, self.flow_pred_init,
+                                                                         self.flow_gt)
+        else:
+            self.aee_gt_tgt, self.aee_gt = None, None
+        logging.log_metrics(curr_step, ("aee_pred-tgt", self.aee_tgt), ("aee_gt-tgt", self.aee_gt_tgt),
+                            ("aee_pred-gt", self.aee_gt))
+        logging.log_metric(key="optim_mu", value=optim_mu, step=curr_step)
+
+        model.zero_grad()
+        self.optimizer.zero_grad()
+
+        self.delta_below_threshold = False
+        self.delta12_min_val = float('inf')
+        self.aee_adv_tgt_min_val = float('inf')
+        self.aee_adv_pred_min_val = 0.
+        self.delta1_min = self.delta2_min = self.flow_pred_min = None
+        self.flow_pred = self.flow_pred_init
+        self.delta1, self.delta2 = delta1, delta2
+        self.aee_adv_gt = 0.
+        self.aee_adv_tgt = self.aee_adv_pred = 0.
+        self.l2_delta1 = self.l2_delta2 = self.l2_delta12 = 0.
+        self.steps_done = 0
+        self.closures = 0
+
+        self.graphed = self.repredict = None
+        if use_graph is None:
+            use_graph = _graphs_enabled(device, args)
+        if use_graph:
+            self.enable_graph()
+
+    # ---- pieces of the closure (attack_PCFA.py:175-192) ---------------------------------------------------------
+    def predict(self):
+        out = ownutilities.compute_flow(self.model, "scaled_input_model", self.nw_input1, self.nw_input2,
+                                        test_mode=True, **self.fwd_kwargs)
+        [out] = ownutilities.postprocess_flow(self.args.net, self.padder, out)
         return out
 
-    def current_deltas():
-        if args.joint_perturbation:
-            return extract_deltas_joint(nw_delta, images_max, images_min)
-        return extract_deltas(nw_input1, nw_input2, image1, image2, args.boxconstraint, eps_box=eps_box)
+    def current_deltas(self):
+        if self.args.joint_perturbation:
+            return extract_deltas_joint(self.nw_delta, self.images_max, self.images_min)
+        return extract_deltas(self.nw_input1, self.nw_input2, self.image1, self.image2, self.args.boxconstraint,
+                              eps_box=self.eps_box)
 
-    with torch.no_grad():
-        flow_pred_init = predict().detach().clone()
-    target = targets.get_target(args.target, flow_pred_init, custom_target_path=args.custom_target_path,
-                                device=device).to(device)
-    target.requires_grad = False
-
-    aee_tgt = logging.calc_metrics_const(target, flow_pred_init)
-    if has_gt:
-        aee_gt_tgt, aee_gt = logging.calc_metrics_const_gt(target, flow_pred_init, flow)
-    else:
-        aee_gt_tgt, aee_gt = None, None
-    logging.log_metrics(curr_step, ("aee_pred-tgt", aee_tgt), ("aee_gt-tgt", aee_gt_tgt), ("aee_pred-gt", aee_gt))
-    logging.log_metric(key="optim_mu", value=optim_mu, step=curr_step)
-
-    model.zero_grad()
-    optimizer.zero_grad()
-
-    delta_below_threshold = False
-    delta12_min_val = float('inf')
-    aee_adv_tgt_min_val = float('inf')
-    aee_adv_pred_min_val = 0.
-    delta1_min = delta2_min = flow_pred_min = None
-    flow_pred = flow_pred_init
-
-    def closure_body():
-        flow_closure = predict()
-        d1, d2 = current_deltas()
-        loss_closure = losses.loss_delta_constraint(flow_closure, target, d1, d2, device,
-                                                    delta_bound=args.delta_bound, mu=optim_mu, f_type=args.loss)
+    def closure_body(self):
+        flow_closure = self.predict()
+        d1, d2 = self.current_deltas()
+        loss_closure = losses.loss_delta_constraint(flow_closure, self.target, d1, d2, self.device,
+                                                    delta_bound=self.args.delta_bound, mu=self.optim_mu,
+                                                    f_type=self.args.loss)
         loss_closure.backward()
         return loss_closure
 
-    # On the GPU the closure (static shapes, variables updated in place by L-BFGS) is captured once per pair
-    # into a hipGraph and replayed: same kernels in the same order, no per-launch host work (PCFA_HIP_GRAPH=0 disables).
-    graphed = repredict = None
-    if torch.device(device).type == "cuda" and os.environ.get("PCFA_HIP_GRAPH", "1") == "1" and args.steps > 0:
-        from .graphed import GraphedClosure, GraphedForward
-        graphed = GraphedClosure(closure_body, optimizer.param_groups[0]["params"])
-        repredict = GraphedForward(lambda: (current_deltas(), predict()), device)
+    def _repredict_body(self):
+        return self.current_deltas(), self.predict()
 
-    def closure():
-        if graphed is not None:
-            return graphed()
-        optimizer.zero_grad()
-        return closure_body()
+    def enable_graph(self):
+        try:
+            from .graphed import GraphedClosure, GraphedForward
+            self.graphed = GraphedClosure(self.closure_body, self.params)
+            self.repredict = GraphedForward(self._repredict_body, self.device)
+        except Exception as e:  # noqa: BLE001 -- the eager closure launches the same kernels in the same order
+            import logging as pylog
+            pylog.warning("hipGraph capture of the closure failed (%r): launching eagerly", e)
+            self.graphed = self.repredict = None
 
-    for steps in range(args.steps):
-        curr_step = batch * args.steps + steps
-        logging.log_metrics(curr_step, ("batch", batch), ("steps", steps), ("epoch", 0))
+    def closure(self):
+        self.closures += 1
+        if self.graphed is not None:
+            return self.graphed()
+        self.optimizer.zero_grad()
+        return self.closure_body()
 
-        optimizer.step(closure)
+    # ---- one `--steps` iteration (attack_PCFA.py:155-247) -------------------------------------------------------
+    def step(self):
+        args = self.args
+        steps = self.steps_done
+        curr_step = self.batch * args.steps + steps
+        logging.log_metrics(curr_step, ("batch", self.batch), ("steps", steps), ("epoch", 0))
 
-        if repredict is not None:
-            (delta1, delta2), flow_pred = repredict()
+        self.optimizer.step(self.closure)
+
+        if self.repredict is not None:
+            (delta1, delta2), flow_pred = self.repredict()
         else:
             with torch.no_grad():
-                delta1, delta2 = current_deltas()
-                flow_pred = predict()
+                (delta1, delta2), flow_pred = self._repredict_body()
+        self.delta1, self.delta2, self.flow_pred = delta1, delta2, flow_pred
 
-        aee_adv_tgt, aee_adv_pred = logging.calc_metrics_adv(flow_pred, target, flow_pred_init)
-        aee_adv_gt = logging.calc_metrics_adv_gt(flow_pred, flow) if has_gt else None
+        aee_adv_tgt, aee_adv_pred = logging.calc_metrics_adv(flow_pred, self.target, self.flow_pred_init)
+        self.aee_adv_gt = logging.calc_metrics_adv_gt(flow_pred, self.flow_gt) if self.has_gt else None
         logging.log_metrics(curr_step, ("aee_predadv-tgt", aee_adv_tgt), ("aee_pred-predadv", aee_adv_pred),
-                            ("aee_predadv-gt", aee_adv_gt))
+                            ("aee_predadv-gt", self.aee_adv_gt))
         l2_delta1, l2_delta2, l2_delta12 = logging.calc_delta_metrics(delta1, delta2, curr_step)
         logging.log_metrics(curr_step, ("l2_delta1", l2_delta1), ("l2_delta2", l2_delta2),
                             ("l2_delta-avg", l2_delta12))
+        self.aee_adv_tgt, self.aee_adv_pred = aee_adv_tgt, aee_adv_pred
+        self.l2_delta1, self.l2_delta2, self.l2_delta12 = l2_delta1, l2_delta2, l2_delta12
 
         # best-iterate rule, attack_PCFA.py:226-243
         update_minima = False
-        if not delta_below_threshold:
-            if l2_delta12 < delta12_min_val or (l2_delta12 == delta12_min_val and aee_adv_tgt < aee_adv_tgt_min_val):
+        if not self.delta_below_threshold:
+            if l2_delta12 < self.delta12_min_val or (l2_delta12 == self.delta12_min_val
+                                                     and aee_adv_tgt < self.aee_adv_tgt_min_val):
                 update_minima = True
                 if l2_delta12 <= args.delta_bound:
-                    delta_below_threshold = True
-        elif l2_delta12 <= args.delta_bound and aee_adv_tgt < aee_adv_tgt_min_val:
+                    self.delta_below_threshold = True
+        elif l2_delta12 <= args.delta_bound and aee_adv_tgt < self.aee_adv_tgt_min_val:
             update_minima = True
         if update_minima:
-            delta12_min_val = l2_delta12
-            aee_adv_tgt_min_val = aee_adv_tgt
-            aee_adv_pred_min_val = aee_adv_pred
-            delta1_min = delta1.detach().clone()
-            delta2_min = delta2.detach().clone()
-            flow_pred_min = flow_pred.detach().clone()
-        logging.log_metrics(curr_step, ("aee_pred-tgt_min", aee_adv_tgt_min_val),
-                            ("l2_delta-avg_min", delta12_min_val), ("aee_pred-predadv_min", aee_adv_pred_min_val))
+            self.delta12_min_val = l2_delta12
+            self.aee_adv_tgt_min_val = aee_adv_tgt
+            self.aee_adv_pred_min_val = aee_adv_pred
+            self.delta1_min = delta1.detach().clone()
+            self.delta2_min = delta2.detach().clone()
+            self.flow_pred_min = flow_pred.detach().clone()
+        logging.log_metrics(curr_step, ("aee_pred-tgt_min", self.aee_adv_tgt_min_val),
+                            ("l2_delta-avg_min", self.delta12_min_val),
+                            ("aee_pred-predadv_min", self.aee_adv_pred_min_val))
+        self.steps_done += 1
+        return aee_adv_tgt, aee_adv_pred, l2_delta12
 
-    if distortion_folder is not None and _should_save(batch, args):
-        for tens, name in ((delta1, "delta1_final"), (delta2, "delta2_final"), (delta1_min, "delta1_best"),
-                           (delta2_min, "delta2_best"), (image1, "image1"), (image2, "image2"), (target, "target"),
-                           (flow_pred, "flow_pred_final"), (flow_pred_min, "flow_pred_best"),
-                           (flow_pred_init, "flow_pred_init")):
+    def save(self, distortion_folder):
+        batch = self.batch
+        for tens, name in ((self.delta1, "delta1_final"), (self.delta2, "delta2_final"),
+                           (self.delta1_min, "delta1_best"), (self.delta2_min, "delta2_best"),
+                           (self.image1, "image1"), (self.image2, "image2"), (self.target, "target"),
+                           (self.flow_pred, "flow_pred_final"), (self.flow_pred_min, "flow_pred_best"),
+                           (self.flow_pred_init, "flow_pred_init")):
             logging.save_tensor(tens, name, batch, distortion_folder)
-        if has_gt:
-            logging.save_tensor(flow, "flow_gt", batch, distortion_folder)
+        if self.has_gt:
+            logging.save_tensor(self.flow_gt, "flow_gt", batch, distortion_folder)
 
-    return (aee_gt, aee_tgt, aee_gt_tgt, aee_adv_gt, aee_adv_tgt, aee_adv_pred, l2_delta1, l2_delta2, l2_delta12,
-            aee_adv_tgt_min_val, aee_adv_pred_min_val, delta12_min_val)
+    def result(self):
+        """The reference's 12-tuple (attack_PCFA.py:294)."""
+        return (self.aee_gt, self.aee_tgt, self.aee_gt_tgt, self.aee_adv_gt, self.aee_adv_tgt, self.aee_adv_pred,
+                self.l2_delta1, self.l2_delta2, self.l2_delta12, self.aee_adv_tgt_min_val,
+                self.aee_adv_pred_min_val, self.delta12_min_val)
+
+
+def pcfa_attack(model, image1, image2, flow, batch, distortion_folder, eps_box, device, has_gt, optim_mu, args,
+                statistics_in_every_step=True):
+    """Attack one image pair; returns the reference's 12-tuple (attack_PCFA.py:40-294)."""
+    st = PairAttack(model, image1, image2, flow, batch, eps_box, device, has_gt, optim_mu, args)
+    if args.steps == 0:  # the reference returns its initial zeros for the adversarial statistics
+        st.aee_gt = st.aee_gt if has_gt else None
+    for _ in range(args.steps):
+        st.step()
+    if distortion_folder is not None and _should_save(batch, args):
+        st.save(distortion_folder)
+    return st.result()
 
 
 def _load_model(args, device, variable_change):
@@ -289,15 +351,154 @@ def attack_l2(args, data_loader=None, has_gt=None):
     return result
 
 
-def attack_l2_universal(args, data_loader=None, has_gt=None):
-    """One perturbation for a whole dataset (attack_PCFA.py:297-566), data parallel over the batch.
+class _UniversalBatchState:
+    """Static device buffers + captured hipGraphs of the universal closure for ONE batch shape."""
 
-    Every rank holds batch_size/world_size pairs of each global batch, a replica of delta and of
-    the L-BFGS state.  Per closure: local forward/backward, then one all-reduce(AVG) of
-    d(loss)/d(delta) and of the scalar loss.  The penalty depends on delta only, so it is identical
-    on every rank and its average is itself; the similarity term is a mean over the batch, so the
-    average of the local means equals the reference's single-process mean over the global batch.
-    """
+    def __init__(self, image1, image2, padder):
+        self.image1 = image1.clone()
+        self.image2 = image2.clone()
+        self.padder = padder
+        self.target = None
+        self.graphed = None
+        self.repredict = None
+        self.tried_graph = False
+
+
+class UniversalAttack:
+    """State of attack_l2_universal (attack_PCFA.py:297-566): ONE perturbation (pair) `[3,Hp,Wp]` shared by every
+    image, ONE L-BFGS optimiser for the whole run, data parallel over the batch.
+
+    Every rank holds batch_size/world_size pairs of each global batch, a replica of delta and of the L-BFGS
+    state.  Per closure: local forward/backward, then ONE all-reduce of a flat buffer holding d(loss)/d(delta) of
+    both perturbations and the scalar loss (sharding.FlatReducer).  The penalty depends on delta only, so it is
+    identical on every rank and its average is itself; the similarity term is a mean over the batch, so the
+    average of the local means equals the reference's single-process mean over the global batch
+    (attack_PCFA.py:469-490).
+
+    On the GPU forward + loss + backward (+ the packing of gradients and loss for the all-reduce) is captured ONCE
+    per batch shape into a hipGraph: delta is updated in place by L-BFGS and the images / target of a new batch
+    are copied into the same static buffers, so every closure evaluation of every batch replays the same graph;
+    the collective runs between replays, outside the graph (PCFA_HIP_GRAPH=0 disables capture)."""
+
+    def __init__(self, model, delta_like1, delta_like2, device, optim_mu, args, use_graph=None):
+        self.model, self.args, self.device, self.optim_mu = model, args, device, optim_mu
+        self.world = sharding.world_size()
+        if self.world > 1 and args.loss == "cosim":
+            raise NotImplementedError("cosim is a ratio of batch sums and does not decompose over ranks")
+        self.unit_input = ownutilities.model_takes_unit_input(args.net)
+        self.nw_delta1 = torch.zeros_like(delta_like1).to(device)
+        self.nw_delta2 = torch.zeros_like(delta_like2).to(device)
+        self.nw_delta1.requires_grad = True
+        if args.joint_perturbation:
+            self.params = [self.nw_delta1]
+        else:
+            self.nw_delta2.requires_grad = True
+            self.params = [self.nw_delta1, self.nw_delta2]
+        self.optimizer = ops.get().LBFGS(self.params, max_iter=10)
+        self.reducer = sharding.FlatReducer(self.params) if self.world > 1 else None
+        self.use_graph = _graphs_enabled(device, args) if use_graph is None else use_graph
+        self.states = {}   # batch shape -> _UniversalBatchState
+        self.st = None
+        self.flow_pred_init = None
+        self.closures = 0
+
+    def deltas(self):
+        if self.args.joint_perturbation:
+            return self.nw_delta1, self.nw_delta1
+        return self.nw_delta1, self.nw_delta2
+
+    def predict(self, perturbed=True):
+        st, kw = self.st, {}
+        if perturbed:
+            kw = {"delta1": self.nw_delta1} if self.args.joint_perturbation else {"delta1": self.nw_delta1,
+                                                                                   "delta2": self.nw_delta2}
+        out = ownutilities.compute_flow(self.model, "scaled_input_model", st.image1, st.image2, test_mode=True, **kw)
+        [out] = ownutilities.postprocess_flow(self.args.net, st.padder, out)
+        return out
+
+    def closure_body(self):
+        d1, d2 = self.deltas()
+        loss_closure = losses.loss_delta_constraint(self.predict(), self.st.target, d1, d2, self.device,
+                                                    delta_bound=self.args.delta_bound, mu=self.optim_mu,
+                                                    f_type=self.args.loss)
+        loss_closure.backward()
+        if self.reducer is not None:
+            self.reducer.pack(loss_closure)
+        return loss_closure
+
+    def closure(self):
+        self.closures += 1
+        if self.st.graphed is not None:
+            loss_closure = self.st.graphed()
+        else:
+            self.optimizer.zero_grad()
+            loss_closure = self.closure_body()
+        return self.reducer.reduce() if self.reducer is not None else loss_closure
+
+    def begin_batch(self, image1, image2):
+        """Upload a batch (this rank's slice), predict the unattacked flow, set the target (attack_PCFA.py:404-452).
+        Returns AEE(target, unattacked flow) averaged over ranks."""
+        device = self.device
+        image1, image2 = image1.to(device), image2.to(device)
+        if not self.unit_input:
+            image1 = image1 / 255.
+            image2 = image2 / 255.
+        padder, [image1, image2] = ownutilities.preprocess_img(self.args.net, image1, image2)
+        st = self.states.get(tuple(image1.shape))
+        if st is None:
+            st = self.states[tuple(image1.shape)] = _UniversalBatchState(image1, image2, padder)
+        else:
+            st.image1.copy_(image1)
+            st.image2.copy_(image2)
+        self.st = st
+        with torch.no_grad():
+            self.flow_pred_init = self.predict(perturbed=False).detach().clone()
+        target = targets.get_target(self.args.target, self.flow_pred_init,
+                                    custom_target_path=self.args.custom_target_path, device=device).to(device)
+        if st.target is None:
+            st.target = target.clone()
+        else:
+            st.target.copy_(target)
+        self.model.zero_grad()
+        self.optimizer.zero_grad()
+        if self.use_graph and not st.tried_graph:
+            st.tried_graph = True
+            try:
+                from .graphed import GraphedClosure, GraphedForward
+                st.graphed = GraphedClosure(self.closure_body, self.params)
+                st.repredict = GraphedForward(self.predict, device)
+            except Exception as e:  # noqa: BLE001 -- the eager closure computes the same thing
+                import logging as pylog
+                pylog.warning("hipGraph capture of the universal closure failed (%r): launching eagerly", e)
+                st.graphed = st.repredict = None
+        return sharding.mean_scalar(logging.calc_metrics_const(st.target, self.flow_pred_init), device)
+
+    def step(self):
+        """One `--steps` iteration on the current batch (attack_PCFA.py:455-517): L-BFGS step (10 closures, each
+        followed by the all-reduce), re-prediction, metrics (averaged over ranks)."""
+        st = self.st
+        self.optimizer.step(self.closure)
+        if st.repredict is not None:
+            flow_pred = st.repredict()
+        else:
+            with torch.no_grad():
+                flow_pred = self.predict()
+        d1, d2 = self.deltas()
+        aee_adv_tgt, aee_adv_pred = logging.calc_metrics_adv(flow_pred, st.target, self.flow_pred_init)
+        if self.world > 1:
+            aee_adv_tgt, aee_adv_pred = sharding.mean_scalars((aee_adv_tgt, aee_adv_pred), self.device)
+        l2_delta1, l2_delta2, l2_delta12 = logging.calc_delta_metrics(d1.detach(), d2.detach())
+        return {"aee_predadv-tgt": aee_adv_tgt, "aee_pred-predadv": aee_adv_pred, "l2_delta1": l2_delta1,
+                "l2_delta2": l2_delta2, "l2_delta-avg": l2_delta12}
+
+    @property
+    def graphed(self):
+        return any(s_.graphed is not None for s_ in self.states.values())
+
+
+def attack_l2_universal(args, data_loader=None, has_gt=None):
+    """One perturbation for a whole dataset (attack_PCFA.py:297-566), data parallel over the batch: see
+    `UniversalAttack`.  Returns the final perturbations, the per-step metric history and how many collectives ran."""
     optim_mu = default_mu(args)
     rank, world = sharding.rank(), sharding.world_size()
     if world > 1 and args.loss == "cosim":
@@ -310,88 +511,38 @@ def attack_l2_universal(args, data_loader=None, has_gt=None):
         data_loader, has_gt = datasets.prepare_dataloader(args, batch_size=args.batch_size // world, shuffle=True,
                                                           shard=(rank, world))
     model = _load_model(args, device, variable_change=False)  # universal = clipping only (attack_PCFA.py:365)
-    model_takes_unit_input = ownutilities.model_takes_unit_input(args.net)
 
     image1_init, image2_init, _, _ = next(iter(data_loader))
     _, [image1_init, image2_init] = ownutilities.preprocess_img(args.net, image1_init, image2_init)
-    nw_delta1 = torch.zeros_like(image1_init[0, :, :, :]).to(device)
-    nw_delta2 = torch.zeros_like(image2_init[0, :, :, :]).to(device)
-    nw_delta1.requires_grad = True
-    if args.joint_perturbation:
-        params = [nw_delta1]
-    else:
-        nw_delta2.requires_grad = True
-        params = [nw_delta1, nw_delta2]
-    optimizer = ops.get().LBFGS(params, max_iter=10)
-
-    def deltas():
-        return (nw_delta1, nw_delta1) if args.joint_perturbation else (nw_delta1, nw_delta2)
+    ua = UniversalAttack(model, image1_init[0, :, :, :], image2_init[0, :, :, :], device, optim_mu, args)
 
     history = []
+    batches = []
     batch_ctr = -1
     for epoch in range(args.epochs):
         for batch, (image1, image2, flow, _) in enumerate(data_loader):
             batch_ctr += 1
             curr_step = batch_ctr * args.steps
-            image1, image2 = image1.to(device), image2.to(device)
-            if has_gt:
-                flow = flow.to(device)
-            if not model_takes_unit_input:
-                image1 = image1 / 255.
-                image2 = image2 / 255.
-            padder, [image1, image2] = ownutilities.preprocess_img(args.net, image1, image2)
-
-            def predict(perturbed=True):
-                kw = {}
-                if perturbed:
-                    kw = {"delta1": nw_delta1} if args.joint_perturbation else {"delta1": nw_delta1,
-                                                                                  "delta2": nw_delta2}
-                out = ownutilities.compute_flow(model, "scaled_input_model", image1, image2, test_mode=True, **kw)
-                [out] = ownutilities.postprocess_flow(args.net, padder, out)
-                return out
-
-            with torch.no_grad():
-                flow_pred_init = predict(perturbed=False).detach().clone()
-            target = targets.get_target(args.target, flow_pred_init, custom_target_path=args.custom_target_path,
-                                        device=device).to(device)
-            aee_tgt = sharding.mean_scalar(logging.calc_metrics_const(target, flow_pred_init), device)
+            aee_tgt = ua.begin_batch(image1, image2)
             logging.log_metrics(curr_step, ("aee_pred-tgt", aee_tgt))
-            model.zero_grad()
-            optimizer.zero_grad()
-
-            def closure():
-                optimizer.zero_grad()
-                d1, d2 = deltas()
-                loss_closure = losses.loss_delta_constraint(predict(), target, d1, d2, device,
-                                                            delta_bound=args.delta_bound, mu=optim_mu,
-                                                            f_type=args.loss)
-                loss_closure.backward()
-                return sharding.allreduce_closure(params, loss_closure)
-
+            batches.append({"epoch": epoch, "batch": batch, "aee_pred-tgt": aee_tgt})
             for steps in range(args.steps):
                 curr_step = batch_ctr * args.steps + steps
                 logging.log_metrics(curr_step, ("steps", steps), ("batch", batch), ("epoch", epoch))
-                optimizer.step(closure)
-                with torch.no_grad():
-                    flow_pred = predict()
-                d1, d2 = deltas()
-                aee_adv_tgt, aee_adv_pred = logging.calc_metrics_adv(flow_pred, target, flow_pred_init)
-                aee_adv_tgt = sharding.mean_scalar(aee_adv_tgt, device)
-                aee_adv_pred = sharding.mean_scalar(aee_adv_pred, device)
-                l2_delta1, l2_delta2, l2_delta12 = logging.calc_delta_metrics(d1.detach(), d2.detach(), curr_step)
-                logging.log_metrics(curr_step, ("aee_predadv-tgt", aee_adv_tgt), ("aee_pred-predadv", aee_adv_pred),
-                                    ("l2_delta1", l2_delta1), ("l2_delta2", l2_delta2), ("l2_delta-avg", l2_delta12))
-                history.append({"epoch": epoch, "batch": batch, "step": steps, "aee_predadv-tgt": aee_adv_tgt,
-                                "aee_pred-predadv": aee_adv_pred, "l2_delta-avg": l2_delta12})
+                m = ua.step()
+                logging.log_metrics(curr_step, *m.items())
+                history.append(dict(m, epoch=epoch, batch=batch, step=steps))
             if distortion_folder is not None and _should_save(batch_ctr, args):
-                logging.save_tensor(nw_delta1, "delta1_b" + str(batch_ctr), batch_ctr, distortion_folder)
-                logging.save_tensor(deltas()[1], "delta2_b" + str(batch_ctr), batch_ctr, distortion_folder)
+                logging.save_tensor(ua.nw_delta1, "delta1_b" + str(batch_ctr), batch_ctr, distortion_folder)
+                logging.save_tensor(ua.deltas()[1], "delta2_b" + str(batch_ctr), batch_ctr, distortion_folder)
         if distortion_folder is not None:
             # `NNNNN_delta1_e{E}.npy`: the pattern evaluate_PCFA.py:42-43 looks for
-            logging.save_tensor(nw_delta1, "delta1_e" + str(epoch), batch_ctr, distortion_folder)
+            logging.save_tensor(ua.nw_delta1, "delta1_e" + str(epoch), batch_ctr, distortion_folder)
             if not args.joint_perturbation:
-                logging.save_tensor(nw_delta2, "delta2_e" + str(epoch), batch_ctr, distortion_folder)
-    return {"delta1": nw_delta1.detach(), "delta2": deltas()[1].detach(), "history": history}
+                logging.save_tensor(ua.nw_delta2, "delta2_e" + str(epoch), batch_ctr, distortion_folder)
+    return {"delta1": ua.nw_delta1.detach(), "delta2": ua.deltas()[1].detach(), "history": history,
+            "batches": batches, "collectives": ua.reducer.collectives if ua.reducer is not None else 0,
+            "graphed": ua.graphed}
 
 
 def main(argv=None):

@@ -3,9 +3,10 @@
 The PCFA path shards in two ways:
   * per-pair attacks: independent image pairs, round-robin over ranks, NO data-path collective;
     only the 13 result floats per pair are gathered on rank 0 at the end (`gather_rows`);
-  * universal attack: data parallel over the batch; per closure one all-reduce(AVG) of
-    d(loss)/d(delta) (<= 10.8 MB fp32) and of the scalar loss (`allreduce_closure`).  All ranks
-    receive identical reduced values, so their L-BFGS states stay bit-identical.
+  * universal attack: data parallel over the batch; per closure ONE all-reduce of a flat buffer
+    holding d(loss)/d(delta) of both perturbations and the scalar loss (<= 10.8 MB + 4 B fp32,
+    `FlatReducer` / `allreduce_closure`).  All ranks receive identical reduced values, so their
+    L-BFGS states stay bit-identical.
 Without an initialised process group every helper degrades to the single-process identity.
 """
 import os
@@ -52,18 +53,54 @@ def barrier():
         dist.barrier()
 
 
-def allreduce_closure(params, loss):
-    """Average the parameter gradients and the loss over ranks (in place); returns the averaged loss."""
+class FlatReducer:
+    """d(loss)/d(delta) of every parameter and the scalar loss in ONE buffer: one collective per closure.
+
+    `pack(loss)` copies the parameters' gradients and the loss into the buffer (plain device copies: it may run
+    inside a captured hipGraph, right behind the backward pass); `reduce()` issues the single all-reduce(SUM),
+    scales by 1/world and points every `p.grad` at its slice of the buffer, returning the averaged loss.
+    The buffer holds sum(numel) + 1 floats (10.8 MB + 4 B for two 3x440x1024 perturbations)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        self.n = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(self.n + 1, dtype=p0.dtype, device=p0.device)
+        self.collectives = 0
+
+    def pack(self, loss):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        self.flat[self.n:].copy_(loss.detach().reshape(1))
+
+    def reduce(self):
+        if is_dist():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.collectives += 1
+            self.flat.mul_(1.0 / world_size())
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+        return self.flat[self.n]
+
+
+def allreduce_closure(params, loss, reducer=None):
+    """Average the parameter gradients and the loss over ranks with ONE all-reduce; returns the averaged loss
+    (and leaves every p.grad pointing into the reducer's buffer)."""
     if not is_dist():
         return loss
-    n = world_size()
-    for p in params:
-        if p.grad is not None:
-            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
-            p.grad.div_(n)
-    red = loss.detach().clone()
-    dist.all_reduce(red, op=dist.ReduceOp.SUM)
-    return red / n
+    if reducer is None:
+        reducer = FlatReducer(params)
+    reducer.pack(loss)
+    return reducer.reduce()
 
 
 def mean_scalar(value, device):
@@ -73,6 +110,15 @@ def mean_scalar(value, device):
     t = torch.tensor([float(value)], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item() / world_size())
+
+
+def mean_scalars(values, device):
+    """Means of several python floats over ranks with one collective."""
+    if not is_dist():
+        return tuple(values)
+    t = torch.tensor([float(v) for v in values], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return tuple((t / world_size()).tolist())
 
 
 def max_scalar(value, device):

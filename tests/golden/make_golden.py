@@ -20,6 +20,8 @@ Fixtures:
   attack_math.npz         losses / extract_deltas / ScaledInputModel prologue
   closure_<net>.npz       one PCFA closure: flow, loss, d loss / d nw_input  (128x160 or 128x192)
   trajectory_raft.npz     5-step pcfa_attack, at 8 and at 3 CPU threads (noise floor)
+  universal_raft.npz      attack_l2_universal (attack_PCFA.py:297-566): RAFT 128x160, 2 batches of 2 pairs, 2 steps each,
+                          deltas after each batch / the epoch + the metric stream, at 8 and at 3 CPU threads
   closure_flownet2.npz    one PCFA closure of FlowNet2 (128x192).  WIRING ONLY: the reference's Python model code
                           (models/FlowNet/FlowNet2.py, FlowNetC/S/SD/Fusion.py, submodules.py and the three
                           autograd Functions correlation.py / resample2d.py / channelnorm.py) runs for real, but its
@@ -41,6 +43,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 REF = "/root/reference"
 OUT = os.path.join(REPO, "tests", "golden")
 WEIGHT_SEED = 1234
+METRIC_LOG = None  # list of (key, value, step) while a golden run wants the reference's mlflow metrics recorded
 
 
 # ----------------------------------------------------------------------------- environment
@@ -58,8 +61,15 @@ def install_stubs():
     noop = lambda *a, **k: None
     cv2 = stub("cv2", setNumThreads=noop)
     cv2.ocl = types.SimpleNamespace(setUseOpenCL=noop)
-    ml = stub("mlflow", log_metric=noop, log_param=noop, log_artifact=noop, log_artifacts=noop, set_experiment=noop,
-              start_run=noop, set_tracking_uri=noop)
+
+    def log_metric(key=None, value=None, step=None, **kw):  # the reference binds this name at import time
+        if METRIC_LOG is not None:
+            METRIC_LOG.append((key, float(value), step))
+
+    import contextlib
+    ml = stub("mlflow", log_metric=log_metric, log_param=noop, log_artifact=noop, log_artifacts=noop,
+              set_experiment=noop, start_run=lambda *a, **k: contextlib.nullcontext(), set_tracking_uri=noop,
+              create_experiment=noop, get_experiment_by_name=lambda name: types.SimpleNamespace(experiment_id=0))
     ml.exceptions = stub("mlflow.exceptions", MlflowException=Exception)
     tv = stub("torchvision")
     tv.datasets = stub("torchvision.datasets")
@@ -376,10 +386,62 @@ def golden_trajectory():
     save("trajectory_raft", image1=im1.to(torch.uint8), image2=im2.to(torch.uint8), **res)
 
 
+def golden_universal():
+    """The reference's own attack_l2_universal (attack_PCFA.py:297-566) on a fixed synthetic loader: RAFT 128x160,
+    clipping (universal mode allows nothing else, :365), zero target, AEE, 4 pairs in 2 batches of 2, one epoch,
+    2 L-BFGS steps per batch (44 closure evaluations, one optimiser for the whole run).  The loader is a list, so
+    the reference's unseeded shuffle (:347) has nothing to permute.  Recorded: the .npy artefacts the reference
+    writes (per-batch and per-epoch deltas) and the metric stream it sends to mlflow, at 8 and at 3 CPU threads
+    (the reference's own noise floor for this schedule)."""
+    global METRIC_LOG
+    import glob
+    import shutil
+    import tempfile
+    import attack_PCFA
+    from argparse import Namespace
+    from helper_functions import logging as rlog, ownutilities
+    H, W, NB, BS, STEPS = 128, 160, 2, 2, 2
+    pairs = [test_images(20 + i, H, W) for i in range(NB * BS)]
+    im1 = torch.cat([p[0] for p in pairs])
+    im2 = torch.cat([p[1] for p in pairs])
+    loader = [(im1[b * BS:(b + 1) * BS].clone(), im2[b * BS:(b + 1) * BS].clone(),
+               torch.zeros(BS, 2, H, W), torch.ones(BS, H, W)) for b in range(NB)]
+    ownutilities.prepare_dataloader = lambda *a, **k: (loader, False)
+    rlog.save_image = lambda *a, **k: None      # PNG dumps (flow_library / pypng): outside the path
+    rlog.save_flow = lambda *a, **k: None
+    res = {}
+    for threads in (8, 3):
+        torch.set_num_threads(threads)
+        out = tempfile.mkdtemp(prefix="pcfa_universal_golden_")
+        args = Namespace(net="RAFT", steps=STEPS, joint_perturbation=False, universal_perturbation=True,
+                         boxconstraint="clipping", delta_bound=0.005, mu=-1., target="zero", custom_target_path="",
+                         loss="aee", save_frequency=1, small_save=False, no_save=False, unregistered_artifacts=True,
+                         output_folder=out, dataset="Sintel", dataset_stage="training", dstype="final",
+                         batch_size=BS, epochs=1, small_run=False)
+        METRIC_LOG = []
+        with patched_torch_load("RAFT"):
+            attack_PCFA.attack_l2_universal(args)
+        log, METRIC_LOG = METRIC_LOG, None
+        torch.autograd.set_detect_anomaly(False)
+        tag = "_t%d" % threads
+        for name in ("delta1_b0", "delta2_b0", "delta1_b1", "delta2_b1", "delta1_e0", "delta2_e0"):
+            [f] = glob.glob(os.path.join(out, "**", "*_%s.npy" % name), recursive=True)
+            res[name + tag] = np.load(f)
+        for i in "12":  # the epoch artefact is the perturbation after the last batch: stored once
+            assert np.array_equal(res.pop("delta%s_e0" % i + tag), res["delta%s_b1" % i + tag])
+        for key in ("aee_pred-tgt", "aee_predadv-tgt", "aee_pred-predadv", "l2_delta1", "l2_delta2", "l2_delta-avg"):
+            res[key + tag] = np.array([v for k, v, _ in log if k == key], dtype=np.float64)
+        print("threads", threads, {k: res[k + tag] for k in ("aee_predadv-tgt", "aee_pred-predadv", "l2_delta-avg")})
+        shutil.rmtree(out)
+    torch.set_num_threads(8)
+    save("universal_raft", image1=im1.to(torch.uint8), image2=im2.to(torch.uint8),
+         meta=np.array([H, W, NB, BS, STEPS]), **res)
+
+
 if __name__ == "__main__":
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["corr", "scorr", "math", "closures", "trajectory", "flownet2"]
+    which = sys.argv[1:] or ["corr", "scorr", "math", "closures", "trajectory", "flownet2", "universal"]
     if "corr" in which:
         golden_corr_block()
     if "scorr" in which:
@@ -392,3 +454,5 @@ if __name__ == "__main__":
         golden_trajectory()
     if "flownet2" in which:
         golden_flownet2()
+    if "universal" in which:
+        golden_universal()

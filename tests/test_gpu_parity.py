@@ -714,6 +714,34 @@ def test_closure_on_gpu_vs_reference_golden(name):
         assert rel_l2(gr, t(g["grad%d" % i])) < 1e-2
 
 
+BASELINE_CASES = {
+    # BASELINE.json configs 2, 3, 4 at their full sizes (the reference cannot travel: the checker is the CPU port,
+    # i.e. pcfa_amd's host code on the oracle operators, itself pinned to the reference at 128x160 above)
+    "raft_436x1024": ("RAFT", 436, 1024, "change_of_variables", False, "zero", "aee", 11),
+    "gma_436x1024": ("GMA", 436, 1024, "change_of_variables", False, "neg_flow", "aee", 12),
+    "pwcnet_375x1242": ("PWCNet", 375, 1242, "clipping", True, "zero", "aee", 13),
+}
+
+
+@pytest.mark.parametrize("name", list(BASELINE_CASES))
+def test_closure_at_baseline_size_vs_cpu_port(oracle_ops, name):
+    """One closure at the BASELINE size on the MI355X vs the CPU port on the same seeded inputs: flow AEE <= 1e-3
+    (north_star's tolerance), loss 1e-4 relative, gradient 1e-2 relative L2 (MIOpen / MFMA vs MKL-DNN convolutions).
+    Reference: attack_PCFA.py:175-192."""
+    net, h, w, box, joint, tgt, loss, seed = BASELINE_CASES[name]
+    torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+    gpu = closure_util.run_closure(net, h, w, box, joint, tgt, loss, seed, torch.device(DEV))
+    with ops.override_for_testing(oracle_ops):
+        cpu = closure_util.run_closure(net, h, w, box, joint, tgt, loss, seed, torch.device("cpu"))
+    closure_util._MODELS.clear()     # 5 M .. 10 M parameters per model and device: do not keep them for later tests
+    for k in ("flow_init", "flow"):
+        d = gpu[k].cpu() - cpu[k]
+        assert float(d.pow(2).sum(1).sqrt().mean()) <= 1e-3, (k, float(d.pow(2).sum(1).sqrt().mean()))
+    assert abs(gpu["loss"] - cpu["loss"]) <= 1e-4 * abs(cpu["loss"]), (gpu["loss"], cpu["loss"])
+    for a, b in zip(gpu["grads"], cpu["grads"]):
+        assert rel_l2(a, b) < 1e-2, rel_l2(a, b)
+
+
 def test_pcfa_attack_on_gpu_vs_reference_trajectory():
     from argparse import Namespace
     from pcfa_amd import attack_PCFA
@@ -788,6 +816,59 @@ def test_universal_attack_runs_on_gpu():
     d = res["delta1"]
     assert d.is_cuda and d.shape == (3, 64, 128) and float(d.abs().max()) > 0
     assert len(res["history"]) == 1 and np.isfinite(res["history"][0]["aee_predadv-tgt"])
+
+
+@pytest.mark.parametrize("graph", ["graph", "eager"])
+def test_universal_attack_on_gpu_vs_reference_golden(graph, monkeypatch):
+    """BASELINE config 5 (RAFT, --universal_perturbation) on the MI355X against the REFERENCE's own
+    attack_l2_universal run (attack_PCFA.py:297-566; tests/golden/make_golden.py::golden_universal): per-step metrics
+    and the final perturbation pair, tolerance = 3x the reference's own 8-vs-3-thread spread.  Run with
+    the closure replayed from its hipGraph (captured once, reused for both batches) and launched eagerly."""
+    from pcfa_amd import attack_PCFA
+    monkeypatch.setenv("PCFA_HIP_GRAPH", "1" if graph == "graph" else "0")
+    g = load_golden("universal_raft")
+    args, loader = closure_util.universal_case(g)
+    res = attack_PCFA.attack_l2_universal(args, data_loader=loader, has_gt=False)
+    assert res["graphed"] == (graph == "graph")
+    closure_util.check_universal_against_golden(res, g, rel_l2)
+
+
+def test_universal_closure_on_gpu_vs_oracle(oracle_ops):
+    """ONE universal closure (batch of 2 pairs, a shared non-zero delta pair, RAFT 128x160) on the GPU against the
+    oracle on CPU: loss 1e-5, d loss / d delta 1e-4 relative L2... measured against the CPU port's own conv noise,
+    see the assert messages.  Also checks the graph replay against the eager launch and the packed buffer of the
+    single all-reduce."""
+    from pcfa_amd import attack_PCFA, sharding
+    g = load_golden("universal_raft")
+    args, loader = closure_util.universal_case(g)
+    gen = torch.Generator().manual_seed(3)
+    d1 = 0.01 * torch.randn(3, 128, 160, generator=gen)
+    d2 = 0.01 * torch.randn(3, 128, 160, generator=gen)
+
+    def run(dev, use_graph):
+        model = closure_util.load_model("RAFT", False, dev)
+        ua = attack_PCFA.UniversalAttack(model, d1, d2, dev, 5e5, args, use_graph=use_graph)
+        with torch.no_grad():
+            ua.nw_delta1.copy_(d1)
+            ua.nw_delta2.copy_(d2)
+        ua.begin_batch(loader[0][0], loader[0][1])
+        loss = float(ua.closure())
+        return ua, loss, [p.grad.detach().clone().cpu() for p in ua.params]
+
+    with ops.override_for_testing(oracle_ops):
+        _, lc, gc = run(torch.device("cpu"), False)
+    ua, le, ge = run(torch.device(DEV), False)
+    _, lg, gg = run(torch.device(DEV), True)
+    assert abs(le - lc) <= 1e-5 * abs(lc), (le, lc)
+    assert abs(lg - le) <= 1e-6 * abs(le)
+    for a, b, c in zip(ge, gg, gc):
+        assert rel_l2(a, c) < 1e-3, rel_l2(a, c)      # MIOpen vs MKL-DNN convolutions (single-pair closures: 1e-2)
+        assert rel_l2(b, a) < 1e-5
+    # the buffer of the single collective: [grad delta1 | grad delta2 | loss]
+    red = sharding.FlatReducer(ua.params)
+    red.pack(torch.tensor(le, device=DEV))
+    assert red.flat.numel() == 2 * 3 * 128 * 160 + 1 and float(red.flat[-1]) == pytest.approx(le)
+    assert torch.equal(red.flat[:3 * 128 * 160].cpu(), ge[0].flatten())
 
 
 @pytest.mark.parametrize("net,size", [("RAFT", (128, 160)), ("FlowNet2", (64, 128))])

@@ -87,6 +87,16 @@ def test_pcfa_attack_trajectory_within_reference_noise():
         assert abs(res[idx] - ref8[idx]) <= tol, (idx, res[idx], ref8[idx], ref3[idx])
 
 
+def test_universal_attack_within_reference_noise():
+    """attack_l2_universal (2 batches x 2 pairs x 2 steps = 44 closures, ONE optimiser across batches) vs the
+    reference's own attack_l2_universal run (attack_PCFA.py:297-566); tolerance by the D10 noise rule."""
+    g = load_golden("universal_raft")
+    args, loader = closure_util.universal_case(g)
+    res = attack_PCFA.attack_l2_universal(args, data_loader=loader, has_gt=False)
+    assert res["collectives"] == 0 and not res["graphed"]      # single process on CPU: eager, no collective
+    closure_util.check_universal_against_golden(res, g, rel_l2)
+
+
 def test_best_iterate_rule_and_schedule():
     """10 closure evaluations + 1 re-prediction per step and the reference's selection rule."""
     calls = {"n": 0}
