@@ -249,12 +249,10 @@ def pwc_kernel_table(timings, hp, wp):
     if "spatial_corr_fwd" in timings:
         us, n = timings["spatial_corr_fwd"]
         rows.append(_row("spatial_corr_fwd (5 levels)", "hbm", fwd, us * 5, n // 5, "per closure: 5 launches summed"))
-    tb = [timings[k] for k in ("spatial_corr_bwd_in1", "spatial_corr_bwd_in2") if k in timings]
-    if tb:
-        tot = sum(us * n for us, n in tb)
-        closures = max(tb[0][1] // 5, 1)
-        rows.append(_row("spatial_corr_bwd (5 levels, both gradients)", "hbm", bwd, tot / closures, closures,
-                         "per closure: all backward launches summed"))
+    if "spatial_corr_bwd" in timings:
+        us, n = timings["spatial_corr_bwd"]
+        rows.append(_row("spatial_corr_bwd (5 levels, both gradients per launch)", "hbm", bwd, us * 5, n // 5,
+                         "per closure: 5 launches summed"))
     if "pwc_warp_fwd" in timings:
         us, n = timings["pwc_warp_fwd"]
         w = sum((2 * PWC_LEVEL_CHANNELS[l] + 2) * (hp >> l) * (wp >> l) * 4 for l in (2, 3, 4, 5))
@@ -270,9 +268,8 @@ TRACED = {  # kernel-name fragment -> label
     "gemm_f32_mfma_kernel<false, true,": "corr_pyramid_gemm_df2ext",
     "box_fwd_kernel": "box_transform_fwd", "box_bwd_kernel": "box_transform_bwd",
     "gru_gates_fwd_kernel": "gru_gates_fwd", "gru_update_fwd_kernel": "gru_update_fwd",
-    "scorr_fwd": "spatial_corr_fwd", "scorr_bwd_fast_kernel<9, 1>": "spatial_corr_bwd_in1",
-    "scorr_bwd_fast_kernel<9, -1>": "spatial_corr_bwd_in2", "scorr_bwd": "spatial_corr_bwd_in1",
-    "pwc_warp_fwd_kernel": "pwc_warp_fwd",
+    "scorr9_fwd_kernel": "spatial_corr_fwd", "scorr9_bwd_kernel": "spatial_corr_bwd",
+    "pwc_warp_fwd_kernel": "pwc_warp_fwd", "pwc_warp_bwd_kernel": "pwc_warp_bwd",
 }
 
 

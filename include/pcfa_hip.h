@@ -143,6 +143,19 @@ PCFA_API int pcfa_spatial_corr_bwd(const float* in1, const float* in2, const flo
                           int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
                           int dil_patchH, int dil_patchW, int dH, int dW, void* stream);
 
+/* PWC-Net's use of the sampler with its two elementwise followers fused in:
+ *   out = leaky_relu(correlate(in1, in2), slope),  correlate = 9x9 cost volume * scale (scale = 1/C)
+ * (models/PWCNet/PWCNet.py:45-58 `correlate`, then self.leakyRELU at :249,264,278,292,308).  k = 1, patch 9,
+ * stride 1, pad 0; out / grad_out: [B][81][iH][iW].  pcfa_cost_volume9_bwd reads the forward's output for the
+ * LeakyReLU mask and applies mask * scale to the gradient taps while staging them: ONE launch for both gradients.
+ * Needs iW % 4 == 0 and 16-B aligned pointers (PCFA_ERR_UNSUPPORTED otherwise: the caller composes
+ * pcfa_spatial_corr_* with elementwise kernels instead). */
+PCFA_API int pcfa_cost_volume9_fwd(const float* in1, const float* in2, float* out, int B, int C, int iH, int iW,
+                          float scale, float slope, void* stream);
+PCFA_API int pcfa_cost_volume9_bwd(const float* in1, const float* in2, const float* fwd_out, const float* grad_out,
+                          float* grad_in1, float* grad_in2, int B, int C, int iH, int iW, float scale,
+                          float slope, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * FlowNet2's native operators (CUDA-only extensions in the
  * reference, no CPU build exists there).

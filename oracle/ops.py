@@ -186,6 +186,13 @@ def spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=1, stri
     return _SpatialCorr.apply(input1, input2, kernel_size, patch_size, stride, padding, dilation, dilation_patch)
 
 
+def pwc_cost_volume(input1, input2, slope=0.1):
+    """leakyRELU(correlate(input1, input2)): models/PWCNet/PWCNet.py:45-58 followed by :249,264,278,292,308."""
+    out = spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=9, stride=1)
+    b, ph, pw, h, w = out.size()
+    return F.leaky_relu(out.view(b, ph * pw, h, w) / input1.size(1), slope)
+
+
 def spatial_correlation_shift_sum(input1, input2, patch_size=9):
     """Independent formulation of the k=1 / stride-1 cost volume (shift, multiply, sum over C)."""
     B, C, H, W = input1.shape

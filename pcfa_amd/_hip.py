@@ -40,6 +40,8 @@ SIGNATURES = {
     "pcfa_spatial_corr_out_size": (c_int, [c_int] * 10 + [POINTER(c_int), POINTER(c_int)]),
     "pcfa_spatial_corr_fwd": (c_int, [_P, _P, _P] + [c_int] * 16 + [_P]),
     "pcfa_spatial_corr_bwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 16 + [_P]),
+    "pcfa_cost_volume9_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    "pcfa_cost_volume9_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "pcfa_flownet_corr_out_size": (c_int, [c_int] * 7 + [POINTER(c_int)] * 3),
     "pcfa_flownet_corr_fwd": (c_int, [_P, _P, _P] + [c_int] * 9 + [_P]),
     "pcfa_flownet_corr_bwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),

@@ -9,75 +9,62 @@
 //   u = h*dH - padH, v = w*dW - padW, sU = (ph - (patchH-1)/2)*dil_patchH (same for V),
 //   terms with either operand outside the image dropped.
 //
-// Fast path (what PWC-Net uses: k=1, stride 1, pad 0, patch PxP, dil_patch 1):
-//   forward : workgroup = 8x32 output pixels, wave z = patch row; a thread owns
-//             4 consecutive pixels x P shifts in registers and streams channel
-//             chunks of both feature maps through LDS (in2 tile carries the halo;
-//             16-B pieces, next chunk prefetched into registers, two LDS stages),
-//             so every input byte is read from HBM once per tile and written
-//             outputs are 16-B vectors.
-//   backward: both gradients are gathers with the same shape,
-//               gin1[c][p] = sum_d g[d][p]   * in2[c][p+d]
-//               gin2[c][p] = sum_d g[d][p-d] * in1[c][p-d]
-//             a thread keeps its P*P gradient taps in registers and walks the
-//             channels through LDS -- no atomics, bitwise reproducible (the CPU
-//             reference accumulates serially, correlation.cpp:148).
+// Fast path (what PWC-Net uses: k=1, stride 1, pad 0, patch 9x9, dil_patch 1, W % 4 == 0):
+//   The five cost volumes of a PWC-Net forward are 0.28 GFLOP on 27 MB -- each launch is a latency chain, not a
+//   stream, and the coarse levels (6x20 ... 24x80 pixels, 96-196 channels) have almost no pixels to spread over
+//   256 CUs.  Both directions are therefore built for parallelism inside the workgroup and ONE round trip to
+//   memory: every load of a workgroup is issued before its first LDS write ("single shot": all channels of the
+//   tile, or as many as fit 144 KB), one barrier, compute from LDS, store.
+//   forward : workgroup = TH x TW output pixels (4x32, 2x32 or 2x16: the smallest levels take the smallest tile)
+//             x NS channel slices.  A thread owns 4 consecutive pixels x 9 horizontal shifts of one patch row
+//             and walks the channels of its slice (1 + 3 aligned ds_read_b128 per 36 FMAs); the NS partial sums
+//             meet in LDS and are added in slice order, so the result does not depend on timing.  An optional
+//             epilogue (scale, LeakyReLU) serves PWC-Net's `leaky_relu(corr / C)` in the same pass.
+//   backward: ONE launch for both gradients (blockIdx.z selects which).  With e = d + 4 in [0,9)^2 both are the
+//             same gather   gin[c][p] = sum_e G[e][p] * X[c][p + e - 4]   with
+//               gin1: X = in2, G[e][p] = g[e][p]
+//               gin2: X = in1, G[e][p] = g[8 - e][p + e - 4]   (the same taps, seen from the other image)
+//             so only the staging of G differs.  Workgroup = 2x32 pixels x 32 channels: the 81 x 64 gradient taps
+//             and the 10x40 halo of 32 channels go to LDS once; a thread owns 4 pixels x 2 channels, reads one
+//             row of taps (9 x b128) per patch row and three aligned b128 of X per channel.  No atomics: bitwise
+//             reproducible (the CPU reference accumulates serially, correlation.cpp:148).  LeakyReLU's mask and the
+//             1/C of PWC-Net's correlate() can be applied to the taps while they are staged.
 // Every other parameter set takes the generic one-thread-per-element kernels.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
 
-constexpr int TH = 8, TW = 32;  // output-pixel tile of the fast path
-constexpr int CC = 8;           // channels per LDS chunk (backward)
-constexpr int FC = 16;          // channels per LDS chunk (forward: half as many latency-bound round trips)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SC_LDS_BUDGET = 144 * 1024;  // bytes of dynamic LDS a forward workgroup may stage into
 
-// Preconditions (checked by the host): W % 4 == 0 and 16-B aligned in1 / in2, so the tiles are staged in 16-B
-// pieces that lie either inside or outside the image.  Two LDS stages: the next channel chunk is fetched into
-// registers before the FMAs of the current one and written to the other stage after them (one barrier per chunk;
-// the coarse pyramid levels are a single workgroup walking up to 25 chunks, i.e. a pure latency chain).
-// THT = tile rows: 8 for the fine levels; 2 for the coarse ones, where 8-row tiles leave 1-30 workgroups walking a
-// serial channel loop on as many CUs (LDS-read bound): four times as many, four times lighter workgroups.
-template <int PS, int THT>
-__global__ __launch_bounds__(8 * THT * PS) void scorr_fwd_fast_kernel(
-    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C,
-    int H, int W) {
-  constexpr int R = (PS - 1) / 2;
-  constexpr int HW2 = TW + 2 * R;  // in2 tile width  (40 for PS=9)
-  constexpr int HH2 = THT + 2 * R;  // in2 tile height (16)
-  static_assert(R % 4 == 0 && HW2 % 4 == 0, "halo must keep the 16-B pieces aligned");
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) float s1[2][FC][THT][TW];
-  __shared__ __attribute__((aligned(16))) float s2[2][FC][HH2][HW2];
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+template <int TH, int TW>
+__global__ __launch_bounds__(576) void scorr9_fwd_kernel(const float* __restrict__ in1,
+                                                         const float* __restrict__ in2,
+                                                         float* __restrict__ out, int C, int H, int W, int NS,
+                                                         int CR, float scale, float slope, int dbg) {
+  constexpr int PS = 9, R = 4;
+  constexpr int QW = TW / 4;                 // pixel quads per tile row
+  constexpr int HW2 = TW + 2 * R, HH2 = TH + 2 * R;
+  constexpr int P1 = TH * QW;                // 16-B pieces of the in1 tile (per channel)
+  constexpr int P2 = HH2 * (HW2 / 4);        // ... of the in2 tile with its halo
+  constexpr int PPC = P1 + P2;               // pieces per channel
+  constexpr int PCF = 4 * PPC;               // floats per channel in LDS: [in1 tile | in2 halo tile]
+  constexpr int TPS = QW * TH * PS;          // threads per channel slice
+  extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int b = blockIdx.z;
-  const int y0 = blockIdx.y * THT, x0 = blockIdx.x * TW;
-  const int tx = threadIdx.x, ty = threadIdx.y, tz = threadIdx.z;  // quad, row, patch row
-  const int tid = tx + 8 * ty + 8 * THT * tz;
-  constexpr int NT = 8 * THT * PS;
+  const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const int tid = threadIdx.x, NT = blockDim.x;
   const size_t plane = (size_t)H * W;
   const float* p1 = in1 + (size_t)b * C * plane;
   const float* p2 = in2 + (size_t)b * C * plane;
 
-  // staging plan (fixed per thread): pieces of the in1 tile and of the in2 tile with its halo
-  constexpr int N1 = FC * THT * (TW / 4), N2 = FC * HH2 * (HW2 / 4);
-  constexpr int S1 = (N1 + NT - 1) / NT, S2 = (N2 + NT - 1) / NT;
-  int o1[S1], d1[S1], o2[S2], d2[S2];  // global offset inside the chunk (-1: outside), LDS float index (-1: none)
-#pragma unroll
-  for (int k = 0; k < S1; ++k) {
-    const int e = tid + k * NT;
-    const int c = e / (THT * (TW / 4)), r = (e / (TW / 4)) % THT, m = e % (TW / 4);
-    const int gy = y0 + r, gx = x0 + 4 * m;
-    o1[k] = (e < N1 && gy < H && gx < W) ? (int)(c * plane) + gy * W + gx : -1;
-    d1[k] = e < N1 ? (c * THT + r) * TW + 4 * m : -1;
-  }
-#pragma unroll
-  for (int k = 0; k < S2; ++k) {
-    const int e = tid + k * NT;
-    const int c = e / (HH2 * (HW2 / 4)), r = (e / (HW2 / 4)) % HH2, m = e % (HW2 / 4);
-    const int gy = y0 + r - R, gx = x0 + 4 * m - R;
-    o2[k] = (e < N2 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (int)(c * plane) + gy * W + gx : -1;
-    d2[k] = e < N2 ? (c * HH2 + r) * HW2 + 4 * m : -1;
-  }
+  const int sl = tid / TPS, t = tid - sl * TPS;
+  const int q = t % QW, r = (t / QW) % TH, ph = t / (QW * TH);
 
   float acc[4][PS];
 #pragma unroll
@@ -85,157 +72,355 @@ __global__ __launch_bounds__(8 * THT * PS) void scorr_fwd_fast_kernel(
 #pragma unroll
     for (int d = 0; d < PS; ++d) acc[p][d] = 0.f;
 
-  f32x4 r1[S1], r2[S2];
-  auto fetch = [&](int c0) {  // branch-free: a dead piece reads offset 0 of the chunk and is zeroed
-    const int climit = (int)((size_t)(C - c0) * plane);
-    const float* b1 = p1 + (size_t)c0 * plane;
-    const float* b2 = p2 + (size_t)c0 * plane;
-#pragma unroll
-    for (int k = 0; k < S1; ++k) {
-      const bool ok = o1[k] >= 0 && o1[k] < climit;
-      const f32x4 t = *reinterpret_cast<const f32x4*>(b1 + (ok ? o1[k] : 0));
-      r1[k] = ok ? t : (f32x4)(0.f);
+  // Staging plan, fixed per thread: thread = (channel lane cl, piece pp of the per-channel pattern), so a piece's
+  // row / column / validity are decoded ONCE and walking the channels is a pointer increment (the first version
+  // decoded every piece from a flat index: ~50 integer instructions per 16-B piece, and the kernel was bound by
+  // that arithmetic, not by memory -- 7-19 us with loads, FMAs and stores all switched off).
+  const int lanes = NT / PPC;                // channels staged per pass (NT >= PPC for every tile shape)
+  const int cl = tid / PPC, pp = tid - cl * PPC;
+  bool pvalid;
+  const float* pbase;
+  {
+    int gy, gx;
+    if (pp < P1) {
+      gy = y0 + pp / QW; gx = x0 + 4 * (pp % QW); pbase = p1;
+    } else {
+      const int m = pp - P1;
+      gy = y0 + m / (HW2 / 4) - R; gx = x0 + 4 * (m % (HW2 / 4)) - R; pbase = p2;
     }
-#pragma unroll
-    for (int k = 0; k < S2; ++k) {
-      const bool ok = o2[k] >= 0 && o2[k] < climit;
-      const f32x4 t = *reinterpret_cast<const f32x4*>(b2 + (ok ? o2[k] : 0));
-      r2[k] = ok ? t : (f32x4)(0.f);
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int k = 0; k < S1; ++k)
-      if (d1[k] >= 0) *reinterpret_cast<f32x4*>(&s1[buf][0][0][0] + d1[k]) = r1[k];
-#pragma unroll
-    for (int k = 0; k < S2; ++k)
-      if (d2[k] >= 0) *reinterpret_cast<f32x4*>(&s2[buf][0][0][0] + d2[k]) = r2[k];
-  };
+    pvalid = cl < lanes && gy >= 0 && gy < H && gx >= 0 && gx < W && !(dbg & 1);
+    if (pvalid) pbase += (size_t)gy * W + gx;
+  }
+  const size_t lstep = (size_t)lanes * plane;
 
-  fetch(0);
-  commit(0);
-  __syncthreads();
-  int cur = 0;
-  for (int c0 = 0; c0 < C; c0 += FC) {
-    const bool more = c0 + FC < C;
-    if (more) fetch(c0 + FC);
-#pragma unroll 2
-    for (int c = 0; c < FC; ++c) {
-      const float4 a = *reinterpret_cast<const float4*>(&s1[cur][c][ty][4 * tx]);
-      float v2[4 + 2 * R];
+  for (int c0 = 0; c0 < C; c0 += CR) {
+    const int cr = min(CR, C - c0);
+    if (c0 > 0) __syncthreads();             // the previous round's readers are done
+    // ---- stage cr channels: every piece is 16 B, fully inside or fully outside the image ----
+    if (cl < lanes) {
+      constexpr int U = 12;
+      const float* gp = pbase + (size_t)(c0 + cl) * plane;
+      float* lp = lds + cl * PCF + 4 * pp;
+#pragma unroll 1
+      for (int cb = cl; cb < cr; cb += lanes * U) {
+        f32x4 v[U];
 #pragma unroll
-      for (int k = 0; k < (4 + 2 * R) / 4; ++k) {
-        const float4 t = *reinterpret_cast<const float4*>(&s2[cur][c][ty + tz][4 * tx + 4 * k]);
-        v2[4 * k] = t.x; v2[4 * k + 1] = t.y; v2[4 * k + 2] = t.z; v2[4 * k + 3] = t.w;
+        for (int k = 0; k < U; ++k) {
+          const bool ok = pvalid && cb + k * lanes < cr;
+          v[k] = *reinterpret_cast<const f32x4*>(ok ? gp : pbase);   // branch-free: a dead piece re-reads a live address
+          if (!ok) v[k] = (f32x4)(0.f);
+          gp += lstep;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          if (cb + k * lanes < cr) *reinterpret_cast<f32x4*>(lp) = v[k];
+          lp += lanes * PCF;
+        }
       }
-      const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int d = 0; d < PS; ++d) acc[p][d] += av[p] * v2[p + d];
     }
-    if (more) commit(cur ^ 1);
     __syncthreads();
-    cur ^= 1;
+    // ---- this slice's channels of the round ----
+    if (sl < NS && !(dbg & 2)) {
+#pragma unroll 2
+      for (int c = sl; c < cr; c += NS) {
+        const float* ch = lds + c * PCF;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ch + (r * QW + q) * 4);
+        const float* row = ch + 4 * P1 + (r + ph) * HW2 + 4 * q;
+        float v2[12];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const f32x4 tt = *reinterpret_cast<const f32x4*>(row + 4 * k);
+          v2[4 * k] = tt.x; v2[4 * k + 1] = tt.y; v2[4 * k + 2] = tt.z; v2[4 * k + 3] = tt.w;
+        }
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int d = 0; d < PS; ++d) acc[p][d] += av[p] * v2[p + d];
+      }
+    }
   }
 
-  const int gy = y0 + ty, gx = x0 + 4 * tx;
-  if (gy >= H || gx >= W) return;
-  float* o = out + (((size_t)b * PS + tz) * PS) * plane + (size_t)gy * W + gx;
-  const bool vec = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  // ---- the NS partial sums meet in LDS and are added in slice order ----
+  constexpr int NO = PS * PS * TH * QW;      // float4 outputs of the tile
+  float* ob = out + (size_t)b * PS * PS * plane;
+  if (NS == 1) {
+    const int gy = y0 + r, gx = x0 + 4 * q;
+    if (tid < TPS && gy < H && gx < W && (!(dbg & 4) || acc[0][0] == 123.f)) {
 #pragma unroll
-  for (int d = 0; d < PS; ++d) {
-    float* od = o + (size_t)d * plane;
-    if (vec) {
-      *reinterpret_cast<float4*>(od) = make_float4(acc[0][d], acc[1][d], acc[2][d], acc[3][d]);
+      for (int d = 0; d < PS; ++d) {
+        f32x4 v = {acc[0][d], acc[1][d], acc[2][d], acc[3][d]};
+        v *= scale;
+        if (slope != 1.f) {
+          v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+          v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+        }
+        *reinterpret_cast<f32x4*>(ob + (size_t)(ph * PS + d) * plane + (size_t)gy * W + gx) = v;
+      }
+    }
+    return;
+  }
+  __syncthreads();
+  if (sl < NS) {
+#pragma unroll
+    for (int d = 0; d < PS; ++d) {
+      const int o = ((ph * PS + d) * TH + r) * QW + q;
+      const f32x4 v = {acc[0][d], acc[1][d], acc[2][d], acc[3][d]};
+      *reinterpret_cast<f32x4*>(lds + 4 * (sl * NO + o)) = v;
+    }
+  }
+  __syncthreads();
+  for (int o = tid; o < NO; o += NT) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(lds + 4 * o);
+    for (int s2 = 1; s2 < NS; ++s2) v += *reinterpret_cast<const f32x4*>(lds + 4 * (s2 * NO + o));
+    v *= scale;
+    if (slope != 1.f) {
+      v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+    }
+    const int d = o / (TH * QW), rem = o - d * (TH * QW);
+    const int gy = y0 + rem / QW, gx = x0 + 4 * (rem % QW);
+    if (gy < H && gx < W && (!(dbg & 4) || v.x == 123.f))
+      *reinterpret_cast<f32x4*>(ob + (size_t)d * plane + (size_t)gy * W + gx) = v;
+  }
+}
+
+struct FwdPlan {
+  int th, tw, ns, cr;
+  size_t lds;
+};
+
+// Tile and slice count for one level: the largest tile that still gives the chip >= 200 workgroups, otherwise the
+// smallest one; as many channel slices as 576 threads hold (each slice keeps >= 4 channels); rounds of equal size.
+FwdPlan plan_fwd(int B, int C, int H, int W) {
+  const int th[3] = {4, 2, 2}, tw[3] = {32, 32, 16}, nsmax[3] = {2, 4, 8};
+  int k = 2;
+  for (int i = 0; i < 3; ++i)
+    if ((long long)pcfa_cdiv(H, th[i]) * pcfa_cdiv(W, tw[i]) * B >= 200) { k = i; break; }
+  FwdPlan P;
+  if (const char* e = getenv("PCFA_SC_TILE")) k = atoi(e);          // tuning overrides (tools/dev only)
+  P.th = th[k]; P.tw = tw[k];
+  P.ns = nsmax[k];
+  while (P.ns > 1 && C / P.ns < 4) P.ns >>= 1;
+  if (const char* e = getenv("PCFA_SC_NS")) P.ns = atoi(e) < nsmax[k] ? atoi(e) : nsmax[k];
+  const int pcf = P.th * P.tw + (P.th + 8) * (P.tw + 8);
+  int crmax = SC_LDS_BUDGET / (pcf * 4);
+  if (const char* e = getenv("PCFA_SC_CR")) crmax = atoi(e) < crmax ? atoi(e) : crmax;
+  const int rounds = pcfa_cdiv(C, crmax);
+  P.cr = pcfa_cdiv(pcfa_cdiv(C, rounds), P.ns) * P.ns;
+  if (P.cr > crmax) P.cr = crmax / P.ns * P.ns;
+  const size_t stage = (size_t)P.cr * pcf * 4;
+  const size_t red = P.ns > 1 ? (size_t)P.ns * 81 * P.th * P.tw * 4 : 0;
+  P.lds = stage > red ? stage : red;
+  return P;
+}
+
+template <int TH, int TW>
+int launch_fwd(const FwdPlan& P, const float* in1, const float* in2, float* out, int B, int C, int H, int W,
+               float scale, float slope, hipStream_t s) {
+  static size_t granted = 0;   // per template instance; the attribute only ever grows
+  if (P.lds > granted) {
+    hipError_t e = hipFuncSetAttribute((const void*)scorr9_fwd_kernel<TH, TW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds);
+    if (e != hipSuccess) return (int)e;
+    granted = P.lds;
+  }
+  const int tps = (TW / 4) * TH * 9;
+  dim3 grid(pcfa_cdiv(W, TW), pcfa_cdiv(H, TH), B), block(tps * P.ns);
+  static const int dbg = getenv("PCFA_SC_DBG") ? atoi(getenv("PCFA_SC_DBG")) : 0;   // phase ablation (tools/dev)
+  pcfa_launch(scorr9_fwd_kernel<TH, TW>, grid, block, P.lds, s, in1, in2, out, C, H, W, P.ns, P.cr, scale, slope,
+              dbg);
+  return PCFA_OK;
+}
+
+int scorr9_forward(const float* in1, const float* in2, float* out, int B, int C, int H, int W, float scale,
+                   float slope, hipStream_t s) {
+  const FwdPlan P = plan_fwd(B, C, H, W);
+  if (P.th == 4) return launch_fwd<4, 32>(P, in1, in2, out, B, C, H, W, scale, slope, s);
+  if (P.tw == 32) return launch_fwd<2, 32>(P, in1, in2, out, B, C, H, W, scale, slope, s);
+  return launch_fwd<2, 16>(P, in1, in2, out, B, C, H, W, scale, slope, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward (both gradients, one launch)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BTW = 32, BCG = 32;   // pixel tile width, channels per workgroup
+
+// BTH = tile rows (2: 64 pixels, 2 channels per thread; 4: 128 pixels, 4 channels per thread -- half the workgroups,
+// the taps staged once per 128 pixels: the fine levels)
+template <int BTH>
+__global__ __launch_bounds__(256) void scorr9_bwd_kernel(const float* __restrict__ in1,
+                                                         const float* __restrict__ in2,
+                                                         const float* __restrict__ gout,
+                                                         const float* __restrict__ fwd_out,
+                                                         float* __restrict__ gin1, float* __restrict__ gin2,
+                                                         int C, int H, int W, float gscale, float slope, int dbg) {
+  constexpr int PS = 9, R = 4;
+  constexpr int QW = BTW / 4, HW2 = BTW + 2 * R, HH2 = BTH + 2 * R;
+  constexpr int NT = 256;
+  constexpr int BCPT = BCG * QW * BTH / NT;      // channels per thread
+  static_assert(QW * BTH * (BCG / BCPT) == NT, "thread map");
+  __shared__ __attribute__((aligned(16))) float Gs[PS * PS][BTH][BTW];
+  __shared__ __attribute__((aligned(16))) float Xs[BCG][HH2][HW2];
+
+  const int ngroups = (C + BCG - 1) / BCG;
+  int z = blockIdx.z;
+  const int which = z & 1; z >>= 1;               // 0: gradient w.r.t. in1, 1: w.r.t. in2
+  const int b = z / ngroups, c0 = (z - b * ngroups) * BCG;
+  const int y0 = blockIdx.y * BTH, x0 = blockIdx.x * BTW;
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t)H * W;
+  const float* X = (which ? in1 : in2) + (size_t)b * C * plane;
+  const float* gb = gout + (size_t)b * PS * PS * plane;
+  const float* fb = fwd_out ? fwd_out + (size_t)b * PS * PS * plane : nullptr;
+  float* po = (which ? gin2 : gin1) + (size_t)b * C * plane;
+
+  // Staging, decoded once per thread and advanced by pointer increments (see the forward kernel): all loads of the
+  // halo tile are in flight before the first LDS write, the gradient taps follow in batches.
+  {
+    // halo tile of BCG channels: thread = (channel lane, 16-B piece of the 10 x 40 pattern)
+    constexpr int XP = HH2 * (HW2 / 4);            // 100 / 120 pieces per channel
+    constexpr int XL = NT / XP;                    // 2 channel lanes
+    constexpr int XU = BCG / XL;                   // 16 loads per thread
+    static_assert(XL * XU == BCG, "halo staging");
+    const int xl = tid / XP, xp = tid - xl * XP;
+    const int xgy = y0 + xp / (HW2 / 4) - R, xgx = x0 + 4 * (xp % (HW2 / 4)) - R;
+    const bool xvalid = xl < XL && xgy >= 0 && xgy < H && xgx >= 0 && xgx < W && !(dbg & 1);
+    const float* xb = X + (xvalid ? (size_t)xgy * W + xgx : 0);
+    f32x4 v[XU];
+#pragma unroll
+    for (int k = 0; k < XU; ++k) {
+      const int c = c0 + xl + k * XL;
+      const bool ok = xvalid && c < C;
+      v[k] = *reinterpret_cast<const f32x4*>(ok ? xb + (size_t)c * plane : xb);
+      if (!ok) v[k] = (f32x4)(0.f);
+    }
+    // ---- the 81 x (2 x 32) gradient taps ----
+    if (dbg & 8) {
+    } else if (which == 0) {
+      // thread = (plane lane, 16-B piece of the 2 x 32 tile): 16 planes per pass
+      constexpr int GP = BTH * QW, GL = NT / GP, GU = (PS * PS + GL - 1) / GL;   // 16, 16, 6  /  32, 8, 11
+      const int gl = tid / GP, gp_ = tid - gl * GP;
+      const int ggy = y0 + gp_ / QW, ggx = x0 + 4 * (gp_ % QW);
+      const bool gvalid = ggy < H && ggx < W;
+      const size_t goff = gvalid ? (size_t)ggy * W + ggx : 0;
+      f32x4 g[GU], f[GU];
+#pragma unroll
+      for (int k = 0; k < GU; ++k) {
+        const int d = gl + k * GL;
+        const size_t off = goff + (size_t)(d < PS * PS ? d : 0) * plane;
+        g[k] = *reinterpret_cast<const f32x4*>(gb + off);
+        f[k] = fb ? *reinterpret_cast<const f32x4*>(fb + off) : (f32x4)(1.f);
+      }
+#pragma unroll
+      for (int k = 0; k < GU; ++k) {
+        const int d = gl + k * GL;
+        f32x4 t = g[k] * gscale;
+        if (fb) {
+          t.x = f[k].x > 0.f ? t.x : t.x * slope; t.y = f[k].y > 0.f ? t.y : t.y * slope;
+          t.z = f[k].z > 0.f ? t.z : t.z * slope; t.w = f[k].w > 0.f ? t.w : t.w * slope;
+        }
+        if (d < PS * PS) *reinterpret_cast<f32x4*>(&Gs[d][0][0] + 4 * gp_) = gvalid ? t : (f32x4)(0.f);
+      }
     } else {
+      // G[e][p] = g[8 - e][p + e - 4]: rows shifted by ex - 4, so single floats (coalesced, unaligned).
+      // thread = (tap lane, pixel of the 2 x 32 tile): 4 taps per pass, 21 passes
+      // one batch for the 2-row tile: every tap load of the thread is in flight at once (three batches of 7 were
+      // three dependent round trips on the critical path of half the workgroups)
+      constexpr int GP = BTH * BTW, GL = NT / GP, UG = BTH == 2 ? 21 : 14;   // 64 pixels, 4 lanes  /  128, 2
+      const int gl = tid / GP, px = tid - gl * GP;
+      const int py = y0 + px / BTW - R, pxx = x0 + px % BTW - R;
+#pragma unroll 1
+      for (int d0 = gl; d0 < PS * PS; d0 += GL * UG) {
+        float g[UG], f[UG];
+        bool okg[UG];
 #pragma unroll
-      for (int p = 0; p < 4; ++p) od[p] = acc[p][d];
+        for (int k = 0; k < UG; ++k) {
+          const int d = d0 + k * GL;
+          const int ey = d / PS, ex = d - ey * PS;
+          const int gy = py + ey, gx = pxx + ex;
+          okg[k] = d < PS * PS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+          const size_t off = okg[k] ? (size_t)(PS * PS - 1 - d) * plane + (size_t)(gy * W + gx) : 0;
+          g[k] = gb[off];
+          f[k] = fb ? fb[off] : 1.f;
+        }
+#pragma unroll
+        for (int k = 0; k < UG; ++k) {
+          const int d = d0 + k * GL;
+          float t = g[k] * gscale;
+          if (fb) t = f[k] > 0.f ? t : t * slope;
+          if (d < PS * PS) (&Gs[d][0][0])[px] = okg[k] ? t : 0.f;
+        }
+      }
+    }
+    if (xl < XL) {
+#pragma unroll
+      for (int k = 0; k < XU; ++k)
+        *reinterpret_cast<f32x4*>(&Xs[xl + k * XL][0][0] + 4 * xp) = v[k];
+    }
+  }
+  __syncthreads();
+
+  // ---- thread = 4 pixels x BCPT channels ----
+  const int q = tid % QW, r = (tid / QW) % BTH, sub = tid / (QW * BTH);
+  float acc[BCPT][4];
+#pragma unroll
+  for (int cc = 0; cc < BCPT; ++cc)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[cc][p] = 0.f;
+#pragma unroll 1
+  for (int ey = 0; ey < ((dbg & 2) ? 0 : PS); ++ey) {
+    f32x4 G[PS];
+#pragma unroll
+    for (int ex = 0; ex < PS; ++ex) G[ex] = *reinterpret_cast<const f32x4*>(&Gs[ey * PS + ex][r][4 * q]);
+#pragma unroll
+    for (int cc = 0; cc < BCPT; ++cc) {
+      const float* row = &Xs[sub * BCPT + cc][r + ey][4 * q];
+      float x[12];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f32x4 tt = *reinterpret_cast<const f32x4*>(row + 4 * k);
+        x[4 * k] = tt.x; x[4 * k + 1] = tt.y; x[4 * k + 2] = tt.z; x[4 * k + 3] = tt.w;
+      }
+#pragma unroll
+      for (int ex = 0; ex < PS; ++ex) {
+        acc[cc][0] += G[ex].x * x[ex];
+        acc[cc][1] += G[ex].y * x[ex + 1];
+        acc[cc][2] += G[ex].z * x[ex + 2];
+        acc[cc][3] += G[ex].w * x[ex + 3];
+      }
+    }
+  }
+  const int gy = y0 + r, gx = x0 + 4 * q;
+  if (gy < H && gx < W && (!(dbg & 4) || acc[0][0] == 123.f)) {
+#pragma unroll
+    for (int cc = 0; cc < BCPT; ++cc) {
+      const int c = c0 + sub * BCPT + cc;
+      if (c < C) {
+        const f32x4 v = {acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]};
+        *reinterpret_cast<f32x4*>(po + (size_t)c * plane + (size_t)gy * W + gx) = v;
+      }
     }
   }
 }
 
-// gin[c][p] = sum_{dy,dx} G(dy,dx) * X[c][p + SIGN*(dy,dx)]
-//   SIGN=+1: G = g[d][p]       X = in2   (gradient w.r.t. in1)
-//   SIGN=-1: G = g[d][p - d]   X = in1   (gradient w.r.t. in2)
-template <int PS, int SIGN>
-__global__ __launch_bounds__(TH* TW) void scorr_bwd_fast_kernel(
-    const float* __restrict__ X, const float* __restrict__ gout, float* __restrict__ gin, int C,
-    int H, int W) {
-  constexpr int R = (PS - 1) / 2;
-  constexpr int HW2 = TW + 2 * R, HH2 = TH + 2 * R;
-  constexpr int S2 = HW2 + 1;
-  __shared__ float sx[CC][HH2][S2];
-
-  const int ngroups = (C + CC - 1) / CC;
-  const int b = blockIdx.z / ngroups;
-  const int c0 = (blockIdx.z - b * ngroups) * CC;
-  const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
-  const int lx = threadIdx.x, ly = threadIdx.y;
-  const int tid = lx + TW * ly;
-  constexpr int NT = TH * TW;
-  const int gy = y0 + ly, gx = x0 + lx;
-  const bool inside = gy < H && gx < W;
-  const size_t plane = (size_t)H * W;
-
-  // Every load below is branch-free (clamped address, value zeroed afterwards) and the staging loop issues a batch
-  // of loads before its LDS writes: with predicated loads the 81 gradient taps and the 20 staging iterations were
-  // each a dependent global round trip, and the kernel was a 17-20 us latency chain.
-  float G[PS][PS];
-  const float* gb = gout + (size_t)b * PS * PS * plane;
-  const int cgy = min(gy, H - 1), cgx = min(gx, W - 1);
-#pragma unroll
-  for (int i = 0; i < PS; ++i)
-#pragma unroll
-    for (int j = 0; j < PS; ++j) {
-      const int sy = (SIGN > 0) ? cgy : cgy - (i - R), sx_ = (SIGN > 0) ? cgx : cgx - (j - R);
-      const bool ok = inside && sy >= 0 && sy < H && sx_ >= 0 && sx_ < W;
-      const float v = gb[(size_t)(i * PS + j) * plane + (ok ? (size_t)sy * W + sx_ : 0)];
-      G[i][j] = ok ? v : 0.f;
-    }
-
-  // The channels are independent in both gradients, so blockIdx.z also splits them: a workgroup stages
-  // ONE chunk of CC channels (no serial channel loop -- the small pyramid levels have only 1-4 pixel tiles).
-  const float* px = X + (size_t)b * C * plane;
-  float* po = gin + (size_t)b * C * plane;
-  {
-    constexpr int NE = CC * HH2 * HW2, BATCH = 10;
-    static_assert(NE % (NT * BATCH) == 0, "staging batches must divide evenly");
-#pragma unroll 1
-    for (int e0 = tid; e0 < NE; e0 += NT * BATCH) {
-      float t[BATCH];
-      bool ok[BATCH];
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k) {
-        const int e = e0 + k * NT;
-        const int c = e / (HH2 * HW2), r = (e / HW2) % HH2, x = e % HW2;
-        const int yy = y0 + r - R, xx = x0 + x - R;
-        ok[k] = c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        t[k] = px[ok[k] ? (size_t)(c0 + c) * plane + (size_t)yy * W + xx : 0];
-      }
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k) {
-        const int e = e0 + k * NT;
-        const int c = e / (HH2 * HW2), r = (e / HW2) % HH2, x = e % HW2;
-        sx[c][r][x] = ok[k] ? t[k] : 0.f;
-      }
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int c = 0; c < CC; ++c) {
-      if (c0 + c >= C) break;
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < PS; ++i)
-#pragma unroll
-        for (int j = 0; j < PS; ++j) {
-          const int r = (SIGN > 0) ? (ly + i) : (ly + 2 * R - i);
-          const int x = (SIGN > 0) ? (lx + j) : (lx + 2 * R - j);
-          s += G[i][j] * sx[c][r][x];
-        }
-      if (inside) po[(size_t)(c0 + c) * plane + (size_t)gy * W + gx] = s;
-    }
+int scorr9_backward(const float* in1, const float* in2, const float* gout, const float* fwd_out, float* gin1,
+                    float* gin2, int B, int C, int H, int W, float gscale, float slope, hipStream_t s) {
+  // 4-row tiles (half the workgroups, taps staged once per 128 pixels) measured SLOWER at every PWC level
+  // (103 KB of LDS = one workgroup per CU, nothing overlaps its load phase): kept for tuning only
+  static const int dbg = getenv("PCFA_SC_DBG") ? atoi(getenv("PCFA_SC_DBG")) : 0;   // phase ablation (tools/dev)
+  bool tall = false;
+  if (const char* e = getenv("PCFA_SC_BTH")) tall = atoi(e) == 4;   // tuning override (tools/dev)
+  if (tall) {
+    dim3 grid(pcfa_cdiv(W, BTW), pcfa_cdiv(H, 4), 2 * B * pcfa_cdiv(C, BCG)), block(256);
+    pcfa_launch(scorr9_bwd_kernel<4>, grid, block, 0, s, in1, in2, gout, fwd_out, gin1, gin2, C, H, W, gscale, slope,
+                dbg);
+  } else {
+    dim3 grid(pcfa_cdiv(W, BTW), pcfa_cdiv(H, 2), 2 * B * pcfa_cdiv(C, BCG)), block(256);
+    pcfa_launch(scorr9_bwd_kernel<2>, grid, block, 0, s, in1, in2, gout, fwd_out, gin1, gin2, C, H, W, gscale, slope,
+                dbg);
   }
+  return PCFA_OK;
 }
 
 struct ScParams {
@@ -367,15 +552,11 @@ extern "C" int pcfa_spatial_corr_fwd(const float* in1, const float* in2, float* 
                    dil_patchW, dH, dW))
     return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const bool aligned = iW % 4 == 0 && ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
+  const bool aligned = iW % 4 == 0 &&
+      ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   if (is_fast(p, 9) && aligned) {
-    if ((long long)iH * iW <= 48 * 160) {  // coarse levels: 2-row tiles
-      dim3 grid(pcfa_cdiv(iW, TW), pcfa_cdiv(iH, 2), B), block(8, 2, 9);
-      pcfa_launch(scorr_fwd_fast_kernel<9, 2>, grid, block, 0, s, in1, in2, out, C, iH, iW);
-    } else {
-      dim3 grid(pcfa_cdiv(iW, TW), pcfa_cdiv(iH, TH), B), block(8, 8, 9);
-      pcfa_launch(scorr_fwd_fast_kernel<9, TH>, grid, block, 0, s, in1, in2, out, C, iH, iW);
-    }
+    const int rc = scorr9_forward(in1, in2, out, B, C, iH, iW, 1.f, 1.f, s);
+    if (rc != PCFA_OK) return rc;
   } else {
     const long long total = (long long)B * patchH * patchW * p.oH * p.oW;
     const int blocks = (int)((total + 255) / 256 < 65535LL * 16 ? (total + 255) / 256 : 65535LL * 16);
@@ -396,13 +577,12 @@ extern "C" int pcfa_spatial_corr_bwd(const float* in1, const float* in2, const f
                    dil_patchW, dH, dW))
     return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (is_fast(p, 9)) {
-    dim3 grid(pcfa_cdiv(iW, TW), pcfa_cdiv(iH, TH), B * pcfa_cdiv(C, CC)), block(TW, TH, 1);
-    pcfa_launch(scorr_bwd_fast_kernel<9, +1>, grid, block, 0, s, in2, grad_out, grad_in1,
-                       C, iH, iW);
-    PCFA_LAUNCH_CHECK();
-    pcfa_launch(scorr_bwd_fast_kernel<9, -1>, grid, block, 0, s, in1, grad_out, grad_in2,
-                       C, iH, iW);
+  const bool aligned = iW % 4 == 0 &&
+      ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2) | reinterpret_cast<uintptr_t>(grad_out) |
+        reinterpret_cast<uintptr_t>(grad_in1) | reinterpret_cast<uintptr_t>(grad_in2)) & 15) == 0;
+  if (is_fast(p, 9) && aligned) {
+    const int rc = scorr9_backward(in1, in2, grad_out, nullptr, grad_in1, grad_in2, B, C, iH, iW, 1.f, 1.f, s);
+    if (rc != PCFA_OK) return rc;
   } else {
     const long long total = (long long)B * C * iH * iW;
     const int blocks = (int)((total + 255) / 256 < 65535LL * 16 ? (total + 255) / 256 : 65535LL * 16);
@@ -412,6 +592,39 @@ extern "C" int pcfa_spatial_corr_bwd(const float* in1, const float* in2, const f
     pcfa_launch(scorr_bwd_generic_kernel<2>, dim3(blocks), dim3(256), 0, s, in1, grad_out,
                        grad_in2, p);
   }
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+// PWC-Net's use of the sampler, fused: out = leaky_relu(correlate(in1, in2)) with correlate = 9x9 cost volume / C
+// (models/PWCNet/PWCNet.py:45-58 followed by self.leakyRELU at :249,264,278,292,308).  scale = 1/C and the
+// LeakyReLU slope ride in the forward epilogue; the backward applies mask * scale to the gradient taps while it
+// stages them (fwd_out = the forward's output, whose sign is the mask).  iW % 4 == 0 and 16-B aligned pointers.
+extern "C" int pcfa_cost_volume9_fwd(const float* in1, const float* in2, float* out, int B, int C, int iH, int iW,
+                                     float scale, float slope, void* stream) {
+  if (!in1 || !in2 || !out || B < 1 || C < 1 || iH < 1 || iW < 1) return PCFA_ERR_INVALID_ARG;
+  if (iW % 4 != 0 ||
+      ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2) | reinterpret_cast<uintptr_t>(out)) & 15))
+    return PCFA_ERR_UNSUPPORTED;
+  const int rc = scorr9_forward(in1, in2, out, B, C, iH, iW, scale, slope, (hipStream_t)stream);
+  if (rc != PCFA_OK) return rc;
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_cost_volume9_bwd(const float* in1, const float* in2, const float* fwd_out, const float* grad_out,
+                                     float* grad_in1, float* grad_in2, int B, int C, int iH, int iW, float scale,
+                                     float slope, void* stream) {
+  if (!in1 || !in2 || !fwd_out || !grad_out || !grad_in1 || !grad_in2 || B < 1 || C < 1 || iH < 1 || iW < 1)
+    return PCFA_ERR_INVALID_ARG;
+  if (iW % 4 != 0 ||
+      ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2) | reinterpret_cast<uintptr_t>(fwd_out) |
+        reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_in1) |
+        reinterpret_cast<uintptr_t>(grad_in2)) & 15))
+    return PCFA_ERR_UNSUPPORTED;
+  const int rc = scorr9_backward(in1, in2, grad_out, fwd_out, grad_in1, grad_in2, B, C, iH, iW, scale, slope,
+                                 (hipStream_t)stream);
+  if (rc != PCFA_OK) return rc;
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }

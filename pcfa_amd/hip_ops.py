@@ -365,6 +365,41 @@ def spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=1, stri
                                                    dilation, dilation_patch)
 
 
+class _PwcCostVolume(torch.autograd.Function):
+    """leaky_relu(spatial_correlation_sample(a, b, patch 9) / C) -- PWCNet.py:45-58 + the LeakyReLU that follows every
+    call (:249,264,278,292,308) -- as ONE forward launch (scale and activation in the epilogue) and ONE backward
+    launch (mask * scale applied to the gradient taps while they are staged; both input gradients)."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, slope):
+        _dev(input1, input2)
+        input1, input2 = input1.contiguous(), input2.contiguous()
+        B, C, H, W = input1.shape
+        out = torch.empty((B, 81, H, W), device=input1.device, dtype=torch.float32)
+        ctx.args = (B, C, H, W, 1.0 / C, float(slope))
+        _call("pcfa_cost_volume9_fwd", _ptr(input1), _ptr(input2), _ptr(out), *ctx.args)
+        ctx.save_for_backward(input1, input2, out)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        input1, input2, out = ctx.saved_tensors
+        g = grad_output.contiguous()
+        g1, g2 = torch.empty_like(input1), torch.empty_like(input2)
+        _call("pcfa_cost_volume9_bwd", _ptr(input1), _ptr(input2), _ptr(out), _ptr(g), _ptr(g1), _ptr(g2), *ctx.args)
+        return g1, g2, None
+
+
+def pwc_cost_volume(input1, input2, slope=0.1):
+    """PWC-Net's `leakyRELU(correlate(input1, input2))`: [B,C,H,W] x2 -> [B,81,H,W]."""
+    if input1.shape[-1] % 4 != 0 or input1.shape != input2.shape:   # the fused kernels stage 16-B pieces
+        out = spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=9, stride=1)
+        b, ph, pw, h, w = out.size()
+        return torch.nn.functional.leaky_relu(out.view(b, ph * pw, h, w) / input1.size(1), slope)
+    return _PwcCostVolume.apply(input1, input2, slope)
+
+
 # --------------------------------------------------------------------------- #
 # FlowNet2's native operators (models/FlowNet/{correlation,resample2d,channelnorm}_package)
 # --------------------------------------------------------------------------- #

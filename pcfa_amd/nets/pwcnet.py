@@ -110,6 +110,10 @@ class PWCDCNet(nn.Module):
         meshgrid / normalise / two grid_sample / compare / multiply sequence."""
         return ops.get().pwc_warp(x, flo, 0.0001)
 
+    def _cost_volume(self, f1, f2):
+        """leakyRELU(corr(f1, f2)) (PWCNet.py:249,264,278,292,308) in one launch per direction."""
+        return ops.get().pwc_cost_volume(f1, f2, self.leakyRELU.negative_slope)
+
     def _decode(self, lvl, x):
         blocks = [getattr(self, "conv%d_%d" % (lvl, i)) for i in range(5)]
         if x.shape[0] == 1 and not any(p.requires_grad for blk in blocks for p in blk.parameters()):
@@ -136,7 +140,7 @@ class PWCDCNet(nn.Module):
 
         c1, c2 = pyramid(im1), pyramid(im2)  # index 0 = level 1 ... index 5 = level 6
 
-        corr6 = self.leakyRELU(self.corr(c1[5], c2[5]))
+        corr6 = self._cost_volume(c1[5], c2[5])
         x = self._decode(6, corr6)
         flow = self.predict_flow6(x)
         flows = {6: flow}
@@ -145,7 +149,7 @@ class PWCDCNet(nn.Module):
         for lvl, scale in ((5, 0.625), (4, 1.25), (3, 2.5), (2, 5.0)):
             f1, f2 = c1[lvl - 1], c2[lvl - 1]
             warped = self.warp(f2, up_flow * scale)
-            corr = self.leakyRELU(self.corr(f1, warped))
+            corr = self._cost_volume(f1, warped)
             x = self._decode(lvl, torch.cat((corr, f1, up_flow, up_feat), 1))
             flow = getattr(self, "predict_flow%d" % lvl)(x)
             flows[lvl] = flow

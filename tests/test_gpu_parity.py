@@ -196,6 +196,31 @@ def test_spatial_corr_pwc_levels_vs_oracle(oracle_ops, shape):
     assert torch.equal(ag2.grad, ag.grad) and torch.equal(bg2.grad, bg.grad)
 
 
+@pytest.mark.parametrize("shape", [(1, 196, 6, 20), (1, 128, 12, 40), (2, 96, 24, 80), (1, 64, 48, 160),
+                                   (1, 32, 96, 320), (1, 32, 112, 256), (1, 5, 7, 36), (2, 33, 3, 8), (1, 3, 1, 4)])
+def test_pwc_cost_volume_fused_vs_oracle(oracle_ops, shape):
+    """leaky_relu(correlate(a, b)) as ONE launch per direction (pcfa_cost_volume9_fwd/bwd; PWCNet.py:45-58 + the
+    LeakyReLU at :249...) against the oracle's composition: the five KITTI level shapes, the Sintel level-2 shape,
+    ragged tiles, channel counts that are not a multiple of the 32-channel backward group.  Forward 2e-6 * max|out|
+    (summation order over C), gradients 1e-5 relative L2, bit-reproducible."""
+    gen = torch.Generator().manual_seed(shape[1] + shape[2])
+    a = torch.randn(*shape, generator=gen).requires_grad_(True)
+    b = torch.randn(*shape, generator=gen).requires_grad_(True)
+    want = oracle_ops.pwc_cost_volume(a, b, 0.1)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    ag, bg = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.pwc_cost_volume(ag, bg, 0.1)
+    assert got.shape == want.shape
+    assert max_abs(got, want) <= 2e-6 * float(want.abs().max()) * max(1.0, np.sqrt(shape[1]))
+    got.backward(go.to(DEV))
+    assert rel_l2(ag.grad, a.grad) < 1e-5 and rel_l2(bg.grad, b.grad) < 1e-5
+    ag2, bg2 = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    got2 = hip_ops.pwc_cost_volume(ag2, bg2, 0.1)
+    got2.backward(go.to(DEV))
+    assert torch.equal(got2, got) and torch.equal(ag2.grad, ag.grad) and torch.equal(bg2.grad, bg.grad)
+
+
 # --------------------------------------------------------------------------- FlowNet2's three operators
 # Oracle = restatement of the CUDA kernels (no reference output exists: CUDA-only extensions), correlation
 # cross-pinned against the reference's C++ sampler in tests/test_oracle_cpu.py.  Tolerances: correlation

@@ -83,6 +83,8 @@ def _worker(rank, world, port, mode, kwargs, outdir):
                                                         **kwargs))
             np.save(os.path.join(outdir, "univ_w%d_r%d.npy" % (world, rank)),
                     torch.stack([res["delta1"], res["delta2"]]).numpy())
+            json.dump({"collectives": res["collectives"], "steps": len(res["history"])},
+                      open(os.path.join(outdir, "univ_w%d_r%d.json" % (world, rank)), "w"))
     sharding.shutdown()
 
 
@@ -125,8 +127,12 @@ def test_universal_allreduce_equals_single_process_global_batch():
         r0 = np.load(os.path.join(d, "univ_w2_r0.npy"))
         r1 = np.load(os.path.join(d, "univ_w2_r1.npy"))
         single = np.load(os.path.join(d, "univ_w1_r0.npy"))
+        meta = json.load(open(os.path.join(d, "univ_w2_r0.json")))
     assert np.array_equal(r0, r1), "replicas of delta diverged across ranks"
     assert np.abs(single).max() > 0
+    # ONE data-path collective per closure evaluation (10 per L-BFGS step): gradients of both perturbations and
+    # the loss travel in one flat buffer
+    assert meta["collectives"] == 10 * meta["steps"], meta
     # 10 L-BFGS iterations on a stiff penalty amplify summation-order noise: loose here,
     # tight at the closure level below
     rel = np.linalg.norm(r0 - single) / np.linalg.norm(single)
