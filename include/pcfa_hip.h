@@ -391,6 +391,10 @@ PCFA_API int pcfa_instnorm_fwd(const float* x, float* y, float* mean_rstd, void*
 PCFA_API int pcfa_instnorm_bwd(const float* x, const float* mean_rstd, const float* grad_out, float* grad_x,
                                void* workspace, int planes, long long plane, int relu, void* stream);
 PCFA_API int pcfa_add_relu_fwd(const float* a, const float* b, float* out, long long n, void* stream);
+/* out = srcs[0] + ... + srcs[n-1], n <= 16 device pointers in a HOST array, summed in index order by one launch.
+ * Backward of a tensor read by every refinement iteration (the hoisted gate pre-activations of SepConvGRU,
+ * models/raft/update.py:45-60: autograd would add the twelve contributions pairwise, eleven launches per tensor). */
+PCFA_API int pcfa_sum_n(const float* const* srcs, int n, float* out, long long numel, void* stream);
 
 /* Metric helpers (helper_functions/losses.py:3-30,129-142): out[0] = sum over
  * pixels of sqrt(du^2+dv^2) / (B*H*W);  pcfa_sum_squares: out[0] = sum x^2. */

@@ -186,6 +186,11 @@ def spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=1, stri
     return _SpatialCorr.apply(input1, input2, kernel_size, patch_size, stride, padding, dilation, dilation_patch)
 
 
+def fanout(x, n):
+    """n uses of x (the product sums their gradients with one kernel; autograd does it here)."""
+    return tuple(x for _ in range(n))
+
+
 def pwc_cost_volume(input1, input2, slope=0.1):
     """leakyRELU(correlate(input1, input2)): models/PWCNet/PWCNet.py:45-58 followed by :249,264,278,292,308."""
     out = spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=9, stride=1)
@@ -600,6 +605,16 @@ def avg_mse(flow1, flow2):
     return torch.mean((flow1 - flow2) ** 2)
 
 
+def f_epe(pred, target):
+    """helper_functions/losses.py:47-58."""
+    return avg_epe(pred, target)
+
+
+def f_mse(pred, target):
+    """helper_functions/losses.py:61-73."""
+    return avg_mse(pred, target)
+
+
 def f_cosim(pred, target):
     """helper_functions/losses.py:76-88 (operator precedence kept: the quotient is MULTIPLIED by |t|)."""
     return 1 - torch.sum(pred * target) / torch.sqrt(torch.sum(pred * pred)) * torch.sqrt(torch.sum(target * target))
@@ -621,6 +636,12 @@ def two_norm_avg_delta_squared(delta1, delta2):
     """helper_functions/losses.py:110-126."""
     n = torch.numel(delta1) + torch.numel(delta2)
     return (torch.sum(torch.pow(torch.flatten(delta1), 2)) + torch.sum(torch.pow(torch.flatten(delta2), 2))) / n
+
+
+def relu_penalty(delta1, delta2, device=None, delta_bound=0.001):
+    """losses.py:177-197."""
+    zero = torch.tensor(0.)
+    return torch.max(zero, two_norm_avg_delta_squared(delta1, delta2) - torch.tensor(delta_bound ** 2))
 
 
 def get_loss(f_type, pred, target):

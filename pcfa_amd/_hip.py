@@ -90,6 +90,7 @@ SIGNATURES = {
     "pcfa_instnorm_fwd": (c_int, [_P, _P, _P, _P, c_int, c_longlong, c_float, c_int, _P]),
     "pcfa_instnorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_longlong, c_int, _P]),
     "pcfa_add_relu_fwd": (c_int, [_P, _P, _P, c_longlong, _P]),
+    "pcfa_sum_n": (c_int, [POINTER(c_void_p), c_int, _P, c_longlong, _P]),
     "pcfa_avg_epe": (c_int, [_P, _S4, _P, _S4, c_int, c_int, c_int, _P, _P, _P]),
     "pcfa_sum_squares": (c_int, [_P, c_longlong, _P, _P, _P]),
 }

@@ -266,3 +266,43 @@ extern "C" int pcfa_relu_bwd(const float* out, const float* grad_out, float* gra
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
+
+// out = srcs[0] + srcs[1] + ... + srcs[n-1] (n <= 16) in index order: the gradient of a tensor that the twelve
+// refinement iterations all read (the hoisted gate pre-activations of SepConvGRU, models/raft/update.py:45-60) summed by
+// ONE launch reading every contribution once, instead of n-1 accumulate kernels of 3 tensor passes each.
+namespace {
+struct SumSrcs {
+  const float* p[16];
+};
+__global__ void sum_n_kernel(SumSrcs s, int n, float* __restrict__ out, long long numel, int vec_ok) {
+  for_each4(numel, vec_ok, [&](long long i, bool vec) {
+    if (vec) {
+      float4 a = LD4(s.p[0], i);
+      for (int k = 1; k < n; ++k) {
+        const float4 b = LD4(s.p[k], i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      ST4(out, i, a);
+    } else {
+      float a = s.p[0][i];
+      for (int k = 1; k < n; ++k) a += s.p[k][i];
+      out[i] = a;
+    }
+  });
+}
+}  // namespace
+
+extern "C" int pcfa_sum_n(const float* const* srcs, int n, float* out, long long numel, void* stream) {
+  if (!srcs || !out || n < 1 || n > 16 || numel < 1) return PCFA_ERR_INVALID_ARG;
+  SumSrcs s;
+  int vec_ok = al16(out);
+  for (int k = 0; k < 16; ++k) {
+    s.p[k] = k < n ? srcs[k] : srcs[0];
+    if (!s.p[k]) return PCFA_ERR_INVALID_ARG;
+    vec_ok = vec_ok && al16(s.p[k]);
+  }
+  pcfa_launch(sum_n_kernel, dim3(blocks_for(numel)), dim3(256), 0, (hipStream_t)stream, s, n, out, numel, vec_ok);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+

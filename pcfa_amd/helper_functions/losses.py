@@ -11,8 +11,34 @@ def avg_epe(flow1, flow2):
     return ops.get().avg_epe(flow1, flow2)
 
 
+def avg_mse(flow1, flow2):
+    """Mean squared error between two flow fields, losses.py:32-44 (differentiable)."""
+    return ops.get().get_loss("mse", flow1, flow2)
+
+
 def f_epe(pred, target):
+    """losses.py:47-58."""
     return avg_epe(pred, target)
+
+
+def f_mse(pred, target):
+    """losses.py:61-73."""
+    return avg_mse(pred, target)
+
+
+def f_cosim(pred, target):
+    """losses.py:76-88 -- bug-compatible: 1 - (p.t / sqrt(p.p)) * sqrt(t.t) (the reference multiplies by |t|)."""
+    return ops.get().get_loss("cosim", pred, target)
+
+
+def two_norm_avg_delta_squared(delta1, delta2):
+    """losses.py:110-126."""
+    return ops.get().two_norm_avg_delta_squared(delta1, delta2)
+
+
+def relu_penalty(delta1, delta2, device=None, delta_bound=0.001):
+    """relu(mean(delta^2) - delta_bound^2), losses.py:177-197."""
+    return ops.get().relu_penalty(delta1, delta2, device, delta_bound)
 
 
 def two_norm_avg_delta(delta1, delta2):

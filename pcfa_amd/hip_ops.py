@@ -252,6 +252,11 @@ class _CorrBuild(torch.autograd.Function):
 class _CorrLookup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, token, coords, state):
+        if coords.requires_grad and torch.is_grad_enabled():
+            # models/raft/corr.py's bilinear_sampler differentiates w.r.t. coords; RAFT / GMA detach them
+            # (raft.py:122-123) and this operator does not implement that gradient: refuse instead of returning zeros
+            raise RuntimeError("CorrBlock lookup: coords.requires_grad is not supported (detach the coordinates, as "
+                               "models/raft/raft.py:122-123 does)")
         lib = _hip.load()
         st = state
         c = coords.contiguous()
@@ -1097,6 +1102,37 @@ class _GruStep(torch.autograd.Function):
         return g, d_rest, None, grads_p[0], None, grads_p[1], None, grads_p[2], None, grads_p[3]
 
 
+class _Fanout(torch.autograd.Function):
+    """x -> n aliases of x, one per consumer.  Forward moves no data; backward receives all n gradients at once and
+    adds them with ONE launch (pcfa_sum_n) instead of the n-1 pairwise accumulations autograd performs when the same
+    tensor feeds n nodes.  Consumers that contributed nothing are skipped."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        live = [g.contiguous() for g in grads if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        _dev(*live)
+        out = torch.empty_like(live[0])
+        for i in range(0, len(live), 15):      # 16 pointers per launch: the running sum + 15 more
+            part = ([out] if i else []) + live[i:i + 15]
+            arr = (ctypes.c_void_p * len(part))(*[t.data_ptr() for t in part])
+            _call("pcfa_sum_n", arr, len(part), _ptr(out), out.numel())
+        return out, None
+
+
+def fanout(x, n):
+    """n aliases of x whose gradients are summed by one kernel (see _Fanout)."""
+    return _Fanout.apply(x, n) if n > 1 else (x,)
+
+
 def gru_step(h, rest, halves):
     """SepConvGRU update from precomputed context parts: halves = ((w_zr, p_zr, w_q, p_q) for the 1x5 half-step,
     (..) for the 5x1 half-step); see _GruStep."""
@@ -1231,9 +1267,16 @@ _WS = {}
 
 
 def _workspace(device):
-    """Per-(device, stream) reduction scratch (allocated once, never freed)."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    """Reduction scratch of the loss / metric kernels (32 KB), one per (device, stream), allocated once.
+    While a hipGraph is being captured the capture stream reuses a buffer that was allocated OUTSIDE any capture
+    (every capture in this package is preceded by eager warm-up calls on the same device), so no scratch comes from --
+    and pins -- a graph's private memory pool; the kernels of one closure are stream-ordered on one stream at a time."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (idx, None if capturing else torch.cuda.current_stream().cuda_stream)
     ws = _WS.get(key)
+    if ws is None and capturing:
+        ws = next((w for (d, s_), w in _WS.items() if d == idx and s_ is not None), None)
     if ws is None:
         nbytes = _hip.load().pcfa_flow_loss_workspace_bytes()
         ws = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
@@ -1307,6 +1350,19 @@ def get_loss(f_type, pred, target):
     """helper_functions/losses.py:145-174: the similarity term alone (penalty weight 0 on a dummy perturbation)."""
     z = torch.zeros(4, device=pred.device, dtype=torch.float32)
     return _LossDeltaConstraint.apply(pred, target, z, z, 1.0, 0.0, f_type)
+
+
+def relu_penalty(delta1, delta2, device=None, delta_bound=0.001):
+    """helper_functions/losses.py:177-197: relu(mean(delta^2) - delta_bound^2), differentiable.  Runs the fused loss
+    kernels with mu = 1 on a zero flow pair, whose MSE similarity term is exactly 0 (value and gradient)."""
+    z = torch.zeros((1, 2, 1, 1), device=delta1.device, dtype=torch.float32)
+    return _LossDeltaConstraint.apply(z, z, delta1, delta2, delta_bound, 1.0, "mse")
+
+
+def two_norm_avg_delta_squared(delta1, delta2):
+    """helper_functions/losses.py:110-126: (sum d1^2 + sum d2^2) / (n1 + n2), differentiable (= the penalty with a
+    zero bound: the mean square is never negative, so the relu is the identity)."""
+    return relu_penalty(delta1, delta2, None, 0.0)
 
 
 def avg_epe(flow1, flow2):

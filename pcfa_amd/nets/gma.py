@@ -94,6 +94,10 @@ class _AttnTimesValue(torch.autograd.Function):
                 sh.buf = torch.matmul(g, v.transpose(-1, -2))
             else:
                 sh.buf.view(-1, n, n).baddbmm_(g.reshape(-1, n, d), v.reshape(-1, n, d).transpose(-1, -2))
+            if sh.pending <= 0:
+                # a second backward through the same forward (retain_graph) would hand autograd a partial sum
+                raise RuntimeError("GMA attention gradient: backward re-entered after the shared buffer was released; "
+                                   "run a fresh forward (retain_graph is not supported on this path)")
             sh.pending -= 1
             if sh.pending == 0:
                 d_attn, sh.buf = sh.buf, None
@@ -186,7 +190,7 @@ class RAFTGMA(nn.Module):
             coords1 = coords1 + flow_init
 
         gru = self.update_block.gru
-        gru_ctx = gru.precompute(inp) if gru.frozen() else None
+        gru_ctx = gru.per_iteration(gru.precompute(inp), iters) if gru.frozen() else None
         flow_predictions = []
         flow_up = None
         attn_grad = _SharedAttnGrad()  # one accumulation buffer for the gradient of `attention` (used `iters` times)
@@ -196,7 +200,8 @@ class RAFTGMA(nn.Module):
             flow = coords1 - coords0
             need_up = (not test_mode) or itr == iters - 1
             net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, attention, want_mask=need_up,
-                                                         gru_ctx=gru_ctx, attn_grad=attn_grad)
+                                                         gru_ctx=None if gru_ctx is None else gru_ctx[itr],
+                                                         attn_grad=attn_grad)
             coords1 = coords1 + delta_flow
             if need_up:
                 flow_up = convex_upsample(coords1 - coords0, up_mask)

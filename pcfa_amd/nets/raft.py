@@ -266,6 +266,13 @@ class SepConvGRU(nn.Module):
             ctx[tag] = (w_dyn, convs[0]._conv_forward(inp, w_const, b))
         return ctx
 
+    def per_iteration(self, ctx, iters):
+        """precompute()'s context for each of `iters` refinement iterations: the cached pre-activations are read by
+        every iteration, so their gradient is a sum of `iters` terms -- ops.fanout hands out one alias per iteration
+        and adds the gradients with one launch per tensor (autograd would accumulate them pairwise)."""
+        fans = {tag: ops.get().fanout(p, iters) for tag, (_, p) in ctx.items()}
+        return [{tag: (ctx[tag][0], fans[tag][i]) for tag in ctx} for i in range(iters)]
+
     def step(self, h, ctx, rest):
         """One GRU update given precompute()'s context; `rest` = the per-iteration part of x (motion features)."""
         # one autograd node per update: sepconv5 reads [h | rest] in place (no torch.cat, no im2col) and the
@@ -373,7 +380,7 @@ class RAFT(nn.Module):
             coords1 = coords1 + flow_init
 
         gru = self.update_block.gru
-        gru_ctx = gru.precompute(inp) if gru.frozen() else None
+        gru_ctx = gru.per_iteration(gru.precompute(inp), iters) if gru.frozen() else None
         flow_predictions = []
         flow_up = None
         for itr in range(iters):
@@ -381,7 +388,8 @@ class RAFT(nn.Module):
             corr = corr_fn(coords1)
             flow = coords1 - coords0
             need_up = (not test_mode) or itr == iters - 1
-            net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, want_mask=need_up, gru_ctx=gru_ctx)
+            net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, want_mask=need_up,
+                                                         gru_ctx=None if gru_ctx is None else gru_ctx[itr])
             coords1 = coords1 + delta_flow
             if need_up:
                 flow_up = convex_upsample(coords1 - coords0, up_mask)

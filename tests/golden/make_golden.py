@@ -18,6 +18,7 @@ Fixtures:
   corr_block_*.npz        CorrBlock build + lookup, forward and backward   (models/raft/corr.py)
   spatial_corr_*.npz      spatial_correlation_sample forward/backward       (reference C++ sampler)
   attack_math.npz         losses / extract_deltas / ScaledInputModel prologue
+  losses_names.npz        avg_mse, f_mse, f_cosim, two_norm_avg_delta_squared, relu_penalty + gradients (losses.py)
   closure_<net>.npz       one PCFA closure: flow, loss, d loss / d nw_input  (128x160 or 128x192)
   trajectory_raft.npz     5-step pcfa_attack, at 8 and at 3 CPU threads (noise floor)
   universal_raft.npz      attack_l2_universal (attack_PCFA.py:297-566): RAFT 128x160, 2 batches of 2 pairs, 2 steps each,
@@ -298,6 +299,36 @@ def golden_attack_math():
     save("attack_math", **out)
 
 
+def golden_losses():
+    """The remaining public names of helper_functions/losses.py (:32-88,110-126,177-197) with their gradients:
+    avg_mse / f_mse, f_cosim, two_norm_avg_delta_squared, relu_penalty (bound inactive, active)."""
+    from helper_functions import losses
+    g = torch.Generator().manual_seed(6)
+    pred = (3 * torch.randn(2, 2, 9, 14, generator=g)).requires_grad_(True)
+    target = 3 * torch.randn(2, 2, 9, 14, generator=g)
+    d1 = (0.02 * torch.randn(1, 3, 12, 16, generator=g)).requires_grad_(True)
+    d2 = (0.01 * torch.randn(1, 3, 12, 16, generator=g)).requires_grad_(True)
+    out = dict(pred=pred, target=target, delta1=d1, delta2=d2)
+
+    def grad_of(fn, *leaves):
+        for l in leaves:
+            l.grad = None
+        v = fn()
+        v.backward()
+        return v, [l.grad.clone() for l in leaves]
+
+    v, (gp,) = grad_of(lambda: losses.avg_mse(pred, target), pred)
+    out.update(avg_mse=v, g_avg_mse=gp, f_mse=losses.f_mse(pred, target))
+    v, (gp,) = grad_of(lambda: losses.f_cosim(pred, target), pred)
+    out.update(f_cosim=v, g_f_cosim=gp)
+    v, (g1, g2) = grad_of(lambda: losses.two_norm_avg_delta_squared(d1, d2), d1, d2)
+    out.update(msq=v, g_msq_1=g1, g_msq_2=g2)
+    for tag, bound in (("active", 0.005), ("inactive", 0.5)):
+        v, (g1, g2) = grad_of(lambda: losses.relu_penalty(d1, d2, torch.device("cpu"), bound), d1, d2)
+        out.update({"penalty_" + tag: v, "g_penalty_%s_1" % tag: g1, "g_penalty_%s_2" % tag: g2})
+    save("losses_names", **out)
+
+
 def closure_case(net, h, w, boxconstraint, joint, target_name, loss_name, seed):
     """One closure evaluation exactly as attack_PCFA.py:175-192 performs it."""
     import attack_PCFA
@@ -441,13 +472,15 @@ def golden_universal():
 if __name__ == "__main__":
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["corr", "scorr", "math", "closures", "trajectory", "flownet2", "universal"]
+    which = sys.argv[1:] or ["corr", "scorr", "math", "losses", "closures", "trajectory", "flownet2", "universal"]
     if "corr" in which:
         golden_corr_block()
     if "scorr" in which:
         golden_spatial_corr()
     if "math" in which:
         golden_attack_math()
+    if "losses" in which:
+        golden_losses()
     if "closures" in which:
         golden_closures()
     if "trajectory" in which:

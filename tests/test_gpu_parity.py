@@ -1011,3 +1011,136 @@ def test_lbfgs_rejects_cpu_parameters():
         LBFGS([torch.zeros(4, requires_grad=True)], max_iter=10)
     with pytest.raises(NotImplementedError):
         LBFGS([torch.zeros(4, device=DEV, requires_grad=True)], line_search_fn="strong_wolfe")
+
+
+# --------------------------------------------------------------------------- #
+# Boundary as files: the drop-in modules of pcfa_amd/dropin carry the names the reference imports
+# (correlation_sampler.cpp:114-124 pybind names; correlation_cuda.cc / resample2d_cuda.cc / channelnorm_cuda.cc).
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("tag", ["pwc_a", "pwc_b", "pwc_c", "gen_a", "gen_b"])
+def test_dropin_sampler_backend_positional_signature(tag):
+    """`import spatial_correlation_sampler_backend` resolves to the drop-in; forward / backward are called with the
+    reference's 12 positional integers (correlation_sampler.cpp:58-112) against the reference sampler's goldens."""
+    from pcfa_amd import dropin
+    dropin.install()
+    import spatial_correlation_sampler_backend as backend
+    assert backend.__file__.startswith(dropin.install())
+    g = load_golden("spatial_corr_" + tag)
+    ks, ps, st, pad, dil, dp = (int(v) for v in g["params"])
+    a, b = t(g["in1"], DEV), t(g["in2"], DEV)
+    out = backend.forward(a, b, ks, ks, ps, ps, pad, pad, dil, dil, dp, dp, st, st)
+    assert tuple(out.shape) == g["out"].shape
+    assert max_abs(out, t(g["out"])) <= 1e-6 * a.shape[1] * float(np.abs(g["out"]).max()) + 1e-6
+    g1, g2 = backend.backward(a, b, t(g["grad_out"], DEV), ks, ks, ps, ps, pad, pad, dil, dil, dp, dp, st, st)
+    assert rel_l2(g1, t(g["gin1"])) < 1e-5 and rel_l2(g2, t(g["gin2"])) < 1e-5
+    with pytest.raises(RuntimeError):
+        backend.forward(a.cpu(), b.cpu(), ks, ks, ps, ps, pad, pad, dil, dil, dp, dp, st, st)
+
+
+def test_dropin_flownet_extensions_positional_signature(oracle_ops):
+    """correlation_cuda / resample2d_cuda / channelnorm_cuda under their reference names: caller-allocated outputs,
+    return value 1 (correlation_cuda.cc:10-87,89-167; resample2d_cuda.cc:6-24; channelnorm_cuda.cc:6-25)."""
+    from pcfa_amd import dropin
+    dropin.install()
+    import channelnorm_cuda
+    import correlation_cuda
+    import resample2d_cuda
+    gen = torch.Generator().manual_seed(5)
+    a = torch.randn(1, 16, 12, 20, generator=gen)
+    b = torch.randn(1, 16, 12, 20, generator=gen)
+    want = oracle_ops.flownet_correlation(a.clone().requires_grad_(True), b.clone().requires_grad_(True), 20, 1, 20, 1, 2)
+    out, r1, r2 = torch.empty(0, device=DEV), torch.empty(0, device=DEV), torch.empty(0, device=DEV)
+    assert correlation_cuda.forward(a.to(DEV), b.to(DEV), r1, r2, out, 20, 1, 20, 1, 2, 1) == 1
+    assert out.shape == want.shape and max_abs(out, want) <= 2e-6 * 16 * float(want.abs().max())
+    go = torch.randn(want.shape, generator=gen)
+    ga, gb = oracle_ops.flownet_corr_backward(a, b, go, 20, 1, 20, 1, 2)
+    g1, g2 = torch.empty(0, device=DEV), torch.empty(0, device=DEV)
+    assert correlation_cuda.backward(a.to(DEV), b.to(DEV), r1, r2, go.to(DEV), g1, g2, 20, 1, 20, 1, 2, 1) == 1
+    assert rel_l2(g1, ga) < 1e-5 and rel_l2(g2, gb) < 1e-5
+    img = torch.randn(1, 3, 16, 24, generator=gen)
+    flo = 2 * torch.randn(1, 2, 16, 24, generator=gen)
+    outr = torch.empty(1, 3, 16, 24, device=DEV)
+    assert resample2d_cuda.forward(img.to(DEV), flo.to(DEV), outr, 1, True) == 1
+    assert max_abs(outr, oracle_ops.resample2d_forward(img, flo, 1, True)) <= 1e-5 * float(img.abs().max())
+    gr = torch.randn(1, 3, 16, 24, generator=gen)
+    wa, wb = oracle_ops.resample2d_backward(img, flo, gr)
+    gi, gf = torch.empty_like(outr), torch.empty(1, 2, 16, 24, device=DEV)
+    assert resample2d_cuda.backward(img.to(DEV), flo.to(DEV), gr.to(DEV), gi, gf, 1, True) == 1
+    assert rel_l2(gi, wa) < 1e-5 and rel_l2(gf, wb) < 1e-4
+    x = torch.randn(2, 3, 8, 8, generator=gen)
+    outn = torch.empty(2, 1, 8, 8, device=DEV)
+    assert channelnorm_cuda.forward(x.to(DEV), outn, 2) == 1
+    wn = oracle_ops.channelnorm_forward(x)
+    assert max_abs(outn, wn) <= 2e-7 * float(wn.abs().max()) + 1e-7
+    gn = torch.randn(2, 1, 8, 8, generator=gen)
+    gx = torch.empty(2, 3, 8, 8, device=DEV)
+    assert channelnorm_cuda.backward(x.to(DEV), outn, gn.to(DEV), gx, 2) == 1
+    assert rel_l2(gx, oracle_ops.channelnorm_backward(x, wn, gn)) < 1e-6
+
+
+def test_losses_names_on_gpu_vs_reference_golden():
+    """avg_mse / f_mse / f_cosim / two_norm_avg_delta_squared / relu_penalty (losses.py:32-88,110-126,177-197) on the
+    fused HIP loss kernels against the reference's values and gradients."""
+    from pcfa_amd.helper_functions import losses
+    from tests.test_oracle_cpu import _check_losses_names
+    _check_losses_names(losses, load_golden("losses_names"), DEV, 2e-6)
+
+
+# --------------------------------------------------------------------------- #
+# SURVEY 8f row f3 on the GPU: attack_FGSM.py:21-56,59-308 and evaluate_PCFA.py:21-79,86-299
+# --------------------------------------------------------------------------- #
+def _f3_cli(**kw):
+    return _cli_args(**dict(dict(boxconstraint="clipping", steps=2, epochs=2, epsilon=0.00025,
+                                 perturbation_sourcefolder=None, origin_net=None, synthetic_size="64x64"), **kw))
+
+
+def test_fgsm_driver_on_gpu_vs_cpu_port(oracle_ops):
+    """I-FGSM (attack_FGSM.py:21-56 step, :59-308 driver): 2 pairs x 2 sign-gradient iterations on the MI355X against
+    the CPU port.  A sign step is discontinuous, so the comparison is on the metrics (1e-3) and on the perturbation
+    norm, which is exact by construction (every element moves by +-epsilon per iteration)."""
+    from pcfa_amd import attack_FGSM
+    a = _f3_cli(loss="mse")
+    got = attack_FGSM.attack(a)
+    import importlib
+    import os
+    os.environ["PCFA_USE_CPU"] = "1"
+    try:
+        from pcfa_amd.helper_functions import config_paths
+        importlib.reload(config_paths)
+        importlib.reload(attack_FGSM)
+        with ops.override_for_testing(oracle_ops):
+            want = attack_FGSM.attack(a)
+    finally:
+        os.environ.pop("PCFA_USE_CPU")
+        importlib.reload(config_paths)
+        importlib.reload(attack_FGSM)
+    assert got["pairs"] == want["pairs"] == 2
+    assert 0 < got["l2_delta-avg"] <= 2 * 0.00025 + 1e-9
+    for k in ("aee_pred-tgt", "aee_predadv-tgt", "l2_delta-avg"):
+        assert abs(got[k] - want[k]) <= 1e-3 * max(1.0, abs(want[k])), (k, got[k], want[k])
+
+
+def test_universal_artifacts_round_trip_through_evaluate_on_gpu(tmp_path):
+    """attack_l2_universal writes `NNNNN_delta1_e{E}.npy` (attack_PCFA.py:524,531); evaluate_PCFA reads the folder back
+    (evaluate_PCFA.py:21-58), re-pads across network families (:60-79) and evaluates on the GPU (:86-299)."""
+    import os
+    from pcfa_amd import attack_PCFA, evaluate_PCFA
+    size = "130x170"   # SpyNet pads it to 192x192 (div 64), RAFT to 136x176 (div 8): the re-padding path is exercised
+    args = _f3_cli(universal_perturbation=True, no_save=False, output_folder=str(tmp_path), steps=1, epochs=2,
+                   synthetic_size=size)
+    res = attack_PCFA.attack_l2_universal(args)
+    run_dir = None
+    for root, dirs, files in os.walk(str(tmp_path)):
+        if os.path.basename(root) == "patches" and any(f.endswith("_delta1_e1.npy") for f in files):
+            run_dir = os.path.dirname(root)
+    assert run_dir is not None
+    epochs, d1, d2 = evaluate_PCFA.extract_epoch_patchlist(run_dir)
+    assert epochs == 2 and len(d1) == 2 and len(d2) == 2
+    assert np.array_equal(np.load(d1[-1]), res["delta1"].cpu().numpy())
+    ev = evaluate_PCFA.eval_l2_universal(_f3_cli(universal_perturbation=True, perturbation_sourcefolder=run_dir,
+                                                 origin_net="SpyNet", synthetic_size=size))
+    assert len(ev) == 2 and ev[0]["images"] == 2 and np.isfinite(ev[1]["epoch_aee_pred-predadv"])
+    # black-box transfer: the SpyNet perturbation (padded to 64) evaluated on RAFT (padded to 8) -- evaluate_PCFA.py:60-79
+    ev2 = evaluate_PCFA.eval_l2_universal(_f3_cli(net="RAFT", universal_perturbation=True, synthetic_size=size,
+                                                  perturbation_sourcefolder=run_dir, origin_net="SpyNet"))
+    assert len(ev2) == 2 and np.isfinite(ev2[1]["epoch_aee_pred-predadv"])

@@ -110,6 +110,41 @@ def _sampler_as_flownet_corr(oracle_ops, a, b, md, s2):
     return out.reshape(a.shape[0], d * d, a.shape[2], a.shape[3]) / a.shape[1]
 
 
+def _check_losses_names(L, g, dev, tol):
+    """Shared by the CPU (oracle) and GPU (product) tests: every remaining public name of losses.py against the
+    reference's values and gradients (tests/golden/losses_names.npz)."""
+    pred = t(g["pred"], dev).requires_grad_(True)
+    target = t(g["target"], dev)
+    d1 = t(g["delta1"], dev).requires_grad_(True)
+    d2 = t(g["delta2"], dev).requires_grad_(True)
+
+    def check(fn, leaves, want, want_grads):
+        for l in leaves:
+            l.grad = None
+        v = fn()
+        assert abs(float(v) - float(want)) <= tol * max(abs(float(want)), 1e-12), (float(v), float(want))
+        v.backward()
+        for l, w in zip(leaves, want_grads):
+            assert rel_l2(l.grad, t(w)) <= 10 * tol
+
+    check(lambda: L.avg_mse(pred, target), [pred], g["avg_mse"], [g["g_avg_mse"]])
+    assert abs(float(L.f_mse(pred, target)) - float(g["f_mse"])) <= tol * abs(float(g["f_mse"]))
+    check(lambda: L.f_cosim(pred, target), [pred], g["f_cosim"], [g["g_f_cosim"]])
+    check(lambda: L.two_norm_avg_delta_squared(d1, d2), [d1, d2], g["msq"], [g["g_msq_1"], g["g_msq_2"]])
+    check(lambda: L.relu_penalty(d1, d2, dev, 0.005), [d1, d2], g["penalty_active"],
+          [g["g_penalty_active_1"], g["g_penalty_active_2"]])
+    for l in (d1, d2):
+        l.grad = None
+    v = L.relu_penalty(d1, d2, dev, 0.5)
+    assert float(v) == 0.0 == float(g["penalty_inactive"])
+    v.backward()
+    assert float(d1.grad.abs().max()) == 0.0 and float(d2.grad.abs().max()) == 0.0
+
+
+def test_losses_names_match_reference(oracle_ops):
+    _check_losses_names(oracle_ops, load_golden("losses_names"), "cpu", 1e-6)
+
+
 @pytest.mark.parametrize("shape,md,s2", [((1, 16, 20, 28), 20, 2), ((2, 5, 9, 13), 4, 2), ((1, 3, 7, 8), 3, 1)])
 def test_flownet_corr_oracle_vs_pinned_sampler(oracle_ops, shape, md, s2):
     """FlowNetC's layer (pad = max_displacement, k = 1, stride1 = 1) is the sampler with patch 2*(md/s2)+1,
