@@ -180,12 +180,12 @@ def event_overhead_us(reps=200):
     return prof.summary()["pcfa_null_launch"][0]
 
 
-def lookup_traffic():
+def lookup_traffic(kernel="corr_lookup_fwd"):
     """HBM bytes per launch of the lookup kernel from rocprofv3 PMC counters (collected offline by
     tools/pmc_traffic.sh with the guide's gfx950 corrections, committed under profiles/); None if absent."""
     path = os.path.join(REPO, "profiles", "lookup_traffic.json")
     try:
-        return json.load(open(path))["corr_lookup_fwd"]["traffic_bytes"]
+        return json.load(open(path))[kernel]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -220,7 +220,10 @@ def kernel_table(timings, hf, wf, hp, wp, dim=256, levels=4, radius=4):
     work = {  # label -> (bound, algorithmic bytes or flop per launch)
         "corr_lookup_fwd": ("hbm", win_b + q * 8 + out_b),
         "corr_lookup_bwd": ("hbm", out_b + q * 8 + 2 * win_b),
-        "corr_lookup_convc1_fwd": ("hbm", win_b + q * 8 + q * 256 * 4),
+        # lookup + convc1 + ReLU fused: W[256][324] . taps[324][Q] on the fp32 matrix cores (arithmetic intensity
+        # 2*256*324*Q flop / (texels + coords + 256*Q*4 B out) = 62 flop/B, above the fp32-matrix ridge of ~20)
+        "corr_lookup_convc1_fwd": ("mfma", 2.0 * 256 * levels * n1 * n1 * q),
+        "corr_lookup_convc1_bwd": ("mfma", 2.0 * 256 * levels * n1 * n1 * q),
         "corr_pyramid_gemm_fwd": ("mfma", gemm),
         "corr_pyramid_gemm_dfmap1": ("mfma", gemm),
         "corr_pyramid_gemm_df2ext": ("mfma", gemm),
@@ -262,7 +265,7 @@ def pwc_kernel_table(timings, hp, wp):
 
 TRACED = {  # kernel-name fragment -> label
     "corr_lookup_fwd_kernel": "corr_lookup_fwd", "corr_lookup_bwd_kernel": "corr_lookup_bwd",
-    "corr_lookup_convc1_fwd_kernel": "corr_lookup_convc1_fwd",
+    "corr_lookup_convc1_fwd_kernel": "corr_lookup_convc1_fwd", "corr_lookup_convc1_bwd_kernel": "corr_lookup_convc1_bwd",
     "gemm_f32_mfma_kernel<true, true,": "corr_pyramid_gemm_fwd",
     "gemm_f32_mfma_kernel<false, false,": "corr_pyramid_gemm_dfmap1",
     "gemm_f32_mfma_kernel<false, true,": "corr_pyramid_gemm_df2ext",
@@ -448,13 +451,16 @@ def main():
         except Exception as e:  # the tracer is an extra: fall back to the eager hipEvent figures
             print("graph-replay kernel trace unavailable: %r" % (e,), file=sys.stderr)
     if use_graph and corr_net:
-        # dispatch-attached events cannot ride inside a captured graph: time the same kernel on the same
-        # data in one extra, eagerly launched step right after the timed region
+        # dispatch-attached events cannot ride inside a captured graph: time the kernels on the same data in one
+        # extra, eagerly launched step right after the timed region -- with the lookup -> convc1 fusion switched OFF,
+        # so that this step also yields the un-fused lookup kernel's own roofline row
         st.graphed = st.repredict = None
+        os.environ["PCFA_FUSED_LOOKUP"] = "0"
         hip_ops.set_dispatch_timer(prof)
         st.step()
         torch.cuda.synchronize()
         hip_ops.set_dispatch_timer(None)
+        os.environ.pop("PCFA_FUSED_LOOKUP")
 
     universal = None
     if world > 1 and not a.no_universal_leg:
@@ -489,26 +495,51 @@ def main():
         if corr_net:
             timings = prof.summary()
             eager_us, eager_n = timings["corr_lookup_fwd"]
-            nbytes = lookup_algorithmic_bytes(hp // 8, wp // 8)
-            if traced and "corr_lookup_fwd" in traced:
+            hf, wf = hp // 8, wp // 8
+            nbytes = lookup_algorithmic_bytes(hf, wf)
+            how_graph = ("dispatch timestamps of every launch inside the hipGraph replays of one attack step right "
+                         "after the timed region (HIP activity tracer via torch.profiler: the timestamps rocprofv3 "
+                         "reads; hipEvents cannot be attached inside a captured graph)")
+            how_eager = ("hipEvents on the dispatch packet (hipExtLaunchKernel), every launch of one eagerly launched "
+                         "step with the lookup -> convc1 fusion switched off")
+            out["kernels"] = kernel_table(traced if traced else timings, hf, wf, hp, wp)
+            unfused = {"kernel": "corr_lookup_fwd_kernel<4> (un-fused lookup, models/raft/corr.py:29-50)", "bound": "hbm",
+                       "bytes_per_launch": nbytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "traffic": lookup_traffic("corr_lookup_fwd"), "event_bracket_overhead_us": event_overhead_us()}
+            if traced and "corr_lookup_fwd" in traced:     # the closure runs the un-fused kernel (fusion off / n.a.)
                 us, n = traced["corr_lookup_fwd"]
-                how = ("dispatch timestamps of every launch inside the hipGraph replays of one attack step right "
-                       "after the timed region (HIP activity tracer via torch.profiler: the timestamps rocprofv3 "
-                       "reads; hipEvents cannot be attached inside a captured graph)")
-                out["kernels"] = kernel_table(traced, hp // 8, wp // 8, hp, wp)
+                unfused.update(mean_launch_us=us, launches_timed=n, timing=how_graph, eager_step_hip_event_us=eager_us)
             else:
                 us, n = eager_us, eager_n
-                how = "hipEvents on the dispatch packet (hipExtLaunchKernel), every launch of one eagerly launched step"
-                out["kernels"] = kernel_table(timings, hp // 8, wp // 8, hp, wp)
-            ach = nbytes / (us * 1e-6) / 1e9
-            out["roofline"] = {"kernel": "corr_lookup_fwd_kernel<4>", "bound": "hbm", "achieved": ach,
-                               "timing": how, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": lookup_traffic(), "bytes_per_launch": nbytes, "mean_launch_us": us,
-                               "launches_timed": n,
-                               "eager_step_hip_event_us": eager_us, "eager_step_launches": eager_n,
-                               "eager_step_frac": nbytes / (eager_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                               "event_bracket_overhead_us": event_overhead_us()}
-            out["kernels_eager_step_hip_events"] = kernel_table(timings, hp // 8, wp // 8, hp, wp)
+                unfused.update(mean_launch_us=us, launches_timed=n, timing=how_eager)
+            unfused["achieved"] = nbytes / (us * 1e-6) / 1e9
+            unfused["frac"] = unfused["achieved"] / HBM_PEAK_GBS
+            if traced and "corr_lookup_convc1_fwd" in traced:
+                # the kernel that runs in the timed region: lookup + convc1 + ReLU in one launch
+                us, n = traced["corr_lookup_convc1_fwd"]
+                q = hf * wf
+                flop = 2.0 * 256 * 324 * q
+                fbytes = q * 4 * 100 * 4 + q * 8 + q * 256 * 4 + 256 * 324 * 4
+                ach = flop / (us * 1e-6) / 1e12
+                out["roofline"] = {
+                    "kernel": "corr_lookup_convc1_fwd_kernel (correlation lookup fused with convc1 + bias + ReLU)",
+                    "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": lookup_traffic("corr_lookup_convc1_fwd"),
+                    "flop_per_launch": flop, "mean_launch_us": us, "launches_timed": n, "timing": how_graph,
+                    "why_mfma": "2*256*324*Q flop over texels + coords + [256][Q] output + weights = %.0f flop/B, "
+                                "above the fp32-matrix ridge (157.3 TFLOP/s / 8 TB/s = 20 flop/B)" % (flop / fbytes),
+                    "hbm_view": {"bytes_per_launch": fbytes, "achieved_GBs": fbytes / (us * 1e-6) / 1e9,
+                                 "frac_of_8TBs": fbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "algorithmic bytes of the fused kernel: 4 levels x 100 texels x 4 B per "
+                                         "query + coords + 256-channel output + weights (the 9.1 MB lookup tensor "
+                                         "is neither written nor re-read)"},
+                    "replaces_per_iteration_us": {"corr_lookup_fwd": eager_us,
+                                                  "note": "+ the library GEMM of convc1 (~28 us) + the bias/ReLU "
+                                                          "pass (~6 us), profiles/r02_closure_kernel_mix*.txt"}}
+                out["roofline_unfused_lookup"] = unfused
+            else:
+                out["roofline"] = unfused
+            out["kernels_eager_step_hip_events"] = kernel_table(timings, hf, wf, hp, wp)
         elif a.net == "PWCNet" and traced:
             rows = pwc_kernel_table(traced, hp, wp)
             out["kernels"] = rows

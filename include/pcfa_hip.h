@@ -122,6 +122,25 @@ PCFA_API int pcfa_corr_lookup_fwd(const float* pyr, const float* coords, float* 
 PCFA_API int pcfa_corr_lookup_bwd(float* dpyr, const float* coords, const float* grad_out, int B, int H,
                          int W, int num_levels, int radius, void* stream);
 
+/* Lookup fused with the motion encoder's first layer:
+ *   out = relu?(convc1(CorrBlock.__call__(coords)))   models/raft/corr.py:29-50 feeding models/raft/update.py:79-93
+ *   (convc1 = Conv2d(4*81, 256, 1)); identical in models/gma.
+ * The [324][Q] lookup result never reaches memory: taps are blended into LDS and multiplied with the weights on the
+ * fp32 matrix cores in the same workgroup (32 queries x 4 levels x 256 channels); the backward multiplies
+ * grad_out * [out > 0] with the transposed weights and scatters straight into dpyr (same ownership as
+ * pcfa_corr_lookup_bwd: no atomics).  `packed` = pcfa_lookup_convc1_pack_weights(weight[256][324]) (both operand
+ * orders, pcfa_lookup_convc1_packed_floats(256) floats).  num_levels = 4, radius = 4, Cout = 256 only
+ * (PCFA_ERR_UNSUPPORTED otherwise: compose pcfa_corr_lookup_* with a convolution).
+ * pyr / dpyr / coords as for pcfa_corr_lookup_fwd / _bwd; out, grad_out: [B][256][H][W]. */
+PCFA_API long long pcfa_lookup_convc1_packed_floats(int Cout);
+PCFA_API int pcfa_lookup_convc1_pack_weights(const float* weight, float* packed, int Cout, int Cin, void* stream);
+PCFA_API int pcfa_lookup_convc1_fwd(const float* pyr, const float* coords, const float* packed, const float* bias,
+                           float* out, int B, int H, int W, int num_levels, int radius, int Cout, int relu,
+                           void* stream);
+PCFA_API int pcfa_lookup_convc1_bwd(float* dpyr, const float* coords, const float* packed, const float* out,
+                           const float* grad_out, int B, int H, int W, int num_levels, int radius, int Cout,
+                           int relu, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * PWC-Net cost volume = spatial_correlation_sampler_backend.forward/backward
  * (models/PWCNet/cpu_spatial_correlation_sampler-0.3.0/Correlation_Module/

@@ -37,6 +37,10 @@ SIGNATURES = {
     "pcfa_corr_pyramid_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_corr_lookup_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_corr_lookup_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_lookup_convc1_packed_floats": (c_longlong, [c_int]),
+    "pcfa_lookup_convc1_pack_weights": (c_int, [_P, _P, c_int, c_int, _P]),
+    "pcfa_lookup_convc1_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_lookup_convc1_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_spatial_corr_out_size": (c_int, [c_int] * 10 + [POINTER(c_int), POINTER(c_int)]),
     "pcfa_spatial_corr_fwd": (c_int, [_P, _P, _P] + [c_int] * 16 + [_P]),
     "pcfa_spatial_corr_bwd": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 16 + [_P]),

@@ -279,6 +279,58 @@ class _CorrLookup(torch.autograd.Function):
         return torch.zeros(1, device=g.device, dtype=torch.float32), None, None
 
 
+_convc1_packs = {}
+
+
+def _convc1_packed(weight):
+    """pcfa_lookup_convc1_pack_weights of a frozen [256, 324, 1, 1] weight (both operand orders), cached per version."""
+    key = id(weight)
+    hit = _convc1_packs.get(key)
+    if hit is None or hit[0]() is not weight or hit[1] != weight._version:
+        lib = _hip.load()
+        cout = weight.shape[0]
+        w = weight.detach().reshape(cout, -1).contiguous()
+        packed = torch.empty(int(lib.pcfa_lookup_convc1_packed_floats(cout)), device=w.device, dtype=torch.float32)
+        _call("pcfa_lookup_convc1_pack_weights", _ptr(w), _ptr(packed), cout, w.shape[1])
+        hit = (weakref.ref(weight, lambda _r, k=key: _convc1_packs.pop(k, None)), weight._version, packed)
+        _convc1_packs[key] = hit
+    return hit[2]
+
+
+class _CorrLookupConv(torch.autograd.Function):
+    """relu(convc1(lookup(coords))) in one launch per direction (pcfa_lookup_convc1_fwd / _bwd): the lookup node of
+    _CorrLookup with the motion encoder's 1x1 convolution (frozen weight) folded in.  Backward accumulates into the
+    shared state.dpyr exactly like _CorrLookup."""
+
+    @staticmethod
+    def forward(ctx, token, coords, state, weight, bias, relu):
+        if coords.requires_grad and torch.is_grad_enabled():
+            raise RuntimeError("CorrBlock lookup: coords.requires_grad is not supported (detach the coordinates, as "
+                               "models/raft/raft.py:122-123 does)")
+        st = state
+        c = coords.contiguous()
+        packed = _convc1_packed(weight)
+        out = torch.empty((st.B, weight.shape[0], st.H, st.W), device=c.device, dtype=torch.float32)
+        _call("pcfa_lookup_convc1_fwd", _ptr(st.pyr), _ptr(c), _ptr(packed), _ptr(bias), _ptr(out), st.B, st.H, st.W,
+              st.L, st.r, weight.shape[0], int(relu))
+        ctx.state, ctx.packed, ctx.relu, ctx.cout = st, packed, int(relu), weight.shape[0]
+        ctx.save_for_backward(c, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            raise RuntimeError("lookup_conv is the frozen-weight path: no weight / bias gradient")
+        st = ctx.state
+        c, out = ctx.saved_tensors
+        if st.dpyr is None:
+            st.dpyr = torch.zeros_like(st.pyr)
+        g = grad_out.contiguous()
+        _call("pcfa_lookup_convc1_bwd", _ptr(st.dpyr), _ptr(c), _ptr(ctx.packed), _ptr(out), _ptr(g), st.B, st.H, st.W,
+              st.L, st.r, ctx.cout, ctx.relu)
+        return torch.zeros(1, device=g.device, dtype=torch.float32), None, None, None, None, None
+
+
 class CorrBlock:
     """Drop-in for models/raft/corr.py:12-50 -- same constructor and __call__."""
 
@@ -302,6 +354,15 @@ class CorrBlock:
     def __call__(self, coords):
         _dev(coords)
         return _CorrLookup.apply(self._token, coords, self._state)
+
+    def lookup_conv_relu(self, coords, weight, bias, relu=True):
+        """relu(conv1x1(self(coords), weight, bias)) without materialising the lookup (update.py:79-93 convc1);
+        None when the shape is not the fused kernel's (4 levels, radius 4, 256 x 324 weight, bias present)."""
+        if (self.num_levels != 4 or self.radius != 4 or bias is None or weight.dim() != 4
+                or tuple(weight.shape) != (256, 324, 1, 1) or weight.requires_grad or bias.requires_grad):
+            return None
+        _dev(coords, weight, bias)
+        return _CorrLookupConv.apply(self._token, coords, self._state, weight, bias, relu)
 
     @property
     def corr_pyramid(self):

@@ -15,7 +15,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .raft import BasicEncoder, BasicMotionEncoder, FlowHead, SepConvGRU, _mask_head, convex_upsample, coords_grid
+from .raft import (BasicEncoder, BasicMotionEncoder, FlowHead, LookupRef, SepConvGRU, _mask_head, convex_upsample,
+                   coords_grid)
 
 
 class RelPosEmb(nn.Module):
@@ -196,7 +197,7 @@ class RAFTGMA(nn.Module):
         attn_grad = _SharedAttnGrad()  # one accumulation buffer for the gradient of `attention` (used `iters` times)
         for itr in range(iters):
             coords1 = coords1.detach()
-            corr = corr_fn(coords1)
+            corr = LookupRef(corr_fn, coords1)
             flow = coords1 - coords0
             need_up = (not test_mode) or itr == iters - 1
             net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, attention, want_mask=need_up,

@@ -16,6 +16,8 @@ Differences that do not change results:
     11, raft.py:131-142);
   * only the full-size model ("small": false in models/_config/raft_config.json).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -280,6 +282,27 @@ class SepConvGRU(nn.Module):
         return ops.get().gru_step(h, rest, tuple(ctx[zr] + ctx[q] for zr, q in (("zr1", "q1"), ("zr2", "q2"))))
 
 
+class LookupRef:
+    """A correlation lookup that has not been evaluated yet: the motion encoder asks for relu(convc1(lookup)) and the
+    operator table may serve both in one launch (CorrBlock.lookup_conv_relu: the [324][Q] tensor never exists);
+    anything else materialises the lookup and runs the layers one by one, as the reference does
+    (models/raft/raft.py:123-124, update.py:79-93)."""
+
+    def __init__(self, corr_fn, coords):
+        self.corr_fn, self.coords = corr_fn, coords
+
+    def tensor(self):
+        return self.corr_fn(self.coords)
+
+    def conv_relu(self, conv):
+        fused = getattr(self.corr_fn, "lookup_conv_relu", None)
+        if fused is not None and _frozen_conv(conv) and os.environ.get("PCFA_FUSED_LOOKUP", "1") == "1":
+            out = fused(self.coords, conv.weight, conv.bias, True)
+            if out is not None:
+                return out
+        return _conv_relu(conv, self.tensor())
+
+
 class BasicMotionEncoder(nn.Module):
     def __init__(self, corr_levels=4, corr_radius=4):
         super().__init__()
@@ -291,13 +314,15 @@ class BasicMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
     def forward(self, flow, corr):
+        """`corr`: the lookup tensor [B,324,H,W] or a LookupRef (lookup + convc1 may then run as one kernel)."""
+        cor1 = corr.conv_relu(self.convc1) if isinstance(corr, LookupRef) else _conv_relu(self.convc1, corr)
         if flow.shape[0] == 1 and _all_frozen(self) and all(_is_plain3x3(c) for c in (self.convc2, self.convf2, self.conv)):
             # the 3x3 convolutions write their channel blocks of the concatenated tensors in place (no torch.cat pass)
             o = ops.get()
-            cor1, flo1 = _conv_relu(self.convc1, corr), _conv_relu(self.convf1, flow)
+            flo1 = _conv_relu(self.convf1, flow)
             cf = o.conv3x3_cat([(cor1, self.convc2.weight, self.convc2.bias), (flo1, self.convf2.weight, self.convf2.bias)])
             return o.conv3x3_cat([(cf, self.conv.weight, self.conv.bias)], (flow,))
-        cor = _conv_relu(self.convc2, _conv_relu(self.convc1, corr))
+        cor = _conv_relu(self.convc2, cor1)
         flo = _conv_relu(self.convf2, _conv_relu(self.convf1, flow))
         out = _conv_relu(self.conv, torch.cat([cor, flo], dim=1))
         return torch.cat([out, flow], dim=1)
@@ -385,7 +410,7 @@ class RAFT(nn.Module):
         flow_up = None
         for itr in range(iters):
             coords1 = coords1.detach()  # the lookup gets no coordinate gradient (raft.py:122-123)
-            corr = corr_fn(coords1)
+            corr = LookupRef(corr_fn, coords1)   # evaluated inside the motion encoder (fused with convc1 where possible)
             flow = coords1 - coords0
             need_up = (not test_mode) or itr == iters - 1
             net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, want_mask=need_up,

@@ -103,7 +103,10 @@ def universal_case(g):
 
 def check_universal_against_golden(res, g, rel_l2):
     """Tolerance = 3x the reference's own 8-vs-3-thread spread, floored at 1e-3 (metrics, relative to
-    max(1, |ref|)) and at 1e-2 relative L2 (final perturbations)."""
+    max(1, |ref|)) and at 3e-2 relative L2 for the final perturbations: 44 L-BFGS closures amplify last-bit noise
+    chaotically -- the reference moves 0.4-0.6 % between two thread counts, and identical GPU runs land 0.4-2.4 % from
+    the reference from run to run (MIOpen's backward convolutions accumulate with atomics; measured with
+    tools/dev/univ_probe.py)."""
     import numpy as np
     assert abs(res["batches"][0]["aee_pred-tgt"] - g["aee_pred-tgt_t8"][0]) < 1e-3   # unattacked: deterministic
     assert abs(res["batches"][1]["aee_pred-tgt"] - g["aee_pred-tgt_t8"][1]) < 1e-3
@@ -117,5 +120,5 @@ def check_universal_against_golden(res, g, rel_l2):
             assert abs(got[i] - ref8[i]) <= tol, (key, i, got[i], ref8[i], ref3[i])
     for i, key in (("1", "delta1"), ("2", "delta2")):
         ref8, ref3 = torch.from_numpy(g["delta%s_b1_t8" % i]), torch.from_numpy(g["delta%s_b1_t3" % i])
-        tol = max(1e-2, 3 * rel_l2(ref3, ref8))
+        tol = max(3e-2, 3 * rel_l2(ref3, ref8))
         assert rel_l2(res[key].cpu(), ref8) <= tol, (key, rel_l2(res[key].cpu(), ref8), tol)

@@ -160,6 +160,53 @@ def test_corr_block_edge_cases():
     assert float(out[0, :, 0, 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 16, 20), (2, 32, 23, 37), (1, 256, 55, 128)])
+def test_lookup_convc1_fused_vs_unfused_and_oracle(oracle_ops, shape):
+    """pcfa_lookup_convc1_fwd / _bwd (lookup -> convc1 -> ReLU in one launch per direction, reference
+    models/raft/corr.py:29-50 + update.py:79-93) against (a) the un-fused HIP path lookup + F.conv2d (same taps bit for
+    bit, so only the fp32 summation order of the 324-term dot product differs: 1e-5 of the output range, gradients 2e-5
+    relative L2) and (b) the oracle on CPU.  Queries not a multiple of 32, two images, coordinates far outside."""
+    import torch.nn.functional as F
+    B, D, H, W = shape
+    gen = torch.Generator().manual_seed(H + W)
+    f1c, f2c = torch.randn(B, D, H, W, generator=gen), torch.randn(B, D, H, W, generator=gen)
+    wc = (torch.randn(256, 324, 1, 1, generator=gen) / 18.0)
+    bc = 0.1 * torch.randn(256, generator=gen)
+    coords = [_grid(B, H, W) + 2.5 * torch.randn(B, 2, H, W, generator=gen),
+              _grid(B, H, W) + 40 * torch.randn(B, 2, H, W, generator=gen)]
+    gos = [torch.randn(B, 256, H, W, generator=gen) for _ in coords]
+
+    def run(block_cls, dev, fused):
+        f1 = f1c.clone().to(dev).requires_grad_(True)
+        f2 = f2c.clone().to(dev).requires_grad_(True)
+        w, b = wc.to(dev), bc.to(dev)
+        blk = block_cls(f1, f2)
+        outs = []
+        for c in coords:
+            o = blk.lookup_conv_relu(c.to(dev), w, b, True) if fused else F.relu(F.conv2d(blk(c.to(dev)), w, b))
+            assert o is not None
+            outs.append(o)
+        sum((o * g.to(dev)).sum() for o, g in zip(outs, gos)).backward()
+        return [o.detach().cpu() for o in outs], f1.grad.cpu(), f2.grad.cpu()
+
+    of, g1f, g2f = run(hip_ops.CorrBlock, DEV, True)
+    ou, g1u, g2u = run(hip_ops.CorrBlock, DEV, False)
+    oc, g1c, g2c = run(oracle_ops.CorrBlock, "cpu", False)
+    omax = max(float(o.abs().max()) for o in oc)
+    for a, b, c in zip(of, ou, oc):
+        assert a.shape == c.shape
+        assert max_abs(a, b) <= 1e-5 * omax, max_abs(a, b) / omax
+        assert max_abs(a, c) <= 5e-5 * omax, max_abs(a, c) / omax
+        assert float(((a > 0) != (b > 0)).float().mean()) < 1e-4      # the ReLU masks agree (ties aside)
+    assert rel_l2(g1f, g1u) < 2e-5 and rel_l2(g2f, g2u) < 2e-5, (rel_l2(g1f, g1u), rel_l2(g2f, g2u))
+    # vs the CPU oracle the pyramid itself differs in the last bits (MKL sgemm vs the MFMA fma chain), which flips the
+    # ReLU of a few pre-activations that sit at zero: a handful of whole gradient rows appear / vanish (1e-3 at D = 256)
+    assert rel_l2(g1f, g1c) < 5e-3 and rel_l2(g2f, g2c) < 5e-3, (rel_l2(g1f, g1c), rel_l2(g2f, g2c))
+    # bit-reproducible (no atomics in the scatter)
+    of2, g1f2, g2f2 = run(hip_ops.CorrBlock, DEV, True)
+    assert all(torch.equal(a, b) for a, b in zip(of, of2)) and torch.equal(g1f, g1f2) and torch.equal(g2f, g2f2)
+
+
 # --------------------------------------------------------------------------- PWC cost volume
 @pytest.mark.parametrize("tag", ["pwc_a", "pwc_b", "pwc_c", "gen_a", "gen_b"])
 def test_spatial_corr_vs_reference_golden(tag):
