@@ -10,7 +10,8 @@ import json
 import os
 import sys
 
-OURS = ("corr_lookup_fwd", "corr_lookup_bwd", "gemm_f32_mfma", "f2ext_", "scorr_", "loss_partial", "box_fwd",
+OURS = ("corr_lookup_convc1_fwd", "corr_lookup_convc1_bwd", "corr_lookup_fwd", "corr_lookup_bwd", "scorr9_fwd",
+        "scorr9_bwd", "sum_n_kernel", "gemm_f32_mfma", "f2ext_", "scorr_", "loss_partial", "box_fwd",
         "deltas_fwd", "instnorm_stats_kernel<false>", "instnorm_stats_kernel<true>", "instnorm_apply_kernel<false>",
         "instnorm_apply_kernel<true>", "add_relu_kernel", "gru_gates_fwd", "gru_update_fwd")
 

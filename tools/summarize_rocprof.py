@@ -4,7 +4,7 @@ small enough to commit under profiles/.  Usage: summarize_rocprof.py <kernel_sta
 import csv
 import sys
 
-OURS = ("corr_lookup", "sepconv5", "lbfgs_", "gemm_f32_mfma", "f2ext", "splitk_reduce", "scorr_", "loss_", "box_", "deltas_", "gru_", "bias_relu", "relu_bwd", "null_kernel")
+OURS = ("corr_lookup", "scorr9", "sum_n", "conv3x3", "instnorm", "conv_fewin", "pwc_warp", "add_relu", "sepconv5", "lbfgs_", "gemm_f32_mfma", "f2ext", "splitk_reduce", "scorr_", "loss_", "box_", "deltas_", "gru_", "bias_relu", "relu_bwd", "null_kernel")
 
 
 def main():
