@@ -19,6 +19,7 @@
 //             corr_lookup_bwd: no atomics, bitwise reproducible.
 // Radius 4, 4 levels (the only configuration RAFT / GMA use, raft_config.json / gma_config.json); other shapes
 // return PCFA_ERR_UNSUPPORTED and the caller composes pcfa_corr_lookup_* with a convolution.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -35,6 +36,9 @@ constexpr int L = 4, TAPS = N1 * N1;                                 // 81 taps 
 constexpr int KL = 88, KG = KL / 8;                                  // padded tap rows per level, groups of 8 rows
 constexpr int KP = L * KL;                                           // 352 padded tap rows
 constexpr int WIN_FLOATS = QT * WS + 4;
+#ifndef PCFA_LC_WD
+#define PCFA_LC_WD 11  // depth of the forward kernel's W register ring (groups of 8 MFMAs per wave)
+#endif
 
 struct Origin {
   int x0, y0;
@@ -145,7 +149,7 @@ __global__ void convc1_pack_kernel(const float* __restrict__ w, float* __restric
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, const float* __restrict__ wp,
-    const float* __restrict__ bias, float* __restrict__ out, int Q, PyrLayout P, int relu) {
+    const float* __restrict__ bias, float* __restrict__ out, int Q, PyrLayout P, int relu, int dbg) {
   constexpr int COUT = 256, MTW = COUT / 32 / 4;     // m-tiles per wave (2)
   __shared__ __attribute__((aligned(16))) float s_win[WIN_FLOATS];
   __shared__ __attribute__((aligned(16))) float s_tap[2][KL][QT];
@@ -167,12 +171,14 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
     s_tap[buf][TAPS + rem / QT][rem % QT] = 0.f;
   }
 
-  // ---- every piece of all four levels is requested before anything waits ----
+  // ---- every piece of all four levels is requested before anything waits; coarsest level first: its windows are
+  //      L2-resident and land first, so the matrix cores start while the level-0 texels are still on their way ----
   f32x4 v[L][NPC];
   unsigned dst[L][NPC];
   float fxs[L], fys[L];
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
+  for (int lr = 0; lr < L; ++lr) {
+    const int l = L - 1 - lr;
     LevelGeo g;
     level_geometry(g, cx, cy, live, l, j, P, tid);
     fxs[l] = g.fx;
@@ -184,25 +190,26 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
     }
   }
 
-  f32x16 acc[MTW];
+  f32x16 acc[MTW];   // starts at the bias: the epilogue then has no dependent loads left
 #pragma unroll
   for (int m = 0; m < MTW; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[m][r] = bias[(wv * MTW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
   const f32x4* wq = reinterpret_cast<const f32x4*>(wp) + ((size_t)(wv * MTW) * (KP / 8)) * 64 + lane;
   // W operands: a register ring WD groups deep over the 44 groups of all four levels (the loops below are fully
   // unrolled, so every ring index is static).  One group = 4 k-pairs = 8 MFMAs of 64 cycles per wave; the loads come
   // from L2 (500-900 cycles), so the ring has to run >= 2 groups ahead -- with one group of lead the matrix pipe
   // idled for the load latency in every group (26 us per launch, 28 % of the fp32 matrix peak).
-  constexpr int WD = 4, NG = L * KG;
+  constexpr int WD = PCFA_LC_WD, NG = L * KG;
   f32x4 wring[WD][MTW];
 #pragma unroll
   for (int d = 0; d < WD; ++d)
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) wring[d][m] = wq[((size_t)m * (KP / 8) + d) * 64];
+    for (int m = 0; m < MTW; ++m) wring[d][m] = wq[((size_t)m * (KP / 8) + (L - 1 - d / KG) * KG + d % KG) * 64];
 
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
+  for (int lr = 0; lr < L; ++lr) {
+    const int l = L - 1 - lr;
     // ---- window images of level l -> LDS (sub-tile offset removed: per-lane unaligned dword stores) ----
     char* lds_bytes = reinterpret_cast<char*>(s_win);
 #pragma unroll
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
     }
     __syncthreads();
     // ---- thread (query j, window row b) blends its 9 taps; row 8 by the first 32 threads ----
-    {
+    if (!(dbg & 2)) {
       const float fx = fxs[l], fy = fys[l];
       const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
       float (*tap)[QT] = s_tap[l & 1];
@@ -236,20 +243,22 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
     }
     __syncthreads();   // taps of level l visible; the window image is free for level l + 1
     // ---- the level's share of W . taps: 11 groups of 4 k-pairs, 2 m-tiles per wave ----
-    {
+    if (!(dbg & 1)) {
       const float (*tap)[QT] = s_tap[l & 1];
 #pragma unroll
       for (int g = 0; g < KG; ++g) {
-        const int G = l * KG + g;                       // compile-time after unrolling
+        const int G = lr * KG + g;                      // position in the W stream (compile-time after unrolling)
         float bv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[e] = tap[8 * g + 2 * e + lh][l31];
         f32x4 wcur[MTW];
 #pragma unroll
         for (int m = 0; m < MTW; ++m) wcur[m] = wring[G % WD][m];
-        if (G + WD < NG) {
+        if (G + WD < NG) {   // group G + WD of the stream: level L-1 - (G+WD)/KG, group (G+WD) % KG
+          constexpr int dummy = 0; (void)dummy;
+          const int Gn = G + WD, ln = L - 1 - Gn / KG, gn = Gn % KG;
 #pragma unroll
-          for (int m = 0; m < MTW; ++m) wring[G % WD][m] = wq[((size_t)m * (KP / 8) + G + WD) * 64];
+          for (int m = 0; m < MTW; ++m) wring[G % WD][m] = wq[((size_t)m * (KP / 8) + ln * KG + gn) * 64];
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = (wv * MTW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      float y = acc[m][r] + bias[n];
+      float y = acc[m][r];
       if (relu) y = fmaxf(y, 0.f);
       if (qlive) ob[(size_t)n * Q] = y;
     }
@@ -497,8 +506,9 @@ extern "C" int pcfa_lookup_convc1_fwd(const float* pyr, const float* coords, con
     return PCFA_ERR_INVALID_ARG;
   if (num_levels != L || radius != R || Cout != 256) return PCFA_ERR_UNSUPPORTED;
   const int Q = H * W;
+  static const int dbg = getenv("PCFA_LC_DBG") ? atoi(getenv("PCFA_LC_DBG")) : 0;   // phase ablation (tools/dev)
   pcfa_launch(corr_lookup_convc1_fwd_kernel, dim3(pcfa_cdiv(Q, QT), 1, B), dim3(NT), 0, (hipStream_t)stream, pyr,
-              coords, packed, bias, out, Q, P, relu);
+              coords, packed, bias, out, Q, P, relu, dbg);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
