@@ -15,6 +15,7 @@
 // 8 input channels x 5 taps through an LDS double buffer.  The global loads of a stage are issued three stages
 // before its MFMAs (ring of four register sets): with one or two workgroups per CU nothing else hides the
 // L2/HBM latency.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -79,12 +80,21 @@ __device__ __forceinline__ f32x4 keep_if(bool ok, f32x4 v) {
 // unconditional float4/dword from a clamped (always valid) address and zero padding is applied when the value
 // is written to LDS -- no branch sits between a load and its use, so the loads really stay in flight across
 // stages.  The generic variant keeps predicated element-wise loads for ragged shapes.
-template <bool VERT, bool FAST>
-__global__ __launch_bounds__(256) void sepconv5_kernel(Operand in, const float* __restrict__ wp,
-                                                       OutSplit out, int Cout, int H, int W,
-                                                       int tiles_x, int vec_w, int vec_x) {
-  __shared__ __attribute__((aligned(16))) float sA[2][A_TILE];
-  __shared__ __attribute__((aligned(16))) float sB[2][VERT ? B_TILE_V : B_TILE_H];
+// KS = 2: in-workgroup split-K.  Two groups of four waves run the same pipeline on the two halves of the input
+// channels (own LDS stages, shared barriers) and the second group's accumulators are added through LDS at the end, in
+// a fixed order.  For launches whose grid is smaller than the chip (the q convolutions: 220 workgroups = one 4-wave
+// workgroup on 220 of 256 CUs, one wave per SIMD and nothing to hide a barrier or an LDS wait behind) this doubles the
+// waves per CU without changing the tile count.
+template <bool VERT, bool FAST, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const float* __restrict__ wp,
+                                                            OutSplit out, int Cout, int H, int W,
+                                                            int tiles_x, int vec_w, int vec_x) {
+  static_assert(KS == 1 || FAST, "split-K rides on the branch-free staging path");
+  __shared__ __attribute__((aligned(16))) float sA_[KS][2][A_TILE];
+  __shared__ __attribute__((aligned(16))) float sB_[KS][2][VERT ? B_TILE_V : B_TILE_H];
+  const int kgrp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);   // which half of K this wave group owns
+  float (*sA)[A_TILE] = sA_[kgrp];
+  float (*sB)[VERT ? B_TILE_V : B_TILE_H] = sB_[kgrp];
 
   const long long plane = (long long)H * W;
   const int y = blockIdx.x / tiles_x;
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(256) void sepconv5_kernel(Operand in, const float* 
   out.a += (long long)blockIdx.z * out.Ca * plane;
   if (out.b) out.b += (long long)blockIdx.z * (Cout - out.Ca) * plane;
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -213,22 +223,23 @@ __global__ __launch_bounds__(256) void sepconv5_kernel(Operand in, const float* 
       }
   };
 
-  const int nstage = (in.Cin + KC - 1) / KC;
+  const int nstage = (in.Cin + KC - 1) / KC / KS;   // stages of this wave group (host: Cin % (KC * NR * KS) == 0)
+  const int cbase = kgrp * nstage * KC;             // its first input channel
   f32x4 ring_a[NR][A_REGS], ring_b[NR][BV_REGS];
   float ring_h[NR];
   if (FAST) {
     // nstage % NR == 0: the unrolled body has no branch at all.  Stages past the end re-load the last one
     // (clamped) and store it to the idle LDS buffer; nothing reads it.
-    const int last = (nstage - 1) * KC;
+    const int last = cbase + (nstage - 1) * KC;
 #pragma unroll
-    for (int j = 0; j < NR - 1; ++j) load_stage(ring_a[j], ring_b[j], ring_h[j], min(j * KC, last));
+    for (int j = 0; j < NR - 1; ++j) load_stage(ring_a[j], ring_b[j], ring_h[j], min(cbase + j * KC, last));
     store_stage(ring_a[0], ring_b[0], ring_h[0], 0);
     __syncthreads();
     for (int s0 = 0; s0 < nstage; s0 += NR) {
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         load_stage(ring_a[(j + NR - 1) % NR], ring_b[(j + NR - 1) % NR], ring_h[(j + NR - 1) % NR],
-                   min((s0 + j + NR - 1) * KC, last));
+                   min(cbase + (s0 + j + NR - 1) * KC, last));
         compute_stage(j & 1);
         store_stage(ring_a[(j + 1) % NR], ring_b[(j + 1) % NR], ring_h[(j + 1) % NR], (j + 1) & 1);
         __syncthreads();
@@ -255,6 +266,18 @@ __global__ __launch_bounds__(256) void sepconv5_kernel(Operand in, const float* 
         }
       }
     }
+  }
+
+  if (KS == 2) {   // second half of K -> LDS -> added by the first group (fixed order: deterministic)
+    float* red = &sA_[0][0][0];                     // 4 waves x 16 x 64 floats = 16 KB <= the first group's A stages
+    if (kgrp == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kgrp == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[(wave * 16 + r) * 64 + lane];
   }
 
   // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -358,6 +381,17 @@ static int sepconv5_launch(const float* in_a, int Ca, const float* in_b, int Cb,
   dim3 grid((unsigned)gx, pcfa_cdiv(Cout, TM), B), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool fast = vec_w && vec_x && (Ca + Cb) % (KC * NR) == 0 && Cout >= 4 && W >= 4;
+  // fewer workgroups than CUs (x 1.25): split K inside the workgroup (8 waves per tile)
+  static const int ks_env = getenv("PCFA_SEPCONV_KS") ? atoi(getenv("PCFA_SEPCONV_KS")) : 0;   // tuning override
+  const long long nwg = gx * pcfa_cdiv(Cout, TM) * B;
+  const bool split2 = fast && (Ca + Cb) % (KC * NR * 2) == 0 && (ks_env ? ks_env == 2 : nwg <= 320);
+  if (split2) {
+    dim3 block2(512);
+    if (vertical) pcfa_launch(sepconv5_kernel<true, true, 2>, grid, block2, 0, s, in, w_packed, out, Cout, H, W, tiles_x, vec_w, vec_x);
+    else pcfa_launch(sepconv5_kernel<false, true, 2>, grid, block2, 0, s, in, w_packed, out, Cout, H, W, tiles_x, vec_w, vec_x);
+    PCFA_LAUNCH_CHECK();
+    return PCFA_OK;
+  }
 #define PCFA_SEPCONV5(V, F) \
   pcfa_launch(sepconv5_kernel<V, F>, grid, block, 0, s, in, w_packed, out, Cout, H, W, tiles_x, vec_w, vec_x)
   if (vertical) {
