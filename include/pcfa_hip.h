@@ -122,6 +122,23 @@ PCFA_API int pcfa_corr_lookup_fwd(const float* pyr, const float* coords, float* 
 PCFA_API int pcfa_corr_lookup_bwd(float* dpyr, const float* coords, const float* grad_out, int B, int H,
                          int W, int num_levels, int radius, void* stream);
 
+/* GMA attention products and softmax (models/gma/gma.py:34-77 Attention, :79-115 Aggregate).
+ * pcfa_gemm_f32: C[b][m][n] = alpha * sum_k A(m,k) B(k,n) on the fp32 matrix cores (the pyramid's GEMM core, exact
+ * fp32 products).  a_kmajor 0: A stored [M][K] (lda = row stride), 1: stored [K][M]; b_kmajor 0: B stored [N][K],
+ * 1: stored [K][N]; (a_kmajor, b_kmajor) = (1, 0) is PCFA_ERR_UNSUPPORTED.  splits > 1: split-K through `workspace`
+ * (pcfa_gemm_f32_workspace_bytes) with an ordered reduction; C must then be dense (ldc = N).
+ *   sim = alpha * q k^T           (0,0)      out = attn v              (0,1)
+ *   dv  = attn^T g                (1,1)      d_attn = [g_1|..|g_6] [v_1|..|v_6]^T   (0,0), ONE product for all iterations
+ * pcfa_softmax_rows_fwd / _bwd: y = softmax(x) along the last axis, gx = y * (gy - sum_j gy_j y_j); a row stays in
+ * registers: one read and one write of the [rows][cols] matrix per direction; x / y and gy / gx may alias. */
+PCFA_API size_t pcfa_gemm_f32_workspace_bytes(int M, int N, int batch, int splits);
+PCFA_API int pcfa_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long long lda, long long ldb,
+                  long long ldc, int a_kmajor, int b_kmajor, int batch, long long bsA, long long bsB, long long bsC,
+                  float alpha, int splits, void* workspace, size_t workspace_bytes, void* stream);
+PCFA_API int pcfa_softmax_rows_fwd(const float* x, float* y, long long rows, int cols, void* stream);
+PCFA_API int pcfa_softmax_rows_bwd(const float* y, const float* grad_y, float* grad_x, long long rows, int cols,
+                          void* stream);
+
 /* Lookup fused with the motion encoder's first layer:
  *   out = relu?(convc1(CorrBlock.__call__(coords)))   models/raft/corr.py:29-50 feeding models/raft/update.py:79-93
  *   (convc1 = Conv2d(4*81, 256, 1)); identical in models/gma.

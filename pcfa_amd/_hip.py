@@ -37,6 +37,11 @@ SIGNATURES = {
     "pcfa_corr_pyramid_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_corr_lookup_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_corr_lookup_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_gemm_f32_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "pcfa_gemm_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_int, c_int, c_int,
+                              c_longlong, c_longlong, c_longlong, c_float, c_int, _P, c_size_t, _P]),
+    "pcfa_softmax_rows_fwd": (c_int, [_P, _P, c_longlong, c_int, _P]),
+    "pcfa_softmax_rows_bwd": (c_int, [_P, _P, _P, c_longlong, c_int, _P]),
     "pcfa_lookup_convc1_packed_floats": (c_longlong, [c_int]),
     "pcfa_lookup_convc1_pack_weights": (c_int, [_P, _P, c_int, c_int, _P]),
     "pcfa_lookup_convc1_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -21,7 +21,12 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
+#ifndef PCFA_GEMM_BK
+#define PCFA_GEMM_BK 16
+#endif
+constexpr int BM = 128, BN = 128, BK = PCFA_GEMM_BK;
+constexpr int NLD = BK / 8;   // float4 per thread and operand tile (128 x BK floats over 256 threads)
+constexpr int KV = BK / 4;    // float4 per row of a k-contiguous operand tile
 constexpr int LDS_KM = 132;  // row stride (floats) when the operand arrives k-major (b128 writes)
 constexpr int LDS_MK = 130;  // row stride when transposing on the way in (conflict-free b32 writes)
 
@@ -29,18 +34,18 @@ constexpr int LDS_MK = 130;  // row stride when transposing on the way in (confl
 // KMAJ: stored [K][dim] (dim contiguous) ; else stored [dim][K] (k contiguous).
 template <bool KMAJ>
 __device__ __forceinline__ void tile_load(const float* __restrict__ X, long long ld, int dim,
-                                          int d0, int k0, int kend, bool vec, float4 (&r)[2]) {
+                                          int d0, int k0, int kend, bool vec, float4 (&r)[NLD]) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = tid + 256 * i;
     int k, d;
     if (KMAJ) {
       k = k0 + f / 32;
       d = d0 + (f % 32) * 4;
     } else {
-      d = d0 + f / 4;
-      k = k0 + (f % 4) * 4;
+      d = d0 + f / KV;
+      k = k0 + (f % KV) * 4;
     }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KMAJ) {
@@ -79,10 +84,10 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ X, long long
 // written to LDS.
 template <bool KMAJ>
 __device__ __forceinline__ void tile_load_fast(const float* __restrict__ X, long long ld, int dim, int d0, int k0,
-                                               int kend, float4 (&r)[2]) {
+                                               int kend, float4 (&r)[NLD]) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = tid + 256 * i;
     int k, d;
     if (KMAJ) {
@@ -90,36 +95,36 @@ __device__ __forceinline__ void tile_load_fast(const float* __restrict__ X, long
       d = min(d0 + (f % 32) * 4, dim - 4);
       r[i] = *reinterpret_cast<const float4*>(X + (long long)k * ld + d);
     } else {
-      d = min(d0 + f / 4, dim - 1);
-      k = min(k0 + (f % 4) * 4, kend - 4);
+      d = min(d0 + f / KV, dim - 1);
+      k = min(k0 + (f % KV) * 4, kend - 4);
       r[i] = *reinterpret_cast<const float4*>(X + (long long)d * ld + k);
     }
   }
 }
 
 template <bool KMAJ>
-__device__ __forceinline__ void tile_mask(int dim, int d0, int k0, int kend, float4 (&r)[2]) {
+__device__ __forceinline__ void tile_mask(int dim, int d0, int k0, int kend, float4 (&r)[NLD]) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = tid + 256 * i;
     const bool ok = KMAJ ? (k0 + f / 32 < kend && d0 + (f % 32) * 4 < dim)
-                         : (d0 + f / 4 < dim && k0 + (f % 4) * 4 < kend);
+                         : (d0 + f / KV < dim && k0 + (f % KV) * 4 < kend);
     if (!ok) r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
 template <bool KMAJ>
-__device__ __forceinline__ void tile_store(float* __restrict__ s, const float4 (&r)[2]) {
+__device__ __forceinline__ void tile_store(float* __restrict__ s, const float4 (&r)[NLD]) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = tid + 256 * i;
     if (KMAJ) {
       const int k = f / 32, d = (f % 32) * 4;
       *reinterpret_cast<float4*>(s + k * LDS_KM + d) = r[i];
     } else {
-      const int d = f / 4, k = (f % 4) * 4;
+      const int d = f / KV, k = (f % KV) * 4;
       s[(k + 0) * LDS_MK + d] = r[i].x;
       s[(k + 1) * LDS_MK + d] = r[i].y;
       s[(k + 2) * LDS_MK + d] = r[i].z;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[2], rb[2];
+  float4 ra[NLD], rb[NLD];
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
     if (FAST) {
@@ -472,3 +477,64 @@ extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, cons
   }
   return PCFA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same GEMM core for GMA's attention products (models/gma/gma.py:34-77 Attention, :79-115
+// Aggregate, used models/gma/update.py:128-130):
+//   C[b][m][n] = alpha * sum_k A(m,k) B(k,n)        exact fp32 products on v_mfma_f32_32x32x2_f32
+// a_kmajor: 0 = A stored [M][K] (k contiguous, lda = row stride), 1 = stored [K][M];  b_kmajor: 0 = B stored [N][K],
+// 1 = stored [K][N].  splits > 1: split-K into `workspace` ([splits][batch][M][N] floats) + an ordered reduction
+// (deterministic) -- for the N = 128 products of Aggregate, whose 128x128 tiles would otherwise be 55 workgroups.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t pcfa_gemm_f32_workspace_bytes(int M, int N, int batch, int splits) {
+  if (M < 1 || N < 1 || batch < 1 || splits < 2) return 0;
+  return sizeof(float) * (size_t)splits * batch * M * N;
+}
+
+extern "C" int pcfa_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long long lda,
+                             long long ldb, long long ldc, int a_kmajor, int b_kmajor, int batch, long long bsA,
+                             long long bsB, long long bsC, float alpha, int splits, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || splits < 1 || alpha == 0.f)
+    return PCFA_ERR_INVALID_ARG;
+  if (a_kmajor == 0 && b_kmajor != 0 && b_kmajor != 1) return PCFA_ERR_INVALID_ARG;
+  if (a_kmajor == 1 && b_kmajor == 0) return PCFA_ERR_UNSUPPORTED;   // no call site; not instantiated
+  hipStream_t s = (hipStream_t)stream;
+  float* dst = C;
+  long long bsD = bsC, ssD = 0, ldd = ldc;
+  int kchunk = ((K + BK - 1) / BK) * BK;
+  if (splits > 1) {
+    if (!workspace || workspace_bytes < pcfa_gemm_f32_workspace_bytes(M, N, batch, splits)) return PCFA_ERR_WORKSPACE;
+    if (ldc != N || (batch > 1 && bsC != (long long)M * N)) return PCFA_ERR_UNSUPPORTED;   // dense C for the reduction
+    dst = (float*)workspace;
+    bsD = (long long)M * N;
+    ssD = (long long)batch * M * N;
+    ldd = N;
+    kchunk = choose_kchunk(K, splits);
+  }
+  const int vecA = aligned16(A) && lda % 4 == 0 && (a_kmajor ? M % 4 == 0 : K % 4 == 0) && bsA % 4 == 0;
+  const int vecB = aligned16(B) && ldb % 4 == 0 && (b_kmajor ? N % 4 == 0 : K % 4 == 0) && bsB % 4 == 0;
+  const bool fast = vecA && vecB && K % 4 == 0 && M >= 4 && N >= 4 && K >= 4;
+  dim3 grid(pcfa_cdiv(N, BN), pcfa_cdiv(M, BM), batch * splits);
+  const float div = 1.0f / alpha;
+#define PCFA_GEMM_ARGS A, B, dst, M, N, K, lda, ldb, ldd, bsA, bsB, bsD, splits, kchunk, ssD, div, vecA, vecB
+#define PCFA_GEMM_GO(AK, BK_)                                                                                \
+  do {                                                                                                       \
+    if (fast) pcfa_launch(gemm_f32_mfma_kernel<AK, BK_, true>, grid, dim3(256), 0, s, PCFA_GEMM_ARGS);       \
+    else pcfa_launch(gemm_f32_mfma_kernel<AK, BK_, false>, grid, dim3(256), 0, s, PCFA_GEMM_ARGS);           \
+  } while (0)
+  if (a_kmajor && b_kmajor) PCFA_GEMM_GO(true, true);
+  else if (!a_kmajor && b_kmajor) PCFA_GEMM_GO(false, true);
+  else PCFA_GEMM_GO(false, false);
+#undef PCFA_GEMM_GO
+#undef PCFA_GEMM_ARGS
+  PCFA_LAUNCH_CHECK();
+  if (splits > 1) {
+    const long long n = (long long)batch * M * N;
+    pcfa_launch(splitk_reduce_kernel, dim3(min(pcfa_cdiv(n, 256), 2048)), dim3(256), 0, s, (const float*)workspace, C,
+                n, splits, n);
+    PCFA_LAUNCH_CHECK();
+  }
+  return PCFA_OK;
+}
+

@@ -53,6 +53,12 @@ class Attention(nn.Module):
         # 'b (h d) x y -> b h (x y) d'
         q = q.reshape(b, heads, -1, h * w).transpose(-1, -2)
         k = k.reshape(b, heads, -1, h * w).transpose(-1, -2)
+        o = ops.get()
+        if (hasattr(o, "attention_softmax") and not getattr(self.args, "position_only", False)
+                and not getattr(self.args, "position_and_content", False)):
+            # similarity product on the fp32 matrix cores, row softmax with one read + one write of the [N, N] matrix
+            # (pcfa_gemm_f32 + pcfa_softmax_rows_*); scale applied to the product instead of to q (gma.py:59)
+            return o.attention_softmax(q.contiguous(), k.contiguous(), self.scale)
         q = self.scale * q
         if getattr(self.args, "position_only", False):
             sim = self.pos_emb(q.reshape(b, heads, h, w, -1)).reshape(b, heads, h * w, h * w)
@@ -120,8 +126,12 @@ class Aggregate(nn.Module):
         b, c, h, w = fmap.shape
         heads = self.heads
         v = self.to_v(fmap).reshape(b, heads, -1, h * w).transpose(-1, -2)  # b h (x y) d
+        o = ops.get()
         if shared is not None and torch.is_grad_enabled() and attn.requires_grad:
-            out = _AttnTimesValue.apply(attn, v.contiguous(), shared)        # b h (x y) d
+            if hasattr(o, "AttnGradShare") and isinstance(shared, o.AttnGradShare):
+                out = o.attn_times_value(attn, v, shared)                    # b h (x y) d, hand-written GEMM path
+            else:
+                out = _AttnTimesValue.apply(attn, v.contiguous(), shared)
         else:
             out = torch.matmul(attn, v)
         out = out.transpose(-1, -2).reshape(b, -1, h, w)                     # b (h d) x y
@@ -194,7 +204,8 @@ class RAFTGMA(nn.Module):
         gru_ctx = gru.per_iteration(gru.precompute(inp), iters) if gru.frozen() else None
         flow_predictions = []
         flow_up = None
-        attn_grad = _SharedAttnGrad()  # one accumulation buffer for the gradient of `attention` (used `iters` times)
+        o = ops.get()   # the gradient of `attention` (used `iters` times) is formed once, by the last node that runs
+        attn_grad = o.AttnGradShare() if hasattr(o, "AttnGradShare") else _SharedAttnGrad()
         for itr in range(iters):
             coords1 = coords1.detach()
             corr = LookupRef(corr_fn, coords1)

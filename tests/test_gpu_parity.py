@@ -207,6 +207,47 @@ def test_lookup_convc1_fused_vs_unfused_and_oracle(oracle_ops, shape):
     assert all(torch.equal(a, b) for a, b in zip(of, of2)) and torch.equal(g1f, g1f2) and torch.equal(g2f, g2f2)
 
 
+@pytest.mark.parametrize("gemm", ["lib", "hip"])
+def test_gma_attention_ops_vs_torch(gemm, monkeypatch):
+    """SURVEY 8f row f1 (models/gma/gma.py:34-77 Attention, :79-115 Aggregate): similarity product + row softmax and
+    the attention-times-value products on the hand-written fp32 MFMA GEMM, against torch in float64.
+    N = 1000 (not a multiple of 128: ragged tiles, rows held in registers) and 2 heads."""
+    monkeypatch.setenv("PCFA_GMA_GEMM", gemm)   # plain products on rocBLAS (default) or on pcfa_gemm_f32
+    gen = torch.Generator().manual_seed(3)
+    h, n, d = 2, 1000, 128
+    q = torch.randn(1, h, n, d, generator=gen).to(DEV).requires_grad_(True)
+    k = torch.randn(1, h, n, d, generator=gen).to(DEV).requires_grad_(True)
+    vs = [torch.randn(1, h, n, d, generator=gen).to(DEV).requires_grad_(True) for _ in range(3)]
+    gos = [torch.randn(1, h, n, d, generator=gen).to(DEV) for _ in range(3)]
+    scale = d ** -0.5
+    attn = hip_ops.attention_softmax(q, k, scale)
+    share = hip_ops.AttnGradShare()
+    outs = [hip_ops.attn_times_value(attn, v, share) for v in vs]
+    sum((o * g).sum() for o, g in zip(outs, gos)).backward()
+    qd, kd = q.detach().double().requires_grad_(True), k.detach().double().requires_grad_(True)
+    vd = [v.detach().double().requires_grad_(True) for v in vs]
+    attn_d = torch.softmax(scale * qd @ kd.transpose(-1, -2), dim=-1)
+    outs_d = [attn_d @ v for v in vd]
+    sum((o * g.double()).sum() for o, g in zip(outs_d, gos)).backward()
+    assert max_abs(attn, attn_d) <= 2e-6 * float(attn_d.max())
+    assert float((attn.sum(-1) - 1).abs().max()) < 1e-5
+    for o, od in zip(outs, outs_d):
+        assert rel_l2(o, od) < 2e-6
+    for v, w in zip(vs, vd):
+        assert rel_l2(v.grad, w.grad) < 2e-6
+    assert rel_l2(q.grad, qd.grad) < 1e-5 and rel_l2(k.grad, kd.grad) < 1e-5
+    # generic softmax fallback (columns not a multiple of 4) and the plain GEMM entry with every layout
+    x = torch.randn(7, 1001, generator=gen).to(DEV)
+    y = torch.empty_like(x)
+    hip_ops._call("pcfa_softmax_rows_fwd", hip_ops._ptr(x), hip_ops._ptr(y), 7, 1001)
+    assert max_abs(y, torch.softmax(x.double(), -1)) < 1e-6
+    a, b = torch.randn(70, 50, generator=gen).to(DEV), torch.randn(50, 33, generator=gen).to(DEV)
+    want = a.double() @ b.double()
+    assert rel_l2(hip_ops.gemm_f32(a, b, 0, 1), want) < 1e-6
+    assert rel_l2(hip_ops.gemm_f32(a, b.t().contiguous(), 0, 0), want) < 1e-6
+    assert rel_l2(hip_ops.gemm_f32(a.t().contiguous(), b, 1, 1, alpha=0.5, splits=3), 0.5 * want) < 1e-6
+
+
 # --------------------------------------------------------------------------- PWC cost volume
 @pytest.mark.parametrize("tag", ["pwc_a", "pwc_b", "pwc_c", "gen_a", "gen_b"])
 def test_spatial_corr_vs_reference_golden(tag):
