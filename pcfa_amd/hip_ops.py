@@ -204,7 +204,7 @@ def _call(name, *args):
 # --------------------------------------------------------------------------- #
 class _CorrState:
     """Device buffers shared by the build node and its lookup nodes."""
-    __slots__ = ("B", "D", "H", "W", "L", "r", "slab", "pyr", "f2ext", "dpyr")
+    __slots__ = ("B", "D", "H", "W", "L", "r", "slab", "pyr", "f2ext", "dpyr", "token_grad")
 
 
 class _CorrBuild(torch.autograd.Function):
@@ -237,6 +237,7 @@ class _CorrBuild(torch.autograd.Function):
         (f1,) = ctx.saved_tensors
         if st.dpyr is None:  # no lookup contributed a gradient
             z = torch.zeros_like(f1)
+            st.token_grad = None
             return z, z.clone(), None
         lib = _hip.load()
         B, D, H, W = st.B, st.D, st.H, st.W
@@ -247,7 +248,18 @@ class _CorrBuild(torch.autograd.Function):
         _call("pcfa_corr_pyramid_bwd", _ptr(st.dpyr), _ptr(f1), _ptr(st.f2ext), _ptr(df1), _ptr(df2),
                                              _ptr(ws), ctypes.c_size_t(nbytes), B, D, H, W, st.L)
         st.dpyr = None
+        st.token_grad = None
         return df1, df2, None
+
+
+def _token_grad(st, device):
+    """The 1-element token only orders the build node behind every lookup node: ONE lookup per backward pass hands it a
+    (zero) gradient, the others return None -- twelve zeros(1) fills and eleven 1-element accumulations per closure
+    otherwise (each a kernel launch)."""
+    if st.token_grad is None:
+        st.token_grad = torch.zeros(1, device=device, dtype=torch.float32)
+        return st.token_grad
+    return None
 
 
 class _CorrLookup(torch.autograd.Function):
@@ -277,7 +289,7 @@ class _CorrLookup(torch.autograd.Function):
             st.dpyr = torch.zeros_like(st.pyr)
         g = grad_out.contiguous()
         _call("pcfa_corr_lookup_bwd", _ptr(st.dpyr), _ptr(c), _ptr(g), st.B, st.H, st.W, st.L, st.r)
-        return torch.zeros(1, device=g.device, dtype=torch.float32), None, None
+        return _token_grad(st, g.device), None, None
 
 
 _convc1_packs = {}
@@ -329,7 +341,7 @@ class _CorrLookupConv(torch.autograd.Function):
         g = grad_out.contiguous()
         _call("pcfa_lookup_convc1_bwd", _ptr(st.dpyr), _ptr(c), _ptr(ctx.packed), _ptr(out), _ptr(g), st.B, st.H, st.W,
               st.L, st.r, ctx.cout, ctx.relu)
-        return torch.zeros(1, device=g.device, dtype=torch.float32), None, None, None, None, None
+        return _token_grad(st, g.device), None, None, None, None, None
 
 
 class CorrBlock:
@@ -349,6 +361,7 @@ class CorrBlock:
         if st.slab <= 0 or (st.H >> (num_levels - 1)) < 1 or (st.W >> (num_levels - 1)) < 1:
             raise ValueError("feature map %dx%d too small for %d pyramid levels" % (st.H, st.W, num_levels))
         st.dpyr = None
+        st.token_grad = None
         self._state = st
         self._token = _CorrBuild.apply(fmap1, fmap2, st)
 

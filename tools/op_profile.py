@@ -27,7 +27,7 @@ def main():
     tot = sum(e.self_device_time_total for e in rows)
     print("total self device time %.2f ms" % (tot / 1e3))
     print("%-44s %6s %10s %6s  %s" % ("op", "calls", "dev_us", "pct", "input shapes"))
-    for e in rows[:90]:
+    for e in rows[:160]:
         if e.self_device_time_total <= 0:
             continue
         print("%-44s %6d %10.1f %6.2f  %s" % (e.key[:44], e.count, e.self_device_time_total,
