@@ -152,7 +152,20 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
   C += batch * bsC + split * ssC;
   const int kbeg = split * kchunk;
   const int kend = min(K, kbeg + kchunk);
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the 8
+  // XCDs, so consecutive linear ids land on different L2s; remapped, every XCD walks a contiguous band of tile rows
+  // and re-reads its A band / the streamed B tiles from its own L2.  Speed only -- any placement is correct.
+  int by = blockIdx.y, bx = blockIdx.x;
+#ifndef PCFA_GEMM_NO_XCD
+  {
+    const int nx = gridDim.x, nwg = nx * gridDim.y;
+    const int orig = by * nx + bx, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    by = wg / nx;
+    bx = wg - by * nx;
+  }
+#endif
+  const int m0 = by * BM, n0 = bx * BN;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;

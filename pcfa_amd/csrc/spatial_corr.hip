@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void scorr9_bwd_kernel(const float* __restrict
   constexpr int NT = 256;
   constexpr int BCPT = BCG * QW * BTH / NT;      // channels per thread
   static_assert(QW * BTH * (BCG / BCPT) == NT, "thread map");
-  __shared__ __attribute__((aligned(16))) float Gs[PS * PS][BTH][BTW];
+  constexpr int GW = BTW + 2 * R;   // tap rows carry the halo columns: grad_in2 reads them shifted by ex (below)
+  __shared__ __attribute__((aligned(16))) float Gs[PS * PS][BTH][GW];
   __shared__ __attribute__((aligned(16))) float Xs[BCG][HH2][HW2];
 
   const int ngroups = (C + BCG - 1) / BCG;
@@ -320,37 +321,39 @@ __global__ __launch_bounds__(256) void scorr9_bwd_kernel(const float* __restrict
           t.x = f[k].x > 0.f ? t.x : t.x * slope; t.y = f[k].y > 0.f ? t.y : t.y * slope;
           t.z = f[k].z > 0.f ? t.z : t.z * slope; t.w = f[k].w > 0.f ? t.w : t.w * slope;
         }
-        if (d < PS * PS) *reinterpret_cast<f32x4*>(&Gs[d][0][0] + 4 * gp_) = gvalid ? t : (f32x4)(0.f);
+        if (d < PS * PS) *reinterpret_cast<f32x4*>(&Gs[d][gp_ / QW][4 * (gp_ % QW)]) = gvalid ? t : (f32x4)(0.f);
       }
     } else {
-      // G[e][p] = g[8 - e][p + e - 4]: rows shifted by ex - 4, so single floats (coalesced, unaligned).
-      // thread = (tap lane, pixel of the 2 x 32 tile): 4 taps per pass, 21 passes
-      // one batch for the 2-row tile: every tap load of the thread is in flight at once (three batches of 7 were
-      // three dependent round trips on the critical path of half the workgroups)
-      constexpr int GP = BTH * BTW, GL = NT / GP, UG = BTH == 2 ? 21 : 14;   // 64 pixels, 4 lanes  /  128, 2
-      const int gl = tid / GP, px = tid - gl * GP;
-      const int py = y0 + px / BTW - R, pxx = x0 + px % BTW - R;
-#pragma unroll 1
-      for (int d0 = gl; d0 < PS * PS; d0 += GL * UG) {
-        float g[UG], f[UG];
-        bool okg[UG];
+      // G[e][p] = g[8 - e][p + e - 4]: tap plane e is plane 8 - e of grad_out read at rows r + ey - 4 and columns
+      // x + ex - 4.  The shift by ex is NOT applied here: the aligned 40-float segment [x0 - 4, x0 + 36) of every row
+      // is staged as ten 16-B pieces (Gs[e][r][0..39]) and the FMA loop reads G at column 4q + ex + p.  (The first
+      // version staged the shifted rows float by float: 42 dword loads per thread with the mask re-read, half of every
+      // launch -- profiles/r02_scorr_microbench_and_ablation.txt.)
+      constexpr int NPI = PS * PS * BTH * (GW / 4);            // 1620 pieces for the 2-row tile
+      constexpr int UG = (NPI + NT - 1) / NT;                  // 7 per thread
+      f32x4 g[UG], f[UG];
+      bool okg[UG];
 #pragma unroll
-        for (int k = 0; k < UG; ++k) {
-          const int d = d0 + k * GL;
-          const int ey = d / PS, ex = d - ey * PS;
-          const int gy = py + ey, gx = pxx + ex;
-          okg[k] = d < PS * PS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-          const size_t off = okg[k] ? (size_t)(PS * PS - 1 - d) * plane + (size_t)(gy * W + gx) : 0;
-          g[k] = gb[off];
-          f[k] = fb ? fb[off] : 1.f;
-        }
+      for (int k = 0; k < UG; ++k) {
+        const int e = tid + k * NT;
+        const int d = e / (BTH * (GW / 4)), rem = e - d * (BTH * (GW / 4));
+        const int rr = rem / (GW / 4), m = rem - rr * (GW / 4);
+        const int ey = d / PS;
+        const int gy = y0 + rr + ey - R, gx = x0 - R + 4 * m;
+        okg[k] = e < NPI && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t off = okg[k] ? (size_t)(PS * PS - 1 - d) * plane + (size_t)(gy * W + gx) : 0;
+        g[k] = *reinterpret_cast<const f32x4*>(gb + off);
+        f[k] = fb ? *reinterpret_cast<const f32x4*>(fb + off) : (f32x4)(1.f);
+      }
 #pragma unroll
-        for (int k = 0; k < UG; ++k) {
-          const int d = d0 + k * GL;
-          float t = g[k] * gscale;
-          if (fb) t = f[k] > 0.f ? t : t * slope;
-          if (d < PS * PS) (&Gs[d][0][0])[px] = okg[k] ? t : 0.f;
+      for (int k = 0; k < UG; ++k) {
+        const int e = tid + k * NT;
+        f32x4 t = g[k] * gscale;
+        if (fb) {
+          t.x = f[k].x > 0.f ? t.x : t.x * slope; t.y = f[k].y > 0.f ? t.y : t.y * slope;
+          t.z = f[k].z > 0.f ? t.z : t.z * slope; t.w = f[k].w > 0.f ? t.w : t.w * slope;
         }
+        if (e < NPI) *reinterpret_cast<f32x4*>(&Gs[0][0][0] + 4 * e) = okg[k] ? t : (f32x4)(0.f);
       }
     }
     if (xl < XL) {
@@ -371,8 +374,16 @@ __global__ __launch_bounds__(256) void scorr9_bwd_kernel(const float* __restrict
 #pragma unroll 1
   for (int ey = 0; ey < ((dbg & 2) ? 0 : PS); ++ey) {
     f32x4 G[PS];
+    if (which == 0) {
 #pragma unroll
-    for (int ex = 0; ex < PS; ++ex) G[ex] = *reinterpret_cast<const f32x4*>(&Gs[ey * PS + ex][r][4 * q]);
+      for (int ex = 0; ex < PS; ++ex) G[ex] = *reinterpret_cast<const f32x4*>(&Gs[ey * PS + ex][r][4 * q]);
+    } else {   // shifted by ex: unaligned, four dword reads per tap
+#pragma unroll
+      for (int ex = 0; ex < PS; ++ex) {
+        const float* gp4 = &Gs[ey * PS + ex][r][4 * q + ex];
+        G[ex] = f32x4{gp4[0], gp4[1], gp4[2], gp4[3]};
+      }
+    }
 #pragma unroll
     for (int cc = 0; cc < BCPT; ++cc) {
       const float* row = &Xs[sub * BCPT + cc][r + ey][4 * q];
