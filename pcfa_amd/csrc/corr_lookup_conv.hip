@@ -37,7 +37,14 @@ constexpr int KL = 88, KG = KL / 8;                                  // padded t
 constexpr int KP = L * KL;                                           // 352 padded tap rows
 constexpr int WIN_FLOATS = QT * WS + 4;
 #ifndef PCFA_LC_WD
-#define PCFA_LC_WD 11  // depth of the forward kernel's W register ring (groups of 8 MFMAs per wave)
+#define PCFA_LC_WD 8         // depth of the forward kernel's W register ring (groups of 8 MFMAs per wave)
+#endif
+#ifndef PCFA_LC_WDB
+#define PCFA_LC_WDB 6         // depth of the backward kernel's W^T ring (groups of 12 MFMAs per wave)
+#endif
+#ifndef PCFA_LC_DBG_BUILD
+#define PCFA_LC_DBG_BUILD 0  // forward phase ablation (tools/dev): 1 = no MFMAs, 2 = no blend, 4 = W stream from L1 (wrong results),
+                             // 8 = per-workgroup phase timestamps instead of results
 #endif
 
 struct Origin {
@@ -61,8 +68,16 @@ __device__ __forceinline__ Origin make_origin(float cx, float cy, int level) {
 // A piece outside its level loads the slab's all-zero tile instead (common.hpp: P.zero): plain loads that hipcc
 // counts itself -- with 20 pieces per thread in flight across a GEMM, hand-counted inline-asm loads (corr_lookup.hip)
 // would leave 80 registers the compiler believes are already written.
+// The explicit global address space matters: through a generic pointer these become flat_load, which also counts
+// against lgkmcnt -- every LDS / scalar-load wait behind them then waits for HBM.
 __device__ __forceinline__ f32x4 load_piece(const float* sbase, unsigned voff_bytes) {
-  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sbase) + voff_bytes);
+  typedef const f32x4 __attribute__((address_space(1))) * gptr;
+  return *(gptr)(reinterpret_cast<unsigned long long>(sbase) + voff_bytes);
+}
+
+__device__ __forceinline__ void store_piece(float* sbase, unsigned voff_bytes, f32x4 t) {
+  typedef f32x4 __attribute__((address_space(1))) * gptr;
+  *(gptr)(reinterpret_cast<unsigned long long>(sbase) + voff_bytes) = t;
 }
 
 template <typename T>
@@ -119,6 +134,61 @@ __device__ __forceinline__ void level_geometry(LevelGeo& g, float cx, float cy, 
   }
 }
 
+// Forward kernel's variant: 8 threads per query (k = tid >> 3), each owning pieces q = sub + 8 i (row q >> 2, tile column
+// q & 3) of that query's window -- no divisions, no cross-lane traffic; the origin is recomputed from the query's own
+// coordinates.  Same piece addresses and LDS image as level_geometry (which the backward still uses: it needs the masks).
+// The first version spent ~800 instructions (4 k cycles at one wave per SIMD) here before the first window load left.
+struct FwdPieces {
+  unsigned goff[NPC], lds[NPC];
+};
+__device__ __forceinline__ void fwd_pieces(FwdPieces& g, float kx, float ky, bool klive, int level, int k, int sub,
+                                           int hl, int tw, int off, int slab, int zero) {
+  static_assert(NPC * 8 == PIECES, "8 threads cover a window's pieces");
+  const Origin o = make_origin(kx, ky, level);
+  const int th4 = ((hl + 3) >> 2) << 2;
+  const int x0 = min(max(o.x0, -16), 4 * tw), y0 = klive ? min(max(o.y0, -16), th4) : th4;
+  const unsigned wB = (unsigned)(off + k * slab) * 4u;
+  const int ox = x0 & 3;
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int q = sub + 8 * i, rr = q >> 2, tx = q & 3;
+    const int y = y0 + rr, gtx = (x0 >> 2) + tx;
+    const bool need = (unsigned)y < (unsigned)hl && (unsigned)gtx < (unsigned)tw && 4 * tx < ox + WIN;
+    g.goff[i] = need ? wB + (((((unsigned)y >> 2) * (unsigned)tw + (unsigned)gtx) << 4) + (((unsigned)y & 3u) << 2)) * 4u
+                     : (unsigned)zero * 4u;   // the first slab's zero tile
+    g.lds[i] = (unsigned)(k * WS + rr * RS + 4 + 4 * tx - ox) * 4u;
+  }
+}
+
+// Backward kernel's variant of fwd_pieces: the same ownership plus the per-texel masks of level_geometry.
+struct BwdPieces {
+  unsigned goff[NPC], lds[NPC];
+  int mask[NPC];   // bits 0-3: texel is a window texel inside the level; bit 4: the piece exists in the level
+};
+__device__ __forceinline__ void bwd_pieces(BwdPieces& g, float kx, float ky, bool klive, int level, int k, int sub,
+                                           int hl, int wl, int tw, int off, int slab, int zero) {
+  const Origin o = make_origin(kx, ky, level);
+  const int th4 = ((hl + 3) >> 2) << 2;
+  const int x0 = min(max(o.x0, -16), 4 * tw), y0 = klive ? min(max(o.y0, -16), th4) : th4;
+  const unsigned wB = (unsigned)(off + k * slab) * 4u;
+  const int ox = x0 & 3;
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int q = sub + 8 * i, rr = q >> 2, tx = q & 3;
+    const int y = y0 + rr, gtx = (x0 >> 2) + tx;
+    const bool need = (unsigned)y < (unsigned)hl && (unsigned)gtx < (unsigned)tw && 4 * tx < ox + WIN;
+    const int c0 = 4 * tx - ox, gx0 = 4 * gtx;
+    int mask = need ? 16 : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((unsigned)(c0 + e) < (unsigned)WIN && gx0 + e < wl) mask |= 1 << e;
+    g.mask[i] = mask;
+    g.goff[i] = need ? wB + (((((unsigned)y >> 2) * (unsigned)tw + (unsigned)gtx) << 4) + (((unsigned)y & 3u) << 2)) * 4u
+                     : (unsigned)zero * 4u;
+    g.lds[i] = (unsigned)(k * WS + rr * RS + 4 + 4 * tx - ox) * 4u;
+  }
+}
+
 // Packed weights (forward): Wp[mtile 8][kg 44][lane 64][4]: float e of lane = W[n = 32 mtile + (lane & 31)][k'] with
 // k' = 8 kg + 2 e + (lane >> 5) in the padded tap space (88 rows per level: 81 taps + 7 zero rows).
 // Packed weights (backward): Wt[mtile 11][ng 32][lane 64][4]: float e = W[n = 8 ng + 2 e + (lane >> 5)][k' = 32 mtile + (lane & 31)].
@@ -149,52 +219,40 @@ __global__ void convc1_pack_kernel(const float* __restrict__ w, float* __restric
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, const float* __restrict__ wp,
-    const float* __restrict__ bias, float* __restrict__ out, int Q, PyrLayout P, int relu, int dbg) {
+    const float* __restrict__ bias, float* __restrict__ out, int Q, PyrLayout P, int relu, int /*unused*/) {
+  constexpr int dbg = PCFA_LC_DBG_BUILD;             // phase ablation is a build-time switch: a runtime one put 130
+                                                     // uniform branches between the MFMAs and the allocator spilled
   constexpr int COUT = 256, MTW = COUT / 32 / 4;     // m-tiles per wave (2)
-  __shared__ __attribute__((aligned(16))) float s_win[WIN_FLOATS];
+  __shared__ __attribute__((aligned(16))) float s_win2[2][WIN_FLOATS];   // two window images: level i+1 is staged while i is read
   __shared__ __attribute__((aligned(16))) float s_tap[2][KL][QT];
+  __shared__ float s_bias[COUT];
+  static_assert(COUT == NT, "one bias value per thread");
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = tid & 31, l31 = lane & 31, lh = lane >> 5;
   const int b_img = blockIdx.z, q0 = blockIdx.x * QT;
   const bool live = q0 + j < Q;
-  float cx = 0.f, cy = 0.f;
-  if (live) {
-    cx = coords[((size_t)b_img * 2 + 0) * Q + q0 + j];
-    cy = coords[((size_t)b_img * 2 + 1) * Q + q0 + j];
-  }
+  unsigned long long ts[12] = {};
+  int nts = 0;
+#define PCFA_LC_STAMP() do { if (dbg & 8) ts[nts++] = __builtin_amdgcn_s_memtime(); } while (0)
+  PCFA_LC_STAMP();
+  // branch-free head: clamped query indices instead of `if (live)` (the branches kept the kernel-argument loads and
+  // the geometry of the four levels from being scheduled together)
+  const int kq = tid >> 3, sub = tid & 7;             // piece ownership: 8 threads per query
+  const bool klive = q0 + kq < Q;
+  const float* cb = coords + (size_t)b_img * 2 * Q;
+  const int qj = min(q0 + j, Q - 1), qk = min(q0 + kq, Q - 1);
+  const float cx = cb[qj], cy = cb[Q + qj], kx = cb[qk], ky = cb[Q + qk];
+  const float bias_mine = bias[tid];                  // -> LDS, read back by the epilogue
   const float* slab0 = scalar_ptr(pyr + ((size_t)b_img * Q + q0) * P.slab);
 
-  // the zero rows of the tap tiles (their weights are zero too, but 0 * garbage may be NaN)
-  for (int e = tid; e < 2 * (KL - TAPS) * QT; e += NT) {
-    const int buf = e / ((KL - TAPS) * QT), rem = e - buf * ((KL - TAPS) * QT);
-    s_tap[buf][TAPS + rem / QT][rem % QT] = 0.f;
-  }
-
   // ---- every piece of all four levels is requested before anything waits; coarsest level first: its windows are
-  //      L2-resident and land first, so the matrix cores start while the level-0 texels are still on their way ----
+  //      L2-resident and land first, so the matrix cores start while the level-0 texels are still on their way.
+  //      Issue order is pinned (sched_barrier): level 3, the W ring's first groups, then levels 2, 1, 0 -- returns are
+  //      in order, so anything issued ahead of the W ring delays the first MFMA. ----
   f32x4 v[L][NPC];
   unsigned dst[L][NPC];
   float fxs[L], fys[L];
-#pragma unroll
-  for (int lr = 0; lr < L; ++lr) {
-    const int l = L - 1 - lr;
-    LevelGeo g;
-    level_geometry(g, cx, cy, live, l, j, P, tid);
-    fxs[l] = g.fx;
-    fys[l] = g.fy;
-#pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-      dst[l][i] = g.pc[i].lds;
-      v[l][i] = load_piece(slab0, g.pc[i].goff);
-    }
-  }
-
-  f32x16 acc[MTW];   // starts at the bias: the epilogue then has no dependent loads left
-#pragma unroll
-  for (int m = 0; m < MTW; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = bias[(wv * MTW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
   const f32x4* wq = reinterpret_cast<const f32x4*>(wp) + ((size_t)(wv * MTW) * (KP / 8)) * 64 + lane;
   // W operands: a register ring WD groups deep over the 44 groups of all four levels (the loops below are fully
   // unrolled, so every ring index is static).  One group = 4 k-pairs = 8 MFMAs of 64 cycles per wave; the loads come
@@ -202,73 +260,164 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
   // idled for the load latency in every group (26 us per launch, 28 % of the fp32 matrix peak).
   constexpr int WD = PCFA_LC_WD, NG = L * KG;
   f32x4 wring[WD][MTW];
+  int Ph[L], Ptw[L], Poff[L];     // all kernel-argument loads up front (the fences below would pin them per level)
 #pragma unroll
-  for (int d = 0; d < WD; ++d)
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) wring[d][m] = wq[((size_t)m * (KP / 8) + (L - 1 - d / KG) * KG + d % KG) * 64];
-
+  for (int l = 0; l < L; ++l) {
+    Ph[l] = P.h[l];
+    Ptw[l] = P.tw[l];
+    Poff[l] = P.off[l];
+  }
+  const int Pslab = P.slab, Pzero = P.zero;
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int lr = 0; lr < L; ++lr) {
     const int l = L - 1 - lr;
-    // ---- window images of level l -> LDS (sub-tile offset removed: per-lane unaligned dword stores) ----
-    char* lds_bytes = reinterpret_cast<char*>(s_win);
+    FwdPieces g;
+    fwd_pieces(g, kx, ky, klive, l, kq, sub, Ph[l], Ptw[l], Poff[l], Pslab, Pzero);
+    const Origin oj = make_origin(cx, cy, l);
+    fxs[l] = oj.fx;
+    fys[l] = oj.fy;
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
-      float* d = reinterpret_cast<float*>(lds_bytes + dst[l][i]);
-      d[0] = v[l][i].x; d[1] = v[l][i].y; d[2] = v[l][i].z; d[3] = v[l][i].w;
+      dst[l][i] = g.lds[i];
+      v[l][i] = load_piece(slab0, g.goff[i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (lr == 0) {
+#pragma unroll
+      for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) wring[d][m] = wq[((size_t)m * (KP / 8) + (L - 1 - d / KG) * KG + d % KG) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  s_bias[tid] = bias_mine;
+
+  // Pipeline over the levels in stream order i = 0..3 (level L-1-i), ONE barrier per level:
+  //   before iteration i : taps(i) are in s_tap[i & 1], the window image of i+1 is in s_win2[(i+1) & 1]
+  //   iteration i        : the MFMAs of level i, and BETWEEN them -- a 64-cycle fp32 MFMA leaves ~12 issue slots --
+  //                        the blend of level i+1 (one tap column per MFMA group) and the image write of level i+2.
+  // The first version ran image write -> barrier -> blend -> barrier -> MFMAs per level with one wave per SIMD, so
+  // none of the ~1 us of staging per level overlapped the matrix work.
+  auto write_image = [&](int i) {
+    const int l = L - 1 - i;
+    char* lds_bytes = reinterpret_cast<char*>(s_win2[i & 1]);
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+      float* d = reinterpret_cast<float*>(lds_bytes + dst[l][k]);
+      d[0] = v[l][k].x; d[1] = v[l][k].y; d[2] = v[l][k].z; d[3] = v[l][k].w;
+    }
+  };
+  // Blend, branch-free and evenly spread: thread (query j, b8 = tid >> 5) owns taps t = b8 + 8k, k = 0..10, of the 88
+  // rows of the tap tile (t >= 81 are the zero rows, rewritten every level); tap t = a*9 + b reads its 2x2 texels
+  // straight from the window image (four dword LDS reads).  The reads (tap_texels) and the arithmetic + store
+  // (tap_store) are separate steps so that a whole MFMA group sits between an LDS read and its first use.
+  struct Texels { float t00, t01, t10, t11; };
+  auto tap_texels = [&](int i, int k) {
+    const int t = (tid >> 5) + 8 * k;
+    const bool valid = t < TAPS;
+    const int a = valid ? (t * 57) >> 9 : 0;            // t / 9 for t < 88
+    const int b = valid ? t - 9 * a : 0;
+    const float* p = &s_win2[i & 1][j * WS + b * RS + 4 + a];
+    return Texels{p[0], p[1], p[RS], p[RS + 1]};
+  };
+  auto tap_store = [&](int i, int k, const Texels& x) {
+    const int l = L - 1 - i;
+    const float fx = fxs[l], fy = fys[l];
+    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+    const int t = (tid >> 5) + 8 * k;
+    const float val = x.t00 * w00 + x.t01 * w01 + x.t10 * w10 + x.t11 * w11;     // as corr_lookup_fwd_body
+    s_tap[i & 1][t][j] = t < TAPS ? val : 0.f;
+  };
+  constexpr int NBK = KL / 8;   // 11 tap slices per level
+  static_assert(NBK == KG, "one tap slice rides under each MFMA group");
+
+  if (dbg & 16) {    // arrival time of every level's windows (the image writes wait for them); results are garbage
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      write_image(i);
+      __builtin_amdgcn_s_waitcnt(0);
+      PCFA_LC_STAMP();
     }
     __syncthreads();
-    // ---- thread (query j, window row b) blends its 9 taps; row 8 by the first 32 threads ----
-    if (!(dbg & 2)) {
-      const float fx = fxs[l], fy = fys[l];
-      const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
-      float (*tap)[QT] = s_tap[l & 1];
+    if (live) out[(size_t)b_img * COUT * Q + (size_t)(8 + (tid >> 5)) * Q + q0 + j] = s_win2[0][tid] + s_win2[1][tid];
+    if (tid == 0)
+      for (int k = 0; k < 5; ++k) out[(size_t)b_img * COUT * Q + (size_t)k * Q + q0] = (float)(ts[k] - ts[0]);
+    return;
+  }
+  write_image(0);
+  __syncthreads();
+  PCFA_LC_STAMP();   // 1: coarsest level's windows have arrived
+  f32x16 acc[MTW];   // starts at the bias (as the un-fused GEMM + bias rounds; the saved output is the ReLU mask)
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int b = pass == 0 ? (tid >> 5) : 8;
-        if (pass == 1 && tid >= 32) break;
-        const float4* row0 = reinterpret_cast<const float4*>(&s_win[j * WS + b * RS + 4]);
-        const float4* row1 = reinterpret_cast<const float4*>(&s_win[j * WS + (b + 1) * RS + 4]);
-        float t0[NRD * 4], t1[NRD * 4];
+  for (int m = 0; m < MTW; ++m)
 #pragma unroll
-        for (int i = 0; i < NRD; ++i) {
-          const float4 u0 = row0[i], u1 = row1[i];
-          t0[4 * i] = u0.x; t0[4 * i + 1] = u0.y; t0[4 * i + 2] = u0.z; t0[4 * i + 3] = u0.w;
-          t1[4 * i] = u1.x; t1[4 * i + 1] = u1.y; t1[4 * i + 2] = u1.z; t1[4 * i + 3] = u1.w;
-        }
+    for (int r = 0; r < 16; ++r) acc[m][r] = s_bias[(wv * MTW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+  if (!(dbg & 2)) {
+    Texels x[NBK];
 #pragma unroll
-        for (int a = 0; a < N1; ++a)   // same expression as corr_lookup_fwd_body: bit-identical taps
-          tap[a * N1 + b][j] = t0[a] * w00 + t0[a + 1] * w01 + t1[a] * w10 + t1[a + 1] * w11;
-      }
-    }
-    __syncthreads();   // taps of level l visible; the window image is free for level l + 1
-    // ---- the level's share of W . taps: 11 groups of 4 k-pairs, 2 m-tiles per wave ----
-    if (!(dbg & 1)) {
-      const float (*tap)[QT] = s_tap[l & 1];
+    for (int k = 0; k < NBK; ++k) x[k] = tap_texels(0, k);
 #pragma unroll
-      for (int g = 0; g < KG; ++g) {
-        const int G = lr * KG + g;                      // position in the W stream (compile-time after unrolling)
-        float bv[4];
+    for (int k = 0; k < NBK; ++k) tap_store(0, k, x[k]);
+  }
+  write_image(1);
+  __syncthreads();
+  PCFA_LC_STAMP();   // 2: prologue done
+
+  // The scheduler is fenced (sched_barrier) at three points of every group.  Left alone it sank each LDS read next to
+  // its use, so every tap cost a full LDS round trip during which the wave could not issue the next MFMA, and the
+  // matrix pipe idled for more than half of the loop (23 us for 9.4 us of MFMA work).
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = tap[8 * g + 2 * e + lh][l31];
-        f32x4 wcur[MTW];
+  for (int i = 0; i < L; ++i) {
+    const float (*tap)[QT] = s_tap[i & 1];
+    float bv[4];
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) wcur[m] = wring[G % WD][m];
-        if (G + WD < NG) {   // group G + WD of the stream: level L-1 - (G+WD)/KG, group (G+WD) % KG
-          constexpr int dummy = 0; (void)dummy;
-          const int Gn = G + WD, ln = L - 1 - Gn / KG, gn = Gn % KG;
+    for (int e = 0; e < 4; ++e) bv[e] = tap[2 * e + lh][l31];     // group 0 of the level: written before the barrier
 #pragma unroll
-          for (int m = 0; m < MTW; ++m) wring[G % WD][m] = wq[((size_t)m * (KP / 8) + ln * KG + gn) * 64];
-        }
+    for (int g = 0; g < KG; ++g) {
+      const int G = i * KG + g;                      // position in the W stream (compile-time after unrolling)
+      // Eight MFMAs, each followed by a small chunk of the other work (a 64-cycle MFMA leaves ~12 issue slots), the
+      // scheduler fenced after every pair so the chunks stay where they are put:
+      //   after MFMA 0: this group's texel reads      after MFMA 1: the next group's tap reads
+      //   after MFMA 2: the W group WD ahead          after MFMA 5: blend arithmetic + tap store (texels are 4 MFMAs old)
+      //   after MFMA 6: (last group) the image of level i + 2
+      Texels x{0.f, 0.f, 0.f, 0.f};
+      float bvn[4] = {0.f, 0.f, 0.f, 0.f};
+      f32x4 wcur[MTW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+      for (int m = 0; m < MTW; ++m) wcur[m] = wring[G % WD][m];
 #pragma unroll
-          for (int m = 0; m < MTW; ++m) {
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+          const int step = e * MTW + m;
+          if (!(dbg & 1)) {
             const float av = e == 0 ? wcur[m].x : e == 1 ? wcur[m].y : e == 2 ? wcur[m].z : wcur[m].w;
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[e], acc[m], 0, 0, 0);
           }
-      }
+          if (step == 0 && i + 1 < L && !(dbg & 2)) x = tap_texels(i + 1, g);
+          if (step == 1 && g + 1 < KG) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) bvn[ee] = tap[8 * (g + 1) + 2 * ee + lh][l31];
+          }
+          if (step == 2 && G + WD < NG) {   // group G + WD of the stream: level L-1 - (G+WD)/KG, group (G+WD) % KG
+            const int Gn = G + WD, ln = L - 1 - Gn / KG, gn = Gn % KG;
+#pragma unroll
+            for (int mm = 0; mm < MTW; ++mm)
+              wring[G % WD][mm] = wq[((size_t)mm * (KP / 8) + ((dbg & 4) ? (gn & 1) : ln * KG + gn)) * 64];
+          }
+          if (step == 5 && i + 1 < L && !(dbg & 2)) {
+            if (dbg & 32) acc[0][0] += x.t00 + x.t01 + x.t10 + x.t11; else tap_store(i + 1, g, x);
+          }
+          if (step == 6 && i + 2 < L && g == KG - 1 && !(dbg & 64)) write_image(i + 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = bvn[e];
     }
+    __syncthreads();   // taps(i+1) and image(i+2) visible; everyone is done with taps(i) and image(i+1)
+    PCFA_LC_STAMP();   // 3..6: level i done
   }
 
   // ---- epilogue: + bias, ReLU, rows of 32 queries (128 B) per half-wave ----
@@ -283,6 +432,12 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
       if (relu) y = fmaxf(y, 0.f);
       if (qlive) ob[(size_t)n * Q] = y;
     }
+  if (dbg & 8) {     // timestamps over the first query's column (tools/dev/lc_stamps.py); 100 MHz ticks
+    PCFA_LC_STAMP();
+    __syncthreads();
+    if (tid == 0)
+      for (int k = 0; k < 8; ++k) out[(size_t)b_img * COUT * Q + (size_t)k * Q + q0] = (float)(ts[k] - ts[0]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -302,62 +457,90 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_bwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = tid & 31, l31 = lane & 31, lh = lane >> 5;
   const int b_img = blockIdx.z, q0 = blockIdx.x * QT;
-  const bool live = q0 + j < Q;
-  float cx = 0.f, cy = 0.f;
-  if (live) {
-    cx = coords[((size_t)b_img * 2 + 0) * Q + q0 + j];
-    cy = coords[((size_t)b_img * 2 + 1) * Q + q0 + j];
-  }
+  unsigned long long ts[12] = {};
+  int nts = 0;
+  constexpr int dbg = PCFA_LC_DBG_BUILD;
+  PCFA_LC_STAMP();
+  // branch-free head; the gradient tile's loads go out FIRST (they gate the matrix work), the window pieces -- needed
+  // only after the GEMM -- behind them.  The first version did the ~800-instruction geometry and the 20 piece loads
+  // first, and the in-order return then held the gradient tile behind all of them.
+  const int kq = tid >> 3, sub = tid & 7;             // piece ownership: 8 threads per query (as the forward)
+  const bool klive = q0 + kq < Q;
+  const float* cb = coords + (size_t)b_img * 2 * Q;
+  const int qj = min(q0 + j, Q - 1), qk = min(q0 + kq, Q - 1);
+  const float cx = cb[qj], cy = cb[Q + qj], kx = cb[qk], ky = cb[Q + qk];
   float* slab0 = scalar_ptr(dpyr + ((size_t)b_img * Q + q0) * P.slab);
-
-  // ---- the read half of the read-modify-write of all four levels goes out first ----
-  f32x4 v[L][NPC];
-  Piece pc[L][NPC];
-  float fxs[L], fys[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    LevelGeo g;
-    level_geometry(g, cx, cy, live, l, j, P, tid);
-    fxs[l] = g.fx;
-    fys[l] = g.fy;
-#pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-      pc[l][i] = g.pc[i];
-      v[l][i] = load_piece(slab0, pc[l][i].goff);
-    }
-  }
 
   // ---- gradient tile: g[n][q] = grad_out * [y > 0]; thread = (4 queries, 8 rows apart): 16-B loads, all 16 of a
   //      thread in flight at once (per-float loads in four dependent batches were ~6 us of the launch) ----
+  const int qq = (tid & 7) * 4, n0 = tid >> 3;      // 8 quads per row, 32 rows per pass, 8 passes
+  const size_t gbase = (size_t)b_img * COUT * Q + q0 + qq;
+  // workgroup-uniform: every row of the tile is 32 whole, 16-B aligned queries.  (A per-thread test here put a
+  // divergent branch in every pass and the loads went out one dependent pair at a time: 9 us before the first MFMA.)
+  const bool full = __builtin_amdgcn_readfirstlane((Q & 3) == 0 && q0 + QT <= Q);
+  f32x4 gg[COUT / 32], yy[COUT / 32];
   {
-    const int qq = (tid & 7) * 4, n0 = tid >> 3;      // 8 quads per row, 32 rows per pass, 8 passes
-    const bool vec = (Q & 3) == 0 && q0 + qq + 3 < Q;
-    const size_t base = (size_t)b_img * COUT * Q + q0 + qq;
-    f32x4 gg[COUT / 32], yy[COUT / 32];
+    // Issued unconditionally (a ragged tile reads clamped, in-bounds addresses and ignores the result): behind a
+    // branch the compiler can no longer count the loads in flight and every later wait becomes a wait for all of them.
+    const float* ysrc = relu ? y : grad_out;   // without the ReLU: a second read of the gradient, mask always true
+    const size_t last = (size_t)gridDim.z * COUT * Q - 4;
 #pragma unroll
     for (int i = 0; i < COUT / 32; ++i) {
-      const size_t o = base + (size_t)(n0 + 32 * i) * Q;
-      if (vec) {
-        gg[i] = *reinterpret_cast<const f32x4*>(grad_out + o);
-        yy[i] = relu ? *reinterpret_cast<const f32x4*>(y + o) : (f32x4)(1.f);
-      } else {
+      const size_t o = min(gbase + (size_t)(n0 + 32 * i) * Q, last);
+      gg[i] = *reinterpret_cast<const f32x4*>(grad_out + o);
+      yy[i] = *reinterpret_cast<const f32x4*>(ysrc + o);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- geometry of the read-modify-write of all four levels (its loads ride inside the GEMM, see below) ----
+  f32x4 v[L][NPC];
+  unsigned pgoff[L][NPC], plds[L][NPC];
+  int pmask[L][NPC];
+  float fxs[L], fys[L];
+  {
+    const int Pslab = P.slab, Pzero = P.zero;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool ok = q0 + qq + e < Q;
-          gg[i][e] = ok ? grad_out[o + e] : 0.f;
-          yy[i][e] = (ok && relu) ? y[o + e] : 1.f;
-        }
+    for (int l = 0; l < L; ++l) {
+      BwdPieces g;
+      bwd_pieces(g, kx, ky, klive, l, kq, sub, P.h[l], P.w[l], P.tw[l], P.off[l], Pslab, Pzero);
+      const Origin oj = make_origin(cx, cy, l);
+      fxs[l] = oj.fx;
+      fys[l] = oj.fy;
+#pragma unroll
+      for (int i = 0; i < NPC; ++i) {
+        pgoff[l][i] = g.goff[i];
+        plds[l][i] = g.lds[i];
+        pmask[l][i] = g.mask[i];
       }
     }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  PCFA_LC_STAMP();   // 1: geometry done (the gradient tile's loads are in flight)
+  if (full) {
+    const float thr = relu ? 0.f : -__builtin_inff();   // no ReLU: every finite or infinite value passes
 #pragma unroll
     for (int i = 0; i < COUT / 32; ++i) {
       f32x4 t;
-      t.x = yy[i].x > 0.f ? gg[i].x : 0.f; t.y = yy[i].y > 0.f ? gg[i].y : 0.f;
-      t.z = yy[i].z > 0.f ? gg[i].z : 0.f; t.w = yy[i].w > 0.f ? gg[i].w : 0.f;
+      t.x = (yy[i].x > thr || !relu) ? gg[i].x : 0.f; t.y = (yy[i].y > thr || !relu) ? gg[i].y : 0.f;
+      t.z = (yy[i].z > thr || !relu) ? gg[i].z : 0.f; t.w = (yy[i].w > thr || !relu) ? gg[i].w : 0.f;
       *reinterpret_cast<f32x4*>(&s_g[n0 + 32 * i][qq]) = t;
+    }
+  } else {   // ragged last tile, or rows that are not 16-B aligned: per-float, rolled
+#pragma unroll 1
+    for (int i = 0; i < COUT / 32; ++i) {
+      const size_t o = gbase + (size_t)(n0 + 32 * i) * Q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = q0 + qq + e < Q;
+        const float gv = ok ? grad_out[o + e] : 0.f;
+        const float yv = (ok && relu) ? y[o + e] : 1.f;
+        s_g[n0 + 32 * i][qq + e] = yv > 0.f ? gv : 0.f;
+      }
     }
   }
   __syncthreads();
+  PCFA_LC_STAMP();   // 2: gradient tile staged
 
   // ---- d taps [352][32] = W^T [352][256] . g [256][32]; wave w owns row tiles w, w + 4, w + 8 ----
   {
@@ -368,42 +551,52 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_bwd_kernel(
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
     const f32x4* wq = reinterpret_cast<const f32x4*>(wt) + lane;
     const int nmt = wv + 8 < MT ? 3 : 2;
-    // W^T operands: register ring 3 groups deep (one group = 12 MFMAs here), all indices static (unrolled by 3)
-    constexpr int WD = 3;
-    static_assert((COUT / 8) % WD != 0 || true, "");
+    // W^T operands: register ring WD groups deep (one group = 12 MFMAs = 768 cycles here), fully unrolled so every
+    // ring index is static; the next group's gradient rows are read one group ahead, and the scheduler is fenced
+    // after every MFMA step so that neither the LDS reads nor the L2 loads sink next to their uses (see the forward).
+    // The first version (ring of 3, reads at their uses) ran this loop at 54 % of the MFMA rate.
+    constexpr int WD = PCFA_LC_WDB, NGB = COUT / 8;
     f32x4 wring[WD][MTW];
     size_t wrow[MTW];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) wrow[m] = (size_t)min(wv + 4 * m, MT - 1) * (COUT / 8);
+    for (int m = 0; m < MTW; ++m) wrow[m] = (size_t)min(wv + 4 * m, MT - 1) * NGB;
 #pragma unroll
     for (int d = 0; d < WD; ++d)
 #pragma unroll
       for (int m = 0; m < MTW; ++m) wring[d][m] = wq[(wrow[m] + d) * 64];
-    for (int g0 = 0; g0 < COUT / 8; g0 += WD) {
+    float bv[4];
 #pragma unroll
-      for (int d = 0; d < WD; ++d) {
-        const int g = g0 + d;
-        if (g < COUT / 8) {
-          float bv[4];
+    for (int e = 0; e < 4; ++e) bv[e] = s_g[2 * e + lh][l31];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bv[e] = s_g[8 * g + 2 * e + lh][l31];
-          f32x4 wcur[MTW];
+    for (int g = 0; g < NGB; ++g) {
+      float bvn[4] = {0.f, 0.f, 0.f, 0.f};
+      f32x4 wcur[MTW];
 #pragma unroll
-          for (int m = 0; m < MTW; ++m) wcur[m] = wring[d][m];
-          const int gn = min(g + WD, COUT / 8 - 1);
+      for (int m = 0; m < MTW; ++m) wcur[m] = wring[g % WD][m];
 #pragma unroll
-          for (int m = 0; m < MTW; ++m) wring[d][m] = wq[(wrow[m] + gn) * 64];
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+        for (int m = 0; m < MTW; ++m) {   // wave 3's third tile is a clamped duplicate, computed and dropped: a
+          // wave-dependent branch around every third MFMA cost more than the MFMA (the other waves run 3 anyway)
+          const int step = e * MTW + m;
+          const float av = e == 0 ? wcur[m].x : e == 1 ? wcur[m].y : e == 2 ? wcur[m].z : wcur[m].w;
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[e], acc[m], 0, 0, 0);
+          if (step == 0 && g + 1 < NGB) {
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-              if (m < nmt) {
-                const float av = e == 0 ? wcur[m].x : e == 1 ? wcur[m].y : e == 2 ? wcur[m].z : wcur[m].w;
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[e], acc[m], 0, 0, 0);
-              }
-            }
+            for (int ee = 0; ee < 4; ++ee) bvn[ee] = s_g[8 * (g + 1) + 2 * ee + lh][l31];
+          }
+          if (step == 1 && g + WD < NGB) {
+#pragma unroll
+            for (int mm = 0; mm < MTW; ++mm) wring[g % WD][mm] = wq[(wrow[mm] + g + WD) * 64];
+          }
+          // The read half of the read-modify-write, one piece per group over the first 20 groups, in the order the
+          // scatter needs them.  All 20 up front (44 MB with the gradient tiles, across the chip) held the gradient
+          // tile back for 9 us; all 20 right before the GEMM would hold the W ring back instead (returns are in order).
+          if (step == 2 && g < L * NPC) v[g / NPC][g % NPC] = load_piece(slab0, pgoff[g / NPC][g % NPC]);
+          __builtin_amdgcn_sched_barrier(0);
         }
-      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = bvn[e];
     }
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
@@ -415,6 +608,7 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_bwd_kernel(
     }
   }
   __syncthreads();   // d taps complete; the gradient tile is dead: its LDS becomes the window image
+  PCFA_LC_STAMP();   // 3: GEMM done
 
   // ---- per level: the lookup's transpose (corr_lookup_bwd_body with the tap gradients read from LDS) ----
 #pragma unroll
@@ -461,17 +655,22 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_bwd_kernel(
     const char* lds_bytes = reinterpret_cast<const char*>(s_win);
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
-      const float* src = reinterpret_cast<const float*>(lds_bytes + pc[l][i].lds);
+      const float* src = reinterpret_cast<const float*>(lds_bytes + plds[l][i]);
       const float e0 = src[0], e1 = src[1], e2 = src[2], e3 = src[3];
-      const int m = pc[l][i].mask;
+      const int m = pmask[l][i];
       f32x4 t = v[l][i];
       t.x += (m & 1) ? e0 : 0.f;
       t.y += (m & 2) ? e1 : 0.f;
       t.z += (m & 4) ? e2 : 0.f;
       t.w += (m & 8) ? e3 : 0.f;
-      if (pc[l][i].need()) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(slab0) + pc[l][i].goff) = t;
+      if (m & 16) store_piece(slab0, pgoff[l][i], t);
     }
     __syncthreads();   // image free for the next level
+    PCFA_LC_STAMP();   // 4..7: level l scattered
+  }
+  if (dbg & 8) {     // timestamps over the first floats of the first query's slab (tools/dev/lc_stamps.py --bwd)
+    if (tid == 0)
+      for (int k = 0; k < 8; ++k) slab0[k] = (float)(ts[k] - ts[0]);
   }
 }
 
@@ -506,9 +705,9 @@ extern "C" int pcfa_lookup_convc1_fwd(const float* pyr, const float* coords, con
     return PCFA_ERR_INVALID_ARG;
   if (num_levels != L || radius != R || Cout != 256) return PCFA_ERR_UNSUPPORTED;
   const int Q = H * W;
-  static const int dbg = getenv("PCFA_LC_DBG") ? atoi(getenv("PCFA_LC_DBG")) : 0;   // phase ablation (tools/dev)
-  pcfa_launch(corr_lookup_convc1_fwd_kernel, dim3(pcfa_cdiv(Q, QT), 1, B), dim3(NT), 0, (hipStream_t)stream, pyr,
-              coords, packed, bias, out, Q, P, relu, dbg);
+  static const int dyn = getenv("PCFA_LC_DYNLDS") ? atoi(getenv("PCFA_LC_DYNLDS")) : 0;
+  pcfa_launch(corr_lookup_convc1_fwd_kernel, dim3(pcfa_cdiv(Q, QT), 1, B), dim3(NT), dyn, (hipStream_t)stream, pyr,
+              coords, packed, bias, out, Q, P, relu, 0);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
