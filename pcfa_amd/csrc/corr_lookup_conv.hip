@@ -42,6 +42,12 @@ constexpr int WIN_FLOATS = QT * WS + 4;
 #ifndef PCFA_LC_WDB
 #define PCFA_LC_WDB 6         // depth of the backward kernel's W^T ring (groups of 12 MFMAs per wave)
 #endif
+#ifndef PCFA_LC_EARLY
+#define PCFA_LC_EARLY 2       // forward: pyramid levels requested up front (the rest ride under the first level's MFMAs)
+#endif
+#ifndef PCFA_LC_AHEAD
+#define PCFA_LC_AHEAD 2       // gradient-tile blocks (32 rows) in flight ahead of the backward GEMM
+#endif
 #ifndef PCFA_LC_DBG_BUILD
 #define PCFA_LC_DBG_BUILD 0  // forward phase ablation (tools/dev): 1 = no MFMAs, 2 = no blend, 4 = W stream from L1 (wrong results),
                              // 8 = per-workgroup phase timestamps instead of results
@@ -251,8 +257,9 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
   //      Issue order is pinned (sched_barrier): level 3, the W ring's first groups, then levels 2, 1, 0 -- returns are
   //      in order, so anything issued ahead of the W ring delays the first MFMA. ----
   f32x4 v[L][NPC];
-  unsigned dst[L][NPC];
+  unsigned dst[L][NPC], goffs[L][NPC];
   float fxs[L], fys[L];
+  constexpr int EARLY = PCFA_LC_EARLY;   // levels (coarsest first) whose windows are requested before the first MFMA
   const f32x4* wq = reinterpret_cast<const f32x4*>(wp) + ((size_t)(wv * MTW) * (KP / 8)) * 64 + lane;
   // W operands: a register ring WD groups deep over the 44 groups of all four levels (the loops below are fully
   // unrolled, so every ring index is static).  One group = 4 k-pairs = 8 MFMAs of 64 cycles per wave; the loads come
@@ -280,7 +287,8 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
       dst[l][i] = g.lds[i];
-      v[l][i] = load_piece(slab0, g.goff[i]);
+      goffs[l][i] = g.goff[i];
+      if (lr < EARLY) v[l][i] = load_piece(slab0, g.goff[i]);   // the two fine levels are requested under level 3's MFMAs
     }
     __builtin_amdgcn_sched_barrier(0);
     if (lr == 0) {
@@ -407,6 +415,10 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
             for (int mm = 0; mm < MTW; ++mm)
               wring[G % WD][mm] = wq[((size_t)mm * (KP / 8) + ((dbg & 4) ? (gn & 1) : ln * KG + gn)) * 64];
           }
+          if (step == 3 && i == 0 && g < (L - EARLY) * NPC) {   // one deferred window piece per group, finer level last
+            const int l = L - 1 - EARLY - g / NPC, k = g % NPC;
+            v[l][k] = load_piece(slab0, goffs[l][k]);
+          }
           if (step == 5 && i + 1 < L && !(dbg & 2)) {
             if (dbg & 32) acc[0][0] += x.t00 + x.t01 + x.t10 + x.t11; else tap_store(i + 1, g, x);
           }
@@ -478,57 +490,74 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_bwd_kernel(
   // workgroup-uniform: every row of the tile is 32 whole, 16-B aligned queries.  (A per-thread test here put a
   // divergent branch in every pass and the loads went out one dependent pair at a time: 9 us before the first MFMA.)
   const bool full = __builtin_amdgcn_readfirstlane((Q & 3) == 0 && q0 + QT <= Q);
-  f32x4 gg[COUT / 32], yy[COUT / 32];
-  {
-    // Issued unconditionally (a ragged tile reads clamped, in-bounds addresses and ignores the result): behind a
-    // branch the compiler can no longer count the loads in flight and every later wait becomes a wait for all of them.
-    const float* ysrc = relu ? y : grad_out;   // without the ReLU: a second read of the gradient, mask always true
-    const size_t last = (size_t)gridDim.z * COUT * Q - 4;
+  // The tile is streamed in 8 blocks of 32 rows (= 4 GEMM groups each), two blocks ahead of the matrix cores: all 16
+  // loads of a thread up front meant 14 MB requested across the chip at once, and the first MFMA waited ~6 us for its
+  // whole tile.  Loads are issued unconditionally (a ragged tile reads clamped, in-bounds addresses and ignores the
+  // result): behind a branch the compiler can no longer count the loads in flight.
+  constexpr int NBLK = COUT / 32, AHEAD = PCFA_LC_AHEAD;
+  f32x4 gg[NBLK], yy[NBLK];
+  const float* ysrc = relu ? y : grad_out;   // without the ReLU: a second read of the gradient, mask always true
+  const size_t glast = (size_t)gridDim.z * COUT * Q - 4;
+  auto tile_load = [&](int i) {
+    const size_t o = min(gbase + (size_t)(n0 + 32 * i) * Q, glast);
+    gg[i] = *reinterpret_cast<const f32x4*>(grad_out + o);
+    yy[i] = *reinterpret_cast<const f32x4*>(ysrc + o);
+  };
+  auto tile_store = [&](int i) {
+    f32x4 t;
+    t.x = (yy[i].x > 0.f || !relu) ? gg[i].x : 0.f; t.y = (yy[i].y > 0.f || !relu) ? gg[i].y : 0.f;
+    t.z = (yy[i].z > 0.f || !relu) ? gg[i].z : 0.f; t.w = (yy[i].w > 0.f || !relu) ? gg[i].w : 0.f;
+    *reinterpret_cast<f32x4*>(&s_g[n0 + 32 * i][qq]) = t;
+  };
 #pragma unroll
-    for (int i = 0; i < COUT / 32; ++i) {
-      const size_t o = min(gbase + (size_t)(n0 + 32 * i) * Q, last);
-      gg[i] = *reinterpret_cast<const f32x4*>(grad_out + o);
-      yy[i] = *reinterpret_cast<const f32x4*>(ysrc + o);
-    }
-  }
+  for (int i = 0; i < AHEAD; ++i) tile_load(i);
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- geometry of the read-modify-write of all four levels (its loads ride inside the GEMM, see below) ----
+  // ---- the read-modify-write of all four levels: its geometry AND its loads ride inside the GEMM (see below); only
+  //      the kernel arguments are fetched here.  Done before the GEMM, the geometry's ~600 dependent instructions
+  //      (one wave per SIMD) held the first MFMA back by ~5 us. ----
   f32x4 v[L][NPC];
   unsigned pgoff[L][NPC], plds[L][NPC];
   int pmask[L][NPC];
-  float fxs[L], fys[L];
-  {
-    const int Pslab = P.slab, Pzero = P.zero;
+  int Ph[L], Pw[L], Ptw[L], Poff[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-      BwdPieces g;
-      bwd_pieces(g, kx, ky, klive, l, kq, sub, P.h[l], P.w[l], P.tw[l], P.off[l], Pslab, Pzero);
-      const Origin oj = make_origin(cx, cy, l);
-      fxs[l] = oj.fx;
-      fys[l] = oj.fy;
-#pragma unroll
-      for (int i = 0; i < NPC; ++i) {
-        pgoff[l][i] = g.goff[i];
-        plds[l][i] = g.lds[i];
-        pmask[l][i] = g.mask[i];
-      }
-    }
+  for (int l = 0; l < L; ++l) {
+    Ph[l] = P.h[l];
+    Pw[l] = P.w[l];
+    Ptw[l] = P.tw[l];
+    Poff[l] = P.off[l];
   }
-  __builtin_amdgcn_sched_barrier(0);
-  PCFA_LC_STAMP();   // 1: geometry done (the gradient tile's loads are in flight)
-  if (full) {
-    const float thr = relu ? 0.f : -__builtin_inff();   // no ReLU: every finite or infinite value passes
+  const int Pslab = P.slab, Pzero = P.zero;
+  struct LevelOrg { int x0, y0, ox; unsigned wB; };
+  LevelOrg org[L];
+  auto level_setup = [&](int l) {
+    const Origin o = make_origin(kx, ky, l);
+    const int th4 = ((Ph[l] + 3) >> 2) << 2;
+    org[l].x0 = min(max(o.x0, -16), 4 * Ptw[l]);
+    org[l].y0 = klive ? min(max(o.y0, -16), th4) : th4;
+    org[l].ox = org[l].x0 & 3;
+    org[l].wB = (unsigned)(Poff[l] + kq * Pslab) * 4u;
+  };
+  auto piece_setup = [&](int l, int i) {   // as bwd_pieces, one piece
+    const int q = sub + 8 * i, rr = q >> 2, tx = q & 3;
+    const int hl = Ph[l], wl = Pw[l], tw = Ptw[l], ox = org[l].ox;
+    const int y = org[l].y0 + rr, gtx = (org[l].x0 >> 2) + tx;
+    const bool need = (unsigned)y < (unsigned)hl && (unsigned)gtx < (unsigned)tw && 4 * tx < ox + WIN;
+    const int c0 = 4 * tx - ox, gx0 = 4 * gtx;
+    int mask = need ? 16 : 0;
 #pragma unroll
-    for (int i = 0; i < COUT / 32; ++i) {
-      f32x4 t;
-      t.x = (yy[i].x > thr || !relu) ? gg[i].x : 0.f; t.y = (yy[i].y > thr || !relu) ? gg[i].y : 0.f;
-      t.z = (yy[i].z > thr || !relu) ? gg[i].z : 0.f; t.w = (yy[i].w > thr || !relu) ? gg[i].w : 0.f;
-      *reinterpret_cast<f32x4*>(&s_g[n0 + 32 * i][qq]) = t;
-    }
-  } else {   // ragged last tile, or rows that are not 16-B aligned: per-float, rolled
+    for (int e = 0; e < 4; ++e)
+      if ((unsigned)(c0 + e) < (unsigned)WIN && gx0 + e < wl) mask |= 1 << e;
+    pmask[l][i] = mask;
+    pgoff[l][i] = need ? org[l].wB + (((((unsigned)y >> 2) * (unsigned)tw + (unsigned)gtx) << 4) + (((unsigned)y & 3u) << 2)) * 4u
+                       : (unsigned)Pzero * 4u;
+    plds[l][i] = (unsigned)(kq * WS + rr * RS + 4 + 4 * tx - ox) * 4u;
+  };
+  __builtin_amdgcn_sched_barrier(0);
+  PCFA_LC_STAMP();   // 1: head done (the gradient tile's loads are in flight)
+  if (!full) {   // ragged last tile, or rows that are not 16-B aligned: the whole tile per-float, rolled, up front
 #pragma unroll 1
-    for (int i = 0; i < COUT / 32; ++i) {
+    for (int i = 0; i < NBLK; ++i) {
       const size_t o = gbase + (size_t)(n0 + 32 * i) * Q;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -539,8 +568,6 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_bwd_kernel(
       }
     }
   }
-  __syncthreads();
-  PCFA_LC_STAMP();   // 2: gradient tile staged
 
   // ---- d taps [352][32] = W^T [352][256] . g [256][32]; wave w owns row tiles w, w + 4, w + 8 ----
   {
@@ -564,11 +591,16 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_bwd_kernel(
     for (int d = 0; d < WD; ++d)
 #pragma unroll
       for (int m = 0; m < MTW; ++m) wring[d][m] = wq[(wrow[m] + d) * 64];
-    float bv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) bv[e] = s_g[2 * e + lh][l31];
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < NGB; ++g) {
+      if (g % 4 == 0) {   // block g / 4 of the tile: registers -> LDS, one barrier, then its four groups
+        if (full) tile_store(g / 4);
+        __syncthreads();
+        if (g == 0) PCFA_LC_STAMP();   // 2: first block of the gradient tile staged
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = s_g[8 * g + 2 * e + lh][l31];
+      }
       float bvn[4] = {0.f, 0.f, 0.f, 0.f};
       f32x4 wcur[MTW];
 #pragma unroll
@@ -581,10 +613,11 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_bwd_kernel(
           const int step = e * MTW + m;
           const float av = e == 0 ? wcur[m].x : e == 1 ? wcur[m].y : e == 2 ? wcur[m].z : wcur[m].w;
           acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[e], acc[m], 0, 0, 0);
-          if (step == 0 && g + 1 < NGB) {
+          if (step == 0 && (g + 1) % 4 != 0) {   // the next group's rows, unless they belong to the next block
 #pragma unroll
             for (int ee = 0; ee < 4; ++ee) bvn[ee] = s_g[8 * (g + 1) + 2 * ee + lh][l31];
           }
+          if (step == 4 && g % 4 == 0 && g / 4 + AHEAD < NBLK) tile_load(g / 4 + AHEAD);
           if (step == 1 && g + WD < NGB) {
 #pragma unroll
             for (int mm = 0; mm < MTW; ++mm) wring[g % WD][mm] = wq[(wrow[mm] + g + WD) * 64];
@@ -592,7 +625,9 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_bwd_kernel(
           // The read half of the read-modify-write, one piece per group over the first 20 groups, in the order the
           // scatter needs them.  All 20 up front (44 MB with the gradient tiles, across the chip) held the gradient
           // tile back for 9 us; all 20 right before the GEMM would hold the W ring back instead (returns are in order).
-          if (step == 2 && g < L * NPC) v[g / NPC][g % NPC] = load_piece(slab0, pgoff[g / NPC][g % NPC]);
+          if (step == 2 && g < L * NPC && g % NPC == 0) level_setup(g / NPC);
+          if (step == 3 && g < L * NPC) piece_setup(g / NPC, g % NPC);
+          if (step == 5 && g < L * NPC) v[g / NPC][g % NPC] = load_piece(slab0, pgoff[g / NPC][g % NPC]);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -613,7 +648,8 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_bwd_kernel(
   // ---- per level: the lookup's transpose (corr_lookup_bwd_body with the tap gradients read from LDS) ----
 #pragma unroll
   for (int l = 0; l < L; ++l) {
-    const float fx = fxs[l], fy = fys[l];
+    const Origin oj = make_origin(cx, cy, l);
+    const float fx = oj.fx, fy = oj.fy;
     const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
