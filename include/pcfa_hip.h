@@ -354,6 +354,15 @@ PCFA_API int pcfa_sepconv5_fwd(const float* in_a, int Ca, const float* in_b, int
 PCFA_API int pcfa_sepconv5_fwd_split(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,
                             float* out_a, int Cout_a, int accumulate_a, float* out_b, int accumulate_b, int B,
                             int Cout, int H, int W, int vertical, void* stream);
+/* The same, and the b part of the result (channels >= Cout_a) additionally passes through a deferred ReLU backward:
+ * after the (accumulating) write, channels < mask_channels of out_b are zeroed where mask_b <= 0 (mask_b: the tensor
+ * whose ReLU it is, shape of out_b).  Lets the motion encoder's last ReLU (models/raft/update.py:101) be differentiated
+ * by the GRU's backward, which produces that gradient anyway, instead of by a launch of its own.  Must be the LAST
+ * write of out_b. */
+PCFA_API int pcfa_sepconv5_fwd_split_masked(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,
+                                   float* out_a, int Cout_a, int accumulate_a, float* out_b, int accumulate_b,
+                                   const float* mask_b, int mask_channels, int B, int Cout, int H, int W,
+                                   int vertical, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution (the update-block convolutions, models/raft/update.py:6-16,79-101) as Winograd
  * F(2x2,3x3) on the fp32 matrix cores, bias and ReLU fused:  out[b,n] = act(bias[n] + sum_k w[n,k] (*) x[b,k]).
@@ -373,6 +382,11 @@ PCFA_API int pcfa_conv3x3_act_fwd(const float* x, const float* packed, const flo
                          int N, int H, int W, int act, float slope, void* stream);
 PCFA_API int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, float* grad_x, float slope, long long n,
                         void* stream);
+/* pcfa_conv3x3_fwd without bias / activation whose result is zeroed where mask <= 0 (mask: shape of out).  As a data
+ * gradient (packed = bwd_packed) with mask = the convolution's own input this is conv'(g) * [x > 0]: the ReLU backward
+ * of the layer that produced x (models/raft/update.py:92,94 convc2 / convf2 feeding conv), fused into the epilogue. */
+PCFA_API int pcfa_conv3x3_masked_fwd(const float* x, const float* packed, const float* mask, float* out, int B, int K,
+                            int N, int H, int W, void* stream);
 
 /* out = relu(x + bias[c]) and its backward gx = grad_out * (out > 0): the "conv -> +bias -> ReLU" tail of the
  * motion encoder / flow head convolutions (models/raft/update.py:12-16,91-101) in one pass. */

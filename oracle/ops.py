@@ -488,9 +488,10 @@ def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None):
     return F.relu(y) if relu else y
 
 
-def gru_step(h, rest, halves):
+def gru_step(h, rest, halves, rest_relu_channels=0):
     """SepConvGRU update (models/raft/update.py:45-60) from the hoisted context parts, composed from the oracle's own
-    operators: halves = ((w_zr, p_zr, w_q, p_q), (w_zr, p_zr, w_q, p_q))."""
+    operators: halves = ((w_zr, p_zr, w_q, p_q), (w_zr, p_zr, w_q, p_q)).  rest_relu_channels: a scheduling hint of the
+    product (where the ReLU backward of `rest` runs); autograd differentiates every ReLU in place here."""
     for w_zr, p_zr, w_q, p_q in halves:
         z, rh = gru_gates_packed(sepconv5(h, rest, w_zr), h, None, p_zr)
         h = gru_update(z, sepconv5(rh, rest, w_q), h, None, p_q)
@@ -506,8 +507,9 @@ def conv_fewin(x, weight, bias=None, relu=False):
     return F.relu(y) if relu else y
 
 
-def conv3x3_cat(convs, tails=()):
-    """models/raft/update.py:91-101: torch.cat([relu(conv(x)) ...] + tails, dim=1)."""
+def conv3x3_cat(convs, tails=(), grad_premasked=False, mask_input_grads=False):
+    """models/raft/update.py:91-101: torch.cat([relu(conv(x)) ...] + tails, dim=1).  The two flags are scheduling hints
+    of the product (which kernel applies a ReLU mask); they change no value."""
     return torch.cat([F.relu(F.conv2d(x, w, b, stride=1, padding=1)) for x, w, b in convs] + list(tails), dim=1)
 
 

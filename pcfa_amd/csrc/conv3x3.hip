@@ -100,7 +100,8 @@ __device__ __forceinline__ unsigned long long c3_now() {
 template <int ACT, int CBT, int MT, bool KFULL, int NRING>  // ACT: 0 none, 1 ReLU, 2 LeakyReLU(slope)
 __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 1 && NRING == 2 && CBT == 32 ? 3 : (CBT == 64 ? 1 : 2)))) void conv3x3_winograd_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
-    float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x, float slope) {
+    const float* __restrict__ mask, float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x,
+    float slope) {
   constexpr int NT = 256 * MT;                         // threads
   constexpr int TR = 4 * MT, TB = TR * TC;             // tile rows / tiles per workgroup
   constexpr int PR = 2 * TR + 2;                       // input patch rows
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   const long long plane = (long long)H * W;
   x += (long long)blockIdx.z * K * plane;
   out += (long long)blockIdx.z * N * plane;
+  if (mask != nullptr) mask += (long long)blockIdx.z * N * plane;   // same shape as `out`
 
   // ---- per-thread constants of the staging loads (chunk-invariant) ----
   unsigned praw[RAW_LOADS];      // chunk 0 source of the patch element (clamped into the image), floats from x
@@ -302,7 +304,17 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
         y10 = y10 > 0.f ? y10 : y10 * slope; y11 = y11 > 0.f ? y11 : y11 * slope;
       }
       if (n < N && oy < H && ox < W) {
-        float* o = out + (long long)n * plane + (long long)oy * W + ox;
+        const long long oo = (long long)n * plane + (long long)oy * W + ox;
+        if (mask != nullptr) {   // data gradient w.r.t. a ReLU output: the deferred ReLU backward of the producer
+          const float* mk = mask + oo;
+          y00 = mk[0] > 0.f ? y00 : 0.f;
+          if (ox + 1 < W) y01 = mk[1] > 0.f ? y01 : 0.f;
+          if (oy + 1 < H) {
+            y10 = mk[W] > 0.f ? y10 : 0.f;
+            if (ox + 1 < W) y11 = mk[W + 1] > 0.f ? y11 : 0.f;
+          }
+        }
+        float* o = out + oo;
         o[0] = y00;
         if (ox + 1 < W) o[1] = y01;
         if (oy + 1 < H) {
@@ -368,13 +380,27 @@ extern "C" int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, floa
   return PCFA_OK;
 }
 
+static int conv3x3_launch(const float* x, const float* packed, const float* bias, const float* mask, float* out, int B,
+                          int K, int N, int H, int W, int act, float slope, void* stream);
+
 extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K,
                                 int N, int H, int W, int relu, void* stream) {
-  return pcfa_conv3x3_act_fwd(x, packed, bias, out, B, K, N, H, W, relu ? 1 : 0, 0.f, stream);
+  return conv3x3_launch(x, packed, bias, nullptr, out, B, K, N, H, W, relu ? 1 : 0, 0.f, stream);
 }
 
 extern "C" int pcfa_conv3x3_act_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K,
                                     int N, int H, int W, int act, float slope, void* stream) {
+  return conv3x3_launch(x, packed, bias, nullptr, out, B, K, N, H, W, act, slope, stream);
+}
+
+extern "C" int pcfa_conv3x3_masked_fwd(const float* x, const float* packed, const float* mask, float* out, int B, int K,
+                                       int N, int H, int W, void* stream) {
+  if (!mask) return PCFA_ERR_INVALID_ARG;
+  return conv3x3_launch(x, packed, nullptr, mask, out, B, K, N, H, W, 0, 0.f, stream);
+}
+
+static int conv3x3_launch(const float* x, const float* packed, const float* bias, const float* mask, float* out, int B,
+                          int K, int N, int H, int W, int act, float slope, void* stream) {
   if (act < 0 || act > 2) return PCFA_ERR_INVALID_ARG;
   if (!x || !packed || !out || B < 1 || K < 1 || N < 1 || H < 1 || W < 1 || !aligned16(packed))
     return PCFA_ERR_INVALID_ARG;
@@ -397,7 +423,7 @@ extern "C" int pcfa_conv3x3_act_fwd(const float* x, const float* packed, const f
     block.x = 512;
   }
   grid.y = Npad / 32;
-#define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, out, K, N, Npad, H, W, blocks_x, slope
+#define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, mask, out, K, N, Npad, H, W, blocks_x, slope
 #define PCFA_C3_LAUNCH(MT_, KF_, NR_)                                                              \
   do {                                                                                             \
     if (act == 1) pcfa_launch(conv3x3_winograd_kernel<1, 32, MT_, KF_, NR_>, PCFA_C3_ARGS);        \

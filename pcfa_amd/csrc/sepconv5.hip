@@ -52,6 +52,8 @@ struct OutSplit {
   float* b;
   int Ca;
   int acc_a, acc_b;
+  const float* mask_b;   // optional, shape of `b`: channels < mask_cb of the b part are zeroed where mask_b <= 0
+  int mask_cb;           // (the deferred ReLU backward of whoever produced the b operand of the forward)
 };
 
 __device__ __forceinline__ const float* channel_plane(const Operand& in, int ci, long long plane) {
@@ -289,7 +291,17 @@ __global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const fl
       // the wave's 32 channels lie on one side of the split: destination and accumulate flag are wave-uniform
       const bool first = out.b == nullptr || mw < out.Ca;
       float* base = (first ? out.a + (long long)mw * plane : out.b + (long long)(mw - out.Ca) * plane) + pix;
-      if (first ? out.acc_a : out.acc_b) {
+      if (!first && out.mask_b != nullptr) {   // last write of the b part: apply the deferred ReLU mask
+        const float* mk = out.mask_b + (long long)(mw - out.Ca) * plane + pix;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (mw + ml < Cout) {
+            const float v = out.acc_b ? base[ml * plane] + acc[r] : acc[r];
+            base[ml * plane] = (mw - out.Ca + ml >= out.mask_cb || mk[ml * plane] > 0.f) ? v : 0.f;
+          }
+        }
+      } else if (first ? out.acc_a : out.acc_b) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -309,7 +321,11 @@ __global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const fl
         if (m < Cout) {
           const bool first = m < out.Ca;
           float* o = (first ? out.a + (long long)m * plane : out.b + (long long)(m - out.Ca) * plane) + pix;
-          *o = (first ? out.acc_a : out.acc_b) ? *o + acc[r] : acc[r];
+          float v = (first ? out.acc_a : out.acc_b) ? *o + acc[r] : acc[r];
+          if (!first && out.mask_b != nullptr && m - out.Ca < out.mask_cb &&
+              !(out.mask_b[(long long)(m - out.Ca) * plane + pix] > 0.f))
+            v = 0.f;
+          *o = v;
         }
       }
     }
@@ -354,7 +370,7 @@ extern "C" int pcfa_sepconv5_fwd(const float* in_a, int Ca, const float* in_b, i
                                  const float* w_packed, float* out, int B, int Cout, int H, int W,
                                  int vertical, void* stream) {
   if (!out) return PCFA_ERR_INVALID_ARG;
-  return sepconv5_launch(in_a, Ca, in_b, Cb, w_packed, OutSplit{out, nullptr, Cout, 0, 0}, B, Cout, H, W, vertical,
+  return sepconv5_launch(in_a, Ca, in_b, Cb, w_packed, OutSplit{out, nullptr, Cout, 0, 0, nullptr, 0}, B, Cout, H, W, vertical,
                          stream);
 }
 
@@ -363,7 +379,20 @@ extern "C" int pcfa_sepconv5_fwd_split(const float* in_a, int Ca, const float* i
                                        int B, int Cout, int H, int W, int vertical, void* stream) {
   if (!out_a || Cout_a < 1 || Cout_a > Cout || (Cout_a < Cout && !out_b)) return PCFA_ERR_INVALID_ARG;
   return sepconv5_launch(in_a, Ca, in_b, Cb, w_packed,
-                         OutSplit{out_a, Cout_a < Cout ? out_b : nullptr, Cout_a, accumulate_a != 0, accumulate_b != 0},
+                         OutSplit{out_a, Cout_a < Cout ? out_b : nullptr, Cout_a, accumulate_a != 0, accumulate_b != 0,
+                                  nullptr, 0},
+                         B, Cout, H, W, vertical, stream);
+}
+
+extern "C" int pcfa_sepconv5_fwd_split_masked(const float* in_a, int Ca, const float* in_b, int Cb,
+                                              const float* w_packed, float* out_a, int Cout_a, int accumulate_a,
+                                              float* out_b, int accumulate_b, const float* mask_b, int mask_channels,
+                                              int B, int Cout, int H, int W, int vertical, void* stream) {
+  if (!out_a || Cout_a < 1 || Cout_a >= Cout || !out_b || !mask_b || mask_channels < 0 ||
+      mask_channels > Cout - Cout_a)
+    return PCFA_ERR_INVALID_ARG;
+  return sepconv5_launch(in_a, Ca, in_b, Cb, w_packed,
+                         OutSplit{out_a, out_b, Cout_a, accumulate_a != 0, accumulate_b != 0, mask_b, mask_channels},
                          B, Cout, H, W, vertical, stream);
 }
 

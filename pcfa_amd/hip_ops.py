@@ -975,9 +975,10 @@ class _Conv3x3Cat(torch.autograd.Function):
     models/raft/update.py:91-101) are copied behind them -- no torch.cat pass over the convolution outputs."""
 
     @staticmethod
-    def forward(ctx, n_conv, *args):
+    def forward(ctx, n_conv, flags, *args):
         xs, ws, bs = args[0:3 * n_conv:3], args[1:3 * n_conv:3], args[2:3 * n_conv:3]
         tails = args[3 * n_conv:]
+        ctx.grad_premasked, ctx.mask_input_grads = bool(flags & 1), bool(flags & 2)
         _dev(*xs, *ws, *tails)
         xs = [x.contiguous() for x in xs]
         B, _, H, W = xs[0].shape
@@ -999,39 +1000,52 @@ class _Conv3x3Cat(torch.autograd.Function):
             buf[:, off:off + t.shape[1]].copy_(t)
             off += t.shape[1]
         ctx.packs, ctx.dims, ctx.n_conv, ctx.tail_widths = packs, (H, W), n_conv, [t.shape[1] for t in tails]
-        ctx.save_for_backward(buf)
+        ctx.save_for_backward(buf, *(xs if ctx.mask_input_grads else ()))
         return buf
 
     @staticmethod
     def backward(ctx, g):
-        (buf,) = ctx.saved_tensors
+        buf = ctx.saved_tensors[0]
         H, W = ctx.dims
         plane = H * W
         g = g.contiguous()
-        grads = [None]
+        grads = [None, None]
         for i, (bwd, k, n, off) in enumerate(ctx.packs):
-            if ctx.needs_input_grad[2 + 3 * i] or ctx.needs_input_grad[3 + 3 * i]:
+            if ctx.needs_input_grad[3 + 3 * i] or ctx.needs_input_grad[4 + 3 * i]:
                 raise RuntimeError("conv3x3_cat is the frozen-weight path: no weight / bias gradient")
             gx = None
-            if ctx.needs_input_grad[1 + 3 * i]:
-                gm = torch.empty((1, n, H, W), device=g.device, dtype=torch.float32)
-                _call("pcfa_relu_bwd", _ptr_off(buf, off * plane), _ptr_off(g, off * plane), _ptr(gm), n * plane)
+            if ctx.needs_input_grad[2 + 3 * i]:
+                if ctx.grad_premasked:      # the consumer already applied this layer's ReLU mask to its gradient
+                    gm = g[:, off:off + n]  # a channel block of a batch-1 NCHW tensor: contiguous
+                else:
+                    gm = torch.empty((1, n, H, W), device=g.device, dtype=torch.float32)
+                    _call("pcfa_relu_bwd", _ptr_off(buf, off * plane), _ptr_off(g, off * plane), _ptr(gm), n * plane)
                 gx = torch.empty((1, k, H, W), device=g.device, dtype=torch.float32)
-                _call("pcfa_conv3x3_fwd", _ptr(gm), _ptr(bwd), None, _ptr(gx), 1, n, k, H, W, 0)
+                if ctx.mask_input_grads:    # x_i is a ReLU output whose producer left its mask to this epilogue
+                    _call("pcfa_conv3x3_masked_fwd", _ptr(gm), _ptr(bwd), _ptr(ctx.saved_tensors[1 + i]), _ptr(gx), 1, n,
+                          k, H, W)
+                else:
+                    _call("pcfa_conv3x3_fwd", _ptr(gm), _ptr(bwd), None, _ptr(gx), 1, n, k, H, W, 0)
             grads += [gx, None, None]
         off = sum(p[2] for p in ctx.packs)
         for j, tw in enumerate(ctx.tail_widths):
-            grads.append(g[:, off:off + tw] if ctx.needs_input_grad[1 + 3 * ctx.n_conv + j] else None)
+            grads.append(g[:, off:off + tw] if ctx.needs_input_grad[2 + 3 * ctx.n_conv + j] else None)
             off += tw
         return tuple(grads)
 
 
-def conv3x3_cat(convs, tails=()):
-    """convs = [(x, weight, bias), ...] (frozen 3x3 / stride 1 / pad 1, ReLU), tails = tensors appended unchanged."""
+def conv3x3_cat(convs, tails=(), grad_premasked=False, mask_input_grads=False):
+    """convs = [(x, weight, bias), ...] (frozen 3x3 / stride 1 / pad 1, ReLU), tails = tensors appended unchanged.
+    Deferred ReLU masks (each saves one elementwise launch per layer and backward; the CALLER guarantees the contract):
+    grad_premasked   -- every consumer of the result multiplies the gradient of the convolution channels by
+                        [result > 0] itself (conv3x3_cat(mask_input_grads=True), gru_step(rest_relu_channels=...)), so
+                        the backward here skips its ReLU pass;
+    mask_input_grads -- every x_i is a ReLU output produced with grad_premasked=True: its mask [x_i > 0] is applied in
+                        the epilogue of the data-gradient kernel."""
     flat = []
     for x, w, b in convs:
         flat += [x, w, b]
-    return _Conv3x3Cat.apply(len(convs), *flat, *tails)
+    return _Conv3x3Cat.apply(len(convs), int(bool(grad_premasked)) | 2 * int(bool(mask_input_grads)), *flat, *tails)
 
 
 class _DenseBlock(torch.autograd.Function):
@@ -1112,7 +1126,7 @@ class _GruStep(torch.autograd.Function):
     contribution of the constant context features (bias included)."""
 
     @staticmethod
-    def forward(ctx, h, rest, w_zr1, p_zr1, w_q1, p_q1, w_zr2, p_zr2, w_q2, p_q2):
+    def forward(ctx, h, rest, w_zr1, p_zr1, w_q1, p_q1, w_zr2, p_zr2, w_q2, p_q2, rest_relu_channels=0):
         _dev(h, rest, w_zr1, p_zr1, w_q1, p_q1, w_zr2, p_zr2, w_q2, p_q2)
         h, rest = h.contiguous(), rest.contiguous()
         B, C, H, W = h.shape
@@ -1141,7 +1155,10 @@ class _GruStep(torch.autograd.Function):
             saved += [z, r, q, h]
             packs.append((b_zr, b_q, vertical))
             h = hnew
-        ctx.save_for_backward(*saved)
+        ctx.rest_relu = int(rest_relu_channels)
+        if not 0 <= ctx.rest_relu <= Cr:
+            raise ValueError("gru_step: rest_relu_channels %d outside [0, %d]" % (ctx.rest_relu, Cr))
+        ctx.save_for_backward(*saved, *((rest,) if ctx.rest_relu else ()))
         ctx.packs, ctx.dims = packs, (B, C, Cr, H, W)
         return h
 
@@ -1169,12 +1186,17 @@ class _GruStep(torch.autograd.Function):
                 o, oz = b * n, b * 2 * n
                 _call("pcfa_gru_gates_bwd_acc", _ptr_off(z, o), _ptr_off(r, o), _ptr_off(h, o), _ptr_off(dz, o),
                       _ptr_off(drh, o), _ptr_off(dh, o), _ptr_off(dzr, oz), _ptr_off(dzr, oz + n), _ptr_off(dh, o), n)
-            # d[h | rest] of the stacked z|r convolution: both parts accumulate
-            _call("pcfa_sepconv5_fwd_split", _ptr(dzr), 2 * C, None, 0, _ptr(b_zr), _ptr(dh), C, 1, _ptr(d_rest), 1,
-                  B, C + Cr, H, W, vertical)
+            # d[h | rest] of the stacked z|r convolution: both parts accumulate; the step's last write of d_rest also
+            # applies the deferred ReLU mask of the layer that produced `rest`
+            if half == 0 and ctx.rest_relu:
+                _call("pcfa_sepconv5_fwd_split_masked", _ptr(dzr), 2 * C, None, 0, _ptr(b_zr), _ptr(dh), C, 1,
+                      _ptr(d_rest), 1, _ptr(ctx.saved_tensors[8]), ctx.rest_relu, B, C + Cr, H, W, vertical)
+            else:
+                _call("pcfa_sepconv5_fwd_split", _ptr(dzr), 2 * C, None, 0, _ptr(b_zr), _ptr(dh), C, 1, _ptr(d_rest), 1,
+                      B, C + Cr, H, W, vertical)
             grads_p[2 * half], grads_p[2 * half + 1] = dzr, dqc
             g = dh
-        return g, d_rest, None, grads_p[0], None, grads_p[1], None, grads_p[2], None, grads_p[3]
+        return g, d_rest, None, grads_p[0], None, grads_p[1], None, grads_p[2], None, grads_p[3], None
 
 
 # --------------------------------------------------------------------------- #
@@ -1329,11 +1351,13 @@ def fanout(x, n):
     return _Fanout.apply(x, n) if n > 1 else (x,)
 
 
-def gru_step(h, rest, halves):
+def gru_step(h, rest, halves, rest_relu_channels=0):
     """SepConvGRU update from precomputed context parts: halves = ((w_zr, p_zr, w_q, p_q) for the 1x5 half-step,
-    (..) for the 5x1 half-step); see _GruStep."""
+    (..) for the 5x1 half-step); see _GruStep.  rest_relu_channels = n > 0: rest[:, :n] are ReLU outputs whose producer
+    ran with grad_premasked=True and has no other consumer -- the gradient returned for them is already multiplied
+    by [rest > 0] (applied by the kernel that writes it last)."""
     (a, b, c, d), (e, f, g_, i_) = halves
-    return _GruStep.apply(h, rest, a, b, c, d, e, f, g_, i_)
+    return _GruStep.apply(h, rest, a, b, c, d, e, f, g_, i_, int(rest_relu_channels))
 
 
 def sepconv5(a, b, weight):

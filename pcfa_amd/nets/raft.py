@@ -275,11 +275,13 @@ class SepConvGRU(nn.Module):
         fans = {tag: ops.get().fanout(p, iters) for tag, (_, p) in ctx.items()}
         return [{tag: (ctx[tag][0], fans[tag][i]) for tag in ctx} for i in range(iters)]
 
-    def step(self, h, ctx, rest):
-        """One GRU update given precompute()'s context; `rest` = the per-iteration part of x (motion features)."""
+    def step(self, h, ctx, rest, rest_relu_channels=0):
+        """One GRU update given precompute()'s context; `rest` = the per-iteration part of x (motion features).
+        rest_relu_channels: see ops.gru_step (the leading channels of `rest` whose ReLU backward this node applies)."""
         # one autograd node per update: sepconv5 reads [h | rest] in place (no torch.cat, no im2col) and the
         # backward accumulates the gradients of h and rest inside the kernels that produce them
-        return ops.get().gru_step(h, rest, tuple(ctx[zr] + ctx[q] for zr, q in (("zr1", "q1"), ("zr2", "q2"))))
+        return ops.get().gru_step(h, rest, tuple(ctx[zr] + ctx[q] for zr, q in (("zr1", "q1"), ("zr2", "q2"))),
+                                  rest_relu_channels)
 
 
 class LookupRef:
@@ -313,15 +315,29 @@ class BasicMotionEncoder(nn.Module):
         self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
-    def forward(self, flow, corr):
-        """`corr`: the lookup tensor [B,324,H,W] or a LookupRef (lookup + convc1 may then run as one kernel)."""
+    RELU_CHANNELS = 128 - 2   # leading channels of the result that are ReLU outputs (the rest is the flow)
+
+    def can_defer_relu(self, flow):
+        """True when forward(.., defer_relu=True) is available: the in-place concatenation path below."""
+        return (flow.shape[0] == 1 and _all_frozen(self)
+                and all(_is_plain3x3(c) for c in (self.convc2, self.convf2, self.conv)))
+
+    def forward(self, flow, corr, defer_relu=False):
+        """`corr`: the lookup tensor [B,324,H,W] or a LookupRef (lookup + convc1 may then run as one kernel).
+        defer_relu: the caller's ONLY consumer of the result is ops.gru_step(.., rest_relu_channels=RELU_CHANNELS), which
+        applies the last layer's ReLU backward itself; the inner ReLUs are then differentiated by the data-gradient
+        kernels of the layers they feed (ops.conv3x3_cat flags) -- two elementwise launches less per iteration."""
         cor1 = corr.conv_relu(self.convc1) if isinstance(corr, LookupRef) else _conv_relu(self.convc1, corr)
-        if flow.shape[0] == 1 and _all_frozen(self) and all(_is_plain3x3(c) for c in (self.convc2, self.convf2, self.conv)):
+        if self.can_defer_relu(flow):
             # the 3x3 convolutions write their channel blocks of the concatenated tensors in place (no torch.cat pass)
             o = ops.get()
             flo1 = _conv_relu(self.convf1, flow)
-            cf = o.conv3x3_cat([(cor1, self.convc2.weight, self.convc2.bias), (flo1, self.convf2.weight, self.convf2.bias)])
-            return o.conv3x3_cat([(cf, self.conv.weight, self.conv.bias)], (flow,))
+            cf = o.conv3x3_cat([(cor1, self.convc2.weight, self.convc2.bias), (flo1, self.convf2.weight, self.convf2.bias)],
+                               grad_premasked=defer_relu)
+            return o.conv3x3_cat([(cf, self.conv.weight, self.conv.bias)], (flow,), grad_premasked=defer_relu,
+                                 mask_input_grads=defer_relu)
+        if defer_relu:
+            raise RuntimeError("BasicMotionEncoder: defer_relu needs the in-place path (check can_defer_relu first)")
         cor = _conv_relu(self.convc2, cor1)
         flo = _conv_relu(self.convf2, _conv_relu(self.convf1, flow))
         out = _conv_relu(self.conv, torch.cat([cor, flo], dim=1))
@@ -341,9 +357,11 @@ class BasicUpdateBlock(nn.Module):
         self.mask = _mask_head()
 
     def forward(self, net, inp, corr, flow, want_mask=True, gru_ctx=None):
-        motion_features = self.encoder(flow, corr)
+        # frozen weights: the GRU node is the motion features' only consumer and differentiates their ReLU itself
+        defer = gru_ctx is not None and self.encoder.can_defer_relu(flow)
+        motion_features = self.encoder(flow, corr, defer_relu=defer)
         if gru_ctx is not None:   # frozen weights: context-feature part of the gate convolutions hoisted
-            net = self.gru.step(net, gru_ctx, motion_features)
+            net = self.gru.step(net, gru_ctx, motion_features, self.encoder.RELU_CHANNELS if defer else 0)
         else:
             net = self.gru(net, torch.cat([inp, motion_features], dim=1))
         delta_flow = self.flow_head(net)

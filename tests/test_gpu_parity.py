@@ -434,6 +434,39 @@ def test_conv3x3_cat_vs_oracle(oracle_ops):
     assert rel_l2(ag.grad, a.grad) < 1e-4 and rel_l2(bg.grad, b.grad) < 1e-4
 
 
+def test_deferred_relu_masks_change_no_bit():
+    """Motion encoder + GRU update with the ReLU backward of convc2 / convf2 / conv deferred into the kernels that
+    produce those gradients anyway (conv3x3_cat flags, gru_step rest_relu_channels; pcfa_conv3x3_masked_fwd,
+    pcfa_sepconv5_fwd_split_masked) against the same graph with one ReLU launch per layer: a mask multiplies by exactly
+    0 or 1, so every gradient must be bit-identical."""
+    gen = torch.Generator().manual_seed(17)
+    H, W, C = 55, 128, 128
+    rnd = lambda *s: torch.randn(*s, generator=gen)  # noqa: E731
+    a, b, flow = rnd(1, 256, H, W), rnd(1, 128, H, W), rnd(1, 2, H, W)
+    wa, ba = rnd(192, 256, 3, 3) / 48, 0.1 * rnd(192)
+    wb, bb = rnd(64, 128, 3, 3) / 34, 0.1 * rnd(64)
+    wc, bc = rnd(126, 256, 3, 3) / 48, 0.1 * rnd(126)
+    h = torch.tanh(rnd(1, C, H, W))
+    halves = []
+    for k in ((1, 5), (5, 1)):
+        sc = (5 * (2 * C)) ** -.5
+        halves.append((rnd(2 * C, 2 * C, *k) * sc, rnd(1, 2 * C, H, W), rnd(C, 2 * C, *k) * sc, rnd(1, C, H, W)))
+    go = rnd(1, C, H, W)
+    d = lambda t: t.to(DEV)  # noqa: E731
+
+    def run(defer):
+        ag, bg, hg = (t.detach().to(DEV).requires_grad_(True) for t in (a, b, h))
+        cf = hip_ops.conv3x3_cat([(ag, d(wa), d(ba)), (bg, d(wb), d(bb))], grad_premasked=defer)
+        mf = hip_ops.conv3x3_cat([(cf, d(wc), d(bc))], (d(flow),), grad_premasked=defer, mask_input_grads=defer)
+        out = hip_ops.gru_step(hg, mf, tuple(tuple(d(t) for t in hf) for hf in halves), 126 if defer else 0)
+        out.backward(d(go))
+        return out.detach(), ag.grad, bg.grad, hg.grad
+
+    for x, y in zip(run(False), run(True)):
+        assert torch.equal(x, y)
+    assert float(run(True)[1].abs().max()) > 0
+
+
 # --------------------------------------------------------------------------- PWC-Net dense decoder block
 @pytest.mark.parametrize("shape", [(1, 115, 12, 40), (1, 81, 6, 20), (1, 21, 7, 9)])
 def test_dense_block_vs_oracle(oracle_ops, shape):
