@@ -364,6 +364,19 @@ PCFA_API int pcfa_sepconv5_fwd_split_masked(const float* in_a, int Ca, const flo
                                    const float* mask_b, int mask_channels, int B, int Cout, int H, int W,
                                    int vertical, void* stream);
 
+/* SepConvGRU half-step with the gate arithmetic in the convolution's epilogue (models/raft/update.py:45-60; replaces
+ * pcfa_sepconv5_fwd + pcfa_gru_gates_fwd resp. + pcfa_gru_update_fwd; C % 32 == 0):
+ *   gates : z = sigmoid(conv_z([h | rest]) + add_zr[:, :C]),  r = sigmoid(conv_r(..) + add_zr[:, C:]),  rh = r * h
+ *           with the stacked weight w_packed [5][C + Cr][2C];
+ *   update: q = tanh(conv_q([rh | rest]) + add_q),  hnew = (1 - z) * h + z * q,   w_packed [5][C + Cr][C].
+ * add_* = the pre-activation contribution of the constant context features, bias included ([B][2C or C][H][W]). */
+PCFA_API int pcfa_sepconv5_gru_gates_fwd(const float* h, int C, const float* rest, int Cr, const float* w_packed,
+                                const float* add_zr, float* z, float* r, float* rh, int B, int H, int W,
+                                int vertical, void* stream);
+PCFA_API int pcfa_sepconv5_gru_update_fwd(const float* rh, int C, const float* rest, int Cr, const float* w_packed,
+                                 const float* add_q, const float* z, const float* h, float* q, float* hnew, int B,
+                                 int H, int W, int vertical, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution (the update-block convolutions, models/raft/update.py:6-16,79-101) as Winograd
  * F(2x2,3x3) on the fp32 matrix cores, bias and ReLU fused:  out[b,n] = act(bias[n] + sum_k w[n,k] (*) x[b,k]).
  * pcfa_conv3x3_pack_weights: w [Cout][Cin][3][3] -> fwd_packed [16][Cin][pad64(Cout)] = G w G^T and/or
@@ -382,6 +395,13 @@ PCFA_API int pcfa_conv3x3_act_fwd(const float* x, const float* packed, const flo
                          int N, int H, int W, int act, float slope, void* stream);
 PCFA_API int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, float* grad_x, float slope, long long n,
                         void* stream);
+/* Two independent pcfa_conv3x3_act_fwd problems over the same H x W (batch 1) in ONE launch: the motion encoder's
+ * convc2(cor1) and convf2(flo1) (models/raft/update.py:92,94).  Each alone leaves the last round of workgroups partly
+ * empty on the 256 CUs; together the second problem's workgroups fill the first one's tail.  K % 8 == 0 must agree
+ * between the two (one kernel instance). */
+PCFA_API int pcfa_conv3x3_act_fwd_pair(const float* x, const float* packed, const float* bias, float* out, int K, int N,
+                              const float* x2, const float* packed2, const float* bias2, float* out2, int K2, int N2,
+                              int H, int W, int act, float slope, void* stream);
 /* pcfa_conv3x3_fwd without bias / activation whose result is zeroed where mask <= 0 (mask: shape of out).  As a data
  * gradient (packed = bwd_packed) with mask = the convolution's own input this is conv'(g) * [x > 0]: the ReLU backward
  * of the layer that produced x (models/raft/update.py:92,94 convc2 / convf2 feeding conv), fused into the epilogue. */

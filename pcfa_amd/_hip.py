@@ -80,6 +80,10 @@ SIGNATURES = {
     "pcfa_gru_gates_bwd_acc": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, _P]),
     "pcfa_sepconv5_fwd_split_masked": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, c_int,
                                                c_int, c_int, c_int, c_int, _P]),
+    "pcfa_sepconv5_gru_gates_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_sepconv5_gru_update_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_conv3x3_act_fwd_pair": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                          c_float, _P]),
     "pcfa_conv3x3_masked_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_conv3x3_packed_floats": (c_longlong, [c_int, c_int]),
     "pcfa_conv3x3_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, _P]),

@@ -97,11 +97,23 @@ __device__ __forceinline__ unsigned long long c3_now() {
 // one scalar chunk offset; the generic variant clamps and masks the channel index of every element).
 // NRING: depth of the register ring (2: <= 168 registers, 3 waves per SIMD -- large grids; 3: loads two chunks
 // ahead, 2 waves per SIMD -- small grids, where a CU holds one or two workgroups anyway and latency is all).
+// A second, independent convolution over the same image size served by the same launch (blockIdx.y >= nb0): the
+// motion encoder's convc2 (256 -> 192, 336 workgroups) and convf2 (128 -> 64, 112 workgroups) are independent, and
+// launched separately each pays its own partial last round of workgroups on the 256 CUs; together the small
+// problem's workgroups fill the large one's tail (dispatch order: x fastest, then y).  nb0 = gridDim.y: none.
+struct Second {
+  const float* x;
+  const float* U;
+  const float* bias;
+  float* out;
+  int K, N, nb0;
+};
+
 template <int ACT, int CBT, int MT, bool KFULL, int NRING>  // ACT: 0 none, 1 ReLU, 2 LeakyReLU(slope)
 __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 1 && NRING == 2 && CBT == 32 ? 3 : (CBT == 64 ? 1 : 2)))) void conv3x3_winograd_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
     const float* __restrict__ mask, float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x,
-    float slope) {
+    float slope, Second second) {
   constexpr int NT = 256 * MT;                         // threads
   constexpr int TR = 4 * MT, TB = TR * TC;             // tile rows / tiles per workgroup
   constexpr int PR = 2 * TR + 2;                       // input patch rows
@@ -122,7 +134,18 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   const int l31 = lane & 31, lh = lane >> 5;
   const int by = blockIdx.x / blocks_x, bx = blockIdx.x - by * blocks_x;
   const int y0 = by * (2 * TR), x0 = bx * (2 * TC);  // first output pixel of the block
-  const int n0 = blockIdx.y * CBT;
+  int nby = blockIdx.y;
+  if (nby >= second.nb0) {   // workgroup-uniform: this workgroup belongs to the second problem
+    nby -= second.nb0;
+    x = second.x;
+    U = second.U;
+    bias = second.bias;
+    out = second.out;
+    K = second.K;
+    N = second.N;
+    mask = nullptr;
+  }
+  const int n0 = nby * CBT;
   if (n0 >= N) return;  // (the packing pads N to 64: a 32-channel block may lie entirely in the padding)
   const long long plane = (long long)H * W;
   x += (long long)blockIdx.z * K * plane;
@@ -148,7 +171,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   // this lane's 16 B operands of chunk c: packed[((nb * nchunk + c) * 4 + wave) * 64 + lane][16]
   static_assert(CBT == 32, "the packed weight layout is per 32-channel block");
   const int nchunk = (K + KC - 1) / KC;
-  const float* pu = U + (((long long)blockIdx.y * nchunk * 4 + wave) * 64 + lane) * 16;
+  const float* pu = U + (((long long)nby * nchunk * 4 + wave) * 64 + lane) * 16;
 
   // register ring: the global loads of a chunk are issued NRING-1 chunks before its MFMAs
   float ring_raw[NRING][RAW_LOADS];
@@ -381,7 +404,9 @@ extern "C" int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, floa
 }
 
 static int conv3x3_launch(const float* x, const float* packed, const float* bias, const float* mask, float* out, int B,
-                          int K, int N, int H, int W, int act, float slope, void* stream);
+                          int K, int N, int H, int W, int act, float slope, void* stream, const float* x2 = nullptr,
+                          const float* packed2 = nullptr, const float* bias2 = nullptr, float* out2 = nullptr,
+                          int K2 = 0, int N2 = 0);
 
 extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K,
                                 int N, int H, int W, int relu, void* stream) {
@@ -399,8 +424,19 @@ extern "C" int pcfa_conv3x3_masked_fwd(const float* x, const float* packed, cons
   return conv3x3_launch(x, packed, nullptr, mask, out, B, K, N, H, W, 0, 0.f, stream);
 }
 
+extern "C" int pcfa_conv3x3_act_fwd_pair(const float* x, const float* packed, const float* bias, float* out, int K, int N,
+                                         const float* x2, const float* packed2, const float* bias2, float* out2, int K2,
+                                         int N2, int H, int W, int act, float slope, void* stream) {
+  if (!x2 || !packed2 || !out2 || K2 < 1 || N2 < 1 || !aligned16(packed2)) return PCFA_ERR_INVALID_ARG;
+  if ((K % KC == 0) != (K2 % KC == 0)) return PCFA_ERR_UNSUPPORTED;   // one kernel instance serves both
+  if (pcfa_conv3x3_packed_floats(K2, N2) > 0x7fffffffLL || (long long)K2 * H * W > 0x7fffffffLL) return PCFA_ERR_UNSUPPORTED;
+  return conv3x3_launch(x, packed, bias, nullptr, out, 1, K, N, H, W, act, slope, stream, x2, packed2, bias2, out2, K2,
+                        N2);
+}
+
 static int conv3x3_launch(const float* x, const float* packed, const float* bias, const float* mask, float* out, int B,
-                          int K, int N, int H, int W, int act, float slope, void* stream) {
+                          int K, int N, int H, int W, int act, float slope, void* stream, const float* x2,
+                          const float* packed2, const float* bias2, float* out2, int K2, int N2) {
   if (act < 0 || act > 2) return PCFA_ERR_INVALID_ARG;
   if (!x || !packed || !out || B < 1 || K < 1 || N < 1 || H < 1 || W < 1 || !aligned16(packed))
     return PCFA_ERR_INVALID_ARG;
@@ -423,7 +459,13 @@ static int conv3x3_launch(const float* x, const float* packed, const float* bias
     block.x = 512;
   }
   grid.y = Npad / 32;
-#define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, mask, out, K, N, Npad, H, W, blocks_x, slope
+  Second second{x2, packed2, bias2, out2, K2, N2, (int)grid.y};
+  if (x2 != nullptr) {
+    if (mt == 2) return PCFA_ERR_UNSUPPORTED;
+    grid.y += (unsigned)((N2 + CB - 1) / CB * CB / 32);
+    if (grid.y > 65535) return PCFA_ERR_UNSUPPORTED;
+  }
+#define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, mask, out, K, N, Npad, H, W, blocks_x, slope, second
 #define PCFA_C3_LAUNCH(MT_, KF_, NR_)                                                              \
   do {                                                                                             \
     if (act == 1) pcfa_launch(conv3x3_winograd_kernel<1, 32, MT_, KF_, NR_>, PCFA_C3_ARGS);        \

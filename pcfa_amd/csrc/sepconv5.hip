@@ -56,6 +56,23 @@ struct OutSplit {
   int mask_cb;           // (the deferred ReLU backward of whoever produced the b operand of the forward)
 };
 
+// Fused SepConvGRU epilogues (models/raft/update.py:45-60): the gate / update arithmetic of pcfa_gru_gates_fwd and
+// pcfa_gru_update_fwd applied to the accumulators, so the pre-activations never reach memory and two elementwise
+// launches per half-step disappear.  All tensors [B][.][H][W]; C % 32 == 0 (a wave's 32 channels are all z or all r).
+//   mode 1, Cout = 2C: m <  C: z[m] = sigmoid(acc + add[m]);  m >= C: r = sigmoid(acc + add[m]), rh = r * h
+//   mode 2, Cout =  C: q = tanh(acc + add[m]),  hnew = (1 - z) * h + z * q
+struct GruEpi {
+  int mode, C;
+  const float* add;   // mode 1: [B][2C][plane], mode 2: [B][C][plane]  (context contribution, bias included)
+  const float* h;     // [B][C][plane]
+  const float* z;     // mode 2 input
+  float* o0;          // mode 1: z,  mode 2: q
+  float* o1;          // mode 1: r,  mode 2: hnew
+  float* o2;          // mode 1: r * h
+};
+
+__device__ __forceinline__ float sc5_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }   // as gru_math.hip
+
 __device__ __forceinline__ const float* channel_plane(const Operand& in, int ci, long long plane) {
   return ci < in.Ca ? in.a + ci * plane : in.b + (ci - in.Ca) * plane;
 }
@@ -90,7 +107,7 @@ __device__ __forceinline__ f32x4 keep_if(bool ok, f32x4 v) {
 template <bool VERT, bool FAST, int KS = 1>
 __global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const float* __restrict__ wp,
                                                             OutSplit out, int Cout, int H, int W,
-                                                            int tiles_x, int vec_w, int vec_x) {
+                                                            int tiles_x, int vec_w, int vec_x, GruEpi epi) {
   static_assert(KS == 1 || FAST, "split-K rides on the branch-free staging path");
   __shared__ __attribute__((aligned(16))) float sA_[KS][2][A_TILE];
   __shared__ __attribute__((aligned(16))) float sB_[KS][2][VERT ? B_TILE_V : B_TILE_H];
@@ -212,6 +229,29 @@ __global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const fl
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+  // Operands of the fused GRU epilogue, requested before the K loop: read after it (16 x 3 dependent loads per lane,
+  // one wave per SIMD) they sat on the tail of every workgroup and cost more than the two launches they replace.
+  float e_add[16], e_h[16], e_z[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) e_add[r] = e_h[r] = e_z[r] = 0.f;
+  if (epi.mode != 0 && kgrp == 0) {
+    const int ex = min(x0 + wc * 32 + l31, W - 1);
+    const long long epix = (long long)y * W + ex;
+    const int emw = m0 + wr * 32;
+    const bool e_is_z = epi.mode == 1 && emw < epi.C;
+    const long long ia0 = ((long long)blockIdx.z * (epi.mode == 1 ? 2 : 1) * epi.C + emw) * plane + epix;
+    const long long ih0 = ((long long)blockIdx.z * epi.C + (epi.mode == 1 && !e_is_z ? emw - epi.C : emw)) * plane + epix;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (emw + ml < Cout) {
+        e_add[r] = epi.add[ia0 + ml * plane];
+        if (!e_is_z) e_h[r] = epi.h[ih0 + ml * plane];
+        if (epi.mode == 2) e_z[r] = epi.z[ih0 + ml * plane];
+      }
+    }
+  }
+
   auto compute_stage = [&](int buf) {
     const float* ap = sA[buf] + lh * A_STRIDE + wr * 32 + l31;
     const float* bp = sB[buf] + (VERT ? lh * TAPS * BV_ROW : lh * BH_ROW + BH_X0 - 2) + wc * 32 + l31;
@@ -287,7 +327,37 @@ __global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const fl
   if (x < W) {
     const long long pix = (long long)y * W + x;
     const int mw = m0 + wr * 32;  // first output channel of this wave's 32x32 tile
-    if ((out.Ca & 31) == 0 || out.b == nullptr) {
+    if (epi.mode == 1) {
+      const bool is_z = mw < epi.C;
+      const long long io0 = ((long long)blockIdx.z * epi.C + (is_z ? mw : mw - epi.C)) * plane + pix;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (mw + ml < Cout) {
+          const float sg = sc5_sigmoid(acc[r] + e_add[r]);
+          const long long io = io0 + ml * plane;
+          if (is_z) {
+            epi.o0[io] = sg;
+          } else {
+            epi.o1[io] = sg;
+            epi.o2[io] = sg * e_h[r];
+          }
+        }
+      }
+    } else if (epi.mode == 2) {
+      const long long i0 = ((long long)blockIdx.z * epi.C + mw) * plane + pix;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (mw + ml < Cout) {
+          const long long i = i0 + ml * plane;
+          const float qq = tanhf(acc[r] + e_add[r]);
+          const float zz = e_z[r], hh = e_h[r];
+          epi.o0[i] = qq;
+          epi.o1[i] = (1.f - zz) * hh + zz * qq;
+        }
+      }
+    } else if ((out.Ca & 31) == 0 || out.b == nullptr) {
       // the wave's 32 channels lie on one side of the split: destination and accumulate flag are wave-uniform
       const bool first = out.b == nullptr || mw < out.Ca;
       float* base = (first ? out.a + (long long)mw * plane : out.b + (long long)(mw - out.Ca) * plane) + pix;
@@ -364,7 +434,8 @@ extern "C" int pcfa_sepconv5_pack_weights(const float* w, float* fwd_packed, flo
 }
 
 static int sepconv5_launch(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,
-                           OutSplit out, int B, int Cout, int H, int W, int vertical, void* stream);
+                           OutSplit out, int B, int Cout, int H, int W, int vertical, void* stream,
+                           GruEpi epi = GruEpi{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
 
 extern "C" int pcfa_sepconv5_fwd(const float* in_a, int Ca, const float* in_b, int Cb,
                                  const float* w_packed, float* out, int B, int Cout, int H, int W,
@@ -396,8 +467,24 @@ extern "C" int pcfa_sepconv5_fwd_split_masked(const float* in_a, int Ca, const f
                          B, Cout, H, W, vertical, stream);
 }
 
+extern "C" int pcfa_sepconv5_gru_gates_fwd(const float* h, int C, const float* rest, int Cr, const float* w_packed,
+                                           const float* add_zr, float* z, float* r, float* rh, int B, int H, int W,
+                                           int vertical, void* stream) {
+  if (!h || !add_zr || !z || !r || !rh || C < 32 || C % 32 != 0) return PCFA_ERR_INVALID_ARG;
+  return sepconv5_launch(h, C, rest, Cr, w_packed, OutSplit{z, nullptr, 2 * C, 0, 0, nullptr, 0}, B, 2 * C, H, W, vertical,
+                         stream, GruEpi{1, C, add_zr, h, nullptr, z, r, rh});
+}
+
+extern "C" int pcfa_sepconv5_gru_update_fwd(const float* rh, int C, const float* rest, int Cr, const float* w_packed,
+                                            const float* add_q, const float* z, const float* h, float* q, float* hnew,
+                                            int B, int H, int W, int vertical, void* stream) {
+  if (!rh || !add_q || !z || !h || !q || !hnew || C < 32 || C % 32 != 0) return PCFA_ERR_INVALID_ARG;
+  return sepconv5_launch(rh, C, rest, Cr, w_packed, OutSplit{q, nullptr, C, 0, 0, nullptr, 0}, B, C, H, W, vertical,
+                         stream, GruEpi{2, C, add_q, h, z, q, hnew, nullptr});
+}
+
 static int sepconv5_launch(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,
-                           OutSplit out, int B, int Cout, int H, int W, int vertical, void* stream) {
+                           OutSplit out, int B, int Cout, int H, int W, int vertical, void* stream, GruEpi epi) {
   if (!in_a || !w_packed || Ca < 1 || Cb < 0 || (Cb > 0 && !in_b) || B < 1 || Cout < 1 ||
       H < 1 || W < 1)
     return PCFA_ERR_INVALID_ARG;
@@ -416,13 +503,13 @@ static int sepconv5_launch(const float* in_a, int Ca, const float* in_b, int Cb,
   const bool split2 = fast && (Ca + Cb) % (KC * NR * 2) == 0 && (ks_env ? ks_env == 2 : nwg <= 320);
   if (split2) {
     dim3 block2(512);
-    if (vertical) pcfa_launch(sepconv5_kernel<true, true, 2>, grid, block2, 0, s, in, w_packed, out, Cout, H, W, tiles_x, vec_w, vec_x);
-    else pcfa_launch(sepconv5_kernel<false, true, 2>, grid, block2, 0, s, in, w_packed, out, Cout, H, W, tiles_x, vec_w, vec_x);
+    if (vertical) pcfa_launch(sepconv5_kernel<true, true, 2>, grid, block2, 0, s, in, w_packed, out, Cout, H, W, tiles_x, vec_w, vec_x, epi);
+    else pcfa_launch(sepconv5_kernel<false, true, 2>, grid, block2, 0, s, in, w_packed, out, Cout, H, W, tiles_x, vec_w, vec_x, epi);
     PCFA_LAUNCH_CHECK();
     return PCFA_OK;
   }
 #define PCFA_SEPCONV5(V, F) \
-  pcfa_launch(sepconv5_kernel<V, F>, grid, block, 0, s, in, w_packed, out, Cout, H, W, tiles_x, vec_w, vec_x)
+  pcfa_launch(sepconv5_kernel<V, F>, grid, block, 0, s, in, w_packed, out, Cout, H, W, tiles_x, vec_w, vec_x, epi)
   if (vertical) {
     if (fast) PCFA_SEPCONV5(true, true); else PCFA_SEPCONV5(true, false);
   } else {

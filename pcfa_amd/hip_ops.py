@@ -969,6 +969,9 @@ class _Conv3x3(torch.autograd.Function):
         return gin, None, None, None, None
 
 
+_PAIR_LAUNCH = os.environ.get("PCFA_CONV3X3_PAIR", "1") != "0"   # A/B switch (tools/dev)
+
+
 class _Conv3x3Cat(torch.autograd.Function):
     """cat([relu(conv3x3(x_i, w_i, b_i)) for i] + tails, dim=1) in one pre-allocated buffer (batch size 1): the
     convolutions write their channel blocks in place, trailing tensors (e.g. the flow of the motion encoder,
@@ -987,15 +990,25 @@ class _Conv3x3Cat(torch.autograd.Function):
         plane = H * W
         widths = [w.shape[0] for w in ws] + [t.shape[1] for t in tails]
         buf = torch.empty((1, sum(widths), H, W), device=xs[0].device, dtype=torch.float32)
-        off, packs = 0, []
+        off, packs, fwds, offs = 0, [], [], []
         for x, w, b in zip(xs, ws, bs):
             if tuple(x.shape) != (1, w.shape[1], H, W) or tuple(w.shape[2:]) != (3, 3):
                 raise ValueError("conv3x3_cat: input %s does not fit weight %s" % (tuple(x.shape), tuple(w.shape)))
             fwd, bwd = _conv3x3_packed(w)
-            _call("pcfa_conv3x3_act_fwd", _ptr(x), _ptr(fwd), _ptr(b), _ptr_off(buf, off * plane), 1, w.shape[1],
-                  w.shape[0], H, W, 1, 0.)
+            fwds.append(fwd)
+            offs.append(off)
             packs.append((bwd, w.shape[1], w.shape[0], off))
             off += w.shape[0]
+        if n_conv == 2 and (ws[0].shape[1] % 8 == 0) == (ws[1].shape[1] % 8 == 0) and _PAIR_LAUNCH:
+            # two independent convolutions, one launch: the smaller one's workgroups fill the larger one's last round
+            i, j = (0, 1) if ws[0].shape[0] * ws[0].shape[1] >= ws[1].shape[0] * ws[1].shape[1] else (1, 0)
+            _call("pcfa_conv3x3_act_fwd_pair", _ptr(xs[i]), _ptr(fwds[i]), _ptr(bs[i]), _ptr_off(buf, offs[i] * plane),
+                  ws[i].shape[1], ws[i].shape[0], _ptr(xs[j]), _ptr(fwds[j]), _ptr(bs[j]),
+                  _ptr_off(buf, offs[j] * plane), ws[j].shape[1], ws[j].shape[0], H, W, 1, 0.)
+        else:
+            for x, w, b, fwd, o_ in zip(xs, ws, bs, fwds, offs):
+                _call("pcfa_conv3x3_act_fwd", _ptr(x), _ptr(fwd), _ptr(b), _ptr_off(buf, o_ * plane), 1, w.shape[1],
+                      w.shape[0], H, W, 1, 0.)
         for t in tails:
             buf[:, off:off + t.shape[1]].copy_(t)
             off += t.shape[1]
@@ -1116,6 +1129,9 @@ def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None):
     return _Conv3x3.apply(x, weight, bias, relu, leaky_slope)
 
 
+_GRU_EPILOGUES = os.environ.get("PCFA_GRU_EPILOGUES", "1") != "0"   # A/B switch (tools/dev)
+
+
 class _GruStep(torch.autograd.Function):
     """One SepConvGRU update (both half-steps, models/raft/update.py:45-60) as ONE autograd node with a hand-ordered
     backward.  Forward = the same kernel sequence as composing sepconv5 / gru_gates_packed / gru_update.  In the
@@ -1142,16 +1158,24 @@ class _GruStep(torch.autograd.Function):
             f_zr, b_zr = _sepconv5_packed(w_zr)
             f_q, b_q = _sepconv5_packed(w_q)
             p_zr, p_q = p_zr.contiguous(), p_q.contiguous()
-            zr, z, r, rh, qc, q, hnew = new(2 * C), new(C), new(C), new(C), new(C), new(C), new(C)
-            _call("pcfa_sepconv5_fwd", _ptr(h), C, _ptr(rest), Cr, _ptr(f_zr), _ptr(zr), B, 2 * C, H, W, vertical)
-            for b in range(B):  # per batch item the z and r halves of zr are contiguous blocks
-                o, oz = b * n, b * 2 * n
-                _call("pcfa_gru_gates_fwd", _ptr_off(zr, oz), _ptr_off(zr, oz + n), _ptr_off(h, o), None, None,
-                      _ptr_off(p_zr, oz), _ptr_off(p_zr, oz + n), _ptr_off(z, o), _ptr_off(r, o), _ptr_off(rh, o),
-                      n, plane, C)
-            _call("pcfa_sepconv5_fwd", _ptr(rh), C, _ptr(rest), Cr, _ptr(f_q), _ptr(qc), B, C, H, W, vertical)
-            _call("pcfa_gru_update_fwd", _ptr(z), _ptr(qc), _ptr(h), None, _ptr(p_q), _ptr(q), _ptr(hnew),
-                  z.numel(), plane, C)
+            z, r, rh, q, hnew = new(C), new(C), new(C), new(C), new(C)
+            if C % 32 == 0 and _GRU_EPILOGUES:
+                # gate / update arithmetic in the convolutions' epilogues: the pre-activations never reach memory
+                _call("pcfa_sepconv5_gru_gates_fwd", _ptr(h), C, _ptr(rest), Cr, _ptr(f_zr), _ptr(p_zr), _ptr(z), _ptr(r),
+                      _ptr(rh), B, H, W, vertical)
+                _call("pcfa_sepconv5_gru_update_fwd", _ptr(rh), C, _ptr(rest), Cr, _ptr(f_q), _ptr(p_q), _ptr(z), _ptr(h),
+                      _ptr(q), _ptr(hnew), B, H, W, vertical)
+            else:
+                zr, qc = new(2 * C), new(C)
+                _call("pcfa_sepconv5_fwd", _ptr(h), C, _ptr(rest), Cr, _ptr(f_zr), _ptr(zr), B, 2 * C, H, W, vertical)
+                for b in range(B):  # per batch item the z and r halves of zr are contiguous blocks
+                    o, oz = b * n, b * 2 * n
+                    _call("pcfa_gru_gates_fwd", _ptr_off(zr, oz), _ptr_off(zr, oz + n), _ptr_off(h, o), None, None,
+                          _ptr_off(p_zr, oz), _ptr_off(p_zr, oz + n), _ptr_off(z, o), _ptr_off(r, o), _ptr_off(rh, o),
+                          n, plane, C)
+                _call("pcfa_sepconv5_fwd", _ptr(rh), C, _ptr(rest), Cr, _ptr(f_q), _ptr(qc), B, C, H, W, vertical)
+                _call("pcfa_gru_update_fwd", _ptr(z), _ptr(qc), _ptr(h), None, _ptr(p_q), _ptr(q), _ptr(hnew),
+                      z.numel(), plane, C)
             saved += [z, r, q, h]
             packs.append((b_zr, b_q, vertical))
             h = hnew

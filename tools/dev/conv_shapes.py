@@ -12,7 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import bench  # noqa: E402
 from pcfa_amd import hip_ops  # noqa: E402
 
-WATCH = ("pcfa_conv3x3_act_fwd", "pcfa_conv3x3_fwd", "pcfa_sepconv5_fwd", "pcfa_conv3x3_fewout_fwd",
+WATCH = ("pcfa_conv3x3_act_fwd", "pcfa_conv3x3_fwd", "pcfa_conv3x3_act_fwd_pair", "pcfa_conv3x3_masked_fwd",
+         "pcfa_sepconv5_fwd_split", "pcfa_sepconv5_fwd_split_masked", "pcfa_sepconv5_fwd", "pcfa_conv3x3_fewout_fwd",
          "pcfa_conv3x3_fewout_bwd", "pcfa_conv_fewin_fwd")
 
 
