@@ -461,6 +461,11 @@ PCFA_API int pcfa_instnorm_fwd(const float* x, float* y, float* mean_rstd, void*
 PCFA_API int pcfa_instnorm_bwd(const float* x, const float* mean_rstd, const float* grad_out, float* grad_x,
                                void* workspace, int planes, long long plane, int relu, void* stream);
 PCFA_API int pcfa_add_relu_fwd(const float* a, const float* b, float* out, long long n, void* stream);
+/* One refinement iteration's coordinate bookkeeping (models/raft/raft.py:122-137, models/gma/network.py likewise):
+ * coords1_new = coords1 + delta,  flow_new = coords1_new - coords0;  n floats each. */
+PCFA_API int pcfa_flow_step(const float* coords1, const float* delta, const float* coords0, float* coords1_new,
+                   float* flow_new, long long n, void* stream);
+
 /* out = srcs[0] + ... + srcs[n-1], n <= 16 device pointers in a HOST array, summed in index order by one launch.
  * Backward of a tensor read by every refinement iteration (the hoisted gate pre-activations of SepConvGRU,
  * models/raft/update.py:45-60: autograd would add the twelve contributions pairwise, eleven launches per tensor). */

@@ -549,6 +549,12 @@ def instance_norm_relu(x, eps=1e-5, relu=False):
     return F.relu(y) if relu else y
 
 
+def flow_step(coords1, delta, coords0):
+    """models/raft/raft.py:122-137: coords1 = coords1 + delta_flow; the flow is coords1 - coords0."""
+    c = coords1 + delta
+    return c, c - coords0
+
+
 def add_relu(a, b):
     """models/raft/extractor.py:50-58: relu(x + y)."""
     return F.relu(a + b)

@@ -293,6 +293,23 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
 #pragma unroll
   for (int pass = 0; pass < CBT / 16; ++pass) {
     const int nb = pass >> 1, half = pass & 1;
+    // deferred-ReLU mask of this pass's outputs, requested before the LDS round trip instead of on the store path
+    float mk[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+    if (mask != nullptr) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int n = n0 + pass * 16 + e_cl + 8 * q;
+        if (n < N && oy < H && ox < W) {
+          const float* mp = mask + (long long)n * plane + (long long)oy * W + ox;
+          mk[q][0] = mp[0];
+          if (ox + 1 < W) mk[q][1] = mp[1];
+          if (oy + 1 < H) {
+            mk[q][2] = mp[W];
+            if (ox + 1 < W) mk[q][3] = mp[W + 1];
+          }
+        }
+      }
+    }
     if ((l31 >> 4) == half) {
       const int cl = l31 & 15;
 #pragma unroll
@@ -329,13 +346,10 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
       if (n < N && oy < H && ox < W) {
         const long long oo = (long long)n * plane + (long long)oy * W + ox;
         if (mask != nullptr) {   // data gradient w.r.t. a ReLU output: the deferred ReLU backward of the producer
-          const float* mk = mask + oo;
-          y00 = mk[0] > 0.f ? y00 : 0.f;
-          if (ox + 1 < W) y01 = mk[1] > 0.f ? y01 : 0.f;
-          if (oy + 1 < H) {
-            y10 = mk[W] > 0.f ? y10 : 0.f;
-            if (ox + 1 < W) y11 = mk[W + 1] > 0.f ? y11 : 0.f;
-          }
+          y00 = mk[q][0] > 0.f ? y00 : 0.f;
+          y01 = mk[q][1] > 0.f ? y01 : 0.f;
+          y10 = mk[q][2] > 0.f ? y10 : 0.f;
+          y11 = mk[q][3] > 0.f ? y11 : 0.f;
         }
         float* o = out + oo;
         o[0] = y00;

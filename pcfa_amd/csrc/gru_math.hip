@@ -290,7 +290,27 @@ __global__ void sum_n_kernel(SumSrcs s, int n, float* __restrict__ out, long lon
     }
   });
 }
+// coords1_new = coords1 + delta ; flow_new = coords1_new - coords0   (models/raft/raft.py:122-137: the two
+// coordinate updates of a refinement iteration, one launch instead of an add and a subtract)
+__global__ void flow_step_kernel(const float* __restrict__ c1, const float* __restrict__ d,
+                                 const float* __restrict__ c0, float* __restrict__ c1n, float* __restrict__ fl,
+                                 long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = c1[i] + d[i];
+    c1n[i] = v;
+    fl[i] = v - c0[i];
+  }
+}
 }  // namespace
+
+extern "C" int pcfa_flow_step(const float* coords1, const float* delta, const float* coords0, float* coords1_new,
+                              float* flow_new, long long n, void* stream) {
+  if (!coords1 || !delta || !coords0 || !coords1_new || !flow_new || n < 1) return PCFA_ERR_INVALID_ARG;
+  pcfa_launch(flow_step_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, coords1, delta, coords0,
+              coords1_new, flow_new, n);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
 
 extern "C" int pcfa_sum_n(const float* const* srcs, int n, float* out, long long numel, void* stream) {
   if (!srcs || !out || n < 1 || n > 16 || numel < 1) return PCFA_ERR_INVALID_ARG;

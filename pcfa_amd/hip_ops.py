@@ -10,7 +10,7 @@ Operator boundaries mirrored (reference file:line):
   spatial_correlation_sample     .../spatial_correlation_sampler/spatial_correlation_sampler.py:9-91
   flownet_correlation, resample2d, channelnorm   models/FlowNet/{correlation,resample2d,channelnorm}_package/*.py
   pwc_warp, dense_block          models/PWCNet/PWCNet.py:166-206, :234-323
-  conv3x3, conv3x3_fewout, conv3x3_cat, conv_fewin, sepconv5, gru_step, bias_relu
+  conv3x3, conv3x3_fewout, conv3x3_cat, conv_fewin, sepconv5, gru_step, bias_relu, flow_step
                                  models/raft/update.py, models/raft/extractor.py, PWCNet.py:29-38, FlowNet/submodules.py
   instance_norm_relu, add_relu   models/raft/extractor.py:23-58
   box_transform                  helper_functions/own_models.py:62-85
@@ -1368,6 +1368,32 @@ class _Fanout(torch.autograd.Function):
             arr = (ctypes.c_void_p * len(part))(*[t.data_ptr() for t in part])
             _call("pcfa_sum_n", arr, len(part), _ptr(out), out.numel())
         return out, None
+
+
+class _FlowStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coords1, delta, coords0):
+        _dev(coords1, delta, coords0)
+        if not (coords1.shape == delta.shape == coords0.shape):
+            raise ValueError("flow_step: shapes differ: %s %s %s" % (tuple(coords1.shape), tuple(delta.shape),
+                                                                     tuple(coords0.shape)))
+        c1, d, c0 = coords1.contiguous(), delta.contiguous(), coords0.contiguous()
+        c1n, fl = torch.empty_like(c1), torch.empty_like(c1)
+        _call("pcfa_flow_step", _ptr(c1), _ptr(d), _ptr(c0), _ptr(c1n), _ptr(fl), c1.numel())
+        ctx.set_materialize_grads(False)
+        return c1n, fl
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        g = g1 if g2 is None else g2 if g1 is None else g1 + g2
+        return (g if ctx.needs_input_grad[0] else None, g if ctx.needs_input_grad[1] else None,
+                (None if g is None else -g) if ctx.needs_input_grad[2] else None)
+
+
+def flow_step(coords1, delta, coords0):
+    """(coords1 + delta, coords1 + delta - coords0): the coordinate update of a refinement iteration and the flow the
+    next iteration / the upsampler reads (models/raft/raft.py:122-137), one launch."""
+    return _FlowStep.apply(coords1, delta, coords0)
 
 
 def fanout(x, n):

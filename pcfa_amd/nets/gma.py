@@ -206,18 +206,19 @@ class RAFTGMA(nn.Module):
         flow_up = None
         o = ops.get()   # the gradient of `attention` (used `iters` times) is formed once, by the last node that runs
         attn_grad = o.AttnGradShare() if hasattr(o, "AttnGradShare") else _SharedAttnGrad()
+        flow_cur = coords1 - coords0
         for itr in range(iters):
             coords1 = coords1.detach()
             corr = LookupRef(corr_fn, coords1)
-            flow = coords1 - coords0
+            flow = flow_cur.detach()
             need_up = (not test_mode) or itr == iters - 1
             net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, attention, want_mask=need_up,
                                                          gru_ctx=None if gru_ctx is None else gru_ctx[itr],
                                                          attn_grad=attn_grad)
-            coords1 = coords1 + delta_flow
+            coords1, flow_cur = o.flow_step(coords1, delta_flow, coords0)   # see nets/raft.py
             if need_up:
-                flow_up = convex_upsample(coords1 - coords0, up_mask)
+                flow_up = convex_upsample(flow_cur, up_mask)
                 flow_predictions.append(flow_up)
         if test_mode:
-            return coords1 - coords0, flow_up
+            return flow_cur, flow_up
         return flow_predictions

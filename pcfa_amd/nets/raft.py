@@ -426,17 +426,19 @@ class RAFT(nn.Module):
         gru_ctx = gru.per_iteration(gru.precompute(inp), iters) if gru.frozen() else None
         flow_predictions = []
         flow_up = None
+        flow_cur = coords1 - coords0
         for itr in range(iters):
             coords1 = coords1.detach()  # the lookup gets no coordinate gradient (raft.py:122-123)
             corr = LookupRef(corr_fn, coords1)   # evaluated inside the motion encoder (fused with convc1 where possible)
-            flow = coords1 - coords0
+            flow = flow_cur.detach()             # = coords1 - coords0 of the detached coordinates
             need_up = (not test_mode) or itr == iters - 1
             net, up_mask, delta_flow = self.update_block(net, inp, corr, flow, want_mask=need_up,
                                                          gru_ctx=None if gru_ctx is None else gru_ctx[itr])
-            coords1 = coords1 + delta_flow
+            # coords1 + delta_flow and the new flow in one launch (the reference: an add here, a subtract per use)
+            coords1, flow_cur = ops.get().flow_step(coords1, delta_flow, coords0)
             if need_up:
-                flow_up = convex_upsample(coords1 - coords0, up_mask)
+                flow_up = convex_upsample(flow_cur, up_mask)
                 flow_predictions.append(flow_up)
         if test_mode:
-            return coords1 - coords0, flow_up
+            return flow_cur, flow_up
         return flow_predictions
