@@ -267,6 +267,7 @@ TRACED = {  # kernel-name fragment -> label
     "corr_lookup_fwd_kernel": "corr_lookup_fwd", "corr_lookup_bwd_kernel": "corr_lookup_bwd",
     "corr_lookup_convc1_fwd_kernel": "corr_lookup_convc1_fwd", "corr_lookup_convc1_bwd_kernel": "corr_lookup_convc1_bwd",
     "gemm_f32_mfma_kernel<true, true,": "corr_pyramid_gemm_fwd",
+    "corr_pyramid_pool_gemm_kernel": "corr_pyramid_gemm_fwd",   # levels 1-2 pooled in the epilogue (W % 16 == 0)
     "gemm_f32_mfma_kernel<false, false,": "corr_pyramid_gemm_dfmap1",
     "gemm_f32_mfma_kernel<false, true,": "corr_pyramid_gemm_df2ext",
     "box_fwd_kernel": "box_transform_fwd", "box_bwd_kernel": "box_transform_bwd",

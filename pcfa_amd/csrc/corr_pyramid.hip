@@ -135,15 +135,34 @@ __device__ __forceinline__ void tile_store(float* __restrict__ s, const float4 (
 
 // C[m][n] = (sum_k A(m,k) B(k,n)) / div   over k in this block's split.
 // grid = (ceil(N/128), ceil(M/128), batch*splits).
-template <bool A_KM, bool B_KN, bool FAST>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
+// POOL (correlation pyramid forward only): the GEMM runs over the level-0 columns [0, S0) and the tail columns
+// [off_tail, slab) (levels >= 3 and the zero tile, taken from f2ext as before); levels 1 and 2 are average-pooled from
+// the level-0 accumulators in the epilogue, the way the reference pools the correlation volume
+// (models/raft/corr.py:24-27: F.avg_pool2d of the level below) -- 24 % fewer MFMAs than multiplying against the
+// pooled copies of fmap2, and the pooled values round like the reference's.  Needs W % 16 == 0 (no x padding inside
+// the tiles of levels 1 and 2) and L >= 3; the caller checks.
+struct PoolArgs {
+  int nb0;        // N-blocks (of BN columns) covering the level-0 columns
+  int S0;         // level-0 columns (tiles x 16)
+  int off_tail;   // first tail column
+  int tw0, tiles0;
+  int off1, tw1, h1, w1;
+  int off2, tw2, h2, w2;
+};
+constexpr int SC = BN + 4;   // row stride of the epilogue image of the C tile
+
+template <bool A_KM, bool B_KN, bool FAST, bool POOL>
+__device__ __forceinline__ void gemm_f32_mfma_body(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
     int N, int K, long long lda, long long ldb, long long ldc, long long bsA, long long bsB,
-    long long bsC, int splits, int kchunk, long long ssC, float div, int vecA, int vecB) {
+    long long bsC, int splits, int kchunk, long long ssC, float div, int vecA, int vecB, const PoolArgs& pool) {
   constexpr int SA = A_KM ? LDS_KM : LDS_MK;
   constexpr int SB = B_KN ? LDS_KM : LDS_MK;
-  __shared__ __attribute__((aligned(16))) float sA[2][BK * SA];
-  __shared__ __attribute__((aligned(16))) float sB[2][BK * SB];
+  constexpr int STAGE = 2 * BK * SA + 2 * BK * SB;
+  constexpr int LDSF = POOL && BM * SC > STAGE ? BM * SC : STAGE;   // the C image reuses the stage buffers
+  __shared__ __attribute__((aligned(16))) float smem[LDSF];
+  float (*sA)[BK * SA] = reinterpret_cast<float (*)[BK * SA]>(smem);
+  float (*sB)[BK * SB] = reinterpret_cast<float (*)[BK * SB]>(smem + 2 * BK * SA);
 
   const int batch = blockIdx.z / splits;
   const int split = blockIdx.z - batch * splits;
@@ -165,7 +184,17 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
     bx = wg - by * nx;
   }
 #endif
-  const int m0 = by * BM, n0 = bx * BN;
+  const int m0 = by * BM;
+  int n0 = bx * BN;
+  bool pooled = false;
+  if (POOL) {   // workgroup-uniform: a level-0 block (pooled epilogue) or a tail block (columns shifted to off_tail)
+    if (bx < pool.nb0) {
+      pooled = true;
+      N = pool.S0;
+    } else {
+      n0 = pool.off_tail + (bx - pool.nb0) * BN;
+    }
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -238,6 +267,59 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
   int dexp;
   const bool pow2 = frexpf(div, &dexp) == 0.5f;
   const float rdiv = 1.0f / div;
+  if (POOL && pooled) {
+    // ---- C tile -> LDS (the stage buffers are free: the loop ended on a barrier) ----
+    float* sC = smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          sC[row * SC + wc * 64 + j * 32 + l31] = pow2 ? acc[i][j][r] * rdiv : acc[i][j][r] / div;
+        }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    // level 0: rows of 512 B, 16-B stores
+#pragma unroll
+    for (int k = 0; k < BM * BN / 4 / 256; ++k) {
+      const int idx = tid + 256 * k, row = idx >> 5, c4 = (idx & 31) * 4;
+      if (m0 + row < M && n0 + c4 < N)
+        *reinterpret_cast<float4*>(&C[(long long)(m0 + row) * ldc + n0 + c4]) =
+            *reinterpret_cast<const float4*>(&sC[row * SC + c4]);
+    }
+    // levels 1 and 2: thread = (query row, 4x4 tile); sums in avg_pool2d's window order, one division by 4 each
+#pragma unroll
+    for (int k = 0; k < BM * (BN / 16) / 256; ++k) {
+      const int item = tid + 256 * k, row = item >> 3, t = item & 7;
+      const int T0 = n0 / 16 + t;
+      if (m0 + row >= M || T0 >= pool.tiles0) continue;
+      const int ty = T0 / pool.tw0, tx = T0 - ty * pool.tw0;
+      float v[4][4];
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const float4 q4 = *reinterpret_cast<const float4*>(&sC[row * SC + 16 * t + 4 * y]);
+        v[y][0] = q4.x; v[y][1] = q4.y; v[y][2] = q4.z; v[y][3] = q4.w;
+      }
+      float* crow = C + (long long)(m0 + row) * ldc;
+      float l1[2][2];
+#pragma unroll
+      for (int Y = 0; Y < 2; ++Y) {
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+          const float sum = ((v[2 * Y][2 * X] + v[2 * Y][2 * X + 1]) + v[2 * Y + 1][2 * X]) + v[2 * Y + 1][2 * X + 1];
+          l1[Y][X] = (2 * ty + Y < pool.h1 && 2 * tx + X < pool.w1) ? sum * 0.25f : 0.f;
+        }
+        float* d1 = crow + pool.off1 + ((ty >> 1) * pool.tw1 + (tx >> 1)) * 16 + (2 * (ty & 1) + Y) * 4 + 2 * (tx & 1);
+        *reinterpret_cast<float2*>(d1) = make_float2(l1[Y][0], l1[Y][1]);
+      }
+      const float sum2 = ((l1[0][0] + l1[0][1]) + l1[1][0]) + l1[1][1];
+      crow[pool.off2 + ((ty >> 2) * pool.tw2 + (tx >> 2)) * 16 + (ty & 3) * 4 + (tx & 3)] =
+          (ty < pool.h2 && tx < pool.w2) ? sum2 * 0.25f : 0.f;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -250,6 +332,24 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
         if (row < M) C[(long long)row * ldc + col] = pow2 ? acc[i][j][r] * rdiv : acc[i][j][r] / div;
       }
     }
+}
+
+template <bool A_KM, bool B_KN, bool FAST>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
+    int N, int K, long long lda, long long ldb, long long ldc, long long bsA, long long bsB,
+    long long bsC, int splits, int kchunk, long long ssC, float div, int vecA, int vecB) {
+  gemm_f32_mfma_body<A_KM, B_KN, FAST, false>(A, B, C, M, N, K, lda, ldb, ldc, bsA, bsB, bsC, splits, kchunk, ssC, div,
+                                              vecA, vecB, PoolArgs{});
+}
+
+// The correlation pyramid's forward product with levels 1-2 pooled in the epilogue (see PoolArgs).
+__global__ __launch_bounds__(256) void corr_pyramid_pool_gemm_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
+    int N, int K, long long lda, long long ldb, long long ldc, long long bsA, long long bsB,
+    long long bsC, float div, PoolArgs pool) {
+  gemm_f32_mfma_body<true, true, true, true>(A, B, C, M, N, K, lda, ldb, ldc, bsA, bsB, bsC, 1,
+                                             ((K + BK - 1) / BK) * BK, 0LL, div, 1, 1, pool);
 }
 
 // out[i] = sum_s partial[s][i]  (fixed order -> deterministic).  No scaling:
@@ -404,6 +504,24 @@ extern "C" int pcfa_corr_pyramid_fwd(const float* fmap1, const float* f2ext, flo
   const int Q = H * W, S = P.slab;
   const int vecA = (Q % 4 == 0) && aligned16(fmap1);
   const int vecB = aligned16(f2ext);  // slab % 16 == 0 by construction
+  static const bool pool_off = getenv("PCFA_PYRAMID_POOL") && atoi(getenv("PCFA_PYRAMID_POOL")) == 0;   // A/B switch
+  if (vecA && vecB && D % 4 == 0 && Q >= 4 && P.L >= 3 && W % 16 == 0 && !pool_off) {
+    PoolArgs pa;
+    pa.tw0 = P.tw[0];
+    pa.tiles0 = ((P.h[0] + 3) / 4) * P.tw[0];
+    pa.S0 = pa.tiles0 * 16;
+    pa.nb0 = pcfa_cdiv(pa.S0, BN);
+    pa.off_tail = P.L > 3 ? P.off[3] : P.zero;
+    pa.off1 = P.off[1]; pa.tw1 = P.tw[1]; pa.h1 = P.h[1]; pa.w1 = P.w[1];
+    pa.off2 = P.off[2]; pa.tw2 = P.tw[2]; pa.h2 = P.h[2]; pa.w2 = P.w[2];
+    if (pa.S0 != P.off[1] || pa.off_tail % 16 != 0 || pa.off_tail > S) return PCFA_ERR_UNSUPPORTED;
+    dim3 gridp(pa.nb0 + pcfa_cdiv(S - pa.off_tail, BN), pcfa_cdiv(Q, BM), B);
+    pcfa_launch(corr_pyramid_pool_gemm_kernel, gridp, dim3(256), 0, (hipStream_t)stream, fmap1, f2ext, pyr, Q, S, D,
+                (long long)Q, (long long)S, (long long)S, (long long)D * Q, (long long)D * S, (long long)Q * S,
+                sqrtf((float)D), pa);
+    PCFA_LAUNCH_CHECK();
+    return PCFA_OK;
+  }
   dim3 grid(pcfa_cdiv(S, BN), pcfa_cdiv(Q, BM), B);
 #define PCFA_GEMM_ARGS fmap1, f2ext, pyr, Q, S, D, (long long)Q, (long long)S, (long long)S, (long long)D * Q, \
                        (long long)D * S, (long long)Q * S, 1, ((D + BK - 1) / BK) * BK, 0LL, sqrtf((float)D), vecA, vecB

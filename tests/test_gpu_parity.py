@@ -176,7 +176,7 @@ def test_lookup_convc1_fused_vs_unfused_and_oracle(oracle_ops, shape):
               _grid(B, H, W) + 40 * torch.randn(B, 2, H, W, generator=gen)]
     gos = [torch.randn(B, 256, H, W, generator=gen) for _ in coords]
 
-    def run(block_cls, dev, fused):
+    def run(block_cls, dev, fused, grad_outs):
         f1 = f1c.clone().to(dev).requires_grad_(True)
         f2 = f2c.clone().to(dev).requires_grad_(True)
         w, b = wc.to(dev), bc.to(dev)
@@ -186,12 +186,18 @@ def test_lookup_convc1_fused_vs_unfused_and_oracle(oracle_ops, shape):
             o = blk.lookup_conv_relu(c.to(dev), w, b, True) if fused else F.relu(F.conv2d(blk(c.to(dev)), w, b))
             assert o is not None
             outs.append(o)
-        sum((o * g.to(dev)).sum() for o, g in zip(outs, gos)).backward()
+        sum((o * g.to(dev)).sum() for o, g in zip(outs, grad_outs)).backward()
         return [o.detach().cpu() for o in outs], f1.grad.cpu(), f2.grad.cpu()
 
-    of, g1f, g2f = run(hip_ops.CorrBlock, DEV, True)
-    ou, g1u, g2u = run(hip_ops.CorrBlock, DEV, False)
-    oc, g1c, g2c = run(oracle_ops.CorrBlock, "cpu", False)
+    # A pre-activation that sits at zero may round to either side in the two summation orders; one such flip moves a
+    # whole gradient row (1e-3 relative L2 at D = 256).  The tight fused-vs-unfused gradient check therefore runs with
+    # the output gradient zeroed at the (few) flipped positions, which the mask check below bounds.
+    of0, _, _ = run(hip_ops.CorrBlock, DEV, True, gos)
+    ou0, _, _ = run(hip_ops.CorrBlock, DEV, False, gos)
+    gos_tie = [g * ((a > 0) == (b > 0)).float() for g, a, b in zip(gos, of0, ou0)]
+    of, g1f, g2f = run(hip_ops.CorrBlock, DEV, True, gos_tie)
+    ou, g1u, g2u = run(hip_ops.CorrBlock, DEV, False, gos_tie)
+    oc, g1c, g2c = run(oracle_ops.CorrBlock, "cpu", False, gos_tie)
     omax = max(float(o.abs().max()) for o in oc)
     for a, b, c in zip(of, ou, oc):
         assert a.shape == c.shape
@@ -203,7 +209,7 @@ def test_lookup_convc1_fused_vs_unfused_and_oracle(oracle_ops, shape):
     # ReLU of a few pre-activations that sit at zero: a handful of whole gradient rows appear / vanish (1e-3 at D = 256)
     assert rel_l2(g1f, g1c) < 5e-3 and rel_l2(g2f, g2c) < 5e-3, (rel_l2(g1f, g1c), rel_l2(g2f, g2c))
     # bit-reproducible (no atomics in the scatter)
-    of2, g1f2, g2f2 = run(hip_ops.CorrBlock, DEV, True)
+    of2, g1f2, g2f2 = run(hip_ops.CorrBlock, DEV, True, gos_tie)
     assert all(torch.equal(a, b) for a, b in zip(of, of2)) and torch.equal(g1f, g1f2) and torch.equal(g2f, g2f2)
 
 
