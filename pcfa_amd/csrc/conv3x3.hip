@@ -176,10 +176,12 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   // register ring: the global loads of a chunk are issued NRING-1 chunks before its MFMAs
   float ring_raw[NRING][RAW_LOADS];
   float4 ring_u[NRING][4];
-  auto load_chunk = [&](int c0, float (&rraw)[RAW_LOADS], float4 (&ru)[4]) {
+  auto load_u = [&](int c0, float4 (&ru)[4]) {
     const float4* q = reinterpret_cast<const float4*>(pu + (long long)(c0 / KC) * (4 * 64 * 16));
 #pragma unroll
     for (int i = 0; i < 4; ++i) ru[i] = q[i];
+  };
+  auto load_raw = [&](int c0, float (&rraw)[RAW_LOADS]) {
     if (KFULL) {
       const unsigned xo = (unsigned)(c0 * (int)plane);  // wave-uniform chunk offset
 #pragma unroll
@@ -215,7 +217,14 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   const float sa = wave == 2 ? -1.f : 1.f, sb = (wave == 1 || wave == 2) ? 1.f : -1.f;
   const int m_tile = mt * 32 + l31;
   const float* prow = sRaw + (lh * PR + 2 * (m_tile >> 3)) * PCP + 2 * (m_tile & 7);
-  auto mfma_chunk = [&](int buf, const float4 (&ru)[4]) {
+  auto load_chunk = [&](int c0, float (&rraw)[RAW_LOADS], float4 (&ru)[4]) {
+    load_u(c0, ru);
+    load_raw(c0, rraw);
+  };
+  // mid1 / mid2 run after the first / second channel pair's MFMAs, fenced so they stay there: the LDS write of the
+  // next chunk's patch and the global loads of the chunk after it ride in the shadow of this chunk's MFMAs instead of
+  // following them (at one or two waves per SIMD -- every launch at 55x128 -- nothing else hid that tail).
+  auto mfma_chunk = [&](int buf, const float4 (&ru)[4], auto&& mid1, auto&& mid2) {
     // the patch rows of channel pair kp+2 are requested BEFORE the MFMAs of pair kp are issued: an in-order wave
     // otherwise starts the LDS reads only after its fourth MFMA has left the issue stage and the matrix pipe
     // idles for the LDS latency in every pair (stamps: 2000 cycles for 1024 cycles of MFMA work)
@@ -241,6 +250,13 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
         const float bv = kp == 0 ? ru[a].x : kp == 2 ? ru[a].y : kp == 4 ? ru[a].z : ru[a].w;
         acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv, acc[a][0], 0, 0, 0);
       }
+      if (kp == 0) {
+        mid1();
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (kp == 2) {
+        mid2();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
   };
@@ -262,15 +278,15 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
       if (c < nchunk) {
         const int cur = c & 1, nxt = cur ^ 1;
         C3_STAMP(0);
-        mfma_chunk(cur, ring_u[j]);
+        // the patch of chunk c+1 was requested one iteration ago and goes to the LDS buffer chunk c-1 used (free since
+        // the last barrier); the raw slot j is free again once its patch is in LDS, the U slot j after the last MFMA
+        mfma_chunk(cur, ring_u[j],
+                   [&] { store_chunk((c + 1) * KC, nxt, ring_raw[(j + 1) % NRING]); },  // (past the end: zeros, never read)
+                   [&] { load_raw(min((c + NRING) * KC, lastc), ring_raw[j]); });
         __builtin_amdgcn_sched_barrier(0);
         C3_STAMP(1);
-        // the patch of chunk c+1 was requested at the end of the previous iteration: it had this iteration's MFMA
-        // phase to arrive (stored FIRST it stalled every iteration for the full load latency); its LDS buffer is
-        // the one chunk c-1 used, free since the last barrier
-        store_chunk((c + 1) * KC, nxt, ring_raw[(j + 1) % NRING]);  // (past the end: zeros, never read)
         C3_STAMP(2);
-        load_chunk(min((c + NRING) * KC, lastc), ring_raw[j], ring_u[j]);  // slot j is free again
+        load_u(min((c + NRING) * KC, lastc), ring_u[j]);
         C3_STAMP(3);
         __syncthreads();  // patch c+1 visible; everyone done with the patch of chunk c
         C3_STAMP(4);
