@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     const int r = rem / PC, c = rem - r * PC;
     const int yy = y0 - 1 + r, xx = x0 - 1 + c;
     rch[i] = min(ch, KC - 1);
-    rdst[i] = e < KC * PR * PC ? (ch * PR + r) * PCP + c : -1;
+    rdst[i] = e < KC * PR * PC ? (ch * PR + r) * PCP + c : PC;   // past the patch: a padding cell of row 0 (never
+                                                                   // read) -- an `if` here was a branch per store
     rok[i] = e < KC * PR * PC && yy >= 0 && yy < H && xx >= 0 && xx < W;
     praw[i] = (unsigned)(min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1) + (KFULL ? rch[i] * (int)plane : 0));
   }
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     float* sRaw = smem + buf * RAW;
 #pragma unroll
     for (int i = 0; i < RAW_LOADS; ++i)
-      if (rdst[i] >= 0) sRaw[rdst[i]] = (rok[i] && (KFULL || c0 + rch[i] < K)) ? rraw[i] : 0.f;
+      sRaw[rdst[i]] = (rok[i] && (KFULL || c0 + rch[i] < K)) ? rraw[i] : 0.f;
   };
   f32x16 acc[4][NB];
 #pragma unroll

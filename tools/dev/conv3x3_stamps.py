@@ -13,9 +13,9 @@ from pcfa_amd import _hip, hip_ops  # noqa: E402
 lib = _hip.load()
 lib.dev_c3_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 buf = (ctypes.c_ulonglong * 8)()
-names = ["", "MFMA phase (patch rows -> A operands -> 16 MFMAs issued)", "store next patch (waits for its loads)",
-         "issue loads of chunk c+2", "barrier"]
-for B, K, N, H, W in [(1, 256, 192, 55, 128), (1, 128, 256, 55, 128), (2, 64, 64, 220, 512)]:
+names = ["", "MFMA phase (16 MFMAs + next patch -> LDS + raw loads of chunk c+2 in their shadow)", "(empty)",
+         "issue U loads of chunk c+2", "barrier"]
+for B, K, N, H, W in [(1, 256, 192, 55, 128), (1, 256, 126, 55, 128), (1, 128, 256, 55, 128), (2, 64, 64, 220, 512)]:
     x = torch.randn(B, K, H, W, device="cuda")
     w = torch.randn(N, K, 3, 3, device="cuda") / (9 * K) ** .5
     b = torch.randn(N, device="cuda")
