@@ -109,8 +109,12 @@ struct Second {
   int K, N, nb0;
 };
 
-template <int ACT, int CBT, int MT, bool KFULL, int NRING>  // ACT: 0 none, 1 ReLU, 2 LeakyReLU(slope)
-__global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 1 && NRING == 2 && CBT == 32 ? 3 : (CBT == 64 ? 1 : 2)))) void conv3x3_winograd_kernel(
+// KS = 2: in-workgroup split-K for launches of at most one workgroup per CU (e.g. conv 256 -> 126 at 55x128: 224
+// workgroups, one wave per SIMD, 37 us for 17 us of MFMA work).  Two groups of four waves run the same pipeline on
+// the even / odd input-channel chunks (own LDS patch buffers, shared barriers); the second group's accumulators are
+// added through LDS in fixed order (deterministic) and the first group runs the epilogue.  K % 16 == 0.
+template <int ACT, int CBT, int MT, bool KFULL, int NRING, int KS = 1>  // ACT: 0 none, 1 ReLU, 2 LeakyReLU(slope)
+__global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(KS == 2 ? 2 : (MT == 1 && NRING == 2 && CBT == 32 ? 3 : (CBT == 64 ? 1 : 2))))) void conv3x3_winograd_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
     const float* __restrict__ mask, float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x,
     float slope, Second second) {
@@ -125,12 +129,17 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
   // from two patch rows (8 LDS reads, 8 adds), so there is no V image, no transform phase and ONE barrier per chunk.
   // The U operands go from L2 straight into registers (every U element is consumed by exactly one wave).
   constexpr int NB = CBT / 32;
+  static_assert(KS == 1 || (KS == 2 && MT == 1 && CBT == 32), "split-K rides on the 256-thread tile");
   constexpr int EPI = 16 * 16 * (TB + 1);               // epilogue image
-  constexpr int LDSF = 2 * RAW > EPI ? 2 * RAW : EPI;
+  constexpr int RED = KS == 2 ? 4 * 4 * 16 * 64 : 0;    // second group's accumulators (64 KB)
+  constexpr int LDS0 = 2 * KS * RAW > EPI ? 2 * KS * RAW : EPI;
+  constexpr int LDSF = RED > LDS0 ? RED : LDS0;
   __shared__ __attribute__((aligned(16))) float smem[LDSF];
-  float* sRaw = smem;               // [2][RAW]
+  const int kgrp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);   // which half of the chunks this wave group owns
+  float* sRaw = smem + kgrp * 2 * RAW;   // [2][RAW] per group
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, mt = tid >> 8;  // wave: xi group, mt: tile group
+  const int tid = KS == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);
+  const int lane = tid & 63, wave = (tid >> 6) & 3, mt = tid >> 8;  // wave: xi group, mt: tile group
   const int l31 = lane & 31, lh = lane >> 5;
   const int by = blockIdx.x / blocks_x, bx = blockIdx.x - by * blocks_x;
   const int y0 = by * (2 * TR), x0 = bx * (2 * TC);  // first output pixel of the block
@@ -199,10 +208,10 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     }
   };
   auto store_chunk = [&](int c0, int buf, const float (&rraw)[RAW_LOADS]) {
-    float* sRaw = smem + buf * RAW;
+    float* sRawb = sRaw + buf * RAW;
 #pragma unroll
     for (int i = 0; i < RAW_LOADS; ++i)
-      sRaw[rdst[i]] = (rok[i] && (KFULL || c0 + rch[i] < K)) ? rraw[i] : 0.f;
+      sRawb[rdst[i]] = (rok[i] && (KFULL || c0 + rch[i] < K)) ? rraw[i] : 0.f;
   };
   f32x16 acc[4][NB];
 #pragma unroll
@@ -264,30 +273,33 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
 
   // Ring slot c % NRING holds chunk c: its patch is written to LDS one iteration before its MFMAs, its U operands
   // stay in registers until the MFMAs have consumed them; the slot is reloaded (chunk c + NRING) right after.
-  const int lastc = (nchunk - 1) * KC;
+  // local chunk cl of this wave group = global chunk cl * KS + kgrp
+  const int nchunk_g = nchunk / KS;
+  auto gc0 = [&](int cl) { return (cl * KS + kgrp) * KC; };
+  const int lastc = gc0(nchunk_g - 1);
 #ifdef PCFA_C3_STAMPS
   unsigned long long stamp_prev = 0, stamp_acc[5] = {0, 0, 0, 0, 0};
 #endif
 #pragma unroll
-  for (int j = 0; j < NRING; ++j) load_chunk(min(j * KC, lastc), ring_raw[j], ring_u[j]);
-  store_chunk(0, 0, ring_raw[0]);
+  for (int j = 0; j < NRING; ++j) load_chunk(min(gc0(j), lastc), ring_raw[j], ring_u[j]);
+  store_chunk(gc0(0), 0, ring_raw[0]);
   __syncthreads();
-  for (int cbase = 0; cbase < nchunk; cbase += NRING) {
+  for (int cbase = 0; cbase < nchunk_g; cbase += NRING) {
 #pragma unroll
     for (int j = 0; j < NRING; ++j) {
       const int c = cbase + j;
-      if (c < nchunk) {
+      if (c < nchunk_g) {
         const int cur = c & 1, nxt = cur ^ 1;
         C3_STAMP(0);
         // the patch of chunk c+1 was requested one iteration ago and goes to the LDS buffer chunk c-1 used (free since
         // the last barrier); the raw slot j is free again once its patch is in LDS, the U slot j after the last MFMA
         mfma_chunk(cur, ring_u[j],
-                   [&] { store_chunk((c + 1) * KC, nxt, ring_raw[(j + 1) % NRING]); },  // (past the end: zeros, never read)
-                   [&] { load_raw(min((c + NRING) * KC, lastc), ring_raw[j]); });
+                   [&] { store_chunk(gc0(c + 1), nxt, ring_raw[(j + 1) % NRING]); },  // (past the end: never read)
+                   [&] { load_raw(min(gc0(c + NRING), lastc), ring_raw[j]); });
         __builtin_amdgcn_sched_barrier(0);
         C3_STAMP(1);
         C3_STAMP(2);
-        load_u(min((c + NRING) * KC, lastc), ring_u[j]);
+        load_u(min(gc0(c + NRING), lastc), ring_u[j]);
         C3_STAMP(3);
         __syncthreads();  // patch c+1 visible; everyone done with the patch of chunk c
         C3_STAMP(4);
@@ -301,6 +313,24 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     atomicAdd(&c3_stamp_sums[0], (unsigned long long)nchunk);
   }
 #endif
+  if (KS == 2) {   // second group's accumulators -> LDS -> added by the first group (fixed order: deterministic)
+    float* red = smem;
+    if (kgrp == 1) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 4 + a) * 16 + r) * 64 + lane] = acc[a][0][r];
+    }
+    __syncthreads();
+    if (kgrp == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][0][r] += red[((wave * 4 + a) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();   // the image below reuses the same LDS
+  }
+  const bool worker = kgrp == 0;   // the second group only keeps the barriers of the epilogue company
   // ---- epilogue: passes of 16 output channels through LDS (the image reuses the patch buffers) ----
   static_assert(EPI == 16 * 16 * MS, "epilogue image size");
   float* sM = smem;  // [16 xi][16 channels][MS]
@@ -312,7 +342,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
     const int nb = pass >> 1, half = pass & 1;
     // deferred-ReLU mask of this pass's outputs, requested before the LDS round trip instead of on the store path
     float mk[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
-    if (mask != nullptr) {
+    if (mask != nullptr && worker) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int n = n0 + pass * 16 + e_cl + 8 * q;
@@ -327,7 +357,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
         }
       }
     }
-    if ((l31 >> 4) == half) {
+    if ((l31 >> 4) == half && worker) {
       const int cl = l31 & 15;
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -360,7 +390,7 @@ __global__ __launch_bounds__(256 * MT) __attribute__((amdgpu_waves_per_eu(MT == 
         y00 = y00 > 0.f ? y00 : y00 * slope; y01 = y01 > 0.f ? y01 : y01 * slope;
         y10 = y10 > 0.f ? y10 : y10 * slope; y11 = y11 > 0.f ? y11 : y11 * slope;
       }
-      if (n < N && oy < H && ox < W) {
+      if (n < N && oy < H && ox < W && worker) {
         const long long oo = (long long)n * plane + (long long)oy * W + ox;
         if (mask != nullptr) {   // data gradient w.r.t. a ReLU output: the deferred ReLU backward of the producer
           y00 = mk[q][0] > 0.f ? y00 : 0.f;
@@ -504,6 +534,17 @@ static int conv3x3_launch(const float* x, const float* packed, const float* bias
     else pcfa_launch(conv3x3_winograd_kernel<0, 32, MT_, KF_, NR_>, PCFA_C3_ARGS);                 \
   } while (0)
   const bool kfull = K % KC == 0;
+  // at most one workgroup per CU: split K inside the workgroup (8 waves, two per SIMD)
+  static const int ks_env = getenv("PCFA_CONV3X3_KS") ? atoi(getenv("PCFA_CONV3X3_KS")) : 0;   // tuning override (1 / 2)
+  const long long nwg = (long long)grid.x * grid.y * grid.z;
+  if (mt == 1 && x2 == nullptr && K % (2 * KC) == 0 && (ks_env ? ks_env == 2 : nwg <= 256)) {
+    block.x = 512;
+    if (act == 1) pcfa_launch(conv3x3_winograd_kernel<1, 32, 1, true, 2, 2>, PCFA_C3_ARGS);
+    else if (act == 2) pcfa_launch(conv3x3_winograd_kernel<2, 32, 1, true, 2, 2>, PCFA_C3_ARGS);
+    else pcfa_launch(conv3x3_winograd_kernel<0, 32, 1, true, 2, 2>, PCFA_C3_ARGS);
+    PCFA_LAUNCH_CHECK();
+    return PCFA_OK;
+  }
   int deep = 0;  // measured: the 3-deep ring (2 waves per SIMD) is never faster, also not on small grids
   if (const char* e = getenv("PCFA_CONV3X3_RING")) deep = atoi(e) == 3;  // A/B switch for tools/dev
   if (mt == 2) {
