@@ -18,6 +18,10 @@
 #include <cstdlib>
 #include "common.hpp"
 
+#ifndef PCFA_SC5_PRE
+#define PCFA_SC5_PRE 4   // LDS operand reads issued this many MFMAs ahead of their use
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -252,17 +256,30 @@ __global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const fl
     }
   }
 
-  auto compute_stage = [&](int buf) {
+  // The operands of MFMA i + PRE are read from LDS before MFMA i is issued, and the scheduler is fenced per MFMA:
+  // left alone it reused one register pair for all reads, so every pair of MFMAs waited for its own LDS round trip
+  // (read -> wait -> 2 MFMAs -> read ...: ~65 idle cycles per pair at one or two waves per SIMD).
+  auto compute_stage = [&](int buf, auto&& mid1, auto&& mid2) {
     const float* ap = sA[buf] + lh * A_STRIDE + wr * 32 + l31;
     const float* bp = sB[buf] + (VERT ? lh * TAPS * BV_ROW : lh * BH_ROW + BH_X0 - 2) + wc * 32 + l31;
+    constexpr int NM = TAPS * KC / 2, PRE = PCFA_SC5_PRE;
+    float av[NM], bv[NM];
+    auto rd = [&](int i) {
+      const int t = i / (KC / 2), s = 2 * (i % (KC / 2));
+      av[i] = ap[(t * KC + s) * A_STRIDE];
+      bv[i] = VERT ? bp[s * TAPS * BV_ROW + t * BV_ROW] : bp[s * BH_ROW + t];
+    };
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int i = 0; i < PRE; ++i) rd(i);
 #pragma unroll
-      for (int s = 0; s < KC; s += 2) {
-        const float av = ap[(t * KC + s) * A_STRIDE];
-        const float bv = VERT ? bp[s * TAPS * BV_ROW + t * BV_ROW] : bp[s * BH_ROW + t];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-      }
+    for (int i = 0; i < NM; ++i) {
+      if (i + PRE < NM) rd(i + PRE);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+      if (i == 1) mid1();          // global loads of a later stage / LDS write of the next one: in the MFMA shadow
+      if (i == NM / 2) mid2();
+    }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   const int nstage = (in.Cin + KC - 1) / KC / KS;   // stages of this wave group (host: Cin % (KC * NR * KS) == 0)
@@ -280,10 +297,10 @@ __global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const fl
     for (int s0 = 0; s0 < nstage; s0 += NR) {
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        load_stage(ring_a[(j + NR - 1) % NR], ring_b[(j + NR - 1) % NR], ring_h[(j + NR - 1) % NR],
-                   min(cbase + (s0 + j + NR - 1) * KC, last));
-        compute_stage(j & 1);
-        store_stage(ring_a[(j + 1) % NR], ring_b[(j + 1) % NR], ring_h[(j + 1) % NR], (j + 1) & 1);
+        compute_stage(j & 1,
+                      [&] { load_stage(ring_a[(j + NR - 1) % NR], ring_b[(j + NR - 1) % NR], ring_h[(j + NR - 1) % NR],
+                                       min(cbase + (s0 + j + NR - 1) * KC, last)); },
+                      [&] { store_stage(ring_a[(j + 1) % NR], ring_b[(j + 1) % NR], ring_h[(j + 1) % NR], (j + 1) & 1); });
         __syncthreads();
       }
     }
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const fl
           if (st + NR - 1 < nstage)
             load_stage(ring_a[(j + NR - 1) % NR], ring_b[(j + NR - 1) % NR], ring_h[(j + NR - 1) % NR],
                        (st + NR - 1) * KC);
-          compute_stage(j & 1);
+          compute_stage(j & 1, [] {}, [] {});
           if (st + 1 < nstage)
             store_stage(ring_a[(j + 1) % NR], ring_b[(j + 1) % NR], ring_h[(j + 1) % NR], (j + 1) & 1);
           __syncthreads();
