@@ -376,6 +376,22 @@ PCFA_API int pcfa_sepconv5_gru_gates_fwd(const float* h, int C, const float* res
 PCFA_API int pcfa_sepconv5_gru_update_fwd(const float* rh, int C, const float* rest, int Cr, const float* w_packed,
                                  const float* add_q, const float* z, const float* h, float* q, float* hnew, int B,
                                  int H, int W, int vertical, void* stream);
+/* The backward counterparts (data gradients through the same convolutions with the elementwise backward in the
+ * epilogue; w_packed_bwd = the second packing of pcfa_sepconv5_pack_weights; C % 32 == 0):
+ *   gates_bwd : [drh | d_rest] = conv_q'(dqc); drh is consumed at once by pcfa_gru_gates_bwd_acc's arithmetic:
+ *               dzr[:, :C] = dz (1-z) z,  dzr[:, C:] = (drh h)(1-r) r,  dh = dh_in + drh r  (dh_in may be NULL or dh);
+ *               d_rest is written (accumulate_rest = 0) or accumulated.
+ *   update_bwd: [ddh | d_rest] = conv_zr'(dzr); g = dh_acc + ddh is the gradient of the PREVIOUS half-step's output and
+ *               goes straight through pcfa_gru_update_bwd's arithmetic with that half-step's (z, q, h):
+ *               dz_prev = g q - g h,  dqc_prev = (g z)(1 - q q),  dh_prev = g (1 - z);  d_rest accumulates. */
+PCFA_API int pcfa_sepconv5_gru_gates_bwd(const float* dqc, int C, int Cr, const float* w_packed_bwd, const float* z,
+                                const float* r, const float* h, const float* dz, const float* dh_in, float* dzr,
+                                float* dh, float* d_rest, int accumulate_rest, int B, int H, int W, int vertical,
+                                void* stream);
+PCFA_API int pcfa_sepconv5_gru_update_bwd(const float* dzr, int C, int Cr, const float* w_packed_bwd, const float* dh_acc,
+                                 const float* z_prev, const float* q_prev, const float* h_prev, float* dz_prev,
+                                 float* dqc_prev, float* dh_prev, float* d_rest, int B, int H, int W, int vertical,
+                                 void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution (the update-block convolutions, models/raft/update.py:6-16,79-101) as Winograd
  * F(2x2,3x3) on the fp32 matrix cores, bias and ReLU fused:  out[b,n] = act(bias[n] + sum_k w[n,k] (*) x[b,k]).

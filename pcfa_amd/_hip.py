@@ -82,6 +82,10 @@ SIGNATURES = {
                                                c_int, c_int, c_int, c_int, _P]),
     "pcfa_sepconv5_gru_gates_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "pcfa_sepconv5_gru_update_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_sepconv5_gru_gates_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int,
+                                            c_int, c_int, _P]),
+    "pcfa_sepconv5_gru_update_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int,
+                                             c_int, _P]),
     "pcfa_flow_step": (c_int, [_P, _P, _P, _P, _P, c_longlong, _P]),
     "pcfa_conv3x3_act_fwd_pair": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                           c_float, _P]),

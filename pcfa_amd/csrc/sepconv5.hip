@@ -60,19 +60,31 @@ struct OutSplit {
   int mask_cb;           // (the deferred ReLU backward of whoever produced the b operand of the forward)
 };
 
-// Fused SepConvGRU epilogues (models/raft/update.py:45-60): the gate / update arithmetic of pcfa_gru_gates_fwd and
-// pcfa_gru_update_fwd applied to the accumulators, so the pre-activations never reach memory and two elementwise
-// launches per half-step disappear.  All tensors [B][.][H][W]; C % 32 == 0 (a wave's 32 channels are all z or all r).
+// Fused SepConvGRU epilogues (models/raft/update.py:45-60): the arithmetic of pcfa_gru_gates_fwd / _update_fwd and of
+// their backward counterparts applied to the accumulators, so the pre-activations (forward) and the intermediate
+// gradients (backward) never reach memory and the elementwise launches between the convolutions disappear.
+// All tensors [B][.][H][W]; C % 32 == 0 (a wave's 32 channels are all z or all r, all a-part or all b-part).
 //   mode 1, Cout = 2C: m <  C: z[m] = sigmoid(acc + add[m]);  m >= C: r = sigmoid(acc + add[m]), rh = r * h
+//           in: p0 = add [B][2C], p1 = h;  out: o0 = z, o1 = r, o2 = r * h
 //   mode 2, Cout =  C: q = tanh(acc + add[m]),  hnew = (1 - z) * h + z * q
+//           in: p0 = add [B][C], p1 = h, p2 = z;  out: o0 = q, o1 = hnew
+//   mode 3 (data gradient of the q convolution, a-part = d(r h)): pcfa_gru_gates_bwd_acc on acc = drh:
+//           dzc = dz (1 - z) z,  drc = (drh h)(1 - r) r,  dh = dh_in + drh r
+//           in: p0 = z, p1 = r, p2 = h, p3 = dz, p4 = dh_in;  out: o0 = dzr[:, :C], o1 = dzr[:, C:] ([B][2C]), o2 = dh
+//   mode 4 (data gradient of the z|r convolution, a-part = dh): g = dh_acc + acc is the gradient of the PREVIOUS
+//           half-step's output, whose pcfa_gru_update_bwd follows at once:  dz = g q - g h,  dqc = (g z)(1 - q q),
+//           dh = g (1 - z)      in: p0 = dh_acc, p1 = z, p2 = q, p3 = h (previous half);  out: o0 = dz, o1 = dqc, o2 = dh
+// Modes 3 / 4 leave the b-part (the motion-feature gradient) to OutSplit; their a-part output pointer is unused.
 struct GruEpi {
   int mode, C;
-  const float* add;   // mode 1: [B][2C][plane], mode 2: [B][C][plane]  (context contribution, bias included)
-  const float* h;     // [B][C][plane]
-  const float* z;     // mode 2 input
-  float* o0;          // mode 1: z,  mode 2: q
-  float* o1;          // mode 1: r,  mode 2: hnew
-  float* o2;          // mode 1: r * h
+  const float* p0;
+  const float* p1;
+  const float* p2;
+  const float* p3;
+  const float* p4;
+  float* o0;
+  float* o1;
+  float* o2;
 };
 
 __device__ __forceinline__ float sc5_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }   // as gru_math.hip
@@ -233,25 +245,32 @@ __global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const fl
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  // Operands of the fused GRU epilogue, requested before the K loop: read after it (16 x 3 dependent loads per lane,
-  // one wave per SIMD) they sat on the tail of every workgroup and cost more than the two launches they replace.
-  float e_add[16], e_h[16], e_z[16];
+  // Operands of the fused GRU epilogue, requested before the K loop: read after it (16 x 3..5 dependent loads per
+  // lane, one wave per SIMD) they sat on the tail of every workgroup and cost more than the launches they replace.
+  float e0[16], e1[16], e2[16], e3[16], e4[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) e_add[r] = e_h[r] = e_z[r] = 0.f;
-  if (epi.mode != 0 && kgrp == 0) {
-    const int ex = min(x0 + wc * 32 + l31, W - 1);
-    const long long epix = (long long)y * W + ex;
+  for (int r = 0; r < 16; ++r) e0[r] = e1[r] = e2[r] = e3[r] = e4[r] = 0.f;
+  {
     const int emw = m0 + wr * 32;
-    const bool e_is_z = epi.mode == 1 && emw < epi.C;
-    const long long ia0 = ((long long)blockIdx.z * (epi.mode == 1 ? 2 : 1) * epi.C + emw) * plane + epix;
-    const long long ih0 = ((long long)blockIdx.z * epi.C + (epi.mode == 1 && !e_is_z ? emw - epi.C : emw)) * plane + epix;
+    const bool apart = emw < epi.C;   // modes 3 / 4: this wave's channels are the a-part
+    if (epi.mode != 0 && kgrp == 0 && (epi.mode < 3 || apart)) {
+      const int ex = min(x0 + wc * 32 + l31, W - 1);
+      const long long epix = (long long)y * W + ex;
+      const bool is_z = epi.mode == 1 && apart;
+      // index of channel emw in a [B][C] tensor (r-half of mode 1: channel emw - C) and in mode 1's [B][2C] addend
+      const long long ic0 = ((long long)blockIdx.z * epi.C + (epi.mode == 1 && !apart ? emw - epi.C : emw)) * plane + epix;
+      const long long ia0 = epi.mode == 1 ? ((long long)blockIdx.z * 2 * epi.C + emw) * plane + epix : ic0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (emw + ml < Cout) {
-        e_add[r] = epi.add[ia0 + ml * plane];
-        if (!e_is_z) e_h[r] = epi.h[ih0 + ml * plane];
-        if (epi.mode == 2) e_z[r] = epi.z[ih0 + ml * plane];
+      for (int r = 0; r < 16; ++r) {
+        const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (emw + ml < Cout) {
+          const long long ic = ic0 + ml * plane;
+          e0[r] = epi.p0[epi.mode <= 2 ? ia0 + ml * plane : ic];
+          if (!is_z) e1[r] = epi.p1[ic];
+          if (epi.mode >= 2) e2[r] = epi.p2[ic];
+          if (epi.mode >= 3) e3[r] = epi.p3[ic];
+          if (epi.mode == 3 && epi.p4 != nullptr) e4[r] = epi.p4[ic];
+        }
       }
     }
   }
@@ -351,13 +370,13 @@ __global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const fl
       for (int r = 0; r < 16; ++r) {
         const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (mw + ml < Cout) {
-          const float sg = sc5_sigmoid(acc[r] + e_add[r]);
+          const float sg = sc5_sigmoid(acc[r] + e0[r]);
           const long long io = io0 + ml * plane;
           if (is_z) {
             epi.o0[io] = sg;
           } else {
             epi.o1[io] = sg;
-            epi.o2[io] = sg * e_h[r];
+            epi.o2[io] = sg * e1[r];
           }
         }
       }
@@ -368,10 +387,42 @@ __global__ __launch_bounds__(256 * KS) void sepconv5_kernel(Operand in, const fl
         const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (mw + ml < Cout) {
           const long long i = i0 + ml * plane;
-          const float qq = tanhf(acc[r] + e_add[r]);
-          const float zz = e_z[r], hh = e_h[r];
+          const float qq = tanhf(acc[r] + e0[r]);
+          const float zz = e2[r], hh = e1[r];
           epi.o0[i] = qq;
           epi.o1[i] = (1.f - zz) * hh + zz * qq;
+        }
+      }
+    } else if (epi.mode == 3 && mw < epi.C) {   // as gru_gates_bwd_kernel (gru_math.hip), drh = acc
+      const long long i0 = ((long long)blockIdx.z * epi.C + mw) * plane + pix;
+      const long long j0 = ((long long)blockIdx.z * 2 * epi.C + mw) * plane + pix;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (mw + ml < epi.C) {
+          const float z_ = e0[r], r_ = e1[r], h_ = e2[r], dz_ = e3[r], drh_ = acc[r];
+          const float a = dz_ * (1.f - z_) * z_;
+          const float dr = drh_ * h_;
+          const float b = dr * (1.f - r_) * r_;
+          float c = drh_ * r_;
+          if (epi.p4 != nullptr) c += e4[r];
+          epi.o0[j0 + ml * plane] = a;
+          epi.o1[j0 + (long long)(epi.C + ml) * plane] = b;
+          epi.o2[i0 + ml * plane] = c;
+        }
+      }
+    } else if (epi.mode == 4 && mw < epi.C) {   // dh accumulate, then gru_update_bwd_kernel of the previous half-step
+      const long long i0 = ((long long)blockIdx.z * epi.C + mw) * plane + pix;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (mw + ml < epi.C) {
+          const float g_ = e0[r] + acc[r];
+          const float z_ = e1[r], q_ = e2[r], h_ = e3[r];
+          const long long i = i0 + ml * plane;
+          epi.o0[i] = g_ * q_ - g_ * h_;
+          epi.o1[i] = (g_ * z_) * (1.f - q_ * q_);
+          epi.o2[i] = g_ * (1.f - z_);
         }
       }
     } else if ((out.Ca & 31) == 0 || out.b == nullptr) {
@@ -452,7 +503,7 @@ extern "C" int pcfa_sepconv5_pack_weights(const float* w, float* fwd_packed, flo
 
 static int sepconv5_launch(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,
                            OutSplit out, int B, int Cout, int H, int W, int vertical, void* stream,
-                           GruEpi epi = GruEpi{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+                           GruEpi epi = GruEpi{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
 
 extern "C" int pcfa_sepconv5_fwd(const float* in_a, int Ca, const float* in_b, int Cb,
                                  const float* w_packed, float* out, int B, int Cout, int H, int W,
@@ -489,7 +540,7 @@ extern "C" int pcfa_sepconv5_gru_gates_fwd(const float* h, int C, const float* r
                                            int vertical, void* stream) {
   if (!h || !add_zr || !z || !r || !rh || C < 32 || C % 32 != 0) return PCFA_ERR_INVALID_ARG;
   return sepconv5_launch(h, C, rest, Cr, w_packed, OutSplit{z, nullptr, 2 * C, 0, 0, nullptr, 0}, B, 2 * C, H, W, vertical,
-                         stream, GruEpi{1, C, add_zr, h, nullptr, z, r, rh});
+                         stream, GruEpi{1, C, add_zr, h, nullptr, nullptr, nullptr, z, r, rh});
 }
 
 extern "C" int pcfa_sepconv5_gru_update_fwd(const float* rh, int C, const float* rest, int Cr, const float* w_packed,
@@ -497,7 +548,28 @@ extern "C" int pcfa_sepconv5_gru_update_fwd(const float* rh, int C, const float*
                                             int B, int H, int W, int vertical, void* stream) {
   if (!rh || !add_q || !z || !h || !q || !hnew || C < 32 || C % 32 != 0) return PCFA_ERR_INVALID_ARG;
   return sepconv5_launch(rh, C, rest, Cr, w_packed, OutSplit{q, nullptr, C, 0, 0, nullptr, 0}, B, C, H, W, vertical,
-                         stream, GruEpi{2, C, add_q, h, z, q, hnew, nullptr});
+                         stream, GruEpi{2, C, add_q, h, z, nullptr, nullptr, q, hnew, nullptr});
+}
+
+extern "C" int pcfa_sepconv5_gru_gates_bwd(const float* dqc, int C, int Cr, const float* w_packed_bwd, const float* z,
+                                           const float* r, const float* h, const float* dz, const float* dh_in,
+                                           float* dzr, float* dh, float* d_rest, int accumulate_rest, int B, int H, int W,
+                                           int vertical, void* stream) {
+  if (!dqc || !z || !r || !h || !dz || !dzr || !dh || !d_rest || C < 32 || C % 32 != 0 || Cr < 1)
+    return PCFA_ERR_INVALID_ARG;
+  return sepconv5_launch(dqc, C, nullptr, 0, w_packed_bwd, OutSplit{dh, d_rest, C, 0, accumulate_rest != 0, nullptr, 0}, B,
+                         C + Cr, H, W, vertical, stream, GruEpi{3, C, z, r, h, dz, dh_in, dzr, dzr, dh});
+}
+
+extern "C" int pcfa_sepconv5_gru_update_bwd(const float* dzr, int C, int Cr, const float* w_packed_bwd, const float* dh_acc,
+                                            const float* z_prev, const float* q_prev, const float* h_prev, float* dz_prev,
+                                            float* dqc_prev, float* dh_prev, float* d_rest, int B, int H, int W,
+                                            int vertical, void* stream) {
+  if (!dzr || !dh_acc || !z_prev || !q_prev || !h_prev || !dz_prev || !dqc_prev || !dh_prev || !d_rest || C < 32 ||
+      C % 32 != 0 || Cr < 1)
+    return PCFA_ERR_INVALID_ARG;
+  return sepconv5_launch(dzr, 2 * C, nullptr, 0, w_packed_bwd, OutSplit{dh_prev, d_rest, C, 0, 1, nullptr, 0}, B, C + Cr, H,
+                         W, vertical, stream, GruEpi{4, C, dh_acc, z_prev, q_prev, h_prev, nullptr, dz_prev, dqc_prev, dh_prev});
 }
 
 static int sepconv5_launch(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,

@@ -1196,6 +1196,28 @@ class _GruStep(torch.autograd.Function):
         g = g.contiguous()
         d_rest = new(Cr)
         grads_p = [None, None, None, None]  # p_zr1, p_q1, p_zr2, p_q2
+        if C % 32 == 0 and _GRU_EPILOGUES:
+            # Elementwise backward kernels ride in the epilogues of the data-gradient convolutions: only the update
+            # backward of the LAST half-step (its gradient arrives from outside) is a launch of its own.
+            z1, r1, q1, h1 = ctx.saved_tensors[4:8]
+            z0, r0, q0, h0 = ctx.saved_tensors[0:4]
+            (b_zr1, b_q1, v1), (b_zr0, b_q0, v0) = ctx.packs[1], ctx.packs[0]
+            dz1, dqc1, dh1, dzr1 = new(C), new(C), new(C), new(2 * C)
+            _call("pcfa_gru_update_bwd", _ptr(z1), _ptr(q1), _ptr(h1), _ptr(g), _ptr(dz1), _ptr(dqc1), _ptr(dh1), z1.numel())
+            _call("pcfa_sepconv5_gru_gates_bwd", _ptr(dqc1), C, Cr, _ptr(b_q1), _ptr(z1), _ptr(r1), _ptr(h1), _ptr(dz1),
+                  _ptr(dh1), _ptr(dzr1), _ptr(dh1), _ptr(d_rest), 0, B, H, W, v1)
+            dz0, dqc0, dh0, dzr0 = new(C), new(C), new(C), new(2 * C)
+            _call("pcfa_sepconv5_gru_update_bwd", _ptr(dzr1), C, Cr, _ptr(b_zr1), _ptr(dh1), _ptr(z0), _ptr(q0), _ptr(h0),
+                  _ptr(dz0), _ptr(dqc0), _ptr(dh0), _ptr(d_rest), B, H, W, v1)
+            _call("pcfa_sepconv5_gru_gates_bwd", _ptr(dqc0), C, Cr, _ptr(b_q0), _ptr(z0), _ptr(r0), _ptr(h0), _ptr(dz0),
+                  _ptr(dh0), _ptr(dzr0), _ptr(dh0), _ptr(d_rest), 1, B, H, W, v0)
+            if ctx.rest_relu:
+                _call("pcfa_sepconv5_fwd_split_masked", _ptr(dzr0), 2 * C, None, 0, _ptr(b_zr0), _ptr(dh0), C, 1,
+                      _ptr(d_rest), 1, _ptr(ctx.saved_tensors[8]), ctx.rest_relu, B, C + Cr, H, W, v0)
+            else:
+                _call("pcfa_sepconv5_fwd_split", _ptr(dzr0), 2 * C, None, 0, _ptr(b_zr0), _ptr(dh0), C, 1, _ptr(d_rest), 1,
+                      B, C + Cr, H, W, v0)
+            return dh0, d_rest, None, dzr0, None, dqc0, None, dzr1, None, dqc1, None
         rest_started = 0
         for half in (1, 0):
             z, r, q, h = ctx.saved_tensors[4 * half: 4 * half + 4]
