@@ -421,6 +421,11 @@ PCFA_API int pcfa_conv3x3_act_fwd_pair(const float* x, const float* packed, cons
 /* pcfa_conv3x3_fwd without bias / activation whose result is zeroed where mask <= 0 (mask: shape of out).  As a data
  * gradient (packed = bwd_packed) with mask = the convolution's own input this is conv'(g) * [x > 0]: the ReLU backward
  * of the layer that produced x (models/raft/update.py:92,94 convc2 / convf2 feeding conv), fused into the epilogue. */
+/* The general data-gradient form: grad_in = conv'(g) [zeroed where mask <= 0] [+ addend]; mask and addend are optional
+ * (NULL) and have grad_in's shape.  addend = the gradient the same tensor receives from its other consumer -- the
+ * residual path of ResidualBlock (models/raft/extractor.py:50-58) -- summed in the epilogue instead of by autograd. */
+PCFA_API int pcfa_conv3x3_fused_bwd(const float* g, const float* packed_bwd, const float* mask, const float* addend,
+                           float* grad_in, int B, int K, int N, int H, int W, void* stream);
 PCFA_API int pcfa_conv3x3_masked_fwd(const float* x, const float* packed, const float* mask, float* out, int B, int K,
                             int N, int H, int W, void* stream);
 

@@ -479,13 +479,15 @@ def sepconv5(a, b, weight):
     return F.conv2d(x, weight, None, padding=(weight.shape[2] // 2, weight.shape[3] // 2))
 
 
-def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None):
+def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None, skip=False):
     """3x3 / stride 1 / pad 1 convolution (+ bias, + ReLU or LeakyReLU): models/raft/update.py:6-16,79-101,
-    models/PWCNet/PWCNet.py:29-35."""
+    models/PWCNet/PWCNet.py:29-35.  skip: also return x (the product sums the residual path's gradient in a kernel)."""
     y = F.conv2d(x, weight, bias, stride=1, padding=1)
     if leaky_slope is not None:
-        return F.leaky_relu(y, leaky_slope)
-    return F.relu(y) if relu else y
+        y = F.leaky_relu(y, leaky_slope)
+    elif relu:
+        y = F.relu(y)
+    return (y, x) if skip else y
 
 
 def gru_step(h, rest, halves, rest_relu_channels=0):

@@ -116,8 +116,8 @@ struct Second {
 template <int ACT, int CBT, int MT, bool KFULL, int NRING, int KS = 1>  // ACT: 0 none, 1 ReLU, 2 LeakyReLU(slope)
 __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(KS == 2 ? 2 : (MT == 1 && NRING == 2 && CBT == 32 ? 3 : (CBT == 64 ? 1 : 2))))) void conv3x3_winograd_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
-    const float* __restrict__ mask, float* __restrict__ out, int K, int N, int Npad, int H, int W, int blocks_x,
-    float slope, Second second) {
+    const float* __restrict__ mask, const float* __restrict__ addend, float* __restrict__ out, int K, int N, int Npad,
+    int H, int W, int blocks_x, float slope, Second second) {
   constexpr int NT = 256 * MT;                         // threads
   constexpr int TR = 4 * MT, TB = TR * TC;             // tile rows / tiles per workgroup
   constexpr int PR = 2 * TR + 2;                       // input patch rows
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(K
     K = second.K;
     N = second.N;
     mask = nullptr;
+    addend = nullptr;
   }
   const int n0 = nby * CBT;
   if (n0 >= N) return;  // (the packing pads N to 64: a 32-channel block may lie entirely in the padding)
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(K
   x += (long long)blockIdx.z * K * plane;
   out += (long long)blockIdx.z * N * plane;
   if (mask != nullptr) mask += (long long)blockIdx.z * N * plane;   // same shape as `out`
+  if (addend != nullptr) addend += (long long)blockIdx.z * N * plane;
 
   // ---- per-thread constants of the staging loads (chunk-invariant) ----
   unsigned praw[RAW_LOADS];      // chunk 0 source of the patch element (clamped into the image), floats from x
@@ -342,6 +344,22 @@ __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(K
     const int nb = pass >> 1, half = pass & 1;
     // deferred-ReLU mask of this pass's outputs, requested before the LDS round trip instead of on the store path
     float mk[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+    float ad[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // gradient arriving on the residual path
+    if (addend != nullptr && worker) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int n = n0 + pass * 16 + e_cl + 8 * q;
+        if (n < N && oy < H && ox < W) {
+          const float* ap = addend + (long long)n * plane + (long long)oy * W + ox;
+          ad[q][0] = ap[0];
+          if (ox + 1 < W) ad[q][1] = ap[1];
+          if (oy + 1 < H) {
+            ad[q][2] = ap[W];
+            if (ox + 1 < W) ad[q][3] = ap[W + 1];
+          }
+        }
+      }
+    }
     if (mask != nullptr && worker) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -397,6 +415,9 @@ __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(K
           y01 = mk[q][1] > 0.f ? y01 : 0.f;
           y10 = mk[q][2] > 0.f ? y10 : 0.f;
           y11 = mk[q][3] > 0.f ? y11 : 0.f;
+        }
+        if (addend != nullptr) {   // the other consumer's gradient of the same tensor, summed here instead of by autograd
+          y00 += ad[q][0]; y01 += ad[q][1]; y10 += ad[q][2]; y11 += ad[q][3];
         }
         float* o = out + oo;
         o[0] = y00;
@@ -467,7 +488,7 @@ extern "C" int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, floa
 static int conv3x3_launch(const float* x, const float* packed, const float* bias, const float* mask, float* out, int B,
                           int K, int N, int H, int W, int act, float slope, void* stream, const float* x2 = nullptr,
                           const float* packed2 = nullptr, const float* bias2 = nullptr, float* out2 = nullptr,
-                          int K2 = 0, int N2 = 0);
+                          int K2 = 0, int N2 = 0, const float* addend = nullptr);
 
 extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K,
                                 int N, int H, int W, int relu, void* stream) {
@@ -495,9 +516,15 @@ extern "C" int pcfa_conv3x3_act_fwd_pair(const float* x, const float* packed, co
                         N2);
 }
 
+extern "C" int pcfa_conv3x3_fused_bwd(const float* g, const float* packed_bwd, const float* mask, const float* addend,
+                                      float* grad_in, int B, int K, int N, int H, int W, void* stream) {
+  return conv3x3_launch(g, packed_bwd, nullptr, mask, grad_in, B, K, N, H, W, 0, 0.f, stream, nullptr, nullptr, nullptr,
+                        nullptr, 0, 0, addend);
+}
+
 static int conv3x3_launch(const float* x, const float* packed, const float* bias, const float* mask, float* out, int B,
                           int K, int N, int H, int W, int act, float slope, void* stream, const float* x2,
-                          const float* packed2, const float* bias2, float* out2, int K2, int N2) {
+                          const float* packed2, const float* bias2, float* out2, int K2, int N2, const float* addend) {
   if (act < 0 || act > 2) return PCFA_ERR_INVALID_ARG;
   if (!x || !packed || !out || B < 1 || K < 1 || N < 1 || H < 1 || W < 1 || !aligned16(packed))
     return PCFA_ERR_INVALID_ARG;
@@ -526,7 +553,7 @@ static int conv3x3_launch(const float* x, const float* packed, const float* bias
     grid.y += (unsigned)((N2 + CB - 1) / CB * CB / 32);
     if (grid.y > 65535) return PCFA_ERR_UNSUPPORTED;
   }
-#define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, mask, out, K, N, Npad, H, W, blocks_x, slope, second
+#define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, mask, addend, out, K, N, Npad, H, W, blocks_x, slope, second
 #define PCFA_C3_LAUNCH(MT_, KF_, NR_)                                                              \
   do {                                                                                             \
     if (act == 1) pcfa_launch(conv3x3_winograd_kernel<1, 32, MT_, KF_, NR_>, PCFA_C3_ARGS);        \

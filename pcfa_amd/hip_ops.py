@@ -931,8 +931,10 @@ def _conv3x3_packed(weight):
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, slope=None):
+    def forward(ctx, x, weight, bias, relu, slope=None, skip=False):
         _dev(x, weight, bias)
+        ctx.skip = bool(skip)
+        ctx.set_materialize_grads(False)
         if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.dtype != torch.float32:
             raise ValueError("conv3x3 expects a float32 3x3 Conv2d weight, got %s" % (tuple(weight.shape),))
         x = x.contiguous()
@@ -948,13 +950,17 @@ class _Conv3x3(torch.autograd.Function):
         ctx.bwd, ctx.dims, ctx.act, ctx.slope = bwd, (B, K, N, H, W), act, float(slope or 0.)
         if act:
             ctx.save_for_backward(out)
+        if ctx.skip:
+            return out, x.view_as(x)   # the alias feeds the residual path: its gradient is summed in the epilogue below
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_skip=None):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise RuntimeError("conv3x3 is the frozen-weight path: no weight / bias gradient")
         B, K, N, H, W = ctx.dims
+        if g is None:
+            return (None if g_skip is None else g_skip), None, None, None, None, None
         g = g.contiguous()
         if ctx.act:
             (out,) = ctx.saved_tensors
@@ -965,8 +971,12 @@ class _Conv3x3(torch.autograd.Function):
                 _call("pcfa_leaky_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), ctx.slope, g.numel())
             g = gm
         gin = torch.empty((B, K, H, W), device=g.device, dtype=torch.float32)
-        _call("pcfa_conv3x3_fwd", _ptr(g), _ptr(ctx.bwd), None, _ptr(gin), B, N, K, H, W, 0)
-        return gin, None, None, None, None
+        if g_skip is not None:
+            _call("pcfa_conv3x3_fused_bwd", _ptr(g), _ptr(ctx.bwd), None, _ptr(g_skip.contiguous()), _ptr(gin), B, N, K,
+                  H, W)
+        else:
+            _call("pcfa_conv3x3_fwd", _ptr(g), _ptr(ctx.bwd), None, _ptr(gin), B, N, K, H, W, 0)
+        return gin, None, None, None, None, None
 
 
 _PAIR_LAUNCH = os.environ.get("PCFA_CONV3X3_PAIR", "1") != "0"   # A/B switch (tools/dev)
@@ -1122,11 +1132,12 @@ def dense_block(x, layers, slope=0.1):
     return _DenseBlock.apply(x, slope, *flat)
 
 
-def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None):
+def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None, skip=False):
     """act(conv2d(x, weight, bias, stride=1, padding=1)) for a frozen 3x3 weight: Winograd F(2x2,3x3) on the fp32
     matrix cores with bias and ReLU (or LeakyReLU(leaky_slope)) fused into the epilogue; the data gradient runs the
-    same kernel."""
-    return _Conv3x3.apply(x, weight, bias, relu, leaky_slope)
+    same kernel.  skip=True returns (result, x_alias): use x_alias for a residual connection around the convolution --
+    the gradient arriving on it is added in the data-gradient kernel's epilogue instead of by an autograd `add`."""
+    return _Conv3x3.apply(x, weight, bias, relu, leaky_slope, skip)
 
 
 _GRU_EPILOGUES = os.environ.get("PCFA_GRU_EPILOGUES", "1") != "0"   # A/B switch (tools/dev)

@@ -57,7 +57,7 @@ def _fold_batchnorm(conv, bn, cache, tag):
     return hit[1], hit[2]
 
 
-def _conv_norm(conv, norm, x, relu, cache, tag):
+def _conv_norm(conv, norm, x, relu, cache, tag, skip=False):
     """relu?(norm(conv(x))) of the residual encoders (extractor.py:23-58,161-177).
 
     Frozen-weight fast paths (what the attack runs), identical to the reference in exact arithmetic:
@@ -70,17 +70,37 @@ def _conv_norm(conv, norm, x, relu, cache, tag):
             and not (norm.affine and (norm.weight.requires_grad or norm.bias.requires_grad))):
         w, b = _fold_batchnorm(conv, norm, cache, tag)
         if _is_plain3x3(conv):
-            return ops.get().conv3x3(x, w, b, relu)
+            return ops.get().conv3x3(x, w, b, relu, skip=skip)
+        assert not skip
         if relu:
             return ops.get().bias_relu(conv._conv_forward(x, w, None), b)
         return conv._conv_forward(x, w, b)
     if (frozen and isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats):
-        y = (ops.get().conv3x3(x, conv.weight, None, False) if _is_plain3x3(conv)
-             else conv._conv_forward(x, conv.weight, None))
+        xs = None
+        if _is_plain3x3(conv):
+            y = ops.get().conv3x3(x, conv.weight, None, False, skip=skip)
+            if skip:
+                y, xs = y
+        else:
+            assert not skip
+            y = conv._conv_forward(x, conv.weight, None)
         # normalisation + ReLU in two streaming launches per direction instead of the library's 3 + 2 passes
-        return ops.get().instance_norm_relu(y, norm.eps, relu)
+        y = ops.get().instance_norm_relu(y, norm.eps, relu)
+        return (y, xs) if skip else y
+    assert not skip
     y = norm(conv(x))
     return F.relu(y, inplace=True) if relu else y
+
+
+def _can_skip(conv, norm):
+    """_conv_norm(.., skip=True) is available: a frozen plain 3x3 convolution on one of the two fast paths."""
+    frozen = not (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad))
+    if not (frozen and _is_plain3x3(conv)):
+        return False
+    if isinstance(norm, nn.BatchNorm2d):
+        return (not norm.training and norm.track_running_stats
+                and not (norm.affine and (norm.weight.requires_grad or norm.bias.requires_grad)))
+    return isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats
 
 
 class ResidualBlock(nn.Module):
@@ -99,7 +119,12 @@ class ResidualBlock(nn.Module):
         self._fold_cache = {}
 
     def forward(self, x):
-        y = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1")
+        if self.downsample is None and _all_frozen(self) and _can_skip(self.conv1, self.norm1):
+            # the block input feeds conv1 and the residual sum: conv1's data-gradient kernel adds the residual path's
+            # gradient in its epilogue (one autograd `add` over the activation less per block)
+            y, x = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1", skip=True)
+        else:
+            y = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1")
         y = _conv_norm(self.conv2, self.norm2, y, True, self._fold_cache, "2")
         if self.downsample is not None:
             x = _conv_norm(self.downsample[0], self.downsample[1], x, False, self._fold_cache, "d")

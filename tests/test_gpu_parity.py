@@ -440,6 +440,33 @@ def test_conv3x3_cat_vs_oracle(oracle_ops):
     assert rel_l2(ag.grad, a.grad) < 1e-4 and rel_l2(bg.grad, b.grad) < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 40, 48), (1, 12, 12, 9, 21)])
+def test_conv3x3_skip_gradient_sums_in_the_epilogue(shape):
+    """conv3x3(.., skip=True): the gradient arriving on the residual alias is added by the data-gradient kernel
+    (pcfa_conv3x3_fused_bwd) -- against the same graph with autograd's own accumulation: one fp32 add either way, so
+    bit-identical; also with only one of the two outputs used."""
+    B, K, N, H, W = shape
+    gen = torch.Generator().manual_seed(K + W)
+    x0 = torch.randn(B, K, H, W, generator=gen).to(DEV)
+    w = (torch.randn(N, K, 3, 3, generator=gen) / (9 * K) ** .5).to(DEV)
+    b = torch.randn(N, generator=gen).to(DEV)
+    go, gs = torch.randn(B, N, H, W, generator=gen).to(DEV), torch.randn(B, K, H, W, generator=gen).to(DEV)
+
+    def run(skip, use_y=True, use_s=True):
+        x = x0.clone().requires_grad_(True)
+        if skip:
+            y, xs = hip_ops.conv3x3(x, w, b, True, skip=True)
+        else:
+            y, xs = hip_ops.conv3x3(x, w, b, True), x
+        loss = (y * go).sum() * float(use_y) + (xs * gs).sum() * float(use_s)
+        (gx,) = torch.autograd.grad(loss, x)
+        return y.detach(), gx
+
+    for use_y, use_s in ((True, True), (True, False)):
+        (ya, ga), (yb, gb) = run(True, use_y, use_s), run(False, use_y, use_s)
+        assert torch.equal(ya, yb) and torch.equal(ga, gb)
+
+
 def test_deferred_relu_masks_change_no_bit():
     """Motion encoder + GRU update with the ReLU backward of convc2 / convf2 / conv deferred into the kernels that
     produce those gradients anyway (conv3x3_cat flags, gru_step rest_relu_channels; pcfa_conv3x3_masked_fwd,
