@@ -434,6 +434,10 @@ PCFA_API int pcfa_conv3x3_masked_fwd(const float* x, const float* packed, const 
 PCFA_API int pcfa_bias_relu_fwd(const float* x, const float* bias, float* out, long long n, int plane, int channels,
                        void* stream);
 PCFA_API int pcfa_relu_bwd(const float* out, const float* grad_out, float* grad_x, long long n, void* stream);
+/* grad_x = grad_out * [out > 0] and grad_x2 = grad_x * [out2 > 0] in one pass: the backward of relu(a + relu(c)) towards
+ * a and towards c's pre-activation (ResidualBlock, models/raft/extractor.py:50-58, with out2 = relu(c)). */
+PCFA_API int pcfa_relu_bwd2(const float* out, const float* out2, const float* grad_out, float* grad_x, float* grad_x2,
+                   long long n, void* stream);
 
 /* act(conv2d(x, w, bias, stride=1, padding=ksize/2)) for Cin <= 4 input channels, forward only: convf1 of the
  * motion encoder (models/raft/update.py:79-101, Conv2d(2, 128, 7, padding=3) + ReLU on the detached flow).

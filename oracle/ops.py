@@ -479,7 +479,7 @@ def sepconv5(a, b, weight):
     return F.conv2d(x, weight, None, padding=(weight.shape[2] // 2, weight.shape[3] // 2))
 
 
-def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None, skip=False):
+def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None, skip=False, grad_premasked=False, mask_input_grad=False):
     """3x3 / stride 1 / pad 1 convolution (+ bias, + ReLU or LeakyReLU): models/raft/update.py:6-16,79-101,
     models/PWCNet/PWCNet.py:29-35.  skip: also return x (the product sums the residual path's gradient in a kernel)."""
     y = F.conv2d(x, weight, bias, stride=1, padding=1)
@@ -557,8 +557,8 @@ def flow_step(coords1, delta, coords0):
     return c, c - coords0
 
 
-def add_relu(a, b):
-    """models/raft/extractor.py:50-58: relu(x + y)."""
+def add_relu(a, b, b_is_relu=False):
+    """models/raft/extractor.py:50-58: relu(x + y).  b_is_relu: scheduling hint of the product, no effect here."""
     return F.relu(a + b)
 
 

@@ -89,6 +89,7 @@ SIGNATURES = {
     "pcfa_flow_step": (c_int, [_P, _P, _P, _P, _P, c_longlong, _P]),
     "pcfa_conv3x3_act_fwd_pair": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                           c_float, _P]),
+    "pcfa_relu_bwd2": (c_int, [_P, _P, _P, _P, _P, c_longlong, _P]),
     "pcfa_conv3x3_fused_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_conv3x3_masked_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_conv3x3_packed_floats": (c_longlong, [c_int, c_int]),

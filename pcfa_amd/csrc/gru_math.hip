@@ -187,6 +187,28 @@ __global__ void relu_bwd_kernel(const float* __restrict__ out, const float* __re
   });
 }
 
+// gx = gout * [out > 0] ; gx2 = gx * [out2 > 0]: the backward of relu(a + relu(.)) for both of its consumers in one pass
+// (ResidualBlock's output ReLU and the ReLU of its second convolution, models/raft/extractor.py:50-58)
+__global__ void relu_bwd2_kernel(const float* __restrict__ out, const float* __restrict__ out2,
+                                 const float* __restrict__ gout, float* __restrict__ gx, float* __restrict__ gx2,
+                                 long long n, int vec_ok) {
+  for_each4(n, vec_ok, [&](long long i, bool vec) {
+    if (vec) {
+      const float4 o = LD4(out, i), p = LD4(out2, i), g = LD4(gout, i);
+      float4 r, t;
+      r.x = o.x > 0.f ? g.x : 0.f; r.y = o.y > 0.f ? g.y : 0.f;
+      r.z = o.z > 0.f ? g.z : 0.f; r.w = o.w > 0.f ? g.w : 0.f;
+      t.x = p.x > 0.f ? r.x : 0.f; t.y = p.y > 0.f ? r.y : 0.f;
+      t.z = p.z > 0.f ? r.z : 0.f; t.w = p.w > 0.f ? r.w : 0.f;
+      ST4(gx, i, r); ST4(gx2, i, t);
+    } else {
+      const float r = out[i] > 0.f ? gout[i] : 0.f;
+      gx[i] = r;
+      gx2[i] = out2[i] > 0.f ? r : 0.f;
+    }
+  });
+}
+
 inline int blocks_for(long long n) {
   long long b = ((n >> 2) + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -263,6 +285,16 @@ extern "C" int pcfa_relu_bwd(const float* out, const float* grad_out, float* gra
   const int vec_ok = al16(out) && al16(grad_out) && al16(grad_x);
   pcfa_launch(relu_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, out, grad_out,
                      grad_x, n, vec_ok);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_relu_bwd2(const float* out, const float* out2, const float* grad_out, float* grad_x, float* grad_x2,
+                              long long n, void* stream) {
+  if (!out || !out2 || !grad_out || !grad_x || !grad_x2 || n < 1) return PCFA_ERR_INVALID_ARG;
+  const int vec_ok = al16(out) && al16(out2) && al16(grad_out) && al16(grad_x) && al16(grad_x2);
+  pcfa_launch(relu_bwd2_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, out, out2, grad_out, grad_x,
+              grad_x2, n, vec_ok);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }

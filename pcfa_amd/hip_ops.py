@@ -836,29 +836,36 @@ def instance_norm_relu(x, eps=1e-5, relu=False):
 
 class _AddRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, b_is_relu):
         _dev(a, b)
         if a.shape != b.shape:
             raise ValueError("add_relu: shapes differ: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
         a, b = a.contiguous(), b.contiguous()
         out = torch.empty_like(a)
         _call("pcfa_add_relu_fwd", _ptr(a), _ptr(b), _ptr(out), a.numel())
-        ctx.save_for_backward(out)
+        ctx.b_is_relu = bool(b_is_relu)
+        ctx.save_for_backward(out, *((b,) if ctx.b_is_relu else ()))
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        (out,) = ctx.saved_tensors
+        out = ctx.saved_tensors[0]
         g = g.contiguous()
         gm = torch.empty_like(g)
+        if ctx.b_is_relu:   # b = relu(.) of a layer that left its mask to us: its gradient is masked in the same pass
+            gb = torch.empty_like(g)
+            _call("pcfa_relu_bwd2", _ptr(out), _ptr(ctx.saved_tensors[1]), _ptr(g), _ptr(gm), _ptr(gb), g.numel())
+            return gm, gb, None
         _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), g.numel())
-        return gm, gm
+        return gm, gm, None
 
 
-def add_relu(a, b):
-    """relu(a + b): the output of ResidualBlock.forward (models/raft/extractor.py:50-58)."""
-    return _AddRelu.apply(a, b)
+def add_relu(a, b, b_is_relu=False):
+    """relu(a + b): the output of ResidualBlock.forward (models/raft/extractor.py:50-58).  b_is_relu: b is the ReLU output
+    of a layer run with grad_premasked=True and has no other consumer -- the gradient returned for b is already
+    multiplied by [b > 0] (one pass produces both gradients)."""
+    return _AddRelu.apply(a, b, b_is_relu)
 
 
 def _sepconv5_packed(weight):
@@ -931,9 +938,10 @@ def _conv3x3_packed(weight):
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, slope=None, skip=False):
+    def forward(ctx, x, weight, bias, relu, slope=None, skip=False, flags=0):
         _dev(x, weight, bias)
         ctx.skip = bool(skip)
+        ctx.grad_premasked, ctx.mask_input_grad = bool(flags & 1), bool(flags & 2)
         ctx.set_materialize_grads(False)
         if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.dtype != torch.float32:
             raise ValueError("conv3x3 expects a float32 3x3 Conv2d weight, got %s" % (tuple(weight.shape),))
@@ -948,8 +956,9 @@ class _Conv3x3(torch.autograd.Function):
         _call("pcfa_conv3x3_act_fwd", _ptr(x), _ptr(fwd), _ptr(bias), _ptr(out), B, K, N, H, W, act,
               float(slope or 0.))
         ctx.bwd, ctx.dims, ctx.act, ctx.slope = bwd, (B, K, N, H, W), act, float(slope or 0.)
-        if act:
-            ctx.save_for_backward(out)
+        if ctx.grad_premasked and act != 1:
+            raise ValueError("conv3x3: grad_premasked needs relu=True")
+        ctx.save_for_backward(*(([out] if act and not ctx.grad_premasked else []) + ([x] if ctx.mask_input_grad else [])))
         if ctx.skip:
             return out, x.view_as(x)   # the alias feeds the residual path: its gradient is summed in the epilogue below
         return out
@@ -960,10 +969,10 @@ class _Conv3x3(torch.autograd.Function):
             raise RuntimeError("conv3x3 is the frozen-weight path: no weight / bias gradient")
         B, K, N, H, W = ctx.dims
         if g is None:
-            return (None if g_skip is None else g_skip), None, None, None, None, None
+            return (None if g_skip is None else g_skip), None, None, None, None, None, None
         g = g.contiguous()
-        if ctx.act:
-            (out,) = ctx.saved_tensors
+        if ctx.act and not ctx.grad_premasked:
+            out = ctx.saved_tensors[0]
             gm = torch.empty_like(g)
             if ctx.act == 1:
                 _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), g.numel())
@@ -971,12 +980,13 @@ class _Conv3x3(torch.autograd.Function):
                 _call("pcfa_leaky_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), ctx.slope, g.numel())
             g = gm
         gin = torch.empty((B, K, H, W), device=g.device, dtype=torch.float32)
-        if g_skip is not None:
-            _call("pcfa_conv3x3_fused_bwd", _ptr(g), _ptr(ctx.bwd), None, _ptr(g_skip.contiguous()), _ptr(gin), B, N, K,
-                  H, W)
+        if g_skip is not None or ctx.mask_input_grad:
+            xin = ctx.saved_tensors[-1] if ctx.mask_input_grad else None   # = a ReLU output: [xin > 0] is its mask
+            _call("pcfa_conv3x3_fused_bwd", _ptr(g), _ptr(ctx.bwd), _ptr(xin),
+                  _ptr(None if g_skip is None else g_skip.contiguous()), _ptr(gin), B, N, K, H, W)
         else:
             _call("pcfa_conv3x3_fwd", _ptr(g), _ptr(ctx.bwd), None, _ptr(gin), B, N, K, H, W, 0)
-        return gin, None, None, None, None, None
+        return gin, None, None, None, None, None, None
 
 
 _PAIR_LAUNCH = os.environ.get("PCFA_CONV3X3_PAIR", "1") != "0"   # A/B switch (tools/dev)
@@ -1132,12 +1142,15 @@ def dense_block(x, layers, slope=0.1):
     return _DenseBlock.apply(x, slope, *flat)
 
 
-def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None, skip=False):
+def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None, skip=False, grad_premasked=False, mask_input_grad=False):
     """act(conv2d(x, weight, bias, stride=1, padding=1)) for a frozen 3x3 weight: Winograd F(2x2,3x3) on the fp32
     matrix cores with bias and ReLU (or LeakyReLU(leaky_slope)) fused into the epilogue; the data gradient runs the
     same kernel.  skip=True returns (result, x_alias): use x_alias for a residual connection around the convolution --
-    the gradient arriving on it is added in the data-gradient kernel's epilogue instead of by an autograd `add`."""
-    return _Conv3x3.apply(x, weight, bias, relu, leaky_slope, skip)
+    the gradient arriving on it is added in the data-gradient kernel's epilogue instead of by an autograd `add`.
+    grad_premasked / mask_input_grad: the deferred-ReLU contract of conv3x3_cat (the consumer of this layer's output
+    applies [output > 0] to the gradient / this layer applies [x > 0] to the gradient it returns for a ReLU-output x)."""
+    return _Conv3x3.apply(x, weight, bias, relu, leaky_slope, skip,
+                          int(bool(grad_premasked)) | 2 * int(bool(mask_input_grad)))
 
 
 _GRU_EPILOGUES = os.environ.get("PCFA_GRU_EPILOGUES", "1") != "0"   # A/B switch (tools/dev)

@@ -57,7 +57,10 @@ def _fold_batchnorm(conv, bn, cache, tag):
     return hit[1], hit[2]
 
 
-def _conv_norm(conv, norm, x, relu, cache, tag, skip=False):
+_DEFER_RELU = os.environ.get("PCFA_DEFER_RELU", "1") != "0"   # A/B switch: ReLU backward fused into neighbouring kernels
+
+
+def _conv_norm(conv, norm, x, relu, cache, tag, skip=False, grad_premasked=False, mask_input_grad=False):
     """relu?(norm(conv(x))) of the residual encoders (extractor.py:23-58,161-177).
 
     Frozen-weight fast paths (what the attack runs), identical to the reference in exact arithmetic:
@@ -70,8 +73,9 @@ def _conv_norm(conv, norm, x, relu, cache, tag, skip=False):
             and not (norm.affine and (norm.weight.requires_grad or norm.bias.requires_grad))):
         w, b = _fold_batchnorm(conv, norm, cache, tag)
         if _is_plain3x3(conv):
-            return ops.get().conv3x3(x, w, b, relu, skip=skip)
-        assert not skip
+            return ops.get().conv3x3(x, w, b, relu, skip=skip, grad_premasked=grad_premasked,
+                                     mask_input_grad=mask_input_grad)
+        assert not (skip or grad_premasked or mask_input_grad)
         if relu:
             return ops.get().bias_relu(conv._conv_forward(x, w, None), b)
         return conv._conv_forward(x, w, b)
@@ -122,14 +126,21 @@ class ResidualBlock(nn.Module):
         if self.downsample is None and _all_frozen(self) and _can_skip(self.conv1, self.norm1):
             # the block input feeds conv1 and the residual sum: conv1's data-gradient kernel adds the residual path's
             # gradient in its epilogue (one autograd `add` over the activation less per block)
-            y, x = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1", skip=True)
+            y, x = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1", skip=True,
+                              grad_premasked=_DEFER_RELU and isinstance(self.norm1, nn.BatchNorm2d) and isinstance(self.norm2, nn.BatchNorm2d)
+                              and _can_skip(self.conv2, self.norm2))
         else:
             y = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1")
-        y = _conv_norm(self.conv2, self.norm2, y, True, self._fold_cache, "2")
+        # folded-BatchNorm blocks (context encoder) are conv + ReLU chains: conv2's data-gradient kernel applies conv1's
+        # ReLU mask, and the block's output ReLU backward masks conv2's gradient in the same pass (2 launches less)
+        chain = (_DEFER_RELU and _all_frozen(self) and isinstance(self.norm2, nn.BatchNorm2d) and _can_skip(self.conv2, self.norm2)
+                 and _can_skip(self.conv1, self.norm1) and self.downsample is None)
+        y = _conv_norm(self.conv2, self.norm2, y, True, self._fold_cache, "2", grad_premasked=chain, mask_input_grad=chain)
         if self.downsample is not None:
             x = _conv_norm(self.downsample[0], self.downsample[1], x, False, self._fold_cache, "d")
         if _all_frozen(self):
-            return ops.get().add_relu(x, y)  # one pass instead of add + ReLU; one backward kernel for both operands
+            # one pass instead of add + ReLU; one backward kernel for both operands
+            return ops.get().add_relu(x, y, b_is_relu=chain)
         return self.relu(x + y)
 
 
@@ -383,7 +394,7 @@ class BasicUpdateBlock(nn.Module):
 
     def forward(self, net, inp, corr, flow, want_mask=True, gru_ctx=None):
         # frozen weights: the GRU node is the motion features' only consumer and differentiates their ReLU itself
-        defer = gru_ctx is not None and self.encoder.can_defer_relu(flow)
+        defer = _DEFER_RELU and gru_ctx is not None and self.encoder.can_defer_relu(flow)
         motion_features = self.encoder(flow, corr, defer_relu=defer)
         if gru_ctx is not None:   # frozen weights: context-feature part of the gate convolutions hoisted
             net = self.gru.step(net, gru_ctx, motion_features, self.encoder.RELU_CHANNELS if defer else 0)

@@ -467,6 +467,32 @@ def test_conv3x3_skip_gradient_sums_in_the_epilogue(shape):
         assert torch.equal(ya, yb) and torch.equal(ga, gb)
 
 
+def test_context_encoder_block_deferred_masks_change_no_bit(monkeypatch):
+    """A folded-BatchNorm ResidualBlock (context encoder, extractor.py:23-58) with its three ReLU backward passes riding in
+    neighbouring kernels (pcfa_conv3x3_fused_bwd mask + addend, pcfa_relu_bwd2) against one launch per ReLU and autograd's
+    own residual add: masks multiply by exactly 0 or 1 and the residual sum is one fp32 add either way: bit-identical."""
+    from pcfa_amd.nets import raft as raft_mod
+    torch.manual_seed(5)
+    blk = raft_mod.ResidualBlock(64, 64, norm_fn="batch", stride=1).to(DEV).eval()
+    for m in (blk.norm1, blk.norm2):
+        m.running_mean.normal_(0, 0.1)
+        m.running_var.uniform_(0.5, 1.5)
+    for p_ in blk.parameters():
+        p_.requires_grad_(False)
+    x0 = torch.randn(1, 64, 40, 48, device=DEV)
+    go = torch.randn(1, 64, 40, 48, device=DEV)
+
+    def run(defer):
+        monkeypatch.setattr(raft_mod, "_DEFER_RELU", defer)
+        x = x0.clone().requires_grad_(True)
+        out = blk(x)   # the package's operator table is hip_ops
+        (gx,) = torch.autograd.grad((out * go).sum(), x)
+        return out.detach(), gx
+
+    (oa, ga), (ob, gb) = run(True), run(False)
+    assert torch.equal(oa, ob) and torch.equal(ga, gb) and float(ga.abs().max()) > 0
+
+
 def test_deferred_relu_masks_change_no_bit():
     """Motion encoder + GRU update with the ReLU backward of convc2 / convf2 / conv deferred into the kernels that
     produce those gradients anyway (conv3x3_cat flags, gru_step rest_relu_channels; pcfa_conv3x3_masked_fwd,
