@@ -269,6 +269,8 @@ TRACED = {  # kernel-name fragment -> label
     "gemm_f32_mfma_kernel<true, true,": "corr_pyramid_gemm_fwd",
     "corr_pyramid_pool_gemm_kernel": "corr_pyramid_gemm_fwd",   # levels 1-2 pooled in the epilogue (W % 16 == 0)
     "gemm_f32_mfma_kernel<false, false,": "corr_pyramid_gemm_dfmap1",
+    "corr_pyramid_unpool_gemm_kernel<false>": "corr_pyramid_gemm_dfmap1",   # dpyr un-pooled in the operand loader
+    "corr_pyramid_unpool_gemm_kernel<true>": "corr_pyramid_gemm_df2ext",
     "gemm_f32_mfma_kernel<false, true,": "corr_pyramid_gemm_df2ext",
     "box_fwd_kernel": "box_transform_fwd", "box_bwd_kernel": "box_transform_bwd",
     "gru_gates_fwd_kernel": "gru_gates_fwd", "gru_update_fwd_kernel": "gru_update_fwd",

@@ -151,11 +151,72 @@ struct PoolArgs {
 };
 constexpr int SC = BN + 4;   // row stride of the epilogue image of the C tile
 
-template <bool A_KM, bool B_KN, bool FAST, bool POOL>
+// UNPOOL (correlation pyramid backward only, 4 levels, W % 16 == 0): the transposed form of POOL.  The gradient of the
+// reference's volume is g0 + up(g1 + up(g2 + up(g3)/4)/4)/4 (autograd of three F.avg_pool2d, models/raft/corr.py:24-27)
+// and both backward products only need THAT [Q x level-0] matrix: it is formed piece by piece while the dpyr operand
+// is staged -- a 16-B piece of a 4x4 tile plus the 8 B, 4 B and 4 B of its level-1/2/3 parents -- so the GEMMs run
+// over the level-0 columns only (25 % fewer MFMAs than multiplying the pooled columns of f2ext) and df2ext's adjoint
+// pooling pass disappears.
+struct UnpoolArgs {
+  int tw0;
+  int off1, tw1, h1, w1;
+  int off2, tw2, h2, w2;
+  int off3, tw3, h3, w3;
+};
+
+// tile (ty, tx), tile row y of one query's slab `row`; v = the level-0 piece
+__device__ __forceinline__ float4 unpool_piece(const float* __restrict__ row, float4 v, int ty, int tx, int y,
+                                               const UnpoolArgs& u) {
+  const int y3 = ty >> 1, x3 = tx >> 1;
+  const bool ok2 = ty < u.h2 && tx < u.w2, ok3 = ok2 && y3 < u.h3 && x3 < u.w3;
+  // clamped addresses, values masked: no branch around a load
+  const float g3 = row[ok3 ? u.off3 + (((y3 >> 2) * u.tw3 + (x3 >> 2)) << 4) + ((y3 & 3) << 2) + (x3 & 3) : 0];
+  const float g2 = row[ok2 ? u.off2 + (((ty >> 2) * u.tw2 + (tx >> 2)) << 4) + ((ty & 3) << 2) + (tx & 3) : 0];
+  const float d2 = ok2 ? g2 + 0.25f * (ok3 ? g3 : 0.f) : 0.f;
+  const int Y1 = 2 * ty + (y >> 1), X1 = 2 * tx;
+  const bool okY = Y1 < u.h1;
+  const float2 g1 = *reinterpret_cast<const float2*>(
+      row + (okY ? u.off1 + (((Y1 >> 2) * u.tw1 + (X1 >> 2)) << 4) + ((Y1 & 3) << 2) + (X1 & 3) : 0));
+  const float d1a = (okY && X1 < u.w1) ? g1.x + 0.25f * d2 : 0.f;
+  const float d1b = (okY && X1 + 1 < u.w1) ? g1.y + 0.25f * d2 : 0.f;
+  v.x += 0.25f * d1a;
+  v.y += 0.25f * d1a;
+  v.z += 0.25f * d1b;
+  v.w += 0.25f * d1b;
+  return v;
+}
+
+// tile_load_fast of the dpyr operand with the un-pooling applied; `dim` / `kend` bound the LEVEL-0 columns.
+template <bool KMAJ>
+__device__ __forceinline__ void tile_load_unpool(const float* __restrict__ X, long long ld, int dim, int d0, int k0,
+                                                 int kend, const UnpoolArgs& u, float4 (&r)[NLD]) {
+  static_assert(BK == 16, "one 4x4 tile per stage and query");
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int f = tid + 256 * i;
+    int q, col;   // query row of dpyr, level-0 slab column of the piece
+    if (KMAJ) {   // stored [K = query][N = column]
+      q = min(k0 + f / 32, kend - 1);
+      col = min(d0 + (f % 32) * 4, dim - 4);
+    } else {      // stored [N = query][K = column]
+      q = min(d0 + f / KV, dim - 1);
+      col = min(k0 + (f % KV) * 4, kend - 4);
+    }
+    const int T0 = col >> 4, y = (col & 15) >> 2;
+    const int ty = T0 / u.tw0, tx = T0 - ty * u.tw0;
+    const float* row = X + (long long)q * ld;
+    r[i] = unpool_piece(row, *reinterpret_cast<const float4*>(row + col), ty, tx, y, u);
+  }
+}
+
+template <bool A_KM, bool B_KN, bool FAST, bool POOL, bool UNPOOL = false>
 __device__ __forceinline__ void gemm_f32_mfma_body(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
     int N, int K, long long lda, long long ldb, long long ldc, long long bsA, long long bsB,
-    long long bsC, int splits, int kchunk, long long ssC, float div, int vecA, int vecB, const PoolArgs& pool) {
+    long long bsC, int splits, int kchunk, long long ssC, float div, int vecA, int vecB, const PoolArgs& pool,
+    const UnpoolArgs& unpool = UnpoolArgs{}) {
+  static_assert(!UNPOOL || FAST, "the un-pooling loader is the branch-free one");
   constexpr int SA = A_KM ? LDS_KM : LDS_MK;
   constexpr int SB = B_KN ? LDS_KM : LDS_MK;
   constexpr int STAGE = 2 * BK * SA + 2 * BK * SB;
@@ -213,7 +274,8 @@ __device__ __forceinline__ void gemm_f32_mfma_body(
   if (nk > 0) {
     if (FAST) {
       tile_load_fast<A_KM>(A, lda, M, m0, kbeg, kend, ra);
-      tile_load_fast<B_KN>(B, ldb, N, n0, kbeg, kend, rb);
+      if (UNPOOL) tile_load_unpool<B_KN>(B, ldb, N, n0, kbeg, kend, unpool, rb);
+      else tile_load_fast<B_KN>(B, ldb, N, n0, kbeg, kend, rb);
       tile_mask<A_KM>(M, m0, kbeg, kend, ra);
       tile_mask<B_KN>(N, n0, kbeg, kend, rb);
     } else {
@@ -230,7 +292,8 @@ __device__ __forceinline__ void gemm_f32_mfma_body(
     const int k0 = kbeg + (kt + 1) * BK;
     if (FAST) {  // unconditional: the stage past the end re-reads the last one (clamped) and is never stored
       tile_load_fast<A_KM>(A, lda, M, m0, min(k0, kend - 4), kend, ra);
-      tile_load_fast<B_KN>(B, ldb, N, n0, min(k0, kend - 4), kend, rb);
+      if (UNPOOL) tile_load_unpool<B_KN>(B, ldb, N, n0, min(k0, kend - 4), kend, unpool, rb);
+      else tile_load_fast<B_KN>(B, ldb, N, n0, min(k0, kend - 4), kend, rb);
       __builtin_amdgcn_sched_barrier(0);  // keep the loads ABOVE the MFMA block (hipcc otherwise sinks them to their use)
     } else if (more) {
       tile_load<A_KM>(A, lda, M, m0, k0, kend, vecA, ra);
@@ -350,6 +413,31 @@ __global__ __launch_bounds__(256) void corr_pyramid_pool_gemm_kernel(
     long long bsC, float div, PoolArgs pool) {
   gemm_f32_mfma_body<true, true, true, true>(A, B, C, M, N, K, lda, ldb, ldc, bsA, bsB, bsC, 1,
                                              ((K + BK - 1) / BK) * BK, 0LL, div, 1, 1, pool);
+}
+
+// The two backward products over the level-0 columns with the dpyr operand un-pooled on the way in (see UnpoolArgs).
+template <bool B_KN>
+__global__ __launch_bounds__(256) void corr_pyramid_unpool_gemm_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
+    int N, int K, long long lda, long long ldb, long long ldc, long long bsA, long long bsB,
+    long long bsC, int splits, int kchunk, long long ssC, float div, UnpoolArgs unpool) {
+  gemm_f32_mfma_body<false, B_KN, true, false, true>(A, B, C, M, N, K, lda, ldb, ldc, bsA, bsB, bsC, splits, kchunk, ssC,
+                                                     div, 1, 1, PoolArgs{}, unpool);
+}
+
+// dfmap2[b][d][y][x] = sum_s part[s][b][d][tile order of (y, x)]: the split-K reduction of the level-0 product, written
+// back in image order (fixed order -> deterministic)
+__global__ void splitk_reduce_untile_kernel(const float* __restrict__ part, float* __restrict__ out, int planes, int H,
+                                            int W, int tw0, int S0, int splits, long long ss) {
+  const long long n = (long long)planes * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long long pl = i / ((long long)W * H);
+    const long long src = pl * S0 + ((((y >> 2) * tw0 + (x >> 2)) << 4) + ((y & 3) << 2) + (x & 3));
+    float s = part[src];
+    for (int k = 1; k < splits; ++k) s += part[(long long)k * ss + src];
+    out[i] = s;
+  }
 }
 
 // out[i] = sum_s partial[s][i]  (fixed order -> deterministic).  No scaling:
@@ -561,6 +649,45 @@ extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, cons
   float* part2 = part1 + (size_t)BWD_SPLITS * B * D * Q;
   float* df2ext = part2 + (size_t)BWD_SPLITS * B * D * S;
 
+  // Measured and NOT the default: correct (parity-tested with PCFA_PYRAMID_UNPOOL=1) but slower at 55x128 -- 503 / 418 us
+  // against 327 / 307 us for the products over all slab columns: four loads and ~40 VALU instructions per 16-B piece
+  // land after the MFMA block of every stage.  Building the un-pooled tile once per (query, tile) in LDS is the fix.
+  static const bool unpool_on = getenv("PCFA_PYRAMID_UNPOOL") && atoi(getenv("PCFA_PYRAMID_UNPOOL")) == 1;
+  if (P.L == 4 && W % 16 == 0 && Q % 4 == 0 && aligned16(f2ext) && aligned16(dpyr) && aligned16(fmap1) && unpool_on) {
+    UnpoolArgs ua;
+    ua.tw0 = P.tw[0];
+    ua.off1 = P.off[1]; ua.tw1 = P.tw[1]; ua.h1 = P.h[1]; ua.w1 = P.w[1];
+    ua.off2 = P.off[2]; ua.tw2 = P.tw[2]; ua.h2 = P.h[2]; ua.w2 = P.w[2];
+    ua.off3 = P.off[3]; ua.tw3 = P.tw[3]; ua.h3 = P.h[3]; ua.w3 = P.w[3];
+    const int S0 = P.off[1];   // level-0 columns (tiles x 16)
+    // (a) dfmap1[d][q] = sum over level-0 columns n of fmap2_tiled[d][n] * G0[q][n] / sqrt(D)   (f2ext[:, :S0] IS fmap2)
+    {
+      const int kchunk = choose_kchunk(S0, BWD_SPLITS);
+      dim3 grid(pcfa_cdiv(Q, BN), pcfa_cdiv(D, BM), B * BWD_SPLITS);
+      pcfa_launch(corr_pyramid_unpool_gemm_kernel<false>, grid, dim3(256), 0, s, f2ext, dpyr, part1, D, Q, S0,
+                  (long long)S, (long long)S, (long long)Q, (long long)D * S, (long long)Q * S, (long long)D * Q,
+                  BWD_SPLITS, kchunk, (long long)B * D * Q, div, ua);
+      PCFA_LAUNCH_CHECK();
+      const long long n = (long long)B * D * Q;
+      pcfa_launch(splitk_reduce_kernel, dim3(min(pcfa_cdiv(n, 256), 2048)), dim3(256), 0, s, part1, dfmap1, n,
+                  BWD_SPLITS, n);
+      PCFA_LAUNCH_CHECK();
+    }
+    // (b) dfmap2_tiled[d][n] = sum_q fmap1[d][q] * G0[q][n] / sqrt(D), then back to image order
+    {
+      const int kchunk = choose_kchunk(Q, BWD_SPLITS);
+      dim3 grid(pcfa_cdiv(S0, BN), pcfa_cdiv(D, BM), B * BWD_SPLITS);
+      pcfa_launch(corr_pyramid_unpool_gemm_kernel<true>, grid, dim3(256), 0, s, fmap1, dpyr, part2, D, S0, Q,
+                  (long long)Q, (long long)S, (long long)S0, (long long)D * Q, (long long)Q * S, (long long)D * S0,
+                  BWD_SPLITS, kchunk, (long long)B * D * S0, div, ua);
+      PCFA_LAUNCH_CHECK();
+      const long long n = (long long)B * D * Q;
+      pcfa_launch(splitk_reduce_untile_kernel, dim3(min(pcfa_cdiv(n, 256), 2048)), dim3(256), 0, s, part2, dfmap2, B * D,
+                  H, W, P.tw[0], S0, BWD_SPLITS, (long long)B * D * S0);
+      PCFA_LAUNCH_CHECK();
+    }
+    return PCFA_OK;
+  }
   // (a) dfmap1[d][q] = sum_n f2ext[d][n] * dpyr[q][n] / sqrt(D):  A=[M=D][K=S], B=[N=Q][K=S]
   {
     const int kchunk = choose_kchunk(S, BWD_SPLITS);

@@ -96,6 +96,37 @@ def test_corr_block_other_radii_and_levels(oracle_ops, levels, radius):
     assert rel_l2(f1g.grad, f1c.grad) < 2e-5 and rel_l2(f2g.grad, f2c.grad) < 2e-5
 
 
+def test_pyramid_backward_unpool_variant_matches_default():
+    """PCFA_PYRAMID_UNPOOL=1 (opt-in, slower: see corr_pyramid.hip): the backward products over the level-0 columns with
+    dpyr un-pooled in the operand loader, in a child process (the switch is read once per process) against the default
+    products over all slab columns: same mathematics, different rounding order: 2e-6 relative L2."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from pcfa_amd import hip_ops
+g = torch.Generator().manual_seed(3)
+f1 = torch.randn(1, 64, 24, 32, generator=g).cuda().requires_grad_(True)
+f2 = torch.randn(1, 64, 24, 32, generator=g).cuda().requires_grad_(True)
+ys, xs = torch.meshgrid(torch.arange(24), torch.arange(32), indexing="ij")
+c = (torch.stack([xs, ys], 0).float()[None] + 2 * torch.randn(1, 2, 24, 32, generator=g)).cuda()
+out = hip_ops.CorrBlock(f1, f2)(c)
+out.backward(torch.randn(out.shape, generator=g).cuda())
+torch.save((f1.grad.cpu(), f2.grad.cpu()), sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    grads = []
+    for flag in ("0", "1"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            env = dict(os.environ, PCFA_PYRAMID_UNPOOL=flag)
+            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, timeout=300)
+            grads.append(torch.load(f.name))
+    for a, b in zip(*grads):
+        assert rel_l2(b, a) < 2e-6, rel_l2(b, a)
+
+
 def test_lookup_given_same_pyramid_is_tight(oracle_ops):
     """Feed the ORACLE's pyramid into the HIP lookup: isolates the lookup kernel from the GEMM."""
     from pcfa_amd import _hip
