@@ -94,6 +94,7 @@ class LBFGS(Optimizer):
         group = self.param_groups[0]
         lr, max_iter, max_eval = float(group["lr"]), group["max_iter"], group["max_eval"]
         tolerance_grad, tolerance_change = group["tolerance_grad"], group["tolerance_change"]
+        tol_grad32 = float(torch.tensor(tolerance_grad, dtype=torch.float32))
         cap = group["history_size"]
         B = self._buffers()
         n = self._n
@@ -157,16 +158,20 @@ class LBFGS(Optimizer):
                 t = min(1.0, float(1.0 / flat_grad.abs().sum())) * lr  # fp32 reciprocal, as the tensor op in torch
             else:
                 t = lr
-            gtd = float(flat_grad.dot(d))
+            # two host decisions, one synchronisation each (torch reads every scalar on its own): the directional
+            # derivative with max|d| (d does not change until the next direction), and below the loss with max|g|
+            gtd, d_absmax = torch.stack((flat_grad.dot(d), torch.linalg.vector_norm(d, float("inf")))).tolist()
             if gtd > -tolerance_change:
                 break
 
             self._add_grad(t, d)
             ls_func_evals = 0
             if n_iter != max_iter:
-                loss = float(closure())
+                loss_t = closure()
                 flat_grad = self._gather_flat_grad(B["g"])
-                opt_cond = bool(flat_grad.abs().max() <= tolerance_grad)
+                loss_t = torch.as_tensor(loss_t, dtype=flat_grad.dtype, device=flat_grad.device).detach().reshape(())
+                loss, g_absmax = torch.stack((loss_t, torch.linalg.vector_norm(flat_grad, float("inf")))).tolist()   # max|g|: one pass
+                opt_cond = g_absmax <= tol_grad32   # the tensor comparison of torch rounds the tolerance to fp32
                 ls_func_evals = 1
             current_evals += ls_func_evals
             state["func_evals"] += ls_func_evals
@@ -178,7 +183,7 @@ class LBFGS(Optimizer):
                 break
             if opt_cond:
                 break
-            if float(d.abs().max()) * abs(t) <= tolerance_change:
+            if d_absmax * abs(t) <= tolerance_change:
                 break
             if abs(loss - prev_loss) < tolerance_change:
                 break
