@@ -486,6 +486,16 @@ PCFA_API int pcfa_instnorm_fwd(const float* x, float* y, float* mean_rstd, void*
 PCFA_API int pcfa_instnorm_bwd(const float* x, const float* mean_rstd, const float* grad_out, float* grad_x,
                                void* workspace, int planes, long long plane, int relu, void* stream);
 PCFA_API int pcfa_add_relu_fwd(const float* a, const float* b, float* out, long long n, void* stream);
+/* RAFT / GMA convex upsampling (models/raft/raft.py:72-83 upsample_flow; models/gma/network.py likewise):
+ *   out[n, c, 8h + i, 8w + j] = sum_k softmax_k(mask[n, k*64 + i*8 + j, h, w]) * 8 * flow[n, c, h + k/3 - 1, w + k%3 - 1]
+ * flow [N][2][H][W], mask [N][576][H][W] (the 0.25-scaled logits), out [N][2][8H][8W]; zero padding outside the map.
+ * One streaming launch forward; backward = one launch for grad_mask + a 9-tap gather for grad_flow through a
+ * workspace of pcfa_convex_upsample_workspace_floats(N, H, W) floats (no atomics: bitwise reproducible). */
+PCFA_API int pcfa_convex_upsample_fwd(const float* flow, const float* mask, float* out, int N, int H, int W, void* stream);
+PCFA_API long long pcfa_convex_upsample_workspace_floats(int N, int H, int W);
+PCFA_API int pcfa_convex_upsample_bwd(const float* flow, const float* mask, const float* grad_out, float* grad_flow,
+                             float* grad_mask, float* workspace, int N, int H, int W, void* stream);
+
 /* One refinement iteration's coordinate bookkeeping (models/raft/raft.py:122-137, models/gma/network.py likewise):
  * coords1_new = coords1 + delta,  flow_new = coords1_new - coords0;  n floats each. */
 PCFA_API int pcfa_flow_step(const float* coords1, const float* delta, const float* coords0, float* coords1_new,

@@ -551,6 +551,15 @@ def instance_norm_relu(x, eps=1e-5, relu=False):
     return F.relu(y) if relu else y
 
 
+def convex_upsample(flow, mask):
+    """models/raft/raft.py:72-83 upsample_flow: [N,2,H,W] -> [N,2,8H,8W] by a softmax-weighted 3x3 combination."""
+    N, _, H, W = flow.shape
+    mask = torch.softmax(mask.view(N, 1, 9, 8, 8, H, W), dim=2)
+    up = F.unfold(8 * flow, [3, 3], padding=1).view(N, 2, 9, 1, 1, H, W)
+    up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3)
+    return up.reshape(N, 2, 8 * H, 8 * W)
+
+
 def flow_step(coords1, delta, coords0):
     """models/raft/raft.py:122-137: coords1 = coords1 + delta_flow; the flow is coords1 - coords0."""
     c = coords1 + delta

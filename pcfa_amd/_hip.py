@@ -86,6 +86,9 @@ SIGNATURES = {
                                             c_int, c_int, _P]),
     "pcfa_sepconv5_gru_update_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int,
                                              c_int, _P]),
+    "pcfa_convex_upsample_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "pcfa_convex_upsample_workspace_floats": (c_longlong, [c_int, c_int, c_int]),
+    "pcfa_convex_upsample_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "pcfa_flow_step": (c_int, [_P, _P, _P, _P, _P, c_longlong, _P]),
     "pcfa_conv3x3_act_fwd_pair": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                           c_float, _P]),

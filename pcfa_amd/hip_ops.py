@@ -10,7 +10,7 @@ Operator boundaries mirrored (reference file:line):
   spatial_correlation_sample     .../spatial_correlation_sampler/spatial_correlation_sampler.py:9-91
   flownet_correlation, resample2d, channelnorm   models/FlowNet/{correlation,resample2d,channelnorm}_package/*.py
   pwc_warp, dense_block          models/PWCNet/PWCNet.py:166-206, :234-323
-  conv3x3, conv3x3_fewout, conv3x3_cat, conv_fewin, sepconv5, gru_step, bias_relu, flow_step
+  conv3x3, conv3x3_fewout, conv3x3_cat, conv_fewin, sepconv5, gru_step, bias_relu, flow_step, convex_upsample
                                  models/raft/update.py, models/raft/extractor.py, PWCNet.py:29-38, FlowNet/submodules.py
   instance_norm_relu, add_relu   models/raft/extractor.py:23-58
   box_transform                  helper_functions/own_models.py:62-85
@@ -1414,6 +1414,39 @@ class _Fanout(torch.autograd.Function):
             arr = (ctypes.c_void_p * len(part))(*[t.data_ptr() for t in part])
             _call("pcfa_sum_n", arr, len(part), _ptr(out), out.numel())
         return out, None
+
+
+class _ConvexUpsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flow, mask):
+        _dev(flow, mask)
+        N, C, H, W = flow.shape
+        if C != 2 or tuple(mask.shape) != (N, 576, H, W):
+            raise ValueError("convex_upsample: flow %s / mask %s (expected [N,2,H,W] and [N,576,H,W])"
+                             % (tuple(flow.shape), tuple(mask.shape)))
+        flow, mask = flow.contiguous(), mask.contiguous()
+        out = torch.empty((N, 2, 8 * H, 8 * W), device=flow.device, dtype=torch.float32)
+        _call("pcfa_convex_upsample_fwd", _ptr(flow), _ptr(mask), _ptr(out), N, H, W)
+        ctx.save_for_backward(flow, mask)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        flow, mask = ctx.saved_tensors
+        N, _, H, W = flow.shape
+        g = g.contiguous()
+        gflow, gmask = torch.empty_like(flow), torch.empty_like(mask)
+        ws = torch.empty(int(_hip.load().pcfa_convex_upsample_workspace_floats(N, H, W)), device=g.device,
+                         dtype=torch.float32)
+        _call("pcfa_convex_upsample_bwd", _ptr(flow), _ptr(mask), _ptr(g), _ptr(gflow), _ptr(gmask), _ptr(ws), N, H, W)
+        return gflow, gmask
+
+
+def convex_upsample(flow, mask):
+    """[N,2,H,W] -> [N,2,8H,8W] by the softmax-weighted 3x3 combination of RAFT.upsample_flow (raft.py:72-83): one
+    streaming launch per direction instead of softmax + unfold + multiply + reduce + permute over 26 MB temporaries."""
+    return _ConvexUpsample.apply(flow, mask)
 
 
 class _FlowStep(torch.autograd.Function):

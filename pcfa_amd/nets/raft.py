@@ -414,12 +414,9 @@ def coords_grid(batch, ht, wd, device):
 
 
 def convex_upsample(flow, mask):
-    """[N,2,H,W] -> [N,2,8H,8W] by a softmax-weighted 3x3 combination (raft.py:72-83)."""
-    N, _, H, W = flow.shape
-    mask = torch.softmax(mask.view(N, 1, 9, 8, 8, H, W), dim=2)
-    up = F.unfold(8 * flow, [3, 3], padding=1).view(N, 2, 9, 1, 1, H, W)
-    up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3)
-    return up.reshape(N, 2, 8 * H, 8 * W)
+    """[N,2,H,W] -> [N,2,8H,8W] by a softmax-weighted 3x3 combination (raft.py:72-83): the operator table's fused
+    kernel pair (pcfa_convex_upsample_fwd / _bwd on the GPU; the reference's tensor expression in the oracle)."""
+    return ops.get().convex_upsample(flow, mask)
 
 
 class RAFT(nn.Module):

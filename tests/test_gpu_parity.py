@@ -524,6 +524,31 @@ def test_context_encoder_block_deferred_masks_change_no_bit(monkeypatch):
     assert torch.equal(oa, ob) and torch.equal(ga, gb) and float(ga.abs().max()) > 0
 
 
+@pytest.mark.parametrize("shape", [(1, 55, 128), (2, 7, 70), (1, 3, 5)])
+def test_convex_upsample_vs_oracle(oracle_ops, shape):
+    """pcfa_convex_upsample_fwd / _bwd (models/raft/raft.py:72-83) against the reference's tensor expression: same
+    softmax form (max, exp, sum, divide) and 9-term sums in k order: 1e-6 of the output range, gradients 2e-6 relative
+    L2; columns not a multiple of 64, maps smaller than the 3x3 window's reach, two images."""
+    N, H, W = shape
+    gen = torch.Generator().manual_seed(H * 7 + W)
+    flow = 3 * torch.randn(N, 2, H, W, generator=gen)
+    mask = 2 * torch.randn(N, 576, H, W, generator=gen)
+    go = torch.randn(N, 2, 8 * H, 8 * W, generator=gen)
+
+    def run(mod, dev):
+        f, m = flow.clone().to(dev).requires_grad_(True), mask.clone().to(dev).requires_grad_(True)
+        out = mod.convex_upsample(f, m)
+        out.backward(go.to(dev))
+        return out.detach().cpu(), f.grad.cpu(), m.grad.cpu()
+
+    (ow, fw, mw), (og, fg, mg) = run(oracle_ops, "cpu"), run(hip_ops, DEV)
+    assert og.shape == ow.shape
+    assert max_abs(og, ow) <= 1e-6 * float(ow.abs().max())
+    assert rel_l2(fg, fw) < 2e-6 and rel_l2(mg, mw) < 2e-6, (rel_l2(fg, fw), rel_l2(mg, mw))
+    og2, fg2, mg2 = run(hip_ops, DEV)
+    assert torch.equal(og, og2) and torch.equal(fg, fg2) and torch.equal(mg, mg2)   # no atomics
+
+
 def test_deferred_relu_masks_change_no_bit():
     """Motion encoder + GRU update with the ReLU backward of convc2 / convf2 / conv deferred into the kernels that
     produce those gradients anyway (conv3x3_cat flags, gru_step rest_relu_channels; pcfa_conv3x3_masked_fwd,
