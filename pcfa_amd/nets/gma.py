@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from .. import ops
 from .raft import (BasicEncoder, BasicMotionEncoder, FlowHead, LookupRef, SepConvGRU, _mask_head, convex_upsample,
-                   coords_grid)
+                   coords_grid, mask_logits)
 
 
 class RelPosEmb(nn.Module):
@@ -148,6 +148,7 @@ class GMAUpdateBlock(nn.Module):
         self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim + hidden_dim)
         self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
         self.mask = _mask_head()
+        self._mask_cache = {}
         self.aggregator = Aggregate(args=args, dim=128, dim_head=128, heads=args.num_heads)
 
     def forward(self, net, inp, corr, flow, attention, want_mask=True, gru_ctx=None, attn_grad=None):
@@ -158,7 +159,7 @@ class GMAUpdateBlock(nn.Module):
         else:
             net = self.gru(net, torch.cat([inp, motion_features, motion_features_global], dim=1))
         delta_flow = self.flow_head(net)
-        mask = .25 * self.mask(net) if want_mask else None
+        mask = mask_logits(self.mask, net, self._mask_cache) if want_mask else None
         return net, mask, delta_flow
 
 

@@ -386,6 +386,21 @@ def _mask_head():
     return nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(256, 64 * 9, 1, padding=0))
 
 
+def mask_logits(head, net, cache):
+    """.25 * head(net) (update.py:136-139: "scale mask to balance gradients").  Frozen weights: the 3x3 convolution + ReLU
+    run on ops.conv3x3 like every other 3x3 layer, and the factor is folded into the 1x1 convolution's weight and bias --
+    a power of two commutes with every fp32 rounding, so the result is bit-identical and the two passes over the
+    [N,576,H,W] logits (forward and backward) disappear."""
+    c0, c2 = head[0], head[2]
+    if not (_frozen_conv(c0) and _frozen_conv(c2) and _is_plain3x3(c0)):
+        return .25 * head(net)
+    key = (c2.weight.data_ptr(), c2.weight._version, c2.bias.data_ptr(), c2.bias._version)
+    if cache.get("key") != key:
+        with torch.no_grad():
+            cache["key"], cache["w"], cache["b"] = key, (.25 * c2.weight).contiguous(), (.25 * c2.bias).contiguous()
+    return c2._conv_forward(_conv_relu(c0, net), cache["w"], cache["b"])
+
+
 class BasicUpdateBlock(nn.Module):
     def __init__(self, corr_levels=4, corr_radius=4, hidden_dim=128):
         super().__init__()
@@ -393,6 +408,7 @@ class BasicUpdateBlock(nn.Module):
         self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim)
         self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
         self.mask = _mask_head()
+        self._mask_cache = {}
 
     def forward(self, net, inp, corr, flow, want_mask=True, gru_ctx=None):
         # frozen weights: the GRU node is the motion features' only consumer and differentiates their ReLU itself
@@ -403,7 +419,7 @@ class BasicUpdateBlock(nn.Module):
         else:
             net = self.gru(net, torch.cat([inp, motion_features], dim=1))
         delta_flow = self.flow_head(net)
-        mask = .25 * self.mask(net) if want_mask else None  # .25: "scale mask to balance gradients"
+        mask = mask_logits(self.mask, net, self._mask_cache) if want_mask else None
         return net, mask, delta_flow
 
 
