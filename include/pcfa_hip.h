@@ -445,6 +445,13 @@ PCFA_API int pcfa_relu_bwd2(const float* out, const float* out2, const float* gr
  * anything else returns PCFA_ERR_UNSUPPORTED (the caller keeps the library convolution). */
 PCFA_API int pcfa_conv_fewin_fwd(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int N,
                                  int H, int W, int ksize, int relu, void* stream);
+/* The same layer with the frozen weight packed once in MFMA operand order (pcfa_conv_fewin_packed_floats(Cin, N, ksize)
+ * floats, 16-B aligned): operands go from L2 straight into registers, only the flat input range is staged in LDS,
+ * 32-pixel tiles.  Same results as pcfa_conv_fewin_fwd (same products, same k order). */
+PCFA_API long long pcfa_conv_fewin_packed_floats(int Cin, int N, int ksize);
+PCFA_API int pcfa_conv_fewin_pack(const float* w, float* packed, int Cin, int N, int ksize, void* stream);
+PCFA_API int pcfa_conv_fewin_packed_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int Cin,
+                               int N, int H, int W, int ksize, int relu, void* stream);
 
 /* PWC-Net's backward warp (models/PWCNet/PWCNet.py:166-206) as one pass per direction:
  *   out = grid_sample(x, normalise(meshgrid + flo)) * (grid_sample(ones, ...) >= mask_threshold)

@@ -706,6 +706,23 @@ _sepconv_packs = {}  # id(weight) -> (weakref, version, fwd_packed, bwd_packed)
 
 
 FEWIN_SHAPES = {(2, 7), (1, 7), (2, 5), (2, 3)}  # (Cin, ksize) instances of pcfa_conv_fewin_fwd
+_FEWIN_PACKED = os.environ.get("PCFA_FEWIN_PACKED", "1") != "0"   # A/B switch (tools/dev)
+_fewin_packs = {}  # id(weight) -> (weakref, version, packed)
+
+
+def _fewin_packed(weight):
+    """pcfa_conv_fewin_pack of a frozen [N, Cin, k, k] weight (MFMA operand order), cached per tensor version."""
+    key = id(weight)
+    hit = _fewin_packs.get(key)
+    if hit is None or hit[0]() is not weight or hit[1] != weight._version:
+        lib = _hip.load()
+        N, Cin, k, _ = weight.shape
+        w = weight.detach().contiguous()
+        packed = torch.empty(int(lib.pcfa_conv_fewin_packed_floats(Cin, N, k)), device=w.device, dtype=torch.float32)
+        _call("pcfa_conv_fewin_pack", _ptr(w), _ptr(packed), Cin, N, k)
+        hit = (weakref.ref(weight, lambda _r, k_=key: _fewin_packs.pop(k_, None)), weight._version, packed)
+        _fewin_packs[key] = hit
+    return hit[2]
 
 
 def conv_fewin(x, weight, bias=None, relu=False):
@@ -721,8 +738,12 @@ def conv_fewin(x, weight, bias=None, relu=False):
     x = x.contiguous()
     B, _, H, W = x.shape
     out = torch.empty((B, N, H, W), device=x.device, dtype=torch.float32)
-    _call("pcfa_conv_fewin_fwd", _ptr(x), _ptr(weight.contiguous()), _ptr(bias), _ptr(out), B, Cin, N, H, W, kh,
-          int(bool(relu)))
+    if _FEWIN_PACKED:
+        _call("pcfa_conv_fewin_packed_fwd", _ptr(x), _ptr(_fewin_packed(weight)), _ptr(bias), _ptr(out), B, Cin, N, H, W,
+              kh, int(bool(relu)))
+    else:
+        _call("pcfa_conv_fewin_fwd", _ptr(x), _ptr(weight.contiguous()), _ptr(bias), _ptr(out), B, Cin, N, H, W, kh,
+              int(bool(relu)))
     return out
 
 
