@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--pairs-per-gpu", type=int, default=1, help="--universal: local batch size")
     ap.add_argument("--no-universal-leg", action="store_true", help="N > 1: skip the short universal leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shared-forward-leg", action="store_true", help="skip the informational shared-forward leg")
     ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC convolutions")
     ap.add_argument("--no-graph", action="store_true", help="launch the closure eagerly instead of replaying "
                                                             "its hipGraph")
@@ -352,6 +353,28 @@ def timed_steps(st, steps, sharding):
     return time.perf_counter() - t0, st.closures - c0, last
 
 
+def shared_forward_leg(net, h, w, dev, warmup, steps, sharding, model):
+    """Informational, NOT the headline: the same steps with the closure captured as forward + backward graphs
+    (pcfa_amd.graphed.SplitGraphedClosure, PCFA_SHARED_FORWARD=1), so that the re-prediction that ends a step doubles as
+    the forward of the next step's first closure evaluation -- the reference evaluates that forward twice at the same
+    point.  Same kernels on the same data, results unchanged; `value` above keeps the reference's schedule."""
+    try:
+        st = AttackStepper(net, h, w, dev, seed=0, model=model)
+        st.enable_graph(share_forward=True)
+        if st.graphed is None:
+            return {"error": "capture failed"}
+        for _ in range(warmup):
+            st.step()
+        elapsed, closures, _ = timed_steps(st, steps, sharding)
+        return {"value": steps / elapsed, "unit": "attack_steps/s", "ms_per_step": 1e3 * elapsed / steps,
+                "closure_evals_per_step": closures / steps,
+                "forwards_shared_per_step": st.graphed.forwards_shared / max(1, st.steps_done - 1),
+                "note": "re-prediction forward reused by the next step's first closure (backward-only replay); "
+                        "off by default, not part of `value`"}
+    except Exception as e:  # noqa: BLE001 -- an extra: the headline line must survive it
+        return {"error": repr(e)}
+
+
 def universal_leg(net, h, w, dev, rank, world, pairs_per_gpu, warmup, steps, sharding, cdev, model=None,
                   use_graph=None):
     """K steps of UniversalAttack on one global batch of world*pairs_per_gpu pairs (rank r holds pairs
@@ -553,6 +576,8 @@ def main():
                                    "frac": r0["frac"], "traffic": None, "bytes_per_launch": r0["per_launch"],
                                    "mean_launch_us": r0["mean_launch_us"], "launches_timed": r0["launches_timed"],
                                    "timing": "dispatch timestamps inside the hipGraph replays (HIP activity tracer)"}
+        if world == 1 and use_graph and not a.no_shared_forward_leg:
+            out["shared_forward_schedule"] = shared_forward_leg(a.net, h, w, dev, a.warmup, a.steps, sharding, st.model)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], cpu_parity = cpu_baseline(a.net, h, w, a.cpu_closures, a.cpu_threads)
             if gpu_parity is not None:

@@ -187,9 +187,30 @@ class PairAttack:
     def _repredict_body(self):
         return self.current_deltas(), self.predict()
 
-    def enable_graph(self):
+    def _forward_with_loss(self):
+        """closure_body without the backward: (loss, ((delta1, delta2), flow)) -- see graphed.SplitGraphedClosure."""
+        flow = self.predict()
+        d1, d2 = self.current_deltas()
+        loss = losses.loss_delta_constraint(flow, self.target, d1, d2, self.device, delta_bound=self.args.delta_bound,
+                                            mu=self.optim_mu, f_type=self.args.loss)
+        return loss, ((d1, d2), flow)
+
+    def enable_graph(self, share_forward=None):
+        """share_forward (default: PCFA_SHARED_FORWARD=1, off otherwise): capture the closure as forward + backward graphs
+        and let the re-prediction after a step double as the forward of the next step's first closure evaluation."""
+        if share_forward is None:
+            share_forward = os.environ.get("PCFA_SHARED_FORWARD", "0") == "1"
         try:
-            from .graphed import GraphedClosure, GraphedForward
+            from .graphed import GraphedClosure, GraphedForward, SplitGraphedClosure
+            if share_forward:
+                split = SplitGraphedClosure(self._forward_with_loss, self.params)
+                self.graphed = split
+
+                def repredict():
+                    _, ((d1, d2), flow) = split.forward()
+                    return (d1.detach(), d2.detach()), flow.detach()
+                self.repredict = repredict
+                return
             self.graphed = GraphedClosure(self.closure_body, self.params)
             self.repredict = GraphedForward(self._repredict_body, self.device)
         except Exception as e:  # noqa: BLE001 -- the eager closure launches the same kernels in the same order

@@ -1160,6 +1160,35 @@ def test_graphed_closure_matches_eager(net, size):
     assert rel_l2(st.nw1.grad, g_eager[0]) < tol and rel_l2(st.nw2.grad, g_eager[1]) < tol
 
 
+def test_split_closure_shares_the_reprediction_forward():
+    """graphed.SplitGraphedClosure (PCFA_SHARED_FORWARD=1): forward and backward captured as two graphs.  A closure call
+    after forward() replays only the backward and must give the loss and gradient of forward + backward back to back --
+    and both must match the eager closure (1e-6 / 1e-5 as in test_graphed_closure_matches_eager); moving the variables
+    invalidates nothing by itself, the caller does (here: a plain closure call re-runs the forward)."""
+    import bench
+    torch.backends.cudnn.benchmark = False
+    st = bench.AttackStepper("RAFT", 128, 160, torch.device(DEV), seed=3)
+    st.optimizer.zero_grad()
+    l_eager = float(st._closure_body())
+    g_eager = [st.nw1.grad.clone(), st.nw2.grad.clone()]
+    st.enable_graph(share_forward=True)
+    assert st.graphed is not None and hasattr(st.graphed, "forward")
+    for _ in range(2):                                   # forward + backward
+        l = float(st.closure())
+        assert abs(l - l_eager) <= 1e-6 * abs(l_eager)
+        assert rel_l2(st.nw1.grad, g_eager[0]) < 1e-5 and rel_l2(st.nw2.grad, g_eager[1]) < 1e-5
+    (d1, d2), flow = st.repredict()                      # the re-prediction ...
+    assert flow.shape[-2:] == (128, 160) and not flow.requires_grad
+    shared = st.graphed.forwards_shared
+    l = float(st.closure())                              # ... is the forward of this evaluation: backward only
+    assert st.graphed.forwards_shared == shared + 1
+    assert abs(l - l_eager) <= 1e-6 * abs(l_eager)
+    assert rel_l2(st.nw1.grad, g_eager[0]) < 1e-5 and rel_l2(st.nw2.grad, g_eager[1]) < 1e-5
+    with torch.no_grad():
+        st.nw1.add_(0.01)
+    assert abs(float(st.closure()) - l_eager) > 1e-6 * abs(l_eager)   # moved variables: the forward runs again
+
+
 # --------------------------------------------------------------------------- #
 # L-BFGS: pcfa_amd.lbfgs.LBFGS (HIP vector math) against torch.optim.LBFGS, the optimiser of the reference loop
 # (attack_PCFA.py:97,114).  Tolerance: the two run the same operation sequence and differ only in the summation
