@@ -36,7 +36,7 @@ if "--bwd" in sys.argv:
              "level 2 scattered", "level 3 scattered"]
     for k in range(8):
         c = t[:, k]
-        print("%-22s median %8.0f  min %8.0f  max %8.0f ticks" % (names[k], c.median(), c.min(), c.max()))
+        print("%-22s median %8.0f  min %8.0f  max %8.0f cycles" % (names[k], c.median(), c.min(), c.max()))
     sys.exit(0)
 blk = hip_ops.CorrBlock(f1, f2)
 with torch.no_grad():
@@ -49,4 +49,4 @@ names = ["entry", "windows L3 staged", "prologue done", "level 3 done", "level 2
          "stores issued"]
 for k in range(8):
     c = t[:, k]
-    print("%-20s median %8.0f  min %8.0f  max %8.0f ticks (100 MHz)" % (names[k], c.median(), c.min(), c.max()))
+    print("%-20s median %8.0f  min %8.0f  max %8.0f cycles" % (names[k], c.median(), c.min(), c.max()))
