@@ -18,6 +18,16 @@ not a restatement.  Inputs are resident in HBM before the timed region.  Every r
 With N > 1 the default (per-pair) run also appends a short universal leg after the timed region
 (`"universal": {...}` in the JSON line) so that a multi-GPU run exercises the all-reduce path too.
 
+Started WITHOUT torchrun (`python bench.py --gpus N`, no RANK/WORLD_SIZE in the environment) the process becomes a
+launcher: before anything touches the GPU it starts N fresh rank processes of this script (pcfa_amd.launch.spawn_ranks:
+RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, 127.0.0.1 rendezvous), waits for them and exits non-zero if any rank failed;
+rank 0 prints the one JSON line with `n_gpus: N` and every rank's own step time (`per_rank_ms_per_step`).
+
+    --rehearse-cpu   launcher / collective rehearsal WITHOUT a GPU (tests/test_bench_launcher_cpu.py): every rank times
+                     the CPU port (the cpu_baseline leg's objects: pcfa_amd host code + oracle operators) on a tiny
+                     SpyNet pair over gloo and runs the universal leg; the line says `"rehearsal": "cpu-port"` and its
+                     metric is `cpu_port_rehearsal_steps_per_sec` -- never a result.
+
 The JSON line also carries
   roofline            the correlation-lookup forward kernel (the kernel BASELINE's north_star names): algorithmic
                       bytes/launch (SURVEY 8d: 20.44 MB at 55x128) / mean launch duration, against 8 TB/s HBM;
@@ -57,6 +67,8 @@ def parse():
     ap.add_argument("--pairs-per-gpu", type=int, default=1, help="--universal: local batch size")
     ap.add_argument("--no-universal-leg", action="store_true", help="N > 1: skip the short universal leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="no GPU: rehearse launcher + collectives with the CPU port on a tiny workload (not a result)")
     ap.add_argument("--no-shared-forward-leg", action="store_true", help="skip the informational shared-forward leg")
     ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC convolutions")
     ap.add_argument("--no-graph", action="store_true", help="launch the closure eagerly instead of replaying "
@@ -340,16 +352,26 @@ def cpu_baseline(net, h, w, nclosures, threads=0, boxconstraint="change_of_varia
 
 
 # --------------------------------------------------------------------------------------------------------------
+def _sync():
+    if torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+
+
 def timed_steps(st, steps, sharding):
-    torch.cuda.synchronize()
+    """EXACTLY `steps` steps between barrier + device synchronisation on both sides; returns this rank's own time up
+    to its own synchronisation (`own`: what `per_rank_ms_per_step` reports) and the time including the closing
+    barrier."""
+    _sync()
     sharding.barrier()
     c0 = st.closures
     t0 = time.perf_counter()
     last = None
     for _ in range(steps):
         last = st.step()
-    torch.cuda.synchronize()
+    _sync()
+    own = time.perf_counter() - t0
     sharding.barrier()
+    timed_steps.own_s = own
     return time.perf_counter() - t0, st.closures - c0, last
 
 
@@ -398,8 +420,50 @@ def universal_leg(net, h, w, dev, rank, world, pairs_per_gpu, warmup, steps, sha
             "setup_s": setup, "final": last}
 
 
+def rehearse_cpu(a, json_out):
+    """--rehearse-cpu: the launcher, the rendezvous, the max-over-ranks timing, the JSON assembly and the universal
+    leg's all-reduce with NO GPU -- every rank drives the CPU port (as the cpu_baseline leg does) on a 64x64 SpyNet
+    pair over gloo.  Not a measurement of anything."""
+    from oracle import ops as oracle_ops
+    from pcfa_amd import ops, sharding
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.distributed.init_process_group(backend="gloo")
+    rank = sharding.rank()
+    dev = torch.device("cpu")
+    torch.set_num_threads(2)
+    os.environ["PCFA_USE_CPU"] = "1"
+    with ops.override_for_testing(oracle_ops):
+        st = AttackStepper("SpyNet", 64, 64, dev, seed=rank)
+        for _ in range(a.warmup):
+            st.step()
+        elapsed, closures, last = timed_steps(st, a.steps, sharding)
+        per_rank = sharding.all_scalars(timed_steps.own_s, dev)
+        elapsed = sharding.max_scalar(elapsed, dev)
+        universal = None
+        if world > 1 and not a.no_universal_leg:
+            universal = universal_leg("SpyNet", 64, 64, dev, rank, world, 1, 0, 1, sharding, dev, use_graph=False)
+    if rank == 0:
+        out = {"metric": "cpu_port_rehearsal_steps_per_sec", "value": world * a.steps / elapsed, "unit": "steps/s",
+               "rehearsal": "cpu-port", "n_gpus": world, "n_ranks": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": 1e3 * elapsed / a.steps, "per_rank_ms_per_step": [1e3 * t / a.steps for t in per_rank],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "REHEARSAL (no GPU): SpyNet 64x64 on the CPU port, one pair per rank, gloo",
+                          "closure_evals_per_step": closures / a.steps},
+               "final": {"aee_adv_tgt": last[0], "aee_adv_init": last[1], "l2_delta": last[2]}}
+        if universal is not None:
+            out["universal"] = universal
+        print(json.dumps(out), file=json_out, flush=True)
+    sharding.shutdown()
+
+
 def main():
     a = parse()
+    from pcfa_amd import launch
+    if a.gpus > 1 and not launch.inside_rank():
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU (no
+        # torch.cuda call, no kernel library load) and nothing will: it starts N fresh rank processes and waits.
+        sys.exit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], a.gpus))
     from pcfa_amd import sharding
     # stdout carries the ONE JSON line: everything else (the mirrors' chatter, native libraries writing to fd 1) goes
     # to stderr until the line is printed
@@ -407,6 +471,8 @@ def main():
     saved_fd = os.dup(1)
     os.dup2(2, 1)
     json_out = os.fdopen(saved_fd, "w")
+    if a.rehearse_cpu:
+        return rehearse_cpu(a, json_out)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # one process per GPU; PCFA_BENCH_BACKEND=gloo + PCFA_BENCH_SHARE_GPU=1 only exist to exercise the
@@ -467,6 +533,7 @@ def main():
         hip_ops.set_dispatch_timer(prof)
     elapsed, closures, last = timed_steps(st, a.steps, sharding)
     hip_ops.set_dispatch_timer(None)
+    per_rank = sharding.all_scalars(timed_steps.own_s, cdev)
     elapsed = sharding.max_scalar(elapsed, cdev)
     traced = None
     # PCFA_BENCH_NO_TRACER=1: skip the in-process tracer (set when an external profiler already owns it)
@@ -502,6 +569,7 @@ def main():
         out = {
             "metric": "attack_steps_per_sec", "value": world * a.steps / elapsed, "unit": "attack_steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "per_rank_ms_per_step": [1e3 * t / a.steps for t in per_rank],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "%s, 1 synthetic %dx%d pair per GPU (padded %dx%d), disjoint delta, "

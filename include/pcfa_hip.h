@@ -541,6 +541,28 @@ PCFA_API int pcfa_lbfgs_direction(const float* g, const float* S, const float* Y
                                   float* al, float* d, float* workspace, int first, int count, int capacity,
                                   long long ld, long long n, void* stream);
 
+/* The same optimiser step in the coefficient space of the history ("Gram form", pcfa_amd/csrc/lbfgs_gram.hip): the
+ * two-loop recursion of torch.optim.LBFGS.step (attack_PCFA.py:97,114,382,388) is two triangular substitutions on the
+ * inner products s_i.y_j, y_i.y_j, s_i.g, y_i.g, so an iteration reads the history twice instead of 2m+1 times:
+ *   update:    y = g - g_prev, s = t*d into the candidate row (first + count) % (capacity + 1), g_prev = g; inner
+ *              products of g and of the new pair with every stored vector (one sweep); the curvature test
+ *              y.s > 1e-10 of the optimiser is taken ON THE DEVICE: an accepted pair is committed to the ring
+ *              (the oldest one dropped at `capacity` pairs), H = (y.s)/(y.y); then the coefficients of
+ *              d = cg*g + sum_r (cS[r]*S_r + cY[r]*Y_r) are solved in fp64 by one workgroup.
+ *   direction: forms d with that combination (one sweep), out_gtd_dmax = { g.d, max|d| }.
+ * `state` (pcfa_lbfgs_gram_state_bytes, device memory, 16-B aligned) holds the ring position, H, the inner-product
+ * matrices and the coefficients; it begins with { int first, count, accepted, rows; float H, cg, ys, yy, gtd, dmax }
+ * which the caller may read back.  pcfa_lbfgs_gram_reset empties the history (first = count = 0, H = 1).
+ * S, Y: [capacity + 1][ld] rings; every vector has ld floats (ld % 4 == 0, pad elements zero), 16-B aligned.
+ * capacity <= 128 (PCFA_ERR_UNSUPPORTED above: use the two-loop entry points).  Deterministic: no atomics. */
+PCFA_API size_t pcfa_lbfgs_gram_state_bytes(int capacity);
+PCFA_API size_t pcfa_lbfgs_gram_workspace_bytes(int capacity, long long ld);
+PCFA_API int pcfa_lbfgs_gram_reset(void* state, int capacity, void* stream);
+PCFA_API int pcfa_lbfgs_gram_update(const float* g, float* g_prev, const float* d, float t, float* S, float* Y,
+                                    void* state, void* workspace, int capacity, long long ld, void* stream);
+PCFA_API int pcfa_lbfgs_gram_direction(const float* g, const float* S, const float* Y, void* state, float* d,
+                                       float* out_gtd_dmax, void* workspace, int capacity, long long ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

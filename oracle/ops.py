@@ -675,9 +675,23 @@ def get_loss(f_type, pred, target):
         "The requested loss type %s does not exist. Please choose one of 'aee', 'mse' or 'cosim'" % f_type)
 
 
-def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound=0.001, mu=100., f_type="aee"):
-    """helper_functions/losses.py:200-230."""
-    sim = get_loss(f_type, pred, target)
+def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound=0.001, mu=100., f_type="aee",
+                          batch_sums=None):
+    """helper_functions/losses.py:200-230.
+
+    batch_sums (multi-rank universal attack with `--loss cosim` only; None everywhere else): `f_cosim` is a ratio of
+    sums over the WHOLE batch (losses.py:88), so a rank that holds a slice of the batch needs the global sums before
+    its backward.  batch_sums(t) all-reduces the three local sums [p.t, p.p, t.t] in place (SUM) and returns the
+    number of ranks; the value of the loss is then the single-process value on the global batch, and the gradient
+    of the similarity term carries the factor `world` that the averaging all-reduce of the gradients removes."""
+    if batch_sums is not None and f_type == "cosim":
+        local = torch.stack((torch.sum(pred * target), torch.sum(pred * pred), torch.sum(target * target)))
+        glob = local.detach().clone()
+        world = batch_sums(glob)
+        s_ = glob + world * (local - local.detach())       # value: global sums; d/d(local sums): world
+        sim = 1 - s_[0] / torch.sqrt(s_[1]) * torch.sqrt(s_[2])
+    else:
+        sim = get_loss(f_type, pred, target)
     excess = two_norm_avg_delta_squared(delta1, delta2) - torch.tensor(delta_bound ** 2).to(pred.device)
     penalty = torch.max(torch.tensor(0.).to(pred.device), excess)
     return sim + mu * penalty

@@ -100,6 +100,11 @@ SIGNATURES = {
     "pcfa_conv3x3_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_conv3x3_act_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "pcfa_leaky_relu_bwd": (c_int, [_P, _P, _P, c_float, c_longlong, _P]),
+    "pcfa_lbfgs_gram_state_bytes": (c_size_t, [c_int]),
+    "pcfa_lbfgs_gram_workspace_bytes": (c_size_t, [c_int, c_longlong]),
+    "pcfa_lbfgs_gram_reset": (c_int, [_P, c_int, _P]),
+    "pcfa_lbfgs_gram_update": (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_longlong, _P]),
+    "pcfa_lbfgs_gram_direction": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_longlong, _P]),
     "pcfa_lbfgs_workspace_floats": (c_size_t, []),
     "pcfa_lbfgs_pair": (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_longlong, _P]),
     "pcfa_lbfgs_direction": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_longlong, c_longlong,

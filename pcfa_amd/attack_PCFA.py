@@ -404,8 +404,9 @@ class UniversalAttack:
     def __init__(self, model, delta_like1, delta_like2, device, optim_mu, args, use_graph=None):
         self.model, self.args, self.device, self.optim_mu = model, args, device, optim_mu
         self.world = sharding.world_size()
-        if self.world > 1 and args.loss == "cosim":
-            raise NotImplementedError("cosim is a ratio of batch sums and does not decompose over ranks")
+        # cosim is a ratio of sums over the global batch: its three sums are all-reduced between the forward and the
+        # backward pass of every closure (sharding.BatchSums); that collective cannot sit inside a captured graph
+        self.batch_sums = sharding.BatchSums() if (self.world > 1 and args.loss == "cosim") else None
         self.unit_input = ownutilities.model_takes_unit_input(args.net)
         self.nw_delta1 = torch.zeros_like(delta_like1).to(device)
         self.nw_delta2 = torch.zeros_like(delta_like2).to(device)
@@ -418,6 +419,8 @@ class UniversalAttack:
         self.optimizer = ops.get().LBFGS(self.params, max_iter=10)
         self.reducer = sharding.FlatReducer(self.params) if self.world > 1 else None
         self.use_graph = _graphs_enabled(device, args) if use_graph is None else use_graph
+        if self.batch_sums is not None:
+            self.use_graph = False
         self.states = {}   # batch shape -> _UniversalBatchState
         self.st = None
         self.flow_pred_init = None
@@ -441,7 +444,7 @@ class UniversalAttack:
         d1, d2 = self.deltas()
         loss_closure = losses.loss_delta_constraint(self.predict(), self.st.target, d1, d2, self.device,
                                                     delta_bound=self.args.delta_bound, mu=self.optim_mu,
-                                                    f_type=self.args.loss)
+                                                    f_type=self.args.loss, batch_sums=self.batch_sums)
         loss_closure.backward()
         if self.reducer is not None:
             self.reducer.pack(loss_closure)
@@ -522,8 +525,6 @@ def attack_l2_universal(args, data_loader=None, has_gt=None):
     `UniversalAttack`.  Returns the final perturbations, the per-step metric history and how many collectives ran."""
     optim_mu = default_mu(args)
     rank, world = sharding.rank(), sharding.world_size()
-    if world > 1 and args.loss == "cosim":
-        raise NotImplementedError("cosim is a ratio of batch sums and does not decompose over ranks")
     distortion_folder = _output_folder(args, "") if rank == 0 else None
     device = select_device()
     if data_loader is None:
@@ -563,6 +564,7 @@ def attack_l2_universal(args, data_loader=None, has_gt=None):
                 logging.save_tensor(ua.nw_delta2, "delta2_e" + str(epoch), batch_ctr, distortion_folder)
     return {"delta1": ua.nw_delta1.detach(), "delta2": ua.deltas()[1].detach(), "history": history,
             "batches": batches, "collectives": ua.reducer.collectives if ua.reducer is not None else 0,
+            "batch_sum_collectives": ua.batch_sums.collectives if ua.batch_sums is not None else 0,
             "graphed": ua.graphed}
 
 

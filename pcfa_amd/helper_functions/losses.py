@@ -51,10 +51,17 @@ def two_norm_avg(x):
     return ops.get().two_norm_avg(x)
 
 
-def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound=0.001, mu=100., f_type="aee"):
-    """similarity(pred, target) + mu * relu(mean(delta^2) - delta_bound^2), losses.py:200-230."""
+def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound=0.001, mu=100., f_type="aee",
+                          batch_sums=None):
+    """similarity(pred, target) + mu * relu(mean(delta^2) - delta_bound^2), losses.py:200-230.
+
+    `batch_sums` is not part of the reference signature: the multi-rank universal attack passes it with
+    `--loss cosim`, whose three sums run over the global batch (pcfa_amd.sharding.BatchSums)."""
+    if batch_sums is None:
+        return ops.get().loss_delta_constraint(pred, target, delta1, delta2, device, delta_bound=delta_bound, mu=mu,
+                                               f_type=f_type)
     return ops.get().loss_delta_constraint(pred, target, delta1, delta2, device, delta_bound=delta_bound, mu=mu,
-                                           f_type=f_type)
+                                           f_type=f_type, batch_sums=batch_sums)
 
 
 def get_loss(f_type, pred, target):

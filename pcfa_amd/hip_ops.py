@@ -1665,7 +1665,7 @@ def _flow4(t):
 
 class _LossDeltaConstraint(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, delta1, delta2, delta_bound, mu, f_type):
+    def forward(ctx, pred, target, delta1, delta2, delta_bound, mu, f_type, batch_sums=None):
         _dev(pred, target, delta1, delta2)
         lib = _hip.load()
         p, t = _flow4(pred), _flow4(target)
@@ -1678,6 +1678,15 @@ class _LossDeltaConstraint(torch.autograd.Function):
         _call("pcfa_flow_loss_fwd", _ptr(p), _hip.strides4(p), _ptr(t), _hip.strides4(t), B, H, W,
                                           _ptr(d1), d1.numel(), _ptr(d2), d2.numel(), float(delta_bound),
                                           float(mu), ft, _ptr(scal), _ptr(_workspace(p.device)))
+        ctx.sim_scale = 1
+        if batch_sums is not None and f_type == "cosim":
+            # this rank holds a slice of the batch: the three sums of f_cosim (losses.py:88) become the sums over the
+            # global batch before anything reads them (12-byte all-reduce), the scalars are re-derived from them in
+            # the kernel's own operation order, and the backward kernel reads the global sums from `scal`
+            ctx.sim_scale = int(batch_sums(scal[3:6]))
+            sim = 1.0 - scal[3] / torch.sqrt(scal[4]) * torch.sqrt(scal[5])
+            scal[1] = sim
+            scal[0] = sim + float(mu) * torch.clamp_min(scal[6], 0.0)
         ctx.joint = d1.data_ptr() == d2.data_ptr() and d1.numel() == d2.numel()
         ctx.args = (B, H, W, float(mu), ft)
         ctx.pred_shape = pred.shape
@@ -1701,19 +1710,24 @@ class _LossDeltaConstraint(torch.autograd.Function):
                                           _ptr(scal), _ptr(gl), _ptr(gp), _ptr(gd1), _ptr(gd2))
         if gp is not None:
             gp = gp.reshape(ctx.pred_shape)
+            if ctx.sim_scale != 1:   # gradients are AVERAGED over ranks afterwards; the similarity term is a sum
+                gp.mul_(float(ctx.sim_scale))
         if ctx.joint:
             # extract_deltas_joint hands the SAME tensor in twice (attack_PCFA.py:37): autograd adds the
             # two slots, which reproduces the reference's d/d(delta) of |delta|^2 + |delta|^2.
-            return gp, None, (gd1 if need_d1 else None), (gd1 if need_d2 else None), None, None, None
-        return gp, None, gd1, gd2, None, None, None
+            return gp, None, (gd1 if need_d1 else None), (gd1 if need_d2 else None), None, None, None, None
+        return gp, None, gd1, gd2, None, None, None, None
 
 
-def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound=0.001, mu=100., f_type="aee"):
-    """helper_functions/losses.py:200-230 (device argument kept for signature compatibility)."""
+def loss_delta_constraint(pred, target, delta1, delta2, device=None, delta_bound=0.001, mu=100., f_type="aee",
+                          batch_sums=None):
+    """helper_functions/losses.py:200-230 (device argument kept for signature compatibility).
+    batch_sums: multi-rank universal attack with cosim only -- all-reduces [p.t, p.p, t.t] in place, returns the
+    number of ranks (see UniversalAttack); None everywhere else."""
     if f_type not in _hip.PCFA_LOSS:
         raise NotImplementedError(
             "The requested loss type %s does not exist. Please choose one of 'aee', 'mse' or 'cosim'" % f_type)
-    return _LossDeltaConstraint.apply(pred, target, delta1, delta2, delta_bound, mu, f_type)
+    return _LossDeltaConstraint.apply(pred, target, delta1, delta2, delta_bound, mu, f_type, batch_sums)
 
 
 def get_loss(f_type, pred, target):

@@ -8,15 +8,22 @@ the vector work runs:
 
 * the history is two ring buffers ``S, Y [history_size][n]`` instead of Python lists of tensors;
 * ``y = g - g_prev``, ``s = t*d``, ``y.s``, ``y.y`` and the ``g_prev`` refresh are ONE pass (``pcfa_lbfgs_pair``);
-* the two-loop recursion runs as ``2m+1`` fused launches without a host round trip (``pcfa_lbfgs_direction``)
-  instead of ``4m+3`` separately launched vector kernels -- at ``m = 100`` pairs that is the difference between
-  ~7 ms and ~2 ms per iteration next to a 21 ms closure (tools/step_breakdown.py).
+* ``direction="gram"`` (default, history_size <= 128; pcfa_amd/csrc/lbfgs_gram.hip): the two-loop recursion is linear
+  algebra in span{g, s_i, y_i}, so it runs as two triangular substitutions (fp64, one workgroup) on the inner products
+  s_i.y_j, y_i.y_j, s_i.g, y_i.g.  An iteration sweeps the history exactly twice -- once to form the inner products of
+  the new gradient and the new pair with every stored vector (``pcfa_lbfgs_gram_update``, which also takes the
+  curvature decision and commits the pair ON THE DEVICE), once to form d (``pcfa_lbfgs_gram_direction``): 4.3 GB of
+  HBM traffic per iteration at the steady-state history of 100 pairs instead of 8.6 GB, two host synchronisations per
+  iteration instead of three.  Not the optimiser's rounding order: iterates agree with torch.optim.LBFGS to the
+  tolerance stated in tests/test_gpu_parity.py::test_lbfgs_matches_torch_optimizer.
+* ``direction="two_loop"`` (r01/r02 path, kept for A/B and for history_size > 128): the recursion as ``2m+1`` fused
+  launches without a host round trip (``pcfa_lbfgs_direction``) instead of ``4m+3`` separately launched vector kernels;
+  the same sequence of fp32 operations as the optimiser, only the summation order inside a dot product differs.
 
-Arithmetic: the same sequence of fp32 operations; only the summation order inside a dot product differs (block
-partials summed in index order instead of rocBLAS' order).  Checked against torch.optim.LBFGS on the GPU in
-tests/test_gpu_parity.py.  There is no CPU path: CPU tensors raise (tests drive the host logic of the attack with
-the oracle's optimiser, which is torch.optim.LBFGS itself).
+There is no CPU path: CPU tensors raise (tests drive the host logic of the attack with the oracle's optimiser, which is
+torch.optim.LBFGS itself).
 """
+import numpy as np
 import torch
 from torch.optim import Optimizer
 
@@ -33,7 +40,7 @@ def _call(name, *args):
 
 class LBFGS(Optimizer):
     def __init__(self, params, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9,
-                 history_size=100, line_search_fn=None):
+                 history_size=100, line_search_fn=None, direction=None):
         if line_search_fn is not None:
             raise NotImplementedError("pcfa_amd.lbfgs.LBFGS implements the fixed-step variant the PCFA attack uses "
                                       "(line_search_fn=None)")
@@ -51,6 +58,12 @@ class LBFGS(Optimizer):
         self._n = sum(p.numel() for p in self._params)
         self._ld = (self._n + 3) // 4 * 4
         self._bufs = None
+        if direction is None:
+            direction = "gram" if history_size <= 128 else "two_loop"
+        if direction not in ("gram", "two_loop") or (direction == "gram" and history_size > 128):
+            raise ValueError("direction must be 'gram' (history_size <= 128) or 'two_loop'")
+        self.direction = direction
+        self.host_syncs = 0          # host reads of device scalars (each one drains the stream)
 
     # ---- device buffers --------------------------------------------------------------------------------------
     def _buffers(self):
@@ -58,15 +71,24 @@ class LBFGS(Optimizer):
             dev = self._params[0].device
             cap = self.param_groups[0]["history_size"]
             new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
-            ws = int(_hip.load().pcfa_lbfgs_workspace_floats())
+            zeros = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+            lib = _hip.load()
+            ws = int(lib.pcfa_lbfgs_workspace_floats())
+            if self.direction == "gram":
+                ws = max(ws, int(lib.pcfa_lbfgs_gram_workspace_bytes(cap, self._ld)) // 4)
             self._bufs = {
-                "g": new(self._ld), "g_prev": new(self._ld), "d": new(self._ld),
+                # the ld - n pad elements stay zero: the Gram sweeps run over whole 16-B groups
+                "g": zeros(self._ld), "g_prev": zeros(self._ld), "d": zeros(self._ld),
                 # history_size + 1 rows: the candidate pair of an iteration is written before the optimiser knows
                 # whether it keeps it, so it needs a row that is not one of the (up to history_size) live pairs
                 "S": new(cap + 1, self._ld), "Y": new(cap + 1, self._ld),
                 "ro": torch.zeros(cap + 1, dtype=torch.float32, device=dev), "al": new(cap + 1),
                 "H": torch.ones(1, dtype=torch.float32, device=dev), "scal": new(4), "ws": new(ws),
             }
+            if self.direction == "gram":
+                self._bufs["state"] = torch.zeros(int(lib.pcfa_lbfgs_gram_state_bytes(cap)), dtype=torch.uint8,
+                                                  device=dev)
+                self._bufs["out2"] = new(2)
         return self._bufs
 
     def _gather_flat_grad(self, g):
@@ -87,6 +109,18 @@ class LBFGS(Optimizer):
             p.add_(update[off:off + n].view_as(p), alpha=step_size)
             off += n
 
+    def _read(self, *tensors):
+        """One host synchronisation for several device scalars (0-d / 1-element tensors or 1-d packs)."""
+        self.host_syncs += 1
+        return torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors]).tolist()
+
+    def history_count(self):
+        """Pairs currently in the history (torch: len(state['old_dirs'])); a host read in the Gram form."""
+        state = self.state[self._params[0]]
+        if self.direction == "gram" and self._bufs is not None and state.get("n_iter", 0) > 0:
+            return int(self._bufs["state"][:16].view(torch.int32)[1])
+        return state.get("count", 0)
+
     # ---- torch.optim.LBFGS.step, fixed-step branch ---------------------------------------------------------------
     @torch.no_grad()
     def step(self, closure):
@@ -94,8 +128,11 @@ class LBFGS(Optimizer):
         group = self.param_groups[0]
         lr, max_iter, max_eval = float(group["lr"]), group["max_iter"], group["max_eval"]
         tolerance_grad, tolerance_change = group["tolerance_grad"], group["tolerance_change"]
-        tol_grad32 = float(torch.tensor(tolerance_grad, dtype=torch.float32))
+        # torch compares fp32 tensors with these python floats: the scalar is rounded to fp32 first
+        tol_grad32 = float(np.float32(tolerance_grad))
+        tol_change32 = float(np.float32(tolerance_change))
         cap = group["history_size"]
+        gram = self.direction == "gram"
         B = self._buffers()
         n = self._n
         p = lambda t: t.data_ptr()  # noqa: E731
@@ -103,17 +140,21 @@ class LBFGS(Optimizer):
         state = self.state[self._params[0]]
         state.setdefault("func_evals", 0)
         state.setdefault("n_iter", 0)
-        state.setdefault("first", 0)   # ring start (row of the oldest pair)
-        state.setdefault("count", 0)   # pairs in the ring
+        state.setdefault("first", 0)   # ring start (row of the oldest pair)        } two_loop only: the Gram form
+        state.setdefault("count", 0)   # pairs in the ring                          } keeps both on the device
         state.setdefault("has_prev", False)
 
         orig_loss = closure()
-        loss = float(orig_loss)
+        if torch.is_tensor(orig_loss):
+            # a captured closure hands back a static buffer that later evaluations overwrite: return the value of
+            # THIS evaluation, as torch does
+            orig_loss = orig_loss.detach().clone()
         current_evals = 1
         state["func_evals"] += 1
         flat_grad = self._gather_flat_grad(B["g"])
-        opt_cond = bool(flat_grad.abs().max() <= tolerance_grad)
-        if opt_cond:
+        loss, g_absmax = self._read(torch.as_tensor(orig_loss, dtype=torch.float32, device=flat_grad.device),
+                                    torch.linalg.vector_norm(flat_grad, float("inf")))
+        if g_absmax <= tol_grad32:
             return orig_loss
 
         d = B["d"][:n]
@@ -123,13 +164,25 @@ class LBFGS(Optimizer):
         while n_iter < max_iter:
             n_iter += 1
             state["n_iter"] += 1
+            first_ever = state["n_iter"] == 1
 
             # ---- direction -----------------------------------------------------------------------------------
-            if state["n_iter"] == 1:
+            scalars = None
+            if first_ever:
                 torch.neg(flat_grad, out=d)
                 state["first"], state["count"] = 0, 0
                 B["H"].fill_(1.0)
                 B["g_prev"][:n].copy_(flat_grad)
+                if gram:
+                    _call("pcfa_lbfgs_gram_reset", p(B["state"]), cap)
+            elif gram:
+                # sweep 1: new pair, inner products, curvature decision + commit, coefficients (all on the device);
+                # sweep 2: d, g.d and max|d|
+                _call("pcfa_lbfgs_gram_update", p(B["g"]), p(B["g_prev"]), p(B["d"]), float(t), p(B["S"]),
+                      p(B["Y"]), p(B["state"]), p(B["ws"]), cap, self._ld)
+                _call("pcfa_lbfgs_gram_direction", p(B["g"]), p(B["S"]), p(B["Y"]), p(B["state"]), p(B["d"]),
+                      p(B["out2"]), p(B["ws"]), cap, self._ld)
+                scalars = B["out2"]
             else:
                 # candidate pair goes into the row after the newest one; it only counts if y.s > 1e-10
                 first, count = state["first"], state["count"]
@@ -137,7 +190,7 @@ class LBFGS(Optimizer):
                 row = (first + count) % rows
                 _call("pcfa_lbfgs_pair", p(B["g"]), p(B["g_prev"]), p(B["d"]), float(t), p(B["Y"][row]),
                       p(B["S"][row]), p(B["scal"]), p(B["ws"]), 1, n)
-                ys = float(B["scal"][0])  # the optimiser's own host decision (one synchronisation, as in torch)
+                [ys] = self._read(B["scal"][0])  # the optimiser's own host decision (one synchronisation, as in torch)
                 if ys > 1e-10:
                     if count == cap:      # limited memory: forget the oldest pair
                         first = (first + 1) % rows
@@ -153,14 +206,15 @@ class LBFGS(Optimizer):
                     torch.mul(flat_grad, B["H"], out=d).neg_()
             prev_loss = loss
 
-            # ---- step length ---------------------------------------------------------------------------------
-            if state["n_iter"] == 1:
-                t = min(1.0, float(1.0 / flat_grad.abs().sum())) * lr  # fp32 reciprocal, as the tensor op in torch
+            # ---- step length + the directional derivative: ONE host synchronisation ----------------------------
+            if scalars is None:
+                scalars = torch.stack((flat_grad.dot(d), torch.linalg.vector_norm(d, float("inf"))))
+            if first_ever:
+                gtd, d_absmax, g_abssum = self._read(scalars, flat_grad.abs().sum())
+                t = min(1.0, float(np.float32(1.0) / np.float32(g_abssum))) * lr   # fp32 reciprocal, as torch's
             else:
+                gtd, d_absmax = self._read(scalars)
                 t = lr
-            # two host decisions, one synchronisation each (torch reads every scalar on its own): the directional
-            # derivative with max|d| (d does not change until the next direction), and below the loss with max|g|
-            gtd, d_absmax = torch.stack((flat_grad.dot(d), torch.linalg.vector_norm(d, float("inf")))).tolist()
             if gtd > -tolerance_change:
                 break
 
@@ -170,8 +224,8 @@ class LBFGS(Optimizer):
                 loss_t = closure()
                 flat_grad = self._gather_flat_grad(B["g"])
                 loss_t = torch.as_tensor(loss_t, dtype=flat_grad.dtype, device=flat_grad.device).detach().reshape(())
-                loss, g_absmax = torch.stack((loss_t, torch.linalg.vector_norm(flat_grad, float("inf")))).tolist()   # max|g|: one pass
-                opt_cond = g_absmax <= tol_grad32   # the tensor comparison of torch rounds the tolerance to fp32
+                loss, g_absmax = self._read(loss_t, torch.linalg.vector_norm(flat_grad, float("inf")))
+                opt_cond = g_absmax <= tol_grad32
                 ls_func_evals = 1
             current_evals += ls_func_evals
             state["func_evals"] += ls_func_evals
@@ -183,7 +237,8 @@ class LBFGS(Optimizer):
                 break
             if opt_cond:
                 break
-            if d_absmax * abs(t) <= tolerance_change:
+            # torch: d.mul(t).abs().max() <= tolerance_change, an fp32 product against the fp32-rounded tolerance
+            if float(np.float32(d_absmax) * np.float32(abs(t))) <= tol_change32:
                 break
             if abs(loss - prev_loss) < tolerance_change:
                 break

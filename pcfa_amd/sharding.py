@@ -92,6 +92,24 @@ class FlatReducer:
         return self.flat[self.n]
 
 
+class BatchSums:
+    """`--loss cosim` in the multi-rank universal attack: f_cosim = 1 - (p.t / sqrt(p.p)) * sqrt(t.t) (losses.py:88) is a
+    ratio of sums over the WHOLE batch, so the gradient a rank sends into its slice depends on the global sums --
+    they have to be known BEFORE the backward pass and cannot ride in the gradient all-reduce that follows it.
+    Calling the object all-reduces the three local sums in place (12 bytes, SUM) and returns the number of ranks.
+    With cosim a closure therefore costs two collectives (this one + FlatReducer's); aee / mse keep one."""
+
+    def __init__(self):
+        self.collectives = 0
+
+    def __call__(self, sums):
+        if not is_dist():
+            return 1
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        self.collectives += 1
+        return world_size()
+
+
 def allreduce_closure(params, loss, reducer=None):
     """Average the parameter gradients and the loss over ranks with ONE all-reduce; returns the averaged loss
     (and leaves every p.grad pointing into the reducer's buffer)."""
@@ -127,6 +145,16 @@ def max_scalar(value, device):
     t = torch.tensor([float(value)], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_scalars(value, device):
+    """Every rank's python float, in rank order, on every rank."""
+    if not is_dist():
+        return [float(value)]
+    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    out = [torch.zeros_like(t) for _ in range(world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 def gather_rows(rows, width, device):

@@ -1,0 +1,82 @@
+"""`python bench.py --gpus N` started WITHOUT torchrun must become N rank processes.
+
+CPU rehearsal of exactly that command path: the parent (no RANK/WORLD_SIZE in its environment) goes through
+pcfa_amd.launch.spawn_ranks, the ranks rendezvous on 127.0.0.1 over gloo, every rank times its own pair, rank 0
+prints ONE JSON line with n_gpus == N, one step time per rank and the universal leg's all-reduce count.  The ranks
+drive the CPU port (`--rehearse-cpu`: the objects of bench.py's cpu_baseline leg) because there is no GPU here; the
+same launcher with real GPU ranks is tests/test_gpu_parity.py::test_bench_gpus2_spawns_two_ranks_on_one_gpu.
+"""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RANK_KEYS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PCFA_SPAWNED_RANK")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in RANK_KEYS}
+    env["OMP_NUM_THREADS"] = "2"
+    return env
+
+
+def test_bench_gpus2_without_torchrun_starts_two_ranks():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--rehearse-cpu"], env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout            # ONE JSON line on stdout, from rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rehearsal"] == "cpu-port"
+    assert len(out["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in out["per_rank_ms_per_step"])
+    assert out["ms_per_step"] >= max(out["per_rank_ms_per_step"]) * 0.999       # max over ranks, barrier included
+    assert abs(out["value"] - 2 * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"])) < 1e-6 * out["value"]
+    u = out["universal"]                        # the N > 1 run exercises the all-reduce path
+    assert u["global_batch"] == 2 and u["allreduces_per_closure"] == 1.0
+    assert u["allreduce_bytes"] == (2 * 3 * 64 * 64 + 1) * 4
+
+
+def test_bench_gpus1_does_not_spawn():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                        "--rehearse-cpu"], env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip())
+    assert out["n_gpus"] == 1 and "universal" not in out and len(out["per_rank_ms_per_step"]) == 1
+
+
+def test_spawn_ranks_env_and_failure_propagation(tmp_path):
+    from pcfa_amd import launch
+    ok = tmp_path / "ok.py"
+    ok.write_text(textwrap.dedent("""
+        import os, sys
+        import torch.distributed as dist
+        import torch
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(os.environ["RANK"]) + 1.0])
+        dist.all_reduce(t)
+        assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+        open(sys.argv[1] + os.environ["RANK"], "w").write("%d %g" % (dist.get_world_size(), t.item()))
+        dist.destroy_process_group()
+    """))
+    assert launch.spawn_ranks([str(ok), str(tmp_path / "r")], 3, env=_clean_env()) == 0
+    for r in range(3):
+        assert (tmp_path / ("r%d" % r)).read_text() == "3 6"
+
+    bad = tmp_path / "bad.py"     # rank 1 dies; rank 0 would otherwise sleep for a minute
+    bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(60)\n")
+    import time
+    t0 = time.monotonic()
+    assert launch.spawn_ranks([str(bad)], 2, env=_clean_env()) == 7
+    assert time.monotonic() - t0 < 30
+
+
+def test_spawn_ranks_refuses_inside_a_rank(monkeypatch):
+    import pytest
+    from pcfa_amd import launch
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert launch.inside_rank()
+    with pytest.raises(RuntimeError):
+        launch.spawn_ranks(["x.py"], 2)

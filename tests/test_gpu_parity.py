@@ -1217,15 +1217,19 @@ def _lbfgs_problem(seed, shapes):
     return x0, make
 
 
+@pytest.mark.parametrize("direction", ["gram", "two_loop"])
 @pytest.mark.parametrize("history", [100, 4])
-def test_lbfgs_matches_torch_optimizer(history):
+def test_lbfgs_matches_torch_optimizer(history, direction):
+    """Tolerance 2e-4 relative on the iterates after 40 iterations for BOTH forms: "two_loop" runs torch's operation
+    sequence (only the summation order inside a dot product differs), "gram" (the default) evaluates the same
+    recursion on stored inner products -- a different rounding order, fp64 in the coefficient space."""
     from pcfa_amd.lbfgs import LBFGS
     shapes = [(3, 17, 33), (1001,)]          # 2684 elements: exercises the n % 4 tail and two parameter tensors
     x0, make = _lbfgs_problem(5, shapes)
     pa = [x.clone().requires_grad_(True) for x in x0]
     pb = [x.clone().requires_grad_(True) for x in x0]
     oa = torch.optim.LBFGS(pa, max_iter=10, history_size=history)
-    ob = LBFGS(pb, max_iter=10, history_size=history)
+    ob = LBFGS(pb, max_iter=10, history_size=history, direction=direction)
     ca, cb = make(pa), make(pb)
     for step in range(4):                    # 40 iterations: the 4-pair ring wraps many times
         la, lb = float(oa.step(ca)), float(ob.step(cb))
@@ -1234,7 +1238,9 @@ def test_lbfgs_matches_torch_optimizer(history):
             assert rel_l2(b.detach(), a.detach()) < 2e-4, (step, rel_l2(b.detach(), a.detach()))
     assert oa.state[pa[0]]["n_iter"] == ob.state[pb[0]]["n_iter"]
     assert oa.state[pa[0]]["func_evals"] == ob.state[pb[0]]["func_evals"]
-    assert ob.state[pb[0]]["count"] == min(history, len(oa.state[pa[0]]["old_dirs"]))
+    assert ob.history_count() == min(history, len(oa.state[pa[0]]["old_dirs"]))
+    # host synchronisations per iteration: closure scalars + direction scalars (+ the curvature test in two_loop)
+    assert ob.host_syncs <= 4 * (1 + 10 * (2 if direction == "gram" else 3))
     assert la < 0.05 * float(make([x.clone().requires_grad_(True) for x in x0])())   # and it actually minimises
 
 
@@ -1268,6 +1274,61 @@ def test_lbfgs_two_loop_against_dense_reference():
         be = (Yd[r] @ rr) * rod[r]
         rr = rr + (a[r] - be) * Sd[r]
     assert rel_l2(d[:n].double(), rr) < 1e-5
+
+
+def test_lbfgs_gram_form_against_dense_two_loop():
+    """pcfa_lbfgs_gram_update / _direction (the default optimiser path) against the textbook two-loop recursion in
+    float64: 9 candidate pairs fed through a 6-pair ring (it wraps), one of them with y.s < 0 (the optimiser's
+    curvature test must reject it on the device), checked after every update."""
+    from pcfa_amd.hip_ops import _call, _ptr
+    lib = hip_ops._hip.load()
+    g = torch.Generator().manual_seed(13)
+    n, cap, t_step = 4099, 6, 0.75
+    ld = (n + 3) // 4 * 4
+    rows = cap + 1
+    state = torch.zeros(int(lib.pcfa_lbfgs_gram_state_bytes(cap)), dtype=torch.uint8, device=DEV)
+    ws = torch.empty(int(lib.pcfa_lbfgs_gram_workspace_bytes(cap, ld)) // 4, device=DEV)
+    S, Y = torch.zeros(rows, ld, device=DEV), torch.zeros(rows, ld, device=DEV)
+    grad, g_prev, d = torch.zeros(ld, device=DEV), torch.zeros(ld, device=DEV), torch.zeros(ld, device=DEV)
+    out2 = torch.empty(2, device=DEV)
+    grad[:n] = torch.randn(n, generator=g).to(DEV)
+    g_prev.copy_(grad)
+    _call("pcfa_lbfgs_gram_reset", _ptr(state), cap)
+    kept, H = [], 1.0
+    for k in range(9):
+        s_k = torch.randn(n, generator=g).to(DEV)
+        y_k = (s_k + 0.3 * torch.randn(n, generator=g).to(DEV)) * (-1.0 if k == 4 else 1.0)
+        d[:n] = s_k / t_step
+        grad[:n] = g_prev[:n] + y_k                      # the kernel forms y = g - g_prev, s = t d itself
+        s_true, y_true = (d[:n] * t_step).double(), (grad[:n] - g_prev[:n]).double()
+        _call("pcfa_lbfgs_gram_update", _ptr(grad), _ptr(g_prev), _ptr(d), t_step, _ptr(S), _ptr(Y), _ptr(state),
+              _ptr(ws), cap, ld)
+        _call("pcfa_lbfgs_gram_direction", _ptr(grad), _ptr(S), _ptr(Y), _ptr(state), _ptr(d), _ptr(out2), _ptr(ws),
+              cap, ld)
+        hdr = state[:16].view(torch.int32).tolist()
+        ys = float(y_true @ s_true)
+        assert hdr[2] == (1 if ys > 1e-10 else 0), (k, hdr, ys)
+        if ys > 1e-10:
+            kept.append((s_true, y_true))
+            kept = kept[-cap:]
+            H = ys / float(y_true @ y_true)
+        assert hdr[1] == len(kept) and hdr[3] == rows
+        assert torch.equal(g_prev, grad)
+        q = -grad[:n].double()
+        al = []
+        for s_i, y_i in reversed(kept):
+            a = (s_i @ q) / (y_i @ s_i)
+            al.append(a)
+            q = q - a * y_i
+        r = q * H
+        for (s_i, y_i), a in zip(kept, reversed(al)):
+            be = (y_i @ r) / (y_i @ s_i)
+            r = r + (a - be) * s_i
+        assert rel_l2(d[:n].double(), r) < 2e-5, (k, rel_l2(d[:n].double(), r))
+        gtd, dmax = out2.tolist()
+        assert abs(gtd - float(grad[:n].double() @ r)) <= 2e-4 * abs(float(grad[:n].double() @ r))
+        assert abs(dmax - float(r.abs().max())) <= 1e-4 * float(r.abs().max())
+        assert float(d[n:].abs().max()) == 0.0 if ld > n else True
 
 
 def test_lbfgs_rejects_cpu_parameters():

@@ -72,10 +72,17 @@ def _worker(rank, world, port, mode, kwargs, outdir):
             flow = ownutilities.compute_flow(model, "scaled_input_model", im1, im2, test_mode=True, delta1=d1,
                                              delta2=d2)
             [flow] = ownutilities.postprocess_flow("SpyNet", padder, flow)
-            loss = losses.loss_delta_constraint(flow, torch.zeros_like(flow), d1, d2, dev, delta_bound=0.005,
-                                                mu=5e5, f_type="aee")
+            f_type = kwargs.get("loss", "aee")
+            target = torch.zeros_like(flow)
+            bs = None
+            if f_type == "cosim":      # zero target makes the reference's cosim constant: use a fixed non-zero field
+                target = torch.stack((torch.full_like(flow[:, 0], 1.0), torch.full_like(flow[:, 1], -0.5)), 1)
+                bs = sharding.BatchSums() if world > 1 else None
+            loss = losses.loss_delta_constraint(flow, target, d1, d2, dev, delta_bound=0.005,
+                                                mu=5e5, f_type=f_type, batch_sums=bs)
             loss.backward()
             red = sharding.allreduce_closure([d1, d2], loss)
+            assert bs is None or bs.collectives == 1
             np.save(os.path.join(outdir, "clos_w%d_r%d.npy" % (world, rank)),
                     np.concatenate([d1.grad.numpy().ravel(), d2.grad.numpy().ravel(), [float(red)]]))
         else:
@@ -83,7 +90,8 @@ def _worker(rank, world, port, mode, kwargs, outdir):
                                                         **kwargs))
             np.save(os.path.join(outdir, "univ_w%d_r%d.npy" % (world, rank)),
                     torch.stack([res["delta1"], res["delta2"]]).numpy())
-            json.dump({"collectives": res["collectives"], "steps": len(res["history"])},
+            json.dump({"collectives": res["collectives"], "steps": len(res["history"]),
+                       "batch_sum_collectives": res["batch_sum_collectives"]},
                       open(os.path.join(outdir, "univ_w%d_r%d.json" % (world, rank)), "w"))
     sharding.shutdown()
 
@@ -149,6 +157,40 @@ def test_universal_closure_allreduce_is_exact_to_rounding():
     assert np.array_equal(r0, r1)
     assert abs(r0[-1] - single[-1]) <= 1e-6 * abs(single[-1])             # averaged loss
     assert np.linalg.norm(r0[:-1] - single[:-1]) <= 1e-5 * np.linalg.norm(single[:-1])  # averaged gradient
+
+
+def test_universal_cosim_closure_two_ranks_equals_single_process_global_batch():
+    """f_cosim is a ratio of sums over the whole batch (losses.py:76-88; universal loop attack_PCFA.py:469-490): with
+    the batch split over ranks the three sums are all-reduced before the backward (one extra 12-byte collective)."""
+    with tempfile.TemporaryDirectory() as d:
+        _run(2, "closure", {"loss": "cosim"}, d)
+        _run(1, "closure", {"loss": "cosim"}, d)
+        r0 = np.load(os.path.join(d, "clos_w2_r0.npy"))
+        r1 = np.load(os.path.join(d, "clos_w2_r1.npy"))
+        single = np.load(os.path.join(d, "clos_w1_r0.npy"))
+    assert np.array_equal(r0, r1)
+    assert np.abs(single[:-1]).max() > 0 and abs(single[-1] - 1.0) > 1e-3     # the similarity term is live
+    assert abs(r0[-1] - single[-1]) <= 1e-6 * abs(single[-1])
+    assert np.linalg.norm(r0[:-1] - single[:-1]) <= 1e-5 * np.linalg.norm(single[:-1])
+
+
+def test_universal_cosim_attack_two_ranks_runs_with_two_collectives_per_closure():
+    # target: a fixed custom field (cosim is constant for the zero target and stationary at delta = 0 for neg_flow)
+    with tempfile.TemporaryDirectory() as d:
+        tgt = os.path.join(d, "target.npy")
+        yy, xx = np.meshgrid(np.linspace(-1, 1, 64), np.linspace(-1, 1, 64), indexing="ij")
+        np.save(tgt, np.stack((1.0 + 0.5 * xx, -0.5 + 0.25 * yy), -1).astype(np.float32))
+        kw = dict(synthetic_pairs=2, batch_size=2, loss="cosim", target="custom", custom_target_path=tgt)
+        _run(2, "universal", kw, d)
+        _run(1, "universal", kw, d)
+        r0 = np.load(os.path.join(d, "univ_w2_r0.npy"))
+        r1 = np.load(os.path.join(d, "univ_w2_r1.npy"))
+        single = np.load(os.path.join(d, "univ_w1_r0.npy"))
+        meta = json.load(open(os.path.join(d, "univ_w2_r0.json")))
+    assert np.array_equal(r0, r1)
+    assert meta["collectives"] == 10 * meta["steps"] and meta["batch_sum_collectives"] == 10 * meta["steps"]
+    assert np.abs(single).max() > 0
+    assert np.linalg.norm(r0 - single) / np.linalg.norm(single) < 1e-2
 
 
 def test_universal_rejects_indivisible_batch_and_cosim():
