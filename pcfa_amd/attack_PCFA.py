@@ -31,6 +31,7 @@ from .helper_functions import datasets, logging, losses, ownutilities, parsing_f
 from .helper_functions.config_paths import Conf
 
 EPS_BOX = 1e-7  # attack_PCFA.py:608
+REUSE_PAIR_GRAPHS = True  # pairs of one shape share static buffers + hipGraphs (PairAttack(reuse_graphs=None))
 
 
 def extract_deltas(nw_input1, nw_input2, image1, image2, boxconstraint, eps_box=0.):
@@ -71,6 +72,33 @@ def _graphs_enabled(device, args):
     return torch.device(device).type == "cuda" and os.environ.get("PCFA_HIP_GRAPH", "1") == "1" and args.steps > 0
 
 
+class _PairGraphs:
+    """What survives from one image pair to the next of the same shape and flags (attack_PCFA.py:668-670 loops over
+    a batch-1 loader: every KITTI / Sintel pair has the same size): the static device buffers the captured closure
+    reads and writes, the hipGraphs themselves and the optimiser whose flat gradient buffer the closure fills.  A new
+    pair copies its images / initial variables / target into these buffers and resets the optimiser -- no warm-up, no
+    re-capture (`PairAttack(..., reuse_graphs=True)`, the default on the GPU; results equal a fresh capture:
+    tests/test_gpu_parity.py::test_pair_graph_reuse_equals_fresh_capture)."""
+
+    def __init__(self, st):
+        self.image1, self.image2 = st.image1, st.image2
+        self.images_max, self.images_min = st.images_max, st.images_min
+        self.params, self.target, self.optimizer = st.params, st.target, st.optimizer
+        self.graphed, self.repredict = st.graphed, st.repredict
+        self.pairs = 1
+
+
+def _graph_cache(model):
+    cache = getattr(model, "_pcfa_pair_graphs", None)
+    if cache is None:
+        cache = {}
+        try:
+            object.__setattr__(model, "_pcfa_pair_graphs", cache)   # plain attribute: not a module / parameter
+        except Exception:  # noqa: BLE001
+            return {}
+    return cache
+
+
 class PairAttack:
     """Everything pcfa_attack holds for ONE image pair (attack_PCFA.py:40-247): the optimisation variables,
     the optimiser, the target, the best-iterate bookkeeping -- and `step()`, the body of the `--steps` loop.
@@ -81,8 +109,11 @@ class PairAttack:
     (`use_graph=None`: on for CUDA devices unless PCFA_HIP_GRAPH=0; if capture fails the eager closure -- the same
     kernels in the same order -- is used and a warning is logged)."""
 
-    def __init__(self, model, image1, image2, flow, batch, eps_box, device, has_gt, optim_mu, args, use_graph=None):
+    def __init__(self, model, image1, image2, flow, batch, eps_box, device, has_gt, optim_mu, args, use_graph=None,
+                 reuse_graphs=None):
         self.model, self.args, self.device, self.batch = model, args, device, batch
+        if reuse_graphs is None:
+            reuse_graphs = REUSE_PAIR_GRAPHS
         self.has_gt, self.optim_mu, self.eps_box = has_gt, optim_mu, eps_box
         curr_step = batch * args.steps
 
@@ -94,40 +125,90 @@ class PairAttack:
         self.padder, [image1, image2] = ownutilities.preprocess_img(args.net, image1, image2)
         image1.requires_grad = False
         image2.requires_grad = False
-        self.image1, self.image2 = image1, image2
-        self.images_max = torch.max(image1, image2).detach()
-        self.images_min = torch.min(image1, image2).detach()
-
-        delta1 = torch.zeros_like(image1)
-        delta2 = torch.zeros_like(image2)
-        self.nw_delta = None
         cov = args.boxconstraint in ['change_of_variables']
-        if args.joint_perturbation:
-            if cov:
-                raise ValueError("Training a --joint_perturbation with --boxconstraint=change_of_variables is not "
-                                 "defined. Please use --boxconstraint=clipping.")
-            self.nw_delta = delta1
-            self.nw_delta.requires_grad = True
-            self.nw_input1, self.nw_input2 = image1, image2
-            self.params = [self.nw_delta]
-            self.fwd_kwargs = {"delta1": self.nw_delta}
-        else:
-            if cov:
-                self.nw_input1 = torch.atanh(2. * (1. - eps_box) * (image1 + delta1) - (1 - eps_box))
-                self.nw_input2 = torch.atanh(2. * (1. - eps_box) * (image2 + delta2) - (1 - eps_box))
-            else:
-                self.nw_input1 = image1 + delta1
-                self.nw_input2 = image2 + delta2
-            self.nw_input1.requires_grad = True
-            self.nw_input2.requires_grad = True
-            self.params = [self.nw_input1, self.nw_input2]
-            self.fwd_kwargs = {}
-        self.optimizer = ops.get().LBFGS(self.params, max_iter=10)
+        if args.joint_perturbation and cov:
+            raise ValueError("Training a --joint_perturbation with --boxconstraint=change_of_variables is not "
+                             "defined. Please use --boxconstraint=clipping.")
+        if use_graph is None:
+            use_graph = _graphs_enabled(device, args)
+        share_forward = os.environ.get("PCFA_SHARED_FORWARD", "0") == "1"
+        self.graph_key = (args.net, tuple(image1.shape), args.boxconstraint, bool(args.joint_perturbation), args.loss,
+                          float(optim_mu), float(args.delta_bound), float(eps_box), str(device))
+        kept = _graph_cache(model).get(self.graph_key) if (use_graph and reuse_graphs and not share_forward) else None
+        self.graphed = self.repredict = None
+        self.graphs_reused = kept is not None
 
-        with torch.no_grad():
-            self.flow_pred_init = self.predict().detach().clone()
-        self.target = targets.get_target(args.target, self.flow_pred_init,
-                                         custom_target_path=args.custom_target_path, device=device).to(device)
+        if kept is not None:
+            # same shape and flags as an earlier pair: its static buffers, graphs and optimiser, refilled
+            with torch.no_grad():
+                kept.image1.copy_(image1)
+                kept.image2.copy_(image2)
+                kept.images_max.copy_(torch.max(image1, image2))
+                kept.images_min.copy_(torch.min(image1, image2))
+                if args.joint_perturbation:
+                    kept.params[0].zero_()
+                elif cov:
+                    kept.params[0].copy_(torch.atanh(2. * (1. - eps_box) * image1 - (1 - eps_box)))
+                    kept.params[1].copy_(torch.atanh(2. * (1. - eps_box) * image2 - (1 - eps_box)))
+                else:
+                    kept.params[0].copy_(image1)
+                    kept.params[1].copy_(image2)
+            image1, image2 = kept.image1, kept.image2
+            self.image1, self.image2 = image1, image2
+            self.images_max, self.images_min = kept.images_max, kept.images_min
+            self.params = kept.params
+            for p_ in self.params:
+                p_.grad = None
+            kept.optimizer.reset()
+            self.optimizer = kept.optimizer
+            self.graphed, self.repredict = kept.graphed, kept.repredict
+            kept.pairs += 1
+            delta1 = torch.zeros_like(image1)
+            delta2 = torch.zeros_like(image2)
+            if args.joint_perturbation:
+                self.nw_delta = self.params[0]
+                self.nw_input1, self.nw_input2 = image1, image2
+                self.fwd_kwargs = {"delta1": self.nw_delta}
+            else:
+                self.nw_delta = None
+                self.nw_input1, self.nw_input2 = self.params
+                self.fwd_kwargs = {}
+            _, flow0 = self.repredict()           # the captured forward at the initial variables = unattacked flow
+            self.flow_pred_init = flow0.detach().clone()
+            target = targets.get_target(args.target, self.flow_pred_init,
+                                        custom_target_path=args.custom_target_path, device=device).to(device)
+            kept.target.copy_(target)
+            self.target = kept.target
+        else:
+            self.image1, self.image2 = image1, image2
+            self.images_max = torch.max(image1, image2).detach()
+            self.images_min = torch.min(image1, image2).detach()
+            delta1 = torch.zeros_like(image1)
+            delta2 = torch.zeros_like(image2)
+            self.nw_delta = None
+            if args.joint_perturbation:
+                self.nw_delta = delta1
+                self.nw_delta.requires_grad = True
+                self.nw_input1, self.nw_input2 = image1, image2
+                self.params = [self.nw_delta]
+                self.fwd_kwargs = {"delta1": self.nw_delta}
+            else:
+                if cov:
+                    self.nw_input1 = torch.atanh(2. * (1. - eps_box) * (image1 + delta1) - (1 - eps_box))
+                    self.nw_input2 = torch.atanh(2. * (1. - eps_box) * (image2 + delta2) - (1 - eps_box))
+                else:
+                    self.nw_input1 = image1 + delta1
+                    self.nw_input2 = image2 + delta2
+                self.nw_input1.requires_grad = True
+                self.nw_input2.requires_grad = True
+                self.params = [self.nw_input1, self.nw_input2]
+                self.fwd_kwargs = {}
+            self.optimizer = ops.get().LBFGS(self.params, max_iter=10)
+
+            with torch.no_grad():
+                self.flow_pred_init = self.predict().detach().clone()
+            self.target = targets.get_target(args.target, self.flow_pred_init,
+                                             custom_target_path=args.custom_target_path, device=device).to(device)
         self.target.requires_grad = False
 
         self.aee_tgt = logging.calc_metrics_const(self.target, self.flow_pred_init)
@@ -156,10 +237,8 @@ class PairAttack:
         self.steps_done = 0
         self.closures = 0
 
-        self.graphed = self.repredict = None
-        if use_graph is None:
-            use_graph = _graphs_enabled(device, args)
-        if use_graph:
+        self.reuse_graphs = reuse_graphs
+        if use_graph and kept is None:
             self.enable_graph()
 
     # ---- pieces of the closure (attack_PCFA.py:175-192) ---------------------------------------------------------
@@ -211,8 +290,11 @@ class PairAttack:
                     return (d1.detach(), d2.detach()), flow.detach()
                 self.repredict = repredict
                 return
-            self.graphed = GraphedClosure(self.closure_body, self.params)
+            sink = getattr(self.optimizer, "flat_grad_views", None)
+            self.graphed = GraphedClosure(self.closure_body, self.params, grad_sink=sink() if sink else None)
             self.repredict = GraphedForward(self._repredict_body, self.device)
+            if self.reuse_graphs and hasattr(self.optimizer, "reset"):
+                _graph_cache(self.model)[self.graph_key] = _PairGraphs(self)   # the next pair of this shape adopts them
         except Exception as e:  # noqa: BLE001 -- the eager closure launches the same kernels in the same order
             import logging as pylog
             pylog.warning("hipGraph capture of the closure failed (%r): launching eagerly", e)

@@ -169,7 +169,19 @@ __global__ __launch_bounds__(GR_THREADS) void gram_reduce_kernel(const float* __
 
 // ---- coefficients ---------------------------------------------------------------------------------------------------
 // Takes the optimiser's curvature decision, commits the candidate pair and solves the two substitutions.
-__global__ __launch_bounds__(GR_THREADS) void gram_coeff_kernel(unsigned char* __restrict__ state, int rows, int cap,
+// One workgroup of 1024 threads: all of them stage the matrix and form the matrix-vector product, wave 0 runs the two
+// sequential substitutions with the running right-hand side in registers (lane k owns rows k and k + 64) and the pivot
+// broadcast through v_readlane -- one step is a readlane pair, a multiply and two FMAs on LDS operands that were
+// requested a step earlier.
+constexpr int GC_THREADS = 1024;
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__global__ __launch_bounds__(GC_THREADS) void gram_coeff_kernel(unsigned char* __restrict__ state, int rows, int cap,
                                                                 int have_candidate) {
   extern __shared__ double s_mem[];
   GramHeader* hdr = reinterpret_cast<GramHeader*>(state);
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(GR_THREADS) void gram_coeff_kernel(unsigned char* _
     const bool accept = (double)(float)ys > 1e-10;   // torch: `if ys > 1e-10` on the fp32 dot product
     if (accept) {
       // inner products of the new pair with every stored vector: column c of SY, row/column c of YY
-      for (int k = tid; k < count; k += GR_THREADS) {
+      for (int k = tid; k < count; k += GC_THREADS) {
         int r = first + k;
         if (r >= rows) r -= rows;
         SY[r * rows + c] = red[r * 4 + 1];
@@ -228,58 +240,75 @@ __global__ __launch_bounds__(GR_THREADS) void gram_coeff_kernel(unsigned char* _
   if (tid == 0) hdr->cg = -s_H;
   if (m == 0) return;
 
-  // LDS: G[m][m] (upper triangle of SY in live order), then al, de, u, rdiag, b
+  // LDS: G[m][m] (upper triangle of SY in live order, row pitch m), then al, de, u, rdiag
   double* G = s_mem;
   double* al = G + (size_t)m * m;
   double* de = al + m;
   double* u = de + m;
   double* rdiag = u + m;
   auto ring = [&](int k) { int r = first + k; return r >= rows ? r - rows : r; };
-  for (int e = tid; e < m * m; e += GR_THREADS) {
-    const int i = e / m, j = e - i * m;
-    G[e] = (j >= i) ? SY[ring(i) * rows + ring(j)] : 0.0;
+  for (int i = tid >> 7; i < m; i += GC_THREADS >> 7) {       // 8 rows at a time, 128 threads along a row
+    const int ri = ring(i);
+    for (int j = tid & 127; j < m; j += 128) G[i * m + j] = (j >= i) ? SY[ri * rows + ring(j)] : 0.0;
   }
   __syncthreads();
-  for (int k = tid; k < m; k += GR_THREADS) rdiag[k] = 1.0 / G[k * m + k];
+  for (int k = tid; k < m; k += GC_THREADS) rdiag[k] = 1.0 / G[k * m + k];
   __syncthreads();
 
   const int lane = tid & 63;
   const int k0 = lane, k1 = lane + 64;
   if (tid < 64) {
-    // loop 1 (newest -> oldest): R al = -Sg, column-oriented back substitution; lane k owns rhs_k (two per lane)
+    // loop 1 (newest -> oldest): R al = -Sg, column-oriented back substitution
     double r0 = k0 < m ? -red[ring(k0) * 4 + 0] : 0.0;
     double r1 = k1 < m ? -red[ring(k1) * 4 + 0] : 0.0;
-    for (int i = m - 1; i >= 0; --i) {
-      const double ri = __shfl((i >> 6) ? r1 : r0, i & 63, 64);
-      const double a = ri * rdiag[i];
+    const int c0 = k0 < m ? k0 : 0, c1 = k1 < m ? k1 : 0;     // clamped rows: loads are unconditional
+    int i = m - 1;
+    double g0 = G[c0 * m + i], g1 = G[c1 * m + i], rd = rdiag[i];
+    for (; i >= 0; --i) {
+      const int ip = i > 0 ? i - 1 : 0;
+      const double n0 = G[c0 * m + ip], n1 = G[c1 * m + ip], nrd = rdiag[ip];   // next step's operands
+      const double ri = (i >> 6) ? readlane_f64(r1, i & 63) : readlane_f64(r0, i & 63);
+      const double a = ri * rd;
       if (lane == 0) al[i] = a;
-      if (k0 < i) r0 -= G[k0 * m + i] * a;
-      if (k1 < i) r1 -= G[k1 * m + i] * a;
+      if (k0 < i) r0 -= g0 * a;
+      if (k1 < i) r1 -= g1 * a;
+      g0 = n0; g1 = n1; rd = nrd;
     }
   }
   __syncthreads();
-  // u_k = gamma * (-Yg_k - sum_j YY[k][j] al_j)
-  for (int k = tid; k < m; k += GR_THREADS) {
-    const int rk = ring(k);
+  // u_k = gamma * (-Yg_k - sum_j YY[k][j] al_j): 8 threads per row
+  {
+    const int k = tid >> 3, part = tid & 7;
     double acc = 0.0;
-    for (int j = 0; j < m; ++j) acc += YY[rk * rows + ring(j)] * al[j];
-    u[k] = gamma * (-red[rk * 4 + 2] - acc);
+    if (k < m) {
+      const int rk = ring(k);
+      for (int j = part; j < m; j += 8) acc += YY[rk * rows + ring(j)] * al[j];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (k < m && part == 0) u[k] = gamma * (-red[ring(k) * 4 + 2] - acc);
   }
   __syncthreads();
   if (tid < 64) {
     // loop 2 (oldest -> newest): be_i = ro_i (u_i + sum_{j<i} SY[j][i] de_j), de_i = al_i - be_i
     double a0 = k0 < m ? u[k0] : 0.0;
     double a1 = k1 < m ? u[k1] : 0.0;
+    const int c0 = k0 < m ? k0 : 0, c1 = k1 < m ? k1 : 0;
+    double g0 = G[c0], g1 = G[c1], rd = rdiag[0], ali = al[0];
     for (int i = 0; i < m; ++i) {
-      const double ai = __shfl((i >> 6) ? a1 : a0, i & 63, 64);
-      const double dl = al[i] - ai * rdiag[i];
+      const int ip = i + 1 < m ? i + 1 : i;
+      const double n0 = G[ip * m + c0], n1 = G[ip * m + c1], nrd = rdiag[ip], nal = al[ip];
+      const double ai = (i >> 6) ? readlane_f64(a1, i & 63) : readlane_f64(a0, i & 63);
+      const double dl = ali - ai * rd;
       if (lane == 0) de[i] = dl;
-      if (k0 > i && k0 < m) a0 += G[i * m + k0] * dl;
-      if (k1 > i && k1 < m) a1 += G[i * m + k1] * dl;
+      if (k0 > i && k0 < m) a0 += g0 * dl;
+      if (k1 > i && k1 < m) a1 += g1 * dl;
+      g0 = n0; g1 = n1; rd = nrd; ali = nal;
     }
   }
   __syncthreads();
-  for (int k = tid; k < m; k += GR_THREADS) {
+  for (int k = tid; k < m; k += GC_THREADS) {
     const int rk = ring(k);
     cS[rk] = (float)de[k];
     cY[rk] = (float)(-gamma * al[k]);
@@ -287,7 +316,7 @@ __global__ __launch_bounds__(GR_THREADS) void gram_coeff_kernel(unsigned char* _
 }
 
 // ---- sweep 2: the direction ---------------------------------------------------------------------------------------
-// d = cg g + sum over live rows (cS[r] S_r + cY[r] Y_r), oldest pair first; partials of g.d and max|d|.
+// d = cg g + sum over live rows (cS[r] S_r + cY[r] Y_r), newest pair first; partials of g.d and max|d|.
 __global__ __launch_bounds__(GR_THREADS) void gram_direction_kernel(
     const float* __restrict__ g, const float* __restrict__ S, const float* __restrict__ Y,
     const unsigned char* __restrict__ state, float* __restrict__ d, float* __restrict__ partial, int rows,
@@ -305,7 +334,8 @@ __global__ __launch_bounds__(GR_THREADS) void gram_direction_kernel(
   const float4 ga = g4[c0], gb = g4[c1];
   float4 xa = make_float4(cg * ga.x, cg * ga.y, cg * ga.z, cg * ga.w);
   float4 xb = make_float4(cg * gb.x, cg * gb.y, cg * gb.z, cg * gb.w);
-  for (int k = 0; k < count; ++k) {
+  // newest pair first: the rows sweep 1 read last are the ones still in the Infinity Cache
+  for (int k = count - 1; k >= 0; --k) {
     int r = first + k;
     if (r >= rows) r -= rows;
     const float4* Sr = reinterpret_cast<const float4*>(S) + (long long)r * ld4;
@@ -445,7 +475,7 @@ extern "C" int pcfa_lbfgs_gram_update(const float* g, float* g_prev, const float
     if (e != hipSuccess) return (int)e;
     granted = lds;
   }
-  pcfa_launch(gram_coeff_kernel, dim3(1), dim3(GR_THREADS), lds, st, sb, rows, capacity, 1);
+  pcfa_launch(gram_coeff_kernel, dim3(1), dim3(GC_THREADS), lds, st, sb, rows, capacity, 1);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }

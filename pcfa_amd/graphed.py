@@ -36,7 +36,10 @@ class GraphedClosure:
     then try to synchronise that stream with the capture stream -- hipStreamEndCapture crashes on it.
     """
 
-    def __init__(self, closure_fn, params, warmup=2):
+    def __init__(self, closure_fn, params, warmup=2, grad_sink=None):
+        """grad_sink: one tensor per parameter (views of the optimiser's flat gradient buffer,
+        `pcfa_amd.lbfgs.LBFGS.flat_grad_views`): the copies gradient -> flat buffer are captured behind the backward
+        pass and `p.grad` is pointed at the views, so the optimiser finds its flat gradient in place after a replay."""
         self.params = list(params)
         dev = self.params[0].device
         cur = torch.cuda.current_stream(dev)
@@ -54,7 +57,11 @@ class GraphedClosure:
         self.graph = torch.cuda.CUDAGraph()
         with _no_gc(), torch.cuda.graph(self.graph):
             self.loss = closure_fn()
-        self.grads = [p.grad for p in self.params]
+            if grad_sink is not None:
+                with torch.no_grad():
+                    for p, v in zip(self.params, grad_sink):
+                        v.copy_(p.grad)
+        self.grads = [p.grad for p in self.params] if grad_sink is None else list(grad_sink)
         self.replays = 0
 
     def __call__(self):

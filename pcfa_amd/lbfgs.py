@@ -91,12 +91,29 @@ class LBFGS(Optimizer):
                 self._bufs["out2"] = new(2)
         return self._bufs
 
+    def reset(self):
+        """Forget the history and the iteration state (a new image pair on the same variables and buffers)."""
+        self.state.clear()
+        self.host_syncs = 0
+
+    def flat_grad_views(self):
+        """One view per parameter into the optimiser's flat gradient buffer.  A closure that leaves `p.grad` pointing
+        at these views (graphed.GraphedClosure(grad_sink=...)) spares the optimiser its gather copies."""
+        g, off, views = self._buffers()["g"], 0, []
+        for p in self._params:
+            n = p.numel()
+            views.append(g[off:off + n].view_as(p))
+            off += n
+        return views
+
     def _gather_flat_grad(self, g):
         off = 0
         for p in self._params:
             n = p.numel()
             if p.grad is None:
                 g[off:off + n].zero_()
+            elif p.grad.data_ptr() == g.data_ptr() + 4 * off and p.grad.is_contiguous() and not p.grad.is_sparse:
+                pass                                   # already in place (captured closure with grad_sink)
             else:
                 g[off:off + n].copy_((p.grad.to_dense() if p.grad.is_sparse else p.grad).reshape(-1))
             off += n

@@ -122,3 +122,16 @@ def check_universal_against_golden(res, g, rel_l2):
         ref8, ref3 = torch.from_numpy(g["delta%s_b1_t8" % i]), torch.from_numpy(g["delta%s_b1_t3" % i])
         tol = max(3e-2, 3 * rel_l2(ref3, ref8))
         assert rel_l2(res[key].cpu(), ref8) <= tol, (key, rel_l2(res[key].cpu(), ref8), tol)
+
+
+def cli_args(**kw):
+    """attack_PCFA.py CLI namespace with the reference's defaults (parsing_file.py:52-76), synthetic data."""
+    from argparse import Namespace
+    base = dict(net="SpyNet", weights="random:%d" % WEIGHT_SEED, dataset="Synthetic", dataset_stage="evaluation",
+                small_run=False, synthetic_size="64x96", synthetic_pairs=2, dstype="final",
+                output_folder="experiment_data", small_save=False, save_frequency=1, no_save=True,
+                unregistered_artifacts=True, joint_perturbation=False, steps=2, universal_perturbation=False,
+                boxconstraint="change_of_variables", batch_size=2, delta_bound=0.005, mu=-1, epochs=1, target="zero",
+                custom_target_path="", loss="aee")
+    base.update(kw)
+    return Namespace(**base)

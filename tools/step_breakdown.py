@@ -35,9 +35,9 @@ def main():
     t_closure = timed(st.graphed, 20)
     t_fwd = timed(st.repredict, 20)
     hist = []
-    for _ in range(4):
+    for _ in range(int(os.environ.get("STEPS", "12"))):   # history reaches 100 pairs after 10 steps
         os_ = st.optimizer.state[st.optimizer._params[0]]
-        n_old = os_["count"] if "count" in os_ else len(os_.get("old_dirs", []))
+        n_old = st.optimizer.history_count() if hasattr(st.optimizer, "history_count") else len(os_.get("old_dirs", []))
         c0 = st.closures
         t = timed(st.step, 1)
         hist.append((n_old, st.closures - c0, t))
