@@ -299,14 +299,14 @@ TRACED = {  # kernel-name fragment -> label
 LBFGS_LABELS = ("lbfgs_gram_pass", "lbfgs_gram_direction", "lbfgs_gram_coeff", "lbfgs_small", "lbfgs_two_loop_sweep")
 
 
-def lbfgs_record(traced, st):
-    """Device time of the optimiser's own kernels in the traced attack step + what bounds them."""
+def lbfgs_record(traced, st, m):
+    """Device time of the optimiser's own kernels in the traced attack step + what bounds them (m = pairs in the
+    history during that step)."""
     if not traced:
         return None
     rows = {k: {"mean_launch_us": round(traced[k][0], 2), "launches": traced[k][1]} for k in LBFGS_LABELS if k in traced}
     total_ms = sum(traced[k][0] * traced[k][1] for k in LBFGS_LABELS if k in traced) * 1e-3
     opt = st.optimizer
-    m = opt.history_count() if hasattr(opt, "history_count") else None
     rec = {"lbfgs_ms_per_step": total_ms, "history": m, "direction": getattr(opt, "direction", None), "kernels": rows,
            "note": "device time of the optimiser's kernels in one attack step (10 iterations) at the history above; "
                    "the two host synchronisations per iteration and torch's parameter update are not in it"}
@@ -571,6 +571,7 @@ def main():
             traced = graph_replay_kernel_times(st)
         except Exception as e:  # the tracer is an extra: fall back to the eager hipEvent figures
             print("graph-replay kernel trace unavailable: %r" % (e,), file=sys.stderr)
+    lbfgs_history = st.optimizer.history_count() if hasattr(st.optimizer, "history_count") else None
     if use_graph and corr_net:
         # dispatch-attached events cannot ride inside a captured graph: time the kernels on the same data in one
         # extra, eagerly launched step right after the timed region -- with the lookup -> convc1 fusion switched OFF,
@@ -630,7 +631,7 @@ def main():
         }
         if universal is not None:
             out["universal"] = universal
-        lb = lbfgs_record(traced, st)
+        lb = lbfgs_record(traced, st, lbfgs_history)
         if lb is not None:
             out["lbfgs"] = lb
         if corr_net:

@@ -247,9 +247,24 @@ __global__ __launch_bounds__(GC_THREADS) void gram_coeff_kernel(unsigned char* _
   double* u = de + m;
   double* rdiag = u + m;
   auto ring = [&](int k) { int r = first + k; return r >= rows ? r - rows : r; };
-  for (int i = tid >> 7; i < m; i += GC_THREADS >> 7) {       // 8 rows at a time, 128 threads along a row
-    const int ri = ring(i);
-    for (int j = tid & 127; j < m; j += 128) G[i * m + j] = (j >= i) ? SY[ri * rows + ring(j)] : 0.0;
+  {
+    constexpr int NE = (GR_MAX_ROWS * GR_MAX_ROWS + GC_THREADS - 1) / GC_THREADS;   // 17 elements per thread at most
+    double v[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = tid + q * GC_THREADS;
+      const int ec = e < m * m ? e : 0;
+      const int i = ec / m, j = ec - i * m;
+      v[q] = SY[ring(i) * rows + ring(j)];
+    }
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = tid + q * GC_THREADS;
+      if (e < m * m) {
+        const int i = e / m, j = e - i * m;
+        G[e] = (j >= i) ? v[q] : 0.0;
+      }
+    }
   }
   __syncthreads();
   for (int k = tid; k < m; k += GC_THREADS) rdiag[k] = 1.0 / G[k * m + k];
@@ -257,54 +272,82 @@ __global__ __launch_bounds__(GC_THREADS) void gram_coeff_kernel(unsigned char* _
 
   const int lane = tid & 63;
   const int k0 = lane, k1 = lane + 64;
+  const int c0 = k0 < m ? k0 : 0, c1 = k1 < m ? k1 : 0;     // clamped rows: LDS loads are unconditional
+  constexpr int PF = 4;                                       // operands of a step are requested PF steps ahead
   if (tid < 64) {
     // loop 1 (newest -> oldest): R al = -Sg, column-oriented back substitution
     double r0 = k0 < m ? -red[ring(k0) * 4 + 0] : 0.0;
     double r1 = k1 < m ? -red[ring(k1) * 4 + 0] : 0.0;
-    const int c0 = k0 < m ? k0 : 0, c1 = k1 < m ? k1 : 0;     // clamped rows: loads are unconditional
-    int i = m - 1;
-    double g0 = G[c0 * m + i], g1 = G[c1 * m + i], rd = rdiag[i];
-    for (; i >= 0; --i) {
-      const int ip = i > 0 ? i - 1 : 0;
-      const double n0 = G[c0 * m + ip], n1 = G[c1 * m + ip], nrd = rdiag[ip];   // next step's operands
-      const double ri = (i >> 6) ? readlane_f64(r1, i & 63) : readlane_f64(r0, i & 63);
-      const double a = ri * rd;
-      if (lane == 0) al[i] = a;
-      if (k0 < i) r0 -= g0 * a;
-      if (k1 < i) r1 -= g1 * a;
-      g0 = n0; g1 = n1; rd = nrd;
+    double g0[PF], g1[PF], rd[PF];
+#pragma unroll
+    for (int s_ = 0; s_ < PF; ++s_) {
+      const int ii = m - 1 - s_ > 0 ? m - 1 - s_ : 0;
+      g0[s_] = G[c0 * m + ii]; g1[s_] = G[c1 * m + ii]; rd[s_] = rdiag[ii];
+    }
+    for (int ib = m - 1; ib >= 0; ib -= PF) {
+#pragma unroll
+      for (int s_ = 0; s_ < PF; ++s_) {
+        const int i = ib - s_;
+        if (i >= 0) {                                          // uniform
+          const double ri = (i >= 64) ? readlane_f64(r1, i - 64) : readlane_f64(r0, i);
+          const double a = ri * rd[s_];
+          al[i] = a;                                           // every lane, same value
+          r0 = (k0 < i) ? r0 - g0[s_] * a : r0;
+          r1 = (k1 < i) ? r1 - g1[s_] * a : r1;
+        }
+        const int in = i - PF > 0 ? i - PF : 0;
+        g0[s_] = G[c0 * m + in]; g1[s_] = G[c1 * m + in]; rd[s_] = rdiag[in];
+      }
     }
   }
   __syncthreads();
-  // u_k = gamma * (-Yg_k - sum_j YY[k][j] al_j): 8 threads per row
+  // u_k = gamma * (-Yg_k - sum_j YY[k][j] al_j): 8 threads per row, every load of a thread in flight at once
   {
     const int k = tid >> 3, part = tid & 7;
+    const int rk = ring(k < m ? k : 0);
+    constexpr int NJ = (GR_MAX_ROWS + 7) / 8;                  // 17 >= ceil(m / 8)
+    double yv[NJ];
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+      const int j = part + 8 * q;
+      yv[q] = YY[rk * rows + ring(j < m ? j : 0)];
+    }
     double acc = 0.0;
-    if (k < m) {
-      const int rk = ring(k);
-      for (int j = part; j < m; j += 8) acc += YY[rk * rows + ring(j)] * al[j];
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+      const int j = part + 8 * q;
+      acc += (j < m) ? yv[q] * al[j < m ? j : 0] : 0.0;
     }
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
-    if (k < m && part == 0) u[k] = gamma * (-red[ring(k) * 4 + 2] - acc);
+    if (k < m && part == 0) u[k] = gamma * (-red[rk * 4 + 2] - acc);
   }
   __syncthreads();
   if (tid < 64) {
     // loop 2 (oldest -> newest): be_i = ro_i (u_i + sum_{j<i} SY[j][i] de_j), de_i = al_i - be_i
     double a0 = k0 < m ? u[k0] : 0.0;
     double a1 = k1 < m ? u[k1] : 0.0;
-    const int c0 = k0 < m ? k0 : 0, c1 = k1 < m ? k1 : 0;
-    double g0 = G[c0], g1 = G[c1], rd = rdiag[0], ali = al[0];
-    for (int i = 0; i < m; ++i) {
-      const int ip = i + 1 < m ? i + 1 : i;
-      const double n0 = G[ip * m + c0], n1 = G[ip * m + c1], nrd = rdiag[ip], nal = al[ip];
-      const double ai = (i >> 6) ? readlane_f64(a1, i & 63) : readlane_f64(a0, i & 63);
-      const double dl = ali - ai * rd;
-      if (lane == 0) de[i] = dl;
-      if (k0 > i && k0 < m) a0 += g0 * dl;
-      if (k1 > i && k1 < m) a1 += g1 * dl;
-      g0 = n0; g1 = n1; rd = nrd; ali = nal;
+    double g0[PF], g1[PF], rd[PF], ali[PF];
+#pragma unroll
+    for (int s_ = 0; s_ < PF; ++s_) {
+      const int ii = s_ < m ? s_ : m - 1;
+      g0[s_] = G[ii * m + c0]; g1[s_] = G[ii * m + c1]; rd[s_] = rdiag[ii]; ali[s_] = al[ii];
+    }
+    for (int ib = 0; ib < m; ib += PF) {
+#pragma unroll
+      for (int s_ = 0; s_ < PF; ++s_) {
+        const int i = ib + s_;
+        if (i < m) {                                           // uniform
+          const double ai = (i >= 64) ? readlane_f64(a1, i - 64) : readlane_f64(a0, i);
+          const double dl = ali[s_] - ai * rd[s_];
+          de[i] = dl;
+          a0 = (k0 > i && k0 < m) ? a0 + g0[s_] * dl : a0;
+          a1 = (k1 > i && k1 < m) ? a1 + g1[s_] * dl : a1;
+        }
+        const int in = i + PF < m ? i + PF : m - 1;
+        g0[s_] = G[in * m + c0]; g1[s_] = G[in * m + c1]; rd[s_] = rdiag[in]; ali[s_] = al[in];
+      }
     }
   }
   __syncthreads();

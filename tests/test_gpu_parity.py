@@ -1222,39 +1222,47 @@ def test_graphed_closure_matches_eager(net, size):
 def test_pair_graph_reuse_equals_fresh_capture():
     """attack_l2 loops over equal-shape pairs (attack_PCFA.py:668-670): from the second pair on PairAttack adopts the
     first pair's static buffers, hipGraphs and optimiser (images / variables / target copied in, optimiser reset)
-    instead of warming up and capturing again.  Every pair must come out as from a fresh capture; the only difference
-    between the two runs is MIOpen's atomically accumulated backward noise, amplified by 20 L-BFGS closures."""
+    instead of warming up and capturing again.  Every pair must come out as from a fresh capture.  Compared on the
+    unattacked flow (bit-level: forward only) and on the loss of the first six closure evaluations (1e-5 relative; 3e-2 on overshooting steps):
+    this 128x160 random-weight problem bifurcates around the tenth evaluation under last-bit noise (identical fresh
+    runs end 2 % to 180 % apart, tools/dev/firstrun_probe.py), so later iterates say nothing about the mechanism."""
     from pcfa_amd import attack_PCFA
     from pcfa_amd.helper_functions import datasets
     dev = torch.device(DEV)
-    args = closure_util.cli_args(net="RAFT", steps=2)
+    args = closure_util.cli_args(net="RAFT", steps=1)
     mu = attack_PCFA.default_mu(args)
 
     def run(reuse):
-        model = closure_util.load_model("RAFT", True, dev)
+        model = closure_util.load_model("RAFT", True, dev)      # shared with other tests: start from an empty cache
+        if hasattr(model, "_pcfa_pair_graphs"):
+            model._pcfa_pair_graphs.clear()
         out = []
         for seed, (h, w) in ((0, (128, 160)), (1, (128, 160)), (2, (136, 168)), (3, (128, 160))):
             i1, i2, _ = datasets.synthetic_pair(seed, h, w)
             st = attack_PCFA.PairAttack(model, i1[None], i2[None], None, seed, attack_PCFA.EPS_BOX, dev, False, mu,
                                         args, use_graph=True, reuse_graphs=reuse)
             assert st.graphed is not None
-            for _ in range(args.steps):
-                st.step()
-            out.append((st.graphs_reused, st.result(), st.delta1.detach().clone(), st.flow_pred_init.clone(),
-                        st.closures))
+            losses, inner = [], st.closure
+
+            def recording():
+                loss = inner()
+                losses.append(float(loss.detach()))
+                return loss
+            st.closure = recording
+            st.step()
+            out.append((st.graphs_reused, losses, st.flow_pred_init.clone(), st.closures, st.aee_tgt))
         return out, len(getattr(model, "_pcfa_pair_graphs", {}))
 
     reused, n_kept = run(True)
     fresh, n_none = run(False)
     assert [r[0] for r in reused] == [False, True, False, True] and n_kept == 2       # two shapes, two graph sets
     assert not any(r[0] for r in fresh) and n_none == 0
-    for (_, ra, da, fa, ca), (_, rb, db, fb, cb) in zip(reused, fresh):
-        assert ca == cb == 20
-        assert max_abs(fa, fb) < 1e-4                      # unattacked flow: forward only, deterministic kernels
-        assert rel_l2(da, db) < 2e-2, rel_l2(da, db)
-        for va, vb in zip(ra, rb):
-            if va is not None:
-                assert abs(va - vb) <= 2e-3 * max(1.0, abs(vb)), (ra, rb)
+    for (_, la, fa, ca, ta), (_, lb, fb, cb, tb) in zip(reused, fresh):
+        assert ca == cb == 10 and len(la) == len(lb) == 10
+        assert max_abs(fa, fb) < 1e-4 and abs(ta - tb) < 1e-5
+        for k in range(6):   # an un-damped L-BFGS step that overshoots (loss >> start) amplifies last-bit noise
+            tol = 1e-5 if lb[k] < 1.5 * lb[0] else 3e-2
+            assert abs(la[k] - lb[k]) <= tol * abs(lb[k]), (k, la, lb)
 
 
 def test_split_closure_shares_the_reprediction_forward():
