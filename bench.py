@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="no GPU: rehearse launcher + collectives with the CPU port on a tiny workload (not a result)")
     ap.add_argument("--no-shared-forward-leg", action="store_true", help="skip the informational shared-forward leg")
+    ap.add_argument("--no-pwcnet-leg", action="store_true", help="skip the PWC-Net (BASELINE config 4) leg")
     ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC convolutions")
     ap.add_argument("--no-graph", action="store_true", help="launch the closure eagerly instead of replaying "
                                                             "its hipGraph")
@@ -107,13 +108,14 @@ def load_model(net, device, cov):
     return model
 
 
-def AttackStepper(net, h, w, device, seed, boxconstraint="change_of_variables", use_graph=False, model=None):
+def AttackStepper(net, h, w, device, seed, boxconstraint="change_of_variables", use_graph=False, model=None,
+                  joint=False):
     """`pcfa_amd.attack_PCFA.PairAttack` on one synthetic pair (what pcfa_attack builds per pair), graph off unless
     asked: call `.enable_graph()` -- exactly what pcfa_attack does on the GPU."""
     from pcfa_amd import attack_PCFA
     from pcfa_amd.helper_functions import datasets
     cov = boxconstraint == "change_of_variables"
-    args = attack_args(net, boxconstraint)
+    args = attack_args(net, boxconstraint, joint=joint)
     if model is None:
         model = load_model(net, device, cov)
     i1, i2, _ = datasets.synthetic_pair(seed, h, w)
@@ -346,7 +348,7 @@ def graph_replay_kernel_times(st):
 # --------------------------------------------------------------------------------------------------------------
 # CPU baseline (+ the CPU side of the parity record)
 # --------------------------------------------------------------------------------------------------------------
-def cpu_baseline(net, h, w, nclosures, threads=0, boxconstraint="change_of_variables"):
+def cpu_baseline(net, h, w, nclosures, threads=0, boxconstraint="change_of_variables", joint=False):
     """Time the CPU port (pcfa_amd host code + oracle operators) on a bounded sample of the workload.  Its warm-up
     closure is evaluated at the parity point, so the same leg yields the CPU side of `parity_vs_cpu_port`."""
     from oracle import ops as oracle_ops
@@ -354,7 +356,7 @@ def cpu_baseline(net, h, w, nclosures, threads=0, boxconstraint="change_of_varia
     cores = threads if threads > 0 else min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     with ops.override_for_testing(oracle_ops):
-        st = AttackStepper(net, h, w, torch.device("cpu"), seed=0, boxconstraint=boxconstraint)
+        st = AttackStepper(net, h, w, torch.device("cpu"), seed=0, boxconstraint=boxconstraint, joint=joint)
         t0 = time.perf_counter()
         with torch.no_grad():
             st.predict()
@@ -446,6 +448,38 @@ def universal_leg(net, h, w, dev, rank, world, pairs_per_gpu, warmup, steps, sha
             "closure_evals_per_step": closures / steps, "allreduces_per_closure": cols / max(closures, 1),
             "allreduce_bytes": flat, "closure_launch": "hipGraph replay" if ua.graphed else "eager",
             "setup_s": setup, "final": last}
+
+
+def pwcnet_leg(a, dev, sharding):
+    """BASELINE config 4 beside the headline: PWC-Net on one synthetic KITTI-sized pair (375x1242 -> 384x1280),
+    --joint_perturbation --boxconstraint=clipping, delta_bound 0.005, zero target: a few attack steps (the same
+    PairAttack.step), the cost-volume / warp kernels' roofline rows from the graph replays, and one closure against
+    the CPU port at the same point (PWCNet.py:45-58,166-206,227-330 through the HIP spatial-correlation sampler)."""
+    h, w, steps, warmup = 375, 1242, 3, 1
+    st = AttackStepper("PWCNet", h, w, dev, seed=0, boxconstraint="clipping", joint=True)
+    gpu_parity = None if a.no_cpu_baseline else parity_closure(st)
+    st.enable_graph()
+    for _ in range(warmup):
+        st.step()
+    elapsed, closures, last = timed_steps(st, steps, sharding)
+    rec = {"metric": "attack_steps_per_sec", "value": steps / elapsed, "unit": "attack_steps/s", "steps": steps,
+           "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "closure_evals_per_step": closures / steps,
+           "closure_launch": "hipGraph replay" if st.graphed is not None else "eager",
+           "config": {"workload": "PWCNet, 1 synthetic %dx%d pair (padded %dx%d), joint perturbation, clipping, "
+                                  "delta_bound=0.005, zero target, L-BFGS max_iter=10 (BASELINE config 4 shape)"
+                                  % (h, w, st.image1.shape[-2], st.image1.shape[-1])},
+           "final": {"aee_adv_tgt": last[0], "aee_adv_init": last[1], "l2_delta": last[2]}}
+    if os.environ.get("PCFA_BENCH_NO_TRACER", "0") != "1" and st.graphed is not None:
+        try:
+            traced = graph_replay_kernel_times(st)
+            rec["kernels"] = pwc_kernel_table(traced, st.image1.shape[-2], st.image1.shape[-1])
+        except Exception as e:  # noqa: BLE001
+            rec["kernels_error"] = repr(e)
+    if gpu_parity is not None:
+        cpu, cpu_parity = cpu_baseline("PWCNet", h, w, 3, a.cpu_threads, boxconstraint="clipping", joint=True)
+        rec["cpu_baseline"] = cpu
+        rec["parity_vs_cpu_port"] = parity_record(gpu_parity, cpu_parity)
+    return rec
 
 
 def rehearse_cpu(a, json_out):
@@ -698,6 +732,11 @@ def main():
             out["cpu_baseline"], cpu_parity = cpu_baseline(a.net, h, w, a.cpu_closures, a.cpu_threads)
             if gpu_parity is not None:
                 out["parity_vs_cpu_port"] = parity_record(gpu_parity, cpu_parity)
+        if world == 1 and a.net == "RAFT" and not a.no_pwcnet_leg:
+            try:
+                out["pwcnet"] = pwcnet_leg(a, dev, sharding)
+            except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure of the extra leg
+                out["pwcnet"] = {"error": repr(e)}
         print(json.dumps(out), file=json_out, flush=True)
     sharding.shutdown()
     return out

@@ -428,6 +428,21 @@ PCFA_API int pcfa_conv3x3_fused_bwd(const float* g, const float* packed_bwd, con
                            float* grad_in, int B, int K, int N, int H, int W, void* stream);
 PCFA_API int pcfa_conv3x3_masked_fwd(const float* x, const float* packed, const float* mask, float* out, int B, int K,
                             int N, int H, int W, void* stream);
+/* The general form of all of the above, with a choice of transform (pcfa_amd/csrc/conv3x3_f43.hip):
+ *   out = act(bias + conv(x))  [zeroed where mask <= 0]  [+ addend]         (bias, mask, addend optional)
+ * `packed` holds both transforms of the weights (pcfa_conv3x3_pack_weights: [F(2x2,3x3) | F(4x4,3x3)]).  Shapes where
+ * it was measured faster (pcfa_conv3x3_algo: W % 4 == 0, 16-B aligned tensors, maps of >= 100k pixels, or >= 24 x 64
+ * pixels with K * N >= 192 * 256) run as Winograd F(4x4,3x3) -- 36 products per 16 outputs, 1.78x fewer matrix
+ * instructions than F(2x2,3x3); fp32 rounding error ~2e-6 relative per layer instead of ~3.5e-7 -- everything else as
+ * F(2x2,3x3).  Where one launch would leave CUs idle (RAFT's 55 x 128 maps: 56-112
+ * workgroups) the input channels are split over several workgroups that write partial outputs into `workspace`
+ * (pcfa_conv3x3_workspace_bytes, caller-owned, 16-B aligned, may be NULL when that returns 0) and a streaming kernel
+ * adds them in index order: deterministic, no atomics. */
+PCFA_API int pcfa_conv3x3_algo(int B, int K, int N, int H, int W);   /* 23 or 43: the transform pcfa_conv3x3_run picks */
+PCFA_API size_t pcfa_conv3x3_workspace_bytes(int B, int K, int N, int H, int W);
+PCFA_API int pcfa_conv3x3_run(const float* x, const float* packed, const float* bias, const float* mask,
+                     const float* addend, float* out, int B, int K, int N, int H, int W, int act, float slope,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* out = relu(x + bias[c]) and its backward gx = grad_out * (out > 0): the "conv -> +bias -> ReLU" tail of the
  * motion encoder / flow head convolutions (models/raft/update.py:12-16,91-101) in one pass. */

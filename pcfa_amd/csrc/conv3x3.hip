@@ -19,6 +19,7 @@
 // Epilogue: accumulators -> LDS in passes of 16 channels, thread (channel, tile) applies A^T . A, adds the bias,
 // optionally ReLU, stores 2x2 pixels.
 #include "common.hpp"
+#include "conv3x3_f43.hpp"
 #include <cstdlib>
 
 namespace {
@@ -436,9 +437,14 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+static long long f23_packed_floats(int K, int N) {
+  return 16LL * (((long long)K + KC - 1) / KC * KC) * (((long long)N + CB - 1) / CB * CB);
+}
+
+// [F(2x2,3x3) packing | F(4x4,3x3) packing]: both transforms of the same weights, one buffer per direction
 extern "C" long long pcfa_conv3x3_packed_floats(int K, int N) {
   if (K < 1 || N < 1) return -1;
-  return 16LL * (((long long)K + KC - 1) / KC * KC) * (((long long)N + CB - 1) / CB * CB);
+  return f23_packed_floats(K, N) + pcfa_f43_packed_floats(K, N);
 }
 
 extern "C" int pcfa_conv3x3_pack_weights(const float* w, float* fwd_packed, float* bwd_packed, int Cout, int Cin,
@@ -450,10 +456,12 @@ extern "C" int pcfa_conv3x3_pack_weights(const float* w, float* fwd_packed, floa
     if (!dst) continue;
     const int K = dir == 0 ? Cin : Cout, N = dir == 0 ? Cout : Cin;
     const int nchunk = (K + KC - 1) / KC;
-    const long long total = pcfa_conv3x3_packed_floats(K, N);
+    const long long total = f23_packed_floats(K, N);
     pcfa_launch(conv3x3_pack_kernel, dim3((unsigned)min((total + 255) / 256, 8192LL)), dim3(256), 0, s, w, dst, Cout,
                 Cin, dir, K, N, nchunk, total);
     PCFA_LAUNCH_CHECK();
+    const int rc = pcfa_f43_pack(w, dst + total, Cout, Cin, dir, s);
+    if (rc != PCFA_OK) return rc;
   }
   return PCFA_OK;
 }
@@ -511,7 +519,7 @@ extern "C" int pcfa_conv3x3_act_fwd_pair(const float* x, const float* packed, co
                                          int N2, int H, int W, int act, float slope, void* stream) {
   if (!x2 || !packed2 || !out2 || K2 < 1 || N2 < 1 || !aligned16(packed2)) return PCFA_ERR_INVALID_ARG;
   if ((K % KC == 0) != (K2 % KC == 0)) return PCFA_ERR_UNSUPPORTED;   // one kernel instance serves both
-  if (pcfa_conv3x3_packed_floats(K2, N2) > 0x7fffffffLL || (long long)K2 * H * W > 0x7fffffffLL) return PCFA_ERR_UNSUPPORTED;
+  if (f23_packed_floats(K2, N2) > 0x7fffffffLL || (long long)K2 * H * W > 0x7fffffffLL) return PCFA_ERR_UNSUPPORTED;
   return conv3x3_launch(x, packed, bias, nullptr, out, 1, K, N, H, W, act, slope, stream, x2, packed2, bias2, out2, K2,
                         N2);
 }
@@ -519,6 +527,52 @@ extern "C" int pcfa_conv3x3_act_fwd_pair(const float* x, const float* packed, co
 extern "C" int pcfa_conv3x3_fused_bwd(const float* g, const float* packed_bwd, const float* mask, const float* addend,
                                       float* grad_in, int B, int K, int N, int H, int W, void* stream) {
   return conv3x3_launch(g, packed_bwd, nullptr, mask, grad_in, B, K, N, H, W, 0, 0.f, stream, nullptr, nullptr, nullptr,
+                        nullptr, 0, 0, addend);
+}
+
+// Which transform serves a shape.  F(4x4,3x3) needs 1.78x fewer matrix instructions, but three waves per SIMD leave
+// its loop 168 registers (96 of them accumulators): the U operand stream can only run one channel pair ahead and the
+// channel-split path pays for its partial outputs, so it wins where the matrix work dominates -- measured on MI355X
+// (tools/dev/bench_conv3x3.py, device time, F(2x2,3x3) -> F(4x4,3x3)): 256->192 at 55x128 58.6 -> 42.0 us (but see
+// below), 192->256 47.0 -> 42.0, 64->64 at 220x512 (batch 2) 124 -> 106, (batch 1) 64 -> 53.5; 128->256 / 256->126 at
+// 55x128 and 96->96 at 110x256 tie (34 us, 35 us, 68 us) and stay on F(2x2,3x3), whose rounding error is 6x smaller.
+// PCFA_CONV3X3_ALGO=f23|f43 overrides (read once; dev A/B only).
+static bool use_f43(int B, int K, int N, int H, int W) {
+  static const int forced = [] {
+    const char* e = getenv("PCFA_CONV3X3_ALGO");
+    return e == nullptr ? 0 : (e[1] == '4' ? 43 : 23);
+  }();
+  if (!pcfa_f43_supported(B, K, N, H, W)) return false;
+  if (forced) return forced == 43;
+  if (H < 24 || W < 64 || K < 16) return false;
+  // channel-split path: every split is one more partial output to write and re-read (and 256->192, three splits, is
+  // already paired with convf2 in one F(2x2,3x3) launch that fills its tail: 57 us for both against 42 + 19)
+  const int ks = pcfa_f43_ksplit(B, K, N, H, W);
+  if (ks > 1) return ks == 2 && (long long)K * N >= 192LL * 256;
+  return (long long)H * W >= 100000;                                              // enough tiles: large maps only
+}
+
+extern "C" int pcfa_conv3x3_algo(int B, int K, int N, int H, int W) {
+  if (B < 1 || K < 1 || N < 1 || H < 1 || W < 1) return 0;
+  return use_f43(B, K, N, H, W) ? 43 : 23;
+}
+
+extern "C" size_t pcfa_conv3x3_workspace_bytes(int B, int K, int N, int H, int W) {
+  if (B < 1 || K < 1 || N < 1 || H < 1 || W < 1) return 0;
+  return use_f43(B, K, N, H, W) ? pcfa_f43_workspace_bytes(B, K, N, H, W) : 0;
+}
+
+extern "C" int pcfa_conv3x3_run(const float* x, const float* packed, const float* bias, const float* mask,
+                                const float* addend, float* out, int B, int K, int N, int H, int W, int act,
+                                float slope, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !packed || !out || B < 1 || K < 1 || N < 1 || H < 1 || W < 1 || act < 0 || act > 2)
+    return PCFA_ERR_INVALID_ARG;
+  if (use_f43(B, K, N, H, W)) {
+    const int rc = pcfa_f43_run(x, packed + f23_packed_floats(K, N), bias, mask, addend, out, B, K, N, H, W, act,
+                                slope, workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc != PCFA_ERR_UNSUPPORTED) return rc;   // (misaligned views fall through to the F(2x2,3x3) kernel)
+  }
+  return conv3x3_launch(x, packed, bias, mask, out, B, K, N, H, W, act, slope, stream, nullptr, nullptr, nullptr,
                         nullptr, 0, 0, addend);
 }
 
@@ -533,7 +587,7 @@ static int conv3x3_launch(const float* x, const float* packed, const float* bias
   const long long gx = (long long)blocks_x * blocks_y;
   // 32-bit element offsets inside one image and inside the packed weights
   if (gx > 0x7fffffffLL || B > 65535 || Npad / CB > 65535 || (long long)K * H * W > 0x7fffffffLL ||
-      pcfa_conv3x3_packed_floats(K, N) > 0x7fffffffLL)
+      f23_packed_floats(K, N) > 0x7fffffffLL)
     return PCFA_ERR_UNSUPPORTED;
   dim3 grid((unsigned)gx, Npad / CB, B), block(256);
   hipStream_t s = (hipStream_t)stream;

@@ -223,12 +223,16 @@ __global__ void convc1_pack_kernel(const float* __restrict__ w, float* __restric
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
+// MTW = row tiles (32 output channels) per wave: 2 = one workgroup per query tile owns all 256 channels (220 workgroups
+// at 55x128); 1 = the channels are split over two workgroups (blockIdx.y) that both gather and blend the tile's taps
+// and share a CU, two waves per SIMD: each wave's LDS / L2 waits hide behind the other's MFMAs.
+template <int MTW>
 __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, const float* __restrict__ wp,
     const float* __restrict__ bias, float* __restrict__ out, int Q, PyrLayout P, int relu, int /*unused*/) {
   constexpr int dbg = PCFA_LC_DBG_BUILD;             // phase ablation is a build-time switch: a runtime one put 130
                                                      // uniform branches between the MFMAs and the allocator spilled
-  constexpr int COUT = 256, MTW = COUT / 32 / 4;     // m-tiles per wave (2)
+  constexpr int COUT = 256;
   __shared__ __attribute__((aligned(16))) float s_win2[2][WIN_FLOATS];   // two window images: level i+1 is staged while i is read
   __shared__ __attribute__((aligned(16))) float s_tap[2][KL][QT];
   __shared__ float s_bias[COUT];
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = tid & 31, l31 = lane & 31, lh = lane >> 5;
   const int b_img = blockIdx.z, q0 = blockIdx.x * QT;
+  const int mt0 = ((int)blockIdx.y * 4 + wv) * MTW;   // this wave's first row tile
   const bool live = q0 + j < Q;
   unsigned long long ts[12] = {};
   int nts = 0;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
   unsigned dst[L][NPC], goffs[L][NPC];
   float fxs[L], fys[L];
   constexpr int EARLY = PCFA_LC_EARLY;   // levels (coarsest first) whose windows are requested before the first MFMA
-  const f32x4* wq = reinterpret_cast<const f32x4*>(wp) + ((size_t)(wv * MTW) * (KP / 8)) * 64 + lane;
+  const f32x4* wq = reinterpret_cast<const f32x4*>(wp) + ((size_t)mt0 * (KP / 8)) * 64 + lane;
   // W operands: a register ring WD groups deep over the 44 groups of all four levels (the loops below are fully
   // unrolled, so every ring index is static).  One group = 4 k-pairs = 8 MFMAs of 64 cycles per wave; the loads come
   // from L2 (500-900 cycles), so the ring has to run >= 2 groups ahead -- with one group of lead the matrix pipe
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
 #pragma unroll
   for (int m = 0; m < MTW; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = s_bias[(wv * MTW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+    for (int r = 0; r < 16; ++r) acc[m][r] = s_bias[(mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
   if (!(dbg & 2)) {
     Texels x[NBK];
 #pragma unroll
@@ -399,13 +404,14 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
-          const int step = e * MTW + m;
-          if (!(dbg & 1)) {
+          const int step = (e * MTW + m) * (2 / MTW);   // chunk slots 0..7 of a group (MTW = 1: every other one)
+          // tap rows 82..87 of a level are zero rows (81 taps padded to 88): the last group runs its first k-pair only
+          if (!(dbg & 1) && !(g == KG - 1 && e >= 1)) {
             const float av = e == 0 ? wcur[m].x : e == 1 ? wcur[m].y : e == 2 ? wcur[m].z : wcur[m].w;
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[e], acc[m], 0, 0, 0);
           }
           if (step == 0 && i + 1 < L && !(dbg & 2)) x = tap_texels(i + 1, g);
-          if (step == 1 && g + 1 < KG) {
+          if (step == (MTW == 1 ? 0 : 1) && g + 1 < KG) {
 #pragma unroll
             for (int ee = 0; ee < 4; ++ee) bvn[ee] = tap[8 * (g + 1) + 2 * ee + lh][l31];
           }
@@ -415,11 +421,11 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
             for (int mm = 0; mm < MTW; ++mm)
               wring[G % WD][mm] = wq[((size_t)mm * (KP / 8) + ((dbg & 4) ? (gn & 1) : ln * KG + gn)) * 64];
           }
-          if (step == 3 && i == 0 && g < (L - EARLY) * NPC) {   // one deferred window piece per group, finer level last
+          if (step == (MTW == 1 ? 2 : 3) && i == 0 && g < (L - EARLY) * NPC) {   // one deferred window piece per group, finer level last
             const int l = L - 1 - EARLY - g / NPC, k = g % NPC;
             v[l][k] = load_piece(slab0, goffs[l][k]);
           }
-          if (step == 5 && i + 1 < L && !(dbg & 2)) {
+          if (step == (MTW == 1 ? 4 : 5) && i + 1 < L && !(dbg & 2)) {
             if (dbg & 32) acc[0][0] += x.t00 + x.t01 + x.t10 + x.t11; else tap_store(i + 1, g, x);
           }
           if (step == 6 && i + 2 < L && g == KG - 1 && !(dbg & 64)) write_image(i + 2);
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
   for (int m = 0; m < MTW; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = (wv * MTW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int n = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       float y = acc[m][r];
       if (relu) y = fmaxf(y, 0.f);
       if (qlive) ob[(size_t)n * Q] = y;
@@ -741,9 +747,13 @@ extern "C" int pcfa_lookup_convc1_fwd(const float* pyr, const float* coords, con
     return PCFA_ERR_INVALID_ARG;
   if (num_levels != L || radius != R || Cout != 256) return PCFA_ERR_UNSUPPORTED;
   const int Q = H * W;
-  static const int dyn = getenv("PCFA_LC_DYNLDS") ? atoi(getenv("PCFA_LC_DYNLDS")) : 0;
-  pcfa_launch(corr_lookup_convc1_fwd_kernel, dim3(pcfa_cdiv(Q, QT), 1, B), dim3(NT), dyn, (hipStream_t)stream, pyr,
-              coords, packed, bias, out, Q, P, relu, 0);
+  static const int split = getenv("PCFA_LC_CSPLIT") ? atoi(getenv("PCFA_LC_CSPLIT")) : 1;   // dev A/B (tools/dev)
+  if (split == 2)
+    pcfa_launch(corr_lookup_convc1_fwd_kernel<1>, dim3(pcfa_cdiv(Q, QT), 2, B), dim3(NT), 0, (hipStream_t)stream, pyr,
+                coords, packed, bias, out, Q, P, relu, 0);
+  else
+    pcfa_launch(corr_lookup_convc1_fwd_kernel<2>, dim3(pcfa_cdiv(Q, QT), 1, B), dim3(NT), 0, (hipStream_t)stream, pyr,
+                coords, packed, bias, out, Q, P, relu, 0);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }

@@ -957,6 +957,32 @@ def _conv3x3_packed(weight):
     return hit[2], hit[3]
 
 
+_CONV_WS = {}   # device index -> scratch of pcfa_conv3x3_run (split-K partial outputs of the F(4x4,3x3) path)
+
+
+def _conv_workspace(device, nbytes):
+    """One scratch buffer per device, grown on demand OUTSIDE graph captures (every capture in this package follows
+    eager warm-up calls of the same shapes); the convolutions of one closure are stream-ordered on one stream."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _CONV_WS.get(idx)
+    if ws is None or ws.numel() * 4 < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("conv3x3 workspace would have to grow inside a graph capture (no eager warm-up of this "
+                               "shape ran before it)")
+        ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _CONV_WS[idx] = ws
+    return ws
+
+
+def _conv3x3_run(device, x_ptr, packed, bias_ptr, mask_ptr, addend_ptr, out_ptr, B, K, N, H, W, act=0, slope=0.):
+    """out = act(bias + conv3x3(x)) [masked] [+ addend] through pcfa_conv3x3_run (the library picks F(4x4,3x3) or
+    F(2x2,3x3) per shape); pointers are raw device addresses (or None)."""
+    nws = int(_hip.load().pcfa_conv3x3_workspace_bytes(B, K, N, H, W))
+    ws = _conv_workspace(device, nws) if nws else None
+    _call("pcfa_conv3x3_run", x_ptr, _ptr(packed), bias_ptr, mask_ptr, addend_ptr, out_ptr, B, K, N, H, W, int(act),
+          float(slope), _ptr(ws), nws)
+
+
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu, slope=None, skip=False, flags=0):
@@ -974,8 +1000,7 @@ class _Conv3x3(torch.autograd.Function):
         fwd, bwd = _conv3x3_packed(weight)
         out = torch.empty((B, N, H, W), device=x.device, dtype=torch.float32)
         act = 2 if slope is not None else int(bool(relu))
-        _call("pcfa_conv3x3_act_fwd", _ptr(x), _ptr(fwd), _ptr(bias), _ptr(out), B, K, N, H, W, act,
-              float(slope or 0.))
+        _conv3x3_run(x.device, _ptr(x), fwd, _ptr(bias), None, None, _ptr(out), B, K, N, H, W, act, float(slope or 0.))
         ctx.bwd, ctx.dims, ctx.act, ctx.slope = bwd, (B, K, N, H, W), act, float(slope or 0.)
         if ctx.grad_premasked and act != 1:
             raise ValueError("conv3x3: grad_premasked needs relu=True")
@@ -1003,10 +1028,10 @@ class _Conv3x3(torch.autograd.Function):
         gin = torch.empty((B, K, H, W), device=g.device, dtype=torch.float32)
         if g_skip is not None or ctx.mask_input_grad:
             xin = ctx.saved_tensors[-1] if ctx.mask_input_grad else None   # = a ReLU output: [xin > 0] is its mask
-            _call("pcfa_conv3x3_fused_bwd", _ptr(g), _ptr(ctx.bwd), _ptr(xin),
-                  _ptr(None if g_skip is None else g_skip.contiguous()), _ptr(gin), B, N, K, H, W)
+            _conv3x3_run(g.device, _ptr(g), ctx.bwd, None, _ptr(xin),
+                         _ptr(None if g_skip is None else g_skip.contiguous()), _ptr(gin), B, N, K, H, W)
         else:
-            _call("pcfa_conv3x3_fwd", _ptr(g), _ptr(ctx.bwd), None, _ptr(gin), B, N, K, H, W, 0)
+            _conv3x3_run(g.device, _ptr(g), ctx.bwd, None, None, None, _ptr(gin), B, N, K, H, W)
         return gin, None, None, None, None, None, None
 
 
@@ -1040,7 +1065,9 @@ class _Conv3x3Cat(torch.autograd.Function):
             offs.append(off)
             packs.append((bwd, w.shape[1], w.shape[0], off))
             off += w.shape[0]
-        if n_conv == 2 and (ws[0].shape[1] % 8 == 0) == (ws[1].shape[1] % 8 == 0) and _PAIR_LAUNCH:
+        lib = _hip.load()
+        f23 = all(lib.pcfa_conv3x3_algo(1, w.shape[1], w.shape[0], H, W) == 23 for w in ws)
+        if n_conv == 2 and (ws[0].shape[1] % 8 == 0) == (ws[1].shape[1] % 8 == 0) and _PAIR_LAUNCH and f23:
             # two independent convolutions, one launch: the smaller one's workgroups fill the larger one's last round
             i, j = (0, 1) if ws[0].shape[0] * ws[0].shape[1] >= ws[1].shape[0] * ws[1].shape[1] else (1, 0)
             _call("pcfa_conv3x3_act_fwd_pair", _ptr(xs[i]), _ptr(fwds[i]), _ptr(bs[i]), _ptr_off(buf, offs[i] * plane),
@@ -1048,8 +1075,8 @@ class _Conv3x3Cat(torch.autograd.Function):
                   _ptr_off(buf, offs[j] * plane), ws[j].shape[1], ws[j].shape[0], H, W, 1, 0.)
         else:
             for x, w, b, fwd, o_ in zip(xs, ws, bs, fwds, offs):
-                _call("pcfa_conv3x3_act_fwd", _ptr(x), _ptr(fwd), _ptr(b), _ptr_off(buf, o_ * plane), 1, w.shape[1],
-                      w.shape[0], H, W, 1, 0.)
+                _conv3x3_run(x.device, _ptr(x), fwd, _ptr(b), None, None, _ptr_off(buf, o_ * plane), 1, w.shape[1],
+                             w.shape[0], H, W, 1, 0.)
         for t in tails:
             buf[:, off:off + t.shape[1]].copy_(t)
             off += t.shape[1]
@@ -1076,10 +1103,10 @@ class _Conv3x3Cat(torch.autograd.Function):
                     _call("pcfa_relu_bwd", _ptr_off(buf, off * plane), _ptr_off(g, off * plane), _ptr(gm), n * plane)
                 gx = torch.empty((1, k, H, W), device=g.device, dtype=torch.float32)
                 if ctx.mask_input_grads:    # x_i is a ReLU output whose producer left its mask to this epilogue
-                    _call("pcfa_conv3x3_masked_fwd", _ptr(gm), _ptr(bwd), _ptr(ctx.saved_tensors[1 + i]), _ptr(gx), 1, n,
-                          k, H, W)
+                    _conv3x3_run(g.device, _ptr(gm), bwd, None, _ptr(ctx.saved_tensors[1 + i]), None, _ptr(gx), 1, n, k,
+                                 H, W)
                 else:
-                    _call("pcfa_conv3x3_fwd", _ptr(gm), _ptr(bwd), None, _ptr(gx), 1, n, k, H, W, 0)
+                    _conv3x3_run(g.device, _ptr(gm), bwd, None, None, None, _ptr(gx), 1, n, k, H, W)
             grads += [gx, None, None]
         off = sum(p[2] for p in ctx.packs)
         for j, tw in enumerate(ctx.tail_widths):
@@ -1128,8 +1155,8 @@ class _DenseBlock(torch.autograd.Function):
             if tuple(w.shape[1:]) != (k, 3, 3):
                 raise ValueError("dense_block: weight %s does not fit %d input channels" % (tuple(w.shape), k))
             fwd, bwd = _conv3x3_packed(w)
-            _call("pcfa_conv3x3_act_fwd", _ptr_off(buf, start * plane), _ptr(fwd), _ptr(b),
-                  _ptr_off(buf, (start - n) * plane), 1, k, n, H, W, 2, float(slope))
+            _conv3x3_run(x0.device, _ptr_off(buf, start * plane), fwd, _ptr(b), None, None,
+                         _ptr_off(buf, (start - n) * plane), 1, k, n, H, W, 2, float(slope))
             packs.append((bwd, k, n, start))
             start -= n
             k += n
@@ -1150,7 +1177,7 @@ class _DenseBlock(torch.autograd.Function):
             _call("pcfa_leaky_relu_bwd", _ptr_off(buf, (start - n) * plane), _ptr_off(gb, (start - n) * plane), _ptr(gm),
                   ctx.slope, n * plane)
             gin = torch.empty((1, k, H, W), device=g.device, dtype=torch.float32)
-            _call("pcfa_conv3x3_fwd", _ptr(gm), _ptr(bwd), None, _ptr(gin), 1, n, k, H, W, 0)
+            _conv3x3_run(g.device, _ptr(gm), bwd, None, None, None, _ptr(gin), 1, n, k, H, W)
             gb[:, start:].add_(gin)
         return (gb[:, total - K0:], None) + (None,) * (2 * len(ctx.packs))
 
