@@ -284,6 +284,8 @@ TRACED = {  # kernel-name fragment -> label
     "gemm_f32_mfma_kernel<true, true,": "corr_pyramid_gemm_fwd",
     "corr_pyramid_pool_gemm_kernel": "corr_pyramid_gemm_fwd",   # levels 1-2 pooled in the epilogue (W % 16 == 0)
     "gemm_f32_mfma_kernel<false, false,": "corr_pyramid_gemm_dfmap1",
+    "gemm_f32_mfma_sparse_kernel<false>": "corr_pyramid_gemm_dfmap1",   # only the slab columns the lookup windows touched
+    "gemm_f32_mfma_sparse_kernel<true>": "corr_pyramid_gemm_df2ext",
     "corr_pyramid_unpool_gemm_kernel<false>": "corr_pyramid_gemm_dfmap1",   # dpyr un-pooled in the operand loader
     "corr_pyramid_unpool_gemm_kernel<true>": "corr_pyramid_gemm_df2ext",
     "gemm_f32_mfma_kernel<false, true,": "corr_pyramid_gemm_df2ext",

@@ -106,6 +106,19 @@ PCFA_API size_t pcfa_corr_pyramid_bwd_workspace_bytes(int B, int D, int H, int W
 PCFA_API int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, const float* f2ext,
                           float* dfmap1, float* dfmap2, void* workspace, size_t workspace_bytes,
                           int B, int D, int H, int W, int num_levels, void* stream);
+/* The same backward with the lookups' coordinates: dpyr is zero outside the (2r+2)^2 windows its lookups touched
+ * (CorrBlock.__call__, models/raft/corr.py:29-50 -- 12 lookups per RAFT forward, all near the diagonal of the 4D
+ * volume), so both products skip the slab-column / query-row ranges no window reaches (per 128-wide block, bounding
+ * rows of the windows of ALL given lookups, one texel of slack: conservative for any coordinates).  `coords`: host
+ * array of n_coords (<= 32) device pointers to [B][2][H][W] coordinate tensors -- every lookup whose backward
+ * accumulated into dpyr; n_coords = 0 (or misaligned operands) computes the dense products of pcfa_corr_pyramid_bwd.
+ * Results are those of the dense form up to the summation order of the split-K partials (the skipped terms are exact
+ * zeros); deterministic.  workspace >= pcfa_corr_pyramid_bwd_windows_workspace_bytes(). */
+PCFA_API size_t pcfa_corr_pyramid_bwd_windows_workspace_bytes(int B, int D, int H, int W, int num_levels);
+PCFA_API int pcfa_corr_pyramid_bwd_windows(const float* dpyr, const float* fmap1, const float* f2ext, float* dfmap1,
+                                  float* dfmap2, void* workspace, size_t workspace_bytes,
+                                  const float* const* coords, int n_coords, int radius, int B, int D, int H, int W,
+                                  int num_levels, void* stream);
 
 /* CorrBlock.__call__ (models/raft/corr.py:29-50) + bilinear_sampler
  * (models/raft/utils/utils.py:57-71): coords [B][2][H][W] (x then y, pixel

@@ -35,6 +35,9 @@ SIGNATURES = {
     "pcfa_corr_pyramid_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_corr_pyramid_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "pcfa_corr_pyramid_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_corr_pyramid_bwd_windows_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "pcfa_corr_pyramid_bwd_windows": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, POINTER(c_void_p), c_int, c_int, c_int,
+                                              c_int, c_int, c_int, c_int, _P]),
     "pcfa_corr_lookup_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_corr_lookup_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_gemm_f32_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

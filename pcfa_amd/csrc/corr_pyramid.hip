@@ -210,13 +210,19 @@ __device__ __forceinline__ void tile_load_unpool(const float* __restrict__ X, lo
   }
 }
 
-template <bool A_KM, bool B_KN, bool FAST, bool POOL, bool UNPOOL = false>
+// SPARSE: the K range of a column block is a list of up to four segments (multiples of BK, ascending, read from
+// segs[(batch * gridDim.x + column block) * SEG_INTS]) instead of [0, K): the backward products of the correlation
+// pyramid skip the part of dpyr that no lookup window ever touched (corr_window_segments_kernel below).  The splits
+// share the ACTIVE steps of a block evenly.
+constexpr int SEG_INTS = 10;   // { count, (begin, end) x 4, pad }
+template <bool A_KM, bool B_KN, bool FAST, bool POOL, bool UNPOOL = false, bool SPARSE = false>
 __device__ __forceinline__ void gemm_f32_mfma_body(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
     int N, int K, long long lda, long long ldb, long long ldc, long long bsA, long long bsB,
     long long bsC, int splits, int kchunk, long long ssC, float div, int vecA, int vecB, const PoolArgs& pool,
-    const UnpoolArgs& unpool = UnpoolArgs{}) {
+    const UnpoolArgs& unpool = UnpoolArgs{}, const int* __restrict__ segs = nullptr) {
   static_assert(!UNPOOL || FAST, "the un-pooling loader is the branch-free one");
+  static_assert(!SPARSE || (FAST && !POOL && !UNPOOL), "segment lists ride on the branch-free loader");
   constexpr int SA = A_KM ? LDS_KM : LDS_MK;
   constexpr int SB = B_KN ? LDS_KM : LDS_MK;
   constexpr int STAGE = 2 * BK * SA + 2 * BK * SB;
@@ -230,8 +236,8 @@ __device__ __forceinline__ void gemm_f32_mfma_body(
   A += batch * bsA;
   B += batch * bsB;
   C += batch * bsC + split * ssC;
-  const int kbeg = split * kchunk;
-  const int kend = min(K, kbeg + kchunk);
+  int kbeg = split * kchunk;
+  const int kend = SPARSE ? K : min(K, kbeg + kchunk);
   // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the 8
   // XCDs, so consecutive linear ids land on different L2s; remapped, every XCD walks a contiguous band of tile rows
   // and re-reads its A band / the streamed B tiles from its own L2.  Speed only -- any placement is correct.
@@ -270,7 +276,27 @@ __device__ __forceinline__ void gemm_f32_mfma_body(
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[NLD], rb[NLD];
-  const int nk = (kend - kbeg + BK - 1) / BK;
+  int nk = (kend - kbeg + BK - 1) / BK;
+  int sb[4] = {0, 0, 0, 0}, se[4] = {0, 0, 0, 0}, seg = 0;
+  if (SPARSE) {
+    const int* sg = segs + ((long long)batch * gridDim.x + bx) * SEG_INTS;
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sb[i] = sg[1 + 2 * i];
+      se[i] = sg[2 + 2 * i];
+      total += (se[i] - sb[i]) / BK;
+    }
+    const int t0 = (int)((long long)total * split / splits), t1 = (int)((long long)total * (split + 1) / splits);
+    nk = t1 - t0;
+    int rem = t0;
+    while (seg < 3 && rem >= (se[seg] - sb[seg]) / BK) {
+      rem -= (se[seg] - sb[seg]) / BK;
+      ++seg;
+    }
+    kbeg = sb[seg] + rem * BK;   // first stage of this split
+  }
+  int kcur = kbeg;
   if (nk > 0) {
     if (FAST) {
       tile_load_fast<A_KM>(A, lda, M, m0, kbeg, kend, ra);
@@ -289,7 +315,15 @@ __device__ __forceinline__ void gemm_f32_mfma_body(
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    const int k0 = kbeg + (kt + 1) * BK;
+    int k0 = kbeg + (kt + 1) * BK;
+    if (SPARSE) {   // next stage: the following step of the segment, or the first step of the next non-empty segment
+      k0 = kcur + BK;
+      if (k0 >= se[seg] && seg < 3 && se[seg + 1] > sb[seg + 1]) {
+        ++seg;
+        k0 = sb[seg];
+      }
+      kcur = k0;
+    }
     if (FAST) {  // unconditional: the stage past the end re-reads the last one (clamped) and is never stored
       tile_load_fast<A_KM>(A, lda, M, m0, min(k0, kend - 4), kend, ra);
       if (UNPOOL) tile_load_unpool<B_KN>(B, ldb, N, n0, min(k0, kend - 4), kend, unpool, rb);
@@ -395,6 +429,15 @@ __device__ __forceinline__ void gemm_f32_mfma_body(
         if (row < M) C[(long long)row * ldc + col] = pow2 ? acc[i][j][r] * rdiv : acc[i][j][r] / div;
       }
     }
+}
+
+template <bool B_KN>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_sparse_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
+    int N, int K, long long lda, long long ldb, long long ldc, long long bsA, long long bsB,
+    long long bsC, int splits, long long ssC, float div, const int* __restrict__ segs) {
+  gemm_f32_mfma_body<false, B_KN, true, false, false, true>(A, B, C, M, N, K, lda, ldb, ldc, bsA, bsB, bsC, splits, 0,
+                                                            ssC, div, 1, 1, PoolArgs{}, UnpoolArgs{}, segs);
 }
 
 template <bool A_KM, bool B_KN, bool FAST>
@@ -537,6 +580,91 @@ size_t pooled_lds_bytes(const PyrLayout& P) {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 constexpr int BWD_SPLITS = 8;
+constexpr int MAX_COORDS = 32;
+
+struct CoordList {
+  const float* p[MAX_COORDS];
+  int n;
+};
+
+// Which part of dpyr can be non-zero?  Every lookup's backward adds into the (2r+2)^2 texels around
+// (cx / 2^l, cy / 2^l) of its queries (corr_lookup.hip); with the coordinates of all lookups of this backward pass the
+// rows a query row can have touched at level l are  floor(min cy / 2^l) - r - 1 .. floor(max cy / 2^l) + r + 2  (one
+// texel of slack on either side).  In the 4x4-tiled slab a range of tile rows is a contiguous range of columns, so
+//   segA[b][query block j] : per level, the slab-column segment the 128 queries of block j can have touched
+//                            (K segments of  dfmap1 = f2ext . dpyr^T);
+//   segB[b][column block j]: the range of query rows that can have touched the block's slab columns
+//                            (one K segment of  df2ext = fmap1 . dpyr).
+// One workgroup per batch item; rows first (thread per query row), then the two tables (thread per block).
+__global__ __launch_bounds__(256) void corr_window_segments_kernel(CoordList cl, int B, int H, int W, int r, PyrLayout P,
+                                                                    int nbA, int nbB, int* __restrict__ segA,
+                                                                    int* __restrict__ segB) {
+  extern __shared__ int s_rows[];   // [L][H][2]: lowest / highest texel row of level l touched by query row qy
+  const int b = blockIdx.x, Q = H * W;
+  for (int qy = threadIdx.x; qy < H; qy += blockDim.x) {
+    float lo = 3.0e38f, hi = -3.0e38f;
+    for (int i = 0; i < cl.n; ++i) {
+      const float* cy = cl.p[i] + ((long long)b * 2 + 1) * Q + (long long)qy * W;
+      for (int x = 0; x < W; ++x) {
+        const float v = cy[x];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+      }
+    }
+    for (int l = 0; l < P.L; ++l) {
+      const float inv = 1.0f / (float)(1 << l);
+      const float flo = fminf(fmaxf(floorf(lo * inv), -1.0e8f), 1.0e8f), fhi = fminf(fmaxf(floorf(hi * inv), -1.0e8f), 1.0e8f);
+      int ylo = (int)flo - r - 1, yhi = (int)fhi + r + 2;
+      if (!(lo <= hi)) { ylo = 0; yhi = P.h[l] - 1; }          // NaN coordinates: assume everything
+      s_rows[(l * H + qy) * 2] = max(ylo, 0);
+      s_rows[(l * H + qy) * 2 + 1] = min(yhi, P.h[l] - 1);     // (may be < the low end: nothing touched)
+    }
+  }
+  __syncthreads();
+  // table A: query block j = queries [128 j, 128 j + 127] = query rows qa..qb
+  for (int j = threadIdx.x; j < nbA; j += blockDim.x) {
+    const int qa = (j * BN) / W, qb = min((j * BN + BN - 1) / W, H - 1);
+    int* o = segA + ((long long)b * nbA + j) * SEG_INTS;
+    int n = 0;
+    for (int l = 0; l < P.L; ++l) {
+      int ylo = 1 << 30, yhi = -1;
+      for (int qy = qa; qy <= qb; ++qy) {
+        const int a = s_rows[(l * H + qy) * 2], c = s_rows[(l * H + qy) * 2 + 1];
+        if (a <= c) { ylo = min(ylo, a); yhi = max(yhi, c); }
+      }
+      if (ylo <= yhi) {
+        const int beg = P.off[l] + (ylo >> 2) * P.tw[l] * 16, end = P.off[l] + ((yhi >> 2) + 1) * P.tw[l] * 16;
+        if (n > 0 && o[2 * n] == beg) o[2 * n] = end;           // adjacent to the previous segment: merge
+        else { o[1 + 2 * n] = beg; o[2 + 2 * n] = end; ++n; }
+      }
+    }
+    o[0] = n;
+    for (int i = n; i < 4; ++i) { o[1 + 2 * i] = 0; o[2 + 2 * i] = 0; }
+    o[9] = 0;
+  }
+  // table B: column block j = slab columns [128 j, 128 j + 127]: hull of the query rows that reach any of its tile rows
+  for (int j = threadIdx.x; j < nbB; j += blockDim.x) {
+    const int ca = j * BN, cb = min(j * BN + BN, P.slab) - 1;
+    int qlo = 1 << 30, qhi = -1;
+    for (int l = 0; l < P.L; ++l) {
+      const int lbeg = P.off[l], lend = (l + 1 < P.L ? P.off[l + 1] : P.zero) - 1;
+      const int a = max(ca, lbeg), c = min(cb, lend);
+      if (a > c) continue;
+      const int ya = ((a - lbeg) / (P.tw[l] * 16)) * 4, yb = ((c - lbeg) / (P.tw[l] * 16)) * 4 + 3;   // texel rows
+      for (int qy = 0; qy < H; ++qy) {
+        const int ra = s_rows[(l * H + qy) * 2], rc = s_rows[(l * H + qy) * 2 + 1];
+        if (ra <= rc && ra <= yb && rc >= ya) { qlo = min(qlo, qy); qhi = max(qhi, qy); }
+      }
+    }
+    int* o = segB + ((long long)b * nbB + j) * SEG_INTS;
+    for (int i = 0; i < SEG_INTS; ++i) o[i] = 0;
+    if (qlo <= qhi) {
+      o[0] = 1;
+      o[1] = (qlo * W) / BK * BK;
+      o[2] = min(((qhi + 1) * W + BK - 1) / BK * BK, (Q + BK - 1) / BK * BK);
+    }
+  }
+}
 
 int choose_kchunk(int K, int splits) {
   int per = (K + splits - 1) / splits;
@@ -632,10 +760,59 @@ extern "C" size_t pcfa_corr_pyramid_bwd_workspace_bytes(int B, int D, int H, int
                           (size_t)B * D * S);
 }
 
+static int pyramid_bwd(const float* dpyr, const float* fmap1, const float* f2ext, float* dfmap1, float* dfmap2,
+                       void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int num_levels, void* stream,
+                       const int* segA, const int* segB);
+
 extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, const float* f2ext,
                                      float* dfmap1, float* dfmap2, void* workspace,
                                      size_t workspace_bytes, int B, int D, int H, int W,
                                      int num_levels, void* stream) {
+  return pyramid_bwd(dpyr, fmap1, f2ext, dfmap1, dfmap2, workspace, workspace_bytes, B, D, H, W, num_levels, stream,
+                     nullptr, nullptr);
+}
+
+extern "C" size_t pcfa_corr_pyramid_bwd_windows_workspace_bytes(int B, int D, int H, int W, int num_levels) {
+  PyrLayout P;
+  const size_t base = pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, num_levels);
+  if (base == 0 || !pcfa_make_layout(P, H, W, num_levels)) return 0;
+  const size_t nbA = (size_t)pcfa_cdiv((long long)H * W, BN), nbB = (size_t)pcfa_cdiv(P.slab, BN);
+  return ((base + 15) & ~(size_t)15) + sizeof(int) * SEG_INTS * B * (nbA + nbB);
+}
+
+extern "C" int pcfa_corr_pyramid_bwd_windows(const float* dpyr, const float* fmap1, const float* f2ext, float* dfmap1,
+                                             float* dfmap2, void* workspace, size_t workspace_bytes,
+                                             const float* const* coords, int n_coords, int radius, int B, int D, int H,
+                                             int W, int num_levels, void* stream) {
+  PyrLayout P;
+  if (!dpyr || !fmap1 || !f2ext || !dfmap1 || !dfmap2 || !workspace || B < 1 || D < 1 || radius < 0 ||
+      !pcfa_make_layout(P, H, W, num_levels))
+    return PCFA_ERR_INVALID_ARG;
+  const size_t base = (pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, num_levels) + 15) & ~(size_t)15;
+  const long long Q = (long long)H * W;
+  const bool fast = Q % 4 == 0 && aligned16(f2ext) && aligned16(dpyr) && aligned16(fmap1) && Q >= 4;
+  const size_t rows_lds = sizeof(int) * 2 * (size_t)P.L * H;
+  if (!coords || n_coords < 1 || n_coords > MAX_COORDS || !fast || rows_lds > 60 * 1024)   // no window information:
+    return pyramid_bwd(dpyr, fmap1, f2ext, dfmap1, dfmap2, workspace, workspace_bytes, B, D, H, W, num_levels, stream,
+                       nullptr, nullptr);                                                   // the dense products
+  if (workspace_bytes < pcfa_corr_pyramid_bwd_windows_workspace_bytes(B, D, H, W, num_levels)) return PCFA_ERR_WORKSPACE;
+  const int nbA = pcfa_cdiv(Q, BN), nbB = pcfa_cdiv(P.slab, BN);
+  int* segA = reinterpret_cast<int*>((char*)workspace + base);
+  int* segB = segA + (size_t)SEG_INTS * B * nbA;
+  CoordList cl;
+  cl.n = n_coords;
+  for (int i = 0; i < MAX_COORDS; ++i) cl.p[i] = i < n_coords ? coords[i] : nullptr;
+  for (int i = 0; i < n_coords; ++i)
+    if (!cl.p[i]) return PCFA_ERR_INVALID_ARG;
+  pcfa_launch(corr_window_segments_kernel, dim3(B), dim3(256), rows_lds, (hipStream_t)stream, cl, B, H, W, radius, P,
+              nbA, nbB, segA, segB);
+  PCFA_LAUNCH_CHECK();
+  return pyramid_bwd(dpyr, fmap1, f2ext, dfmap1, dfmap2, workspace, base, B, D, H, W, num_levels, stream, segA, segB);
+}
+
+static int pyramid_bwd(const float* dpyr, const float* fmap1, const float* f2ext, float* dfmap1, float* dfmap2,
+                       void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int num_levels, void* stream,
+                       const int* segA, const int* segB) {
   PyrLayout P;
   if (!dpyr || !fmap1 || !f2ext || !dfmap1 || !dfmap2 || !workspace || B < 1 || D < 1 ||
       !pcfa_make_layout(P, H, W, num_levels))
@@ -696,7 +873,11 @@ extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, cons
 #define PCFA_GEMM_ARGS f2ext, dpyr, part1, D, Q, S, (long long)S, (long long)S, (long long)Q, (long long)D * S, \
                        (long long)Q * S, (long long)D * Q, BWD_SPLITS, kchunk, (long long)B * D * Q, div, vec, vec
     // FAST: k (= slab index) is the contiguous axis of both operands; slab % 16 == 0 and kchunk % 16 == 0
-    if (vec)
+    if (segA != nullptr)   // only the slab columns some lookup window touched
+      pcfa_launch(gemm_f32_mfma_sparse_kernel<false>, grid, dim3(256), 0, s, f2ext, dpyr, part1, D, Q, S, (long long)S,
+                  (long long)S, (long long)Q, (long long)D * S, (long long)Q * S, (long long)D * Q, BWD_SPLITS,
+                  (long long)B * D * Q, div, segA);
+    else if (vec)
       pcfa_launch(gemm_f32_mfma_kernel<false, false, true>, grid, dim3(256), 0, s, PCFA_GEMM_ARGS);
     else
       pcfa_launch(gemm_f32_mfma_kernel<false, false, false>, grid, dim3(256), 0, s, PCFA_GEMM_ARGS);
@@ -715,7 +896,11 @@ extern "C" int pcfa_corr_pyramid_bwd(const float* dpyr, const float* fmap1, cons
     dim3 grid(pcfa_cdiv(S, BN), pcfa_cdiv(D, BM), B * BWD_SPLITS);
 #define PCFA_GEMM_ARGS fmap1, dpyr, part2, D, S, Q, (long long)Q, (long long)S, (long long)S, (long long)D * Q, \
                        (long long)Q * S, (long long)D * S, BWD_SPLITS, kchunk, (long long)B * D * S, div, vecA, vecB
-    if (vecA && vecB && Q >= 4)   // k = query index: contiguous in fmap1 (Q % 4 == 0), row index of dpyr
+    if (segB != nullptr)   // only the query rows whose windows reach the column block
+      pcfa_launch(gemm_f32_mfma_sparse_kernel<true>, grid, dim3(256), 0, s, fmap1, dpyr, part2, D, S, Q, (long long)Q,
+                  (long long)S, (long long)S, (long long)D * Q, (long long)Q * S, (long long)D * S, BWD_SPLITS,
+                  (long long)B * D * S, div, segB);
+    else if (vecA && vecB && Q >= 4)   // k = query index: contiguous in fmap1 (Q % 4 == 0), row index of dpyr
       pcfa_launch(gemm_f32_mfma_kernel<false, true, true>, grid, dim3(256), 0, s, PCFA_GEMM_ARGS);
     else
       pcfa_launch(gemm_f32_mfma_kernel<false, true, false>, grid, dim3(256), 0, s, PCFA_GEMM_ARGS);

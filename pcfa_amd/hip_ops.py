@@ -90,6 +90,7 @@ class DispatchTimer:
         "pcfa_corr_lookup_bwd": [("corr_lookup_bwd", 0)],
         "pcfa_corr_pyramid_fwd": [("corr_pyramid_gemm_fwd", 0)],
         "pcfa_corr_pyramid_bwd": [("corr_pyramid_gemm_dfmap1", 0), ("corr_pyramid_gemm_df2ext", 2)],
+        "pcfa_corr_pyramid_bwd_windows": [("corr_pyramid_gemm_dfmap1", 1), ("corr_pyramid_gemm_df2ext", 3)],
         "pcfa_corr_f2ext_fwd": [("corr_f2ext_fwd", 0)],
         "pcfa_spatial_corr_fwd": [("spatial_corr_fwd", 0)],
         "pcfa_spatial_corr_bwd": [("spatial_corr_bwd_in1", 0), ("spatial_corr_bwd_in2", 1)],
@@ -202,9 +203,12 @@ def _call(name, *args):
 # --------------------------------------------------------------------------- #
 # RAFT / GMA correlation pyramid
 # --------------------------------------------------------------------------- #
+PYRAMID_BWD_WINDOWS = True   # False: the dense backward products (A/B in tools, parity tests)
+
+
 class _CorrState:
     """Device buffers shared by the build node and its lookup nodes."""
-    __slots__ = ("B", "D", "H", "W", "L", "r", "slab", "pyr", "f2ext", "dpyr", "token_grad")
+    __slots__ = ("B", "D", "H", "W", "L", "r", "slab", "pyr", "f2ext", "dpyr", "token_grad", "coords_bwd")
 
 
 class _CorrBuild(torch.autograd.Function):
@@ -243,12 +247,16 @@ class _CorrBuild(torch.autograd.Function):
         B, D, H, W = st.B, st.D, st.H, st.W
         df1 = torch.empty_like(f1)
         df2 = torch.empty_like(f1)
-        nbytes = lib.pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, st.L)
+        # the coordinates of every lookup that accumulated into dpyr: the products skip what no window touched
+        cs = st.coords_bwd if (st.coords_bwd and len(st.coords_bwd) <= 32 and PYRAMID_BWD_WINDOWS) else []
+        nbytes = lib.pcfa_corr_pyramid_bwd_windows_workspace_bytes(B, D, H, W, st.L)
         ws = torch.empty((nbytes + 3) // 4, device=f1.device, dtype=torch.float32)
-        _call("pcfa_corr_pyramid_bwd", _ptr(st.dpyr), _ptr(f1), _ptr(st.f2ext), _ptr(df1), _ptr(df2),
-                                             _ptr(ws), ctypes.c_size_t(nbytes), B, D, H, W, st.L)
+        ptrs = (ctypes.c_void_p * max(len(cs), 1))(*[c.data_ptr() for c in cs])
+        _call("pcfa_corr_pyramid_bwd_windows", _ptr(st.dpyr), _ptr(f1), _ptr(st.f2ext), _ptr(df1), _ptr(df2), _ptr(ws),
+              ctypes.c_size_t(nbytes), ptrs, len(cs), st.r, B, D, H, W, st.L)
         st.dpyr = None
         st.token_grad = None
+        st.coords_bwd = None
         return df1, df2, None
 
 
@@ -287,6 +295,8 @@ class _CorrLookup(torch.autograd.Function):
         lib = _hip.load()
         if st.dpyr is None:
             st.dpyr = torch.zeros_like(st.pyr)
+            st.coords_bwd = []
+        st.coords_bwd.append(c)
         g = grad_out.contiguous()
         _call("pcfa_corr_lookup_bwd", _ptr(st.dpyr), _ptr(c), _ptr(g), st.B, st.H, st.W, st.L, st.r)
         return _token_grad(st, g.device), None, None
@@ -338,6 +348,8 @@ class _CorrLookupConv(torch.autograd.Function):
         c, out = ctx.saved_tensors
         if st.dpyr is None:
             st.dpyr = torch.zeros_like(st.pyr)
+            st.coords_bwd = []
+        st.coords_bwd.append(c)
         g = grad_out.contiguous()
         _call("pcfa_lookup_convc1_bwd", _ptr(st.dpyr), _ptr(c), _ptr(ctx.packed), _ptr(out), _ptr(g), st.B, st.H, st.W,
               st.L, st.r, ctx.cout, ctx.relu)
@@ -362,6 +374,7 @@ class CorrBlock:
             raise ValueError("feature map %dx%d too small for %d pyramid levels" % (st.H, st.W, num_levels))
         st.dpyr = None
         st.token_grad = None
+        st.coords_bwd = None
         self._state = st
         self._token = _CorrBuild.apply(fmap1, fmap2, st)
 

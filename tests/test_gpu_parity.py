@@ -96,6 +96,50 @@ def test_corr_block_other_radii_and_levels(oracle_ops, levels, radius):
     assert rel_l2(f1g.grad, f1c.grad) < 2e-5 and rel_l2(f2g.grad, f2c.grad) < 2e-5
 
 
+@pytest.mark.parametrize("case", ["raft", "wild", "ragged"])
+def test_pyramid_backward_windows_matches_dense(case):
+    """CorrBlock's backward (corr.py:13-27,52-60 through autograd) skips the part of the volume's gradient that no
+    lookup window touched (pcfa_corr_pyramid_bwd_windows: per 128-wide block, bounding rows of ALL lookups' windows).
+    The skipped terms are exact zeros, so the result must equal the dense products up to the order in which the
+    split-K partials are summed: 2e-6 relative L2.  'raft': 12 lookups drifting from the identity like a refinement;
+    'wild': coordinates far outside the map, huge jumps between lookups, one lookup whose output gets no gradient;
+    'ragged': 23 x 37 features (blocks straddle query rows, Q % 16 != 0 -> the dense fallback must still agree)."""
+    B, D, H, W = (1, 64, 23, 37) if case == "ragged" else (2, 64, 55, 128)
+    gen = torch.Generator().manual_seed(17)
+    f1 = torch.randn(B, D, H, W, generator=gen).to(DEV)
+    f2 = torch.randn(B, D, H, W, generator=gen).to(DEV)
+    base = _grid(B, H, W)
+    coords, n = [], 12 if case == "raft" else 5
+    for i in range(n):
+        if case == "wild":
+            c = base + (40.0 * i) * torch.randn(B, 2, 1, 1, generator=gen) + 30 * torch.randn(B, 2, H, W, generator=gen)
+        else:
+            c = base + 0.7 * i * torch.randn(B, 2, 1, 1, generator=gen) + (0.3 + 0.2 * i) * torch.randn(B, 2, H, W, generator=gen)
+        coords.append(c.to(DEV))
+    gos = [torch.randn(B, 324, H, W, generator=gen).to(DEV) for _ in range(n)]
+
+    def run(windows):
+        hip_ops.PYRAMID_BWD_WINDOWS = windows
+        try:
+            a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+            blk = hip_ops.CorrBlock(a, b)
+            loss = 0.
+            for i, (c, g) in enumerate(zip(coords, gos)):
+                out = blk(c)
+                if not (case == "wild" and i == 2):      # this lookup's backward never runs
+                    loss = loss + (out * g).sum()
+            loss.backward()
+            return a.grad, b.grad
+        finally:
+            hip_ops.PYRAMID_BWD_WINDOWS = True
+
+    (a1, b1), (a0, b0) = run(True), run(False)
+    assert float(a0.abs().max()) > 0 and float(b0.abs().max()) > 0
+    assert rel_l2(a1, a0) < 2e-6 and rel_l2(b1, b0) < 2e-6, (rel_l2(a1, a0), rel_l2(b1, b0))
+    (a2, b2) = run(True)
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)       # deterministic
+
+
 def test_pyramid_backward_unpool_variant_matches_default():
     """PCFA_PYRAMID_UNPOOL=1 (opt-in, slower: see corr_pyramid.hip): the backward products over the level-0 columns with
     dpyr un-pooled in the operand loader, in a child process (the switch is read once per process) against the default
