@@ -30,7 +30,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int R = 4, N1 = 9, WIN = 10, TXN = 4, PIECES = WIN * TXN;  // window geometry (corr_lookup.hip, Geo<4>)
 constexpr int RS = 20, WS = WIN * RS + 4, NRD = 3;                    // LDS image: row stride, window stride
 constexpr int QT = 32;                                               // queries per workgroup
-constexpr int NT = 256;                                              // threads (4 waves)
+constexpr int NT = 256;                                              // threads that load / run the matrix work (4 waves)
+constexpr int NTF = NT + 64;                                         // forward: + one auxiliary wave (tap row 8)
 constexpr int NPC = QT * PIECES / NT;                                // 5 pieces per thread and level
 constexpr int L = 4, TAPS = N1 * N1;                                 // 81 taps per level
 constexpr int KL = 88, KG = KL / 8;                                  // padded tap rows per level, groups of 8 rows
@@ -224,10 +225,12 @@ __global__ void convc1_pack_kernel(const float* __restrict__ w, float* __restric
 // forward
 // ---------------------------------------------------------------------------------------------------------------
 // MTW = row tiles (32 output channels) per wave: 2 = one workgroup per query tile owns all 256 channels (220 workgroups
-// at 55x128); 1 = the channels are split over two workgroups (blockIdx.y) that both gather and blend the tile's taps
-// and share a CU, two waves per SIMD: each wave's LDS / L2 waits hide behind the other's MFMAs.
+// at 55x128).  (MTW = 1 -- the channels split over two workgroups per tile that share a CU, two waves per SIMD -- was
+// measured: both workgroups gather and blend the whole tile, 21.0 us against 19.8.)
+// Threads: waves 0-3 load the windows, blend tap rows 0-7 and run the matrix work; wave 4 only blends tap row 8 (9 rows
+// x 32 queries = 288 (query, row) items: 256 + 32).
 template <int MTW>
-__global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
+__global__ __launch_bounds__(NTF) void corr_lookup_convc1_fwd_kernel(
     const float* __restrict__ pyr, const float* __restrict__ coords, const float* __restrict__ wp,
     const float* __restrict__ bias, float* __restrict__ out, int Q, PyrLayout P, int relu, int /*unused*/) {
   constexpr int dbg = PCFA_LC_DBG_BUILD;             // phase ablation is a build-time switch: a runtime one put 130
@@ -254,8 +257,53 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
   const float* cb = coords + (size_t)b_img * 2 * Q;
   const int qj = min(q0 + j, Q - 1), qk = min(q0 + kq, Q - 1);
   const float cx = cb[qj], cy = cb[Q + qj], kx = cb[qk], ky = cb[Q + qk];
-  const float bias_mine = bias[tid];                  // -> LDS, read back by the epilogue
+  const float bias_mine = bias[min(tid, COUT - 1)];   // -> LDS, read back by the epilogue
   const float* slab0 = scalar_ptr(pyr + ((size_t)b_img * Q + q0) * P.slab);
+
+  if (wv == 4) {
+    // ---- auxiliary wave: tap row 8 of every query (lanes 0-31), in step with the main waves' barriers; it also
+    //      clears the zero rows 81..87 of both tap tiles once ----
+    float fxa[L], fya[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const Origin o = make_origin(cx, cy, l);
+      fxa[l] = o.fx;
+      fya[l] = o.fy;
+    }
+    for (int e = lane; e < 2 * (KL - TAPS) * QT; e += 64) {
+      const int buf = e / ((KL - TAPS) * QT), r = e - buf * ((KL - TAPS) * QT);
+      s_tap[buf][TAPS + r / QT][r % QT] = 0.f;
+    }
+    auto aux_blend = [&](int i) {
+      if (lane < QT) {
+        const int l = L - 1 - i;
+        const float fx = fxa[l], fy = fya[l];
+        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+        const f32x4* pa = reinterpret_cast<const f32x4*>(&s_win2[i & 1][j * WS + (N1 - 1) * RS + 4]);
+        const f32x4* pb = reinterpret_cast<const f32x4*>(&s_win2[i & 1][j * WS + N1 * RS + 4]);
+        const f32x4 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+        const float ra[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+        const float rb[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+        for (int a = 0; a < N1; ++a)
+          s_tap[i & 1][a * N1 + (N1 - 1)][j] = ra[a] * w00 + ra[a + 1] * w01 + rb[a] * w10 + rb[a + 1] * w11;
+      }
+    };
+    if (dbg & 16) {
+      __syncthreads();
+      return;
+    }
+    __syncthreads();   // (1) the coarsest level's image is written
+    if (!(dbg & 2)) aux_blend(0);
+    __syncthreads();   // (2) prologue
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      if (i + 1 < L && !(dbg & 2)) aux_blend(i + 1);
+      __syncthreads();
+    }
+    if (dbg & 8) __syncthreads();
+    return;
+  }
 
   // ---- every piece of all four levels is requested before anything waits; coarsest level first: its windows are
   //      L2-resident and land first, so the matrix cores start while the level-0 texels are still on their way.
@@ -305,7 +353,7 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
     }
   }
 
-  s_bias[tid] = bias_mine;
+  s_bias[tid] = bias_mine;   // (tid < 256 here: the auxiliary wave has left)
 
   // Pipeline over the levels in stream order i = 0..3 (level L-1-i), ONE barrier per level:
   //   before iteration i : taps(i) are in s_tap[i & 1], the window image of i+1 is in s_win2[(i+1) & 1]
@@ -322,29 +370,25 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
       d[0] = v[l][k].x; d[1] = v[l][k].y; d[2] = v[l][k].z; d[3] = v[l][k].w;
     }
   };
-  // Blend, branch-free and evenly spread: thread (query j, b8 = tid >> 5) owns taps t = b8 + 8k, k = 0..10, of the 88
-  // rows of the tap tile (t >= 81 are the zero rows, rewritten every level); tap t = a*9 + b reads its 2x2 texels
-  // straight from the window image (four dword LDS reads).  The reads (tap_texels) and the arithmetic + store
-  // (tap_store) are separate steps so that a whole MFMA group sits between an LDS read and its first use.
-  struct Texels { float t00, t01, t10, t11; };
-  auto tap_texels = [&](int i, int k) {
-    const int t = (tid >> 5) + 8 * k;
-    const bool valid = t < TAPS;
-    const int a = valid ? (t * 57) >> 9 : 0;            // t / 9 for t < 88
-    const int b = valid ? t - 9 * a : 0;
-    const float* p = &s_win2[i & 1][j * WS + b * RS + 4 + a];
-    return Texels{p[0], p[1], p[RS], p[RS + 1]};
+  // Blend: thread (query j, b8 = tid >> 5) owns tap ROW b8 of its query's window, the nine taps (a, b8), a = 0..8.  They
+  // share two window rows: six aligned 16-B LDS reads (the un-fused kernel's scheme, corr_lookup.hip) instead of 4 dword
+  // reads per tap -- the first version gave every thread eleven scattered taps (44 dword reads, 77 VALU per level) and
+  // the matrix pipe waited ~1-2 k cycles per level for them.  Row 8 belongs to the auxiliary wave.
+  struct Rows { f32x4 a[3], b[3]; };
+  auto row_read = [&](int i, int b, f32x4 (&dst)[3]) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(&s_win2[i & 1][j * WS + b * RS + 4]);
+    dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
   };
-  auto tap_store = [&](int i, int k, const Texels& x) {
+  auto tap_out = [&](int i, int a, int b, const Rows& R) {   // tap (a, b) of stream level i from rows b, b + 1
     const int l = L - 1 - i;
     const float fx = fxs[l], fy = fys[l];
     const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
-    const int t = (tid >> 5) + 8 * k;
-    const float val = x.t00 * w00 + x.t01 * w01 + x.t10 * w10 + x.t11 * w11;     // as corr_lookup_fwd_body
-    s_tap[i & 1][t][j] = t < TAPS ? val : 0.f;
+    const float t00 = R.a[a >> 2][a & 3], t01 = R.a[(a + 1) >> 2][(a + 1) & 3];
+    const float t10 = R.b[a >> 2][a & 3], t11 = R.b[(a + 1) >> 2][(a + 1) & 3];
+    s_tap[i & 1][a * N1 + b][j] = t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;     // as corr_lookup_fwd_body
   };
-  constexpr int NBK = KL / 8;   // 11 tap slices per level
-  static_assert(NBK == KG, "one tap slice rides under each MFMA group");
+  const int b8 = tid >> 5;
+  static_assert(KG >= N1 + 1, "one tap of the row rides under each of the MFMA groups 1..9");
 
   if (dbg & 16) {    // arrival time of every level's windows (the image writes wait for them); results are garbage
 #pragma unroll
@@ -368,11 +412,11 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = s_bias[(mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
   if (!(dbg & 2)) {
-    Texels x[NBK];
+    Rows R0;
+    row_read(0, b8, R0.a);
+    row_read(0, b8 + 1, R0.b);
 #pragma unroll
-    for (int k = 0; k < NBK; ++k) x[k] = tap_texels(0, k);
-#pragma unroll
-    for (int k = 0; k < NBK; ++k) tap_store(0, k, x[k]);
+    for (int a = 0; a < N1; ++a) tap_out(0, a, b8, R0);
   }
   write_image(1);
   __syncthreads();
@@ -387,15 +431,16 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
     float bv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = tap[2 * e + lh][l31];     // group 0 of the level: written before the barrier
+    Rows R;   // the two window rows of the NEXT level's tap row b8 (read under group 0, one tap per group 1..9)
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       const int G = i * KG + g;                      // position in the W stream (compile-time after unrolling)
       // Eight MFMAs, each followed by a small chunk of the other work (a 64-cycle MFMA leaves ~12 issue slots), the
       // scheduler fenced after every pair so the chunks stay where they are put:
-      //   after MFMA 0: this group's texel reads      after MFMA 1: the next group's tap reads
-      //   after MFMA 2: the W group WD ahead          after MFMA 5: blend arithmetic + tap store (texels are 4 MFMAs old)
+      //   after MFMA 0 / 4 (group 0): the next level's two window rows (3 x 16-B LDS reads each)
+      //   after MFMA 1: the next group's tap reads      after MFMA 2: the W group WD ahead
+      //   after MFMA 5 (groups 1..9): one tap of the next level: blend arithmetic + store
       //   after MFMA 6: (last group) the image of level i + 2
-      Texels x{0.f, 0.f, 0.f, 0.f};
       float bvn[4] = {0.f, 0.f, 0.f, 0.f};
       f32x4 wcur[MTW];
 #pragma unroll
@@ -410,7 +455,8 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
             const float av = e == 0 ? wcur[m].x : e == 1 ? wcur[m].y : e == 2 ? wcur[m].z : wcur[m].w;
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[e], acc[m], 0, 0, 0);
           }
-          if (step == 0 && i + 1 < L && !(dbg & 2)) x = tap_texels(i + 1, g);
+          if (step == 0 && g == 0 && i + 1 < L && !(dbg & 2)) row_read(i + 1, b8, R.a);
+          if (step == 4 && g == 0 && i + 1 < L && !(dbg & 2)) row_read(i + 1, b8 + 1, R.b);
           if (step == (MTW == 1 ? 0 : 1) && g + 1 < KG) {
 #pragma unroll
             for (int ee = 0; ee < 4; ++ee) bvn[ee] = tap[8 * (g + 1) + 2 * ee + lh][l31];
@@ -425,9 +471,7 @@ __global__ __launch_bounds__(NT) void corr_lookup_convc1_fwd_kernel(
             const int l = L - 1 - EARLY - g / NPC, k = g % NPC;
             v[l][k] = load_piece(slab0, goffs[l][k]);
           }
-          if (step == (MTW == 1 ? 4 : 5) && i + 1 < L && !(dbg & 2)) {
-            if (dbg & 32) acc[0][0] += x.t00 + x.t01 + x.t10 + x.t11; else tap_store(i + 1, g, x);
-          }
+          if (step == (MTW == 1 ? 4 : 5) && i + 1 < L && g >= 1 && g <= N1 && !(dbg & 2)) tap_out(i + 1, g - 1, b8, R);
           if (step == 6 && i + 2 < L && g == KG - 1 && !(dbg & 64)) write_image(i + 2);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -747,13 +791,8 @@ extern "C" int pcfa_lookup_convc1_fwd(const float* pyr, const float* coords, con
     return PCFA_ERR_INVALID_ARG;
   if (num_levels != L || radius != R || Cout != 256) return PCFA_ERR_UNSUPPORTED;
   const int Q = H * W;
-  static const int split = getenv("PCFA_LC_CSPLIT") ? atoi(getenv("PCFA_LC_CSPLIT")) : 1;   // dev A/B (tools/dev)
-  if (split == 2)
-    pcfa_launch(corr_lookup_convc1_fwd_kernel<1>, dim3(pcfa_cdiv(Q, QT), 2, B), dim3(NT), 0, (hipStream_t)stream, pyr,
-                coords, packed, bias, out, Q, P, relu, 0);
-  else
-    pcfa_launch(corr_lookup_convc1_fwd_kernel<2>, dim3(pcfa_cdiv(Q, QT), 1, B), dim3(NT), 0, (hipStream_t)stream, pyr,
-                coords, packed, bias, out, Q, P, relu, 0);
+  pcfa_launch(corr_lookup_convc1_fwd_kernel<2>, dim3(pcfa_cdiv(Q, QT), 1, B), dim3(NTF), 0, (hipStream_t)stream, pyr,
+              coords, packed, bias, out, Q, P, relu, 0);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
