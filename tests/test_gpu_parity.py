@@ -1215,6 +1215,25 @@ def test_universal_closure_on_gpu_vs_oracle(oracle_ops):
     assert torch.equal(red.flat[:3 * 128 * 160].cpu(), ge[0].flatten())
 
 
+def test_schedule_parity_at_baseline_size_vs_cpu_port():
+    """The whole schedule at 436x1024 (BASELINE config 2): best-iterate AEE(adv, target), AEE(adv, init) and ||delta|| of
+    a PCFA attack on the GPU against the CPU port, inside 3x the port's own spread between two thread counts
+    (tools/schedule_parity.py).  3 steps (33 closure evaluations) here -- the 20-step run takes ten minutes
+    of host time and is committed as profiles/r03_schedule_parity_20steps.json (PCFA_SCHEDULE_PARITY_STEPS=20 runs it)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    steps = os.environ.get("PCFA_SCHEDULE_PARITY_STEPS", "3")
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "schedule_parity.py"), "--steps", steps,
+                        "--threads", "16,8"], capture_output=True, text=True, timeout=3000, env=_rank_env())
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stderr[-3000:]
+    out = json.loads(lines[-1])
+    assert out["ok"] and r.returncode == 0, out["metrics"]
+
+
 def _rank_env():
     import os
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",

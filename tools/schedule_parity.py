@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""End-of-attack parity at the BASELINE size: the same PCFA schedule -- N steps of
+L-BFGS(max_iter=10) on one synthetic 436x1024 pair, RAFT, change of variables, zero target, delta_bound 0.005
+(attack_PCFA.py:40-294, BASELINE config 2) -- on the GPU (the product: HIP kernels, captured closure) and on the CPU
+port (the same host code with the oracle operators and torch.optim.LBFGS) at TWO host thread counts.  The port's own
+spread between the two thread counts is the noise floor of the comparison: an un-damped L-BFGS attack
+amplifies last-bit differences, so the bar for the best-iterate results (aee_adv_tgt_min, aee_adv_init at the best
+iterate, ||delta|| of the best iterate) is  |gpu - port| <= max(floor, 3 x |port_a - port_b|).
+
+    python tools/schedule_parity.py [--steps 20] [--threads 16,8] [--size 436x1024] [--net RAFT] [--out FILE.json]
+Prints one JSON object; exit code 1 when the bar is missed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+FLOORS = {"aee_adv_tgt_min": 1e-3, "aee_adv_init_at_min": 1e-3, "l2_delta_min": 1e-5}
+
+
+def run(net, h, w, steps, device, threads=None, progress=None):
+    from pcfa_amd import ops
+    t0 = time.perf_counter()
+    if device.type == "cpu":
+        from oracle import ops as oracle_ops
+        torch.set_num_threads(threads)
+        with ops.override_for_testing(oracle_ops):
+            st = bench.AttackStepper(net, h, w, device, seed=0)
+            hist = []
+            for k in range(steps):
+                hist.append(st.step())
+                if progress:
+                    print("%s step %d/%d %s (%.0f s)" % (progress, k + 1, steps, hist[-1], time.perf_counter() - t0),
+                          file=sys.stderr, flush=True)
+            res = st.result()
+    else:
+        st = bench.AttackStepper(net, h, w, device, seed=0, use_graph=True)
+        hist = [st.step() for _ in range(steps)]
+        res = st.result()
+    return {"per_step": [dict(zip(("aee_adv_tgt", "aee_adv_init", "l2_delta"), s)) for s in hist],
+            "aee_adv_tgt_min": res[9], "aee_adv_init_at_min": res[10], "l2_delta_min": res[11],
+            "aee_adv_tgt_final": res[4], "aee_adv_init_final": res[5], "l2_delta_final": res[8],
+            "seconds": time.perf_counter() - t0, "threads": threads}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--threads", default="16,8")
+    ap.add_argument("--size", default="436x1024")
+    ap.add_argument("--net", default="RAFT")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    h, w = (int(v) for v in a.size.split("x"))
+    ta, tb = (int(v) for v in a.threads.split(","))
+    gpu = run(a.net, h, w, a.steps, torch.device("cuda", 0))
+    gpu2 = run(a.net, h, w, a.steps, torch.device("cuda", 0))       # the GPU's own run-to-run spread (MIOpen atomics)
+    pa = run(a.net, h, w, a.steps, torch.device("cpu"), ta, progress="port[%d threads]" % ta)
+    pb = run(a.net, h, w, a.steps, torch.device("cpu"), tb, progress="port[%d threads]" % tb)
+    rows, ok = {}, True
+    for k, floor in FLOORS.items():
+        spread = abs(pa[k] - pb[k])
+        tol = max(floor, 3 * spread)
+        diff = abs(gpu[k] - pa[k])
+        rows[k] = {"gpu": gpu[k], "gpu_rerun": gpu2[k], "port_a": pa[k], "port_b": pb[k], "port_spread": spread,
+                   "gpu_minus_port_a": gpu[k] - pa[k], "tolerance": tol, "ok": diff <= tol}
+        ok = ok and diff <= tol
+    out = {"what": "best-iterate results of a %d-step PCFA attack, %s %dx%d, GPU vs CPU port" % (a.steps, a.net, h, w),
+           "rule": "|gpu - port_a| <= max(floor, 3 x |port_a - port_b|) (SURVEY D10)", "ok": ok, "metrics": rows,
+           "gpu": gpu, "gpu_rerun": gpu2, "port_a": pa, "port_b": pb}
+    txt = json.dumps(out)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(txt + "\n")
+    print(txt)
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
