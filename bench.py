@@ -613,12 +613,13 @@ def main():
         # extra, eagerly launched step right after the timed region -- with the lookup -> convc1 fusion switched OFF,
         # so that this step also yields the un-fused lookup kernel's own roofline row
         st.graphed = st.repredict = None
-        os.environ["PCFA_FUSED_LOOKUP"] = "0"
+        from pcfa_amd.nets import raft as raft_net
+        raft_net.FUSED_LOOKUP = False
         hip_ops.set_dispatch_timer(prof)
         st.step()
         torch.cuda.synchronize()
         hip_ops.set_dispatch_timer(None)
-        os.environ.pop("PCFA_FUSED_LOOKUP")
+        raft_net.FUSED_LOOKUP = True
 
     # a second pair of the same shape: PairAttack adopts the first pair's static buffers, graphs and optimiser
     second_pair = None

@@ -135,6 +135,7 @@ class SplitGraphedClosure:
                 self.loss.backward()
         self.grads = [p.grad for p in self.params]
         self.loss_value = self.loss.detach()
+        self._versions = []
         self.fresh = False          # True: F was replayed at the current values of `params` and B has not consumed it
         self.replays = 0
         self.forwards_shared = 0
@@ -142,12 +143,17 @@ class SplitGraphedClosure:
     def forward(self):
         self.fwd_graph.replay()
         self.fresh = True
+        self._versions = [p._version for p in self.params]
         return self.loss_value, self.aux
 
     def invalidate(self):
         self.fresh = False
 
     def __call__(self):
+        # a forward is only reusable if nobody wrote to the variables since it ran (in-place writes bump _version);
+        # other inputs of the loss (target, images) are the caller's to announce through invalidate()
+        if self.fresh and any(p._version != v for p, v in zip(self.params, self._versions)):
+            self.fresh = False
         if self.fresh:
             self.forwards_shared += 1
         else:

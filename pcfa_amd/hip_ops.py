@@ -479,6 +479,8 @@ class _PwcCostVolume(torch.autograd.Function):
     def backward(ctx, grad_output):
         input1, input2, out = ctx.saved_tensors
         g = grad_output.contiguous()
+        if g.data_ptr() % 16:          # a view with a storage offset: the kernel stages 16-B pieces
+            g = g.clone()
         g1, g2 = torch.empty_like(input1), torch.empty_like(input2)
         _call("pcfa_cost_volume9_bwd", _ptr(input1), _ptr(input2), _ptr(out), _ptr(g), _ptr(g1), _ptr(g2), *ctx.args)
         return g1, g2, None
@@ -486,7 +488,8 @@ class _PwcCostVolume(torch.autograd.Function):
 
 def pwc_cost_volume(input1, input2, slope=0.1):
     """PWC-Net's `leakyRELU(correlate(input1, input2))`: [B,C,H,W] x2 -> [B,81,H,W]."""
-    if input1.shape[-1] % 4 != 0 or input1.shape != input2.shape:   # the fused kernels stage 16-B pieces
+    misaligned = any(t.is_contiguous() and t.data_ptr() % 16 for t in (input1, input2))
+    if input1.shape[-1] % 4 != 0 or input1.shape != input2.shape or misaligned:   # the fused kernels stage 16-B pieces
         out = spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=9, stride=1)
         b, ph, pw, h, w = out.size()
         return torch.nn.functional.leaky_relu(out.view(b, ph * pw, h, w) / input1.size(1), slope)
@@ -1357,11 +1360,14 @@ def gemm_f32(a, b, a_kmajor, b_kmajor, alpha=1.0, splits=1, out=None):
     return out
 
 
+GMA_GEMM = os.environ.get("PCFA_GMA_GEMM", "lib")   # "lib" | "hip": read once at import; tests assign the attribute
+
+
 def _attn_mm(a, b, a_kmajor, b_kmajor, alpha=1.0, splits=1):
     """A plain GEMM of the attention block.  Default: the library (rocBLAS through torch.matmul) -- these are plain
     dense products and it runs them at 107-126 TFLOP/s; PCFA_GMA_GEMM=hip routes them through pcfa_gemm_f32 (80-105
     TFLOP/s, tools/bench_gemm.py), which the parity test exercises either way."""
-    if os.environ.get("PCFA_GMA_GEMM", "lib") == "hip":
+    if GMA_GEMM == "hip":
         return gemm_f32(a, b, a_kmajor, b_kmajor, alpha=alpha, splits=splits)
     at = a.transpose(-1, -2) if a_kmajor else a
     bt = b if b_kmajor else b.transpose(-1, -2)
@@ -1373,7 +1379,7 @@ class _AttentionSoftmax(torch.autograd.Function):
     """attn = softmax(scale * q k^T) (gma.py:52-74, content-only branch): the similarity product (plain GEMM), then the
     row softmax as ONE read and ONE write of the [N, N] matrix, in place (pcfa_softmax_rows_fwd: a 28 KB row lives in
     the registers of one workgroup; the library makes three passes), and the same in the backward: d sim = attn * (g -
-    rowsum(g * attn)) in place on the incoming gradient, dq = scale * dsim k, dk = scale * dsim^T q."""
+    rowsum(g * attn)) in one pass, dq = scale * dsim k, dk = scale * dsim^T q."""
 
     @staticmethod
     def forward(ctx, q, k, scale):
@@ -1392,7 +1398,10 @@ class _AttentionSoftmax(torch.autograd.Function):
         q, k, attn = ctx.saved_tensors
         g = g.contiguous()
         n = attn.shape[-1]
-        ds = g if g.data_ptr() != attn.data_ptr() else torch.empty_like(g)
+        # never in place on `g`: autograd forbids mutating a gradient it hands in (a hook, retain_grad() on the attention
+        # matrix or a second consumer would see the overwritten values).  Same traffic either way (one read of attn and
+        # g, one write); the price is a 198 MB temporary at 55x128.
+        ds = torch.empty_like(g)
         _call("pcfa_softmax_rows_bwd", _ptr(attn), _ptr(g), _ptr(ds), attn.numel() // n, n)
         dq = _attn_mm(ds, k, 0, 1, alpha=ctx.scale, splits=8) if ctx.needs_input_grad[0] else None    # dsim k
         dk = _attn_mm(ds, q, 1, 1, alpha=ctx.scale, splits=8) if ctx.needs_input_grad[1] else None    # dsim^T q

@@ -58,6 +58,9 @@ def _fold_batchnorm(conv, bn, cache, tag):
 
 
 _DEFER_RELU = os.environ.get("PCFA_DEFER_RELU", "1") != "0"   # A/B switch: ReLU backward fused into neighbouring kernels
+# Module-level switches, read from the environment ONCE at import (defaults for tools); code that needs another setting
+# assigns the attribute (bench.py, tests) -- nothing reads os.environ at call time.
+FUSED_LOOKUP = os.environ.get("PCFA_FUSED_LOOKUP", "1") == "1"   # lookup -> convc1 -> ReLU in one launch
 
 
 def _conv_norm(conv, norm, x, relu, cache, tag, skip=False, grad_premasked=False, mask_input_grad=False):
@@ -336,7 +339,7 @@ class LookupRef:
 
     def conv_relu(self, conv):
         fused = getattr(self.corr_fn, "lookup_conv_relu", None)
-        if fused is not None and _frozen_conv(conv) and os.environ.get("PCFA_FUSED_LOOKUP", "1") == "1":
+        if fused is not None and _frozen_conv(conv) and FUSED_LOOKUP:
             out = fused(self.coords, conv.weight, conv.bias, True)
             if out is not None:
                 return out

@@ -110,13 +110,21 @@ class BatchSums:
         return world_size()
 
 
+_REDUCERS = {}
+
+
 def allreduce_closure(params, loss, reducer=None):
-    """Average the parameter gradients and the loss over ranks with ONE all-reduce; returns the averaged loss
-    (and leaves every p.grad pointing into the reducer's buffer)."""
+    """Average the parameter gradients and the loss over ranks with ONE all-reduce; returns the averaged loss.
+    After the call every p.grad ALIASES a slice of the reducer's flat buffer (the next call overwrites it).  Without an
+    explicit `reducer` one is kept per parameter set (identity, sizes, device), so repeated calls reuse one buffer."""
     if not is_dist():
         return loss
     if reducer is None:
-        reducer = FlatReducer(params)
+        params = list(params)
+        key = tuple((id(p), p.numel(), str(p.device)) for p in params)
+        reducer = _REDUCERS.get(key)
+        if reducer is None or any(a is not b for a, b in zip(reducer.params, params)):
+            reducer = _REDUCERS[key] = FlatReducer(params)
     reducer.pack(loss)
     return reducer.reduce()
 

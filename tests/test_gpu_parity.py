@@ -293,7 +293,7 @@ def test_gma_attention_ops_vs_torch(gemm, monkeypatch):
     """SURVEY 8f row f1 (models/gma/gma.py:34-77 Attention, :79-115 Aggregate): similarity product + row softmax and
     the attention-times-value products on the hand-written fp32 MFMA GEMM, against torch in float64.
     N = 1000 (not a multiple of 128: ragged tiles, rows held in registers) and 2 heads."""
-    monkeypatch.setenv("PCFA_GMA_GEMM", gemm)   # plain products on rocBLAS (default) or on pcfa_gemm_f32
+    monkeypatch.setattr(hip_ops, "GMA_GEMM", gemm)   # plain products on rocBLAS (default) or on pcfa_gemm_f32
     gen = torch.Generator().manual_seed(3)
     h, n, d = 2, 1000, 128
     q = torch.randn(1, h, n, d, generator=gen).to(DEV).requires_grad_(True)

@@ -6,7 +6,8 @@ from pcfa_amd import attack_PCFA
 g = load_golden("universal_raft")
 for fused in ("1", "0"):
     for graph in ("1", "0"):
-        os.environ["PCFA_FUSED_LOOKUP"] = fused
+        from pcfa_amd.nets import raft as raft_net
+        raft_net.FUSED_LOOKUP = fused == "1"
         os.environ["PCFA_HIP_GRAPH"] = graph
         closure_util._MODELS.clear()
         args, loader = closure_util.universal_case(g)
