@@ -595,34 +595,57 @@ struct CoordList {
 //                            (K segments of  dfmap1 = f2ext . dpyr^T);
 //   segB[b][column block j]: the range of query rows that can have touched the block's slab columns
 //                            (one K segment of  df2ext = fmap1 . dpyr).
-// One workgroup per batch item; rows first (thread per query row), then the two tables (thread per block).
-__global__ __launch_bounds__(256) void corr_window_segments_kernel(CoordList cl, int B, int H, int W, int r, PyrLayout P,
-                                                                    int nbA, int nbB, int* __restrict__ segA,
-                                                                    int* __restrict__ segB) {
-  extern __shared__ int s_rows[];   // [L][H][2]: lowest / highest texel row of level l touched by query row qy
-  const int b = blockIdx.x, Q = H * W;
-  for (int qy = threadIdx.x; qy < H; qy += blockDim.x) {
-    float lo = 3.0e38f, hi = -3.0e38f;
-    for (int i = 0; i < cl.n; ++i) {
-      const float* cy = cl.p[i] + ((long long)b * 2 + 1) * Q + (long long)qy * W;
-      for (int x = 0; x < W; ++x) {
-        const float v = cy[x];
-        lo = fminf(lo, v);
-        hi = fmaxf(hi, v);
-      }
-    }
-    for (int l = 0; l < P.L; ++l) {
-      const float inv = 1.0f / (float)(1 << l);
-      const float flo = fminf(fmaxf(floorf(lo * inv), -1.0e8f), 1.0e8f), fhi = fminf(fmaxf(floorf(hi * inv), -1.0e8f), 1.0e8f);
-      int ylo = (int)flo - r - 1, yhi = (int)fhi + r + 2;
-      if (!(lo <= hi)) { ylo = 0; yhi = P.h[l] - 1; }          // NaN coordinates: assume everything
-      s_rows[(l * H + qy) * 2] = max(ylo, 0);
-      s_rows[(l * H + qy) * 2 + 1] = min(yhi, P.h[l] - 1);     // (may be < the low end: nothing touched)
+// Two small launches: the rows (workgroup per query row), then the two tables (thread per block).
+// Step 1: one workgroup per (batch item, query row): min / max of cy over the row's queries and all lookups -> the
+// texel rows of every level the row's windows can have touched (rows table [B][L][H][2] in the workspace).
+__global__ __launch_bounds__(256) void corr_window_rows_kernel(CoordList cl, int H, int W, int r, PyrLayout P,
+                                                                int* __restrict__ rows) {
+  __shared__ float s_lo[4], s_hi[4];
+  const int b = blockIdx.y, qy = blockIdx.x, Q = H * W;
+  float lo = 3.0e38f, hi = -3.0e38f;
+  bool bad = false;
+  for (int i = 0; i < cl.n; ++i) {
+    const float* cy = cl.p[i] + ((long long)b * 2 + 1) * Q + (long long)qy * W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+      const float v = cy[x];
+      bad = bad || !(v == v);
+      lo = fminf(lo, v);
+      hi = fmaxf(hi, v);
     }
   }
+  if (bad) { lo = -3.0e38f; hi = 3.0e38f; }   // NaN coordinates: assume every row
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[threadIdx.x >> 6] = lo;
+    s_hi[threadIdx.x >> 6] = hi;
+  }
   __syncthreads();
+  if (threadIdx.x < P.L) {
+    const int l = threadIdx.x;
+    lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+    hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+    const float inv = 1.0f / (float)(1 << l);
+    const float flo = fminf(fmaxf(floorf(lo * inv), -1.0e8f), 1.0e8f), fhi = fminf(fmaxf(floorf(hi * inv), -1.0e8f), 1.0e8f);
+    int* o = rows + (((long long)b * P.L + l) * H + qy) * 2;
+    o[0] = max((int)flo - r - 1, 0);
+    o[1] = min((int)fhi + r + 2, P.h[l] - 1);     // (may be < the low end: nothing touched)
+  }
+}
+
+// Step 2: the two segment tables from the rows table (thread per 128-wide block).
+__global__ __launch_bounds__(256) void corr_window_segments_kernel(const int* __restrict__ rows, int H, int W, PyrLayout P,
+                                                                    int nbA, int nbB, int* __restrict__ segA,
+                                                                    int* __restrict__ segB) {
+  const int b = blockIdx.y, Q = H * W;
+  const int* s_rows = rows + (long long)b * P.L * H * 2;   // [L][H][2]
+  const int j0 = blockIdx.x * blockDim.x + threadIdx.x;
   // table A: query block j = queries [128 j, 128 j + 127] = query rows qa..qb
-  for (int j = threadIdx.x; j < nbA; j += blockDim.x) {
+  if (j0 < nbA) {
+    const int j = j0;
     const int qa = (j * BN) / W, qb = min((j * BN + BN - 1) / W, H - 1);
     int* o = segA + ((long long)b * nbA + j) * SEG_INTS;
     int n = 0;
@@ -643,7 +666,8 @@ __global__ __launch_bounds__(256) void corr_window_segments_kernel(CoordList cl,
     o[9] = 0;
   }
   // table B: column block j = slab columns [128 j, 128 j + 127]: hull of the query rows that reach any of its tile rows
-  for (int j = threadIdx.x; j < nbB; j += blockDim.x) {
+  if (j0 >= nbA && j0 < nbA + nbB) {
+    const int j = j0 - nbA;
     const int ca = j * BN, cb = min(j * BN + BN, P.slab) - 1;
     int qlo = 1 << 30, qhi = -1;
     for (int l = 0; l < P.L; ++l) {
@@ -777,7 +801,7 @@ extern "C" size_t pcfa_corr_pyramid_bwd_windows_workspace_bytes(int B, int D, in
   const size_t base = pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, num_levels);
   if (base == 0 || !pcfa_make_layout(P, H, W, num_levels)) return 0;
   const size_t nbA = (size_t)pcfa_cdiv((long long)H * W, BN), nbB = (size_t)pcfa_cdiv(P.slab, BN);
-  return ((base + 15) & ~(size_t)15) + sizeof(int) * SEG_INTS * B * (nbA + nbB);
+  return ((base + 15) & ~(size_t)15) + sizeof(int) * (SEG_INTS * B * (nbA + nbB) + 2 * (size_t)B * P.L * H);
 }
 
 extern "C" int pcfa_corr_pyramid_bwd_windows(const float* dpyr, const float* fmap1, const float* f2ext, float* dfmap1,
@@ -791,8 +815,7 @@ extern "C" int pcfa_corr_pyramid_bwd_windows(const float* dpyr, const float* fma
   const size_t base = (pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, num_levels) + 15) & ~(size_t)15;
   const long long Q = (long long)H * W;
   const bool fast = Q % 4 == 0 && aligned16(f2ext) && aligned16(dpyr) && aligned16(fmap1) && Q >= 4;
-  const size_t rows_lds = sizeof(int) * 2 * (size_t)P.L * H;
-  if (!coords || n_coords < 1 || n_coords > MAX_COORDS || !fast || rows_lds > 60 * 1024)   // no window information:
+  if (!coords || n_coords < 1 || n_coords > MAX_COORDS || !fast || H > 65535)   // no window information:
     return pyramid_bwd(dpyr, fmap1, f2ext, dfmap1, dfmap2, workspace, workspace_bytes, B, D, H, W, num_levels, stream,
                        nullptr, nullptr);                                                   // the dense products
   if (workspace_bytes < pcfa_corr_pyramid_bwd_windows_workspace_bytes(B, D, H, W, num_levels)) return PCFA_ERR_WORKSPACE;
@@ -804,8 +827,11 @@ extern "C" int pcfa_corr_pyramid_bwd_windows(const float* dpyr, const float* fma
   for (int i = 0; i < MAX_COORDS; ++i) cl.p[i] = i < n_coords ? coords[i] : nullptr;
   for (int i = 0; i < n_coords; ++i)
     if (!cl.p[i]) return PCFA_ERR_INVALID_ARG;
-  pcfa_launch(corr_window_segments_kernel, dim3(B), dim3(256), rows_lds, (hipStream_t)stream, cl, B, H, W, radius, P,
-              nbA, nbB, segA, segB);
+  int* rows = segB + (size_t)SEG_INTS * B * nbB;
+  pcfa_launch(corr_window_rows_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, cl, H, W, radius, P, rows);
+  PCFA_LAUNCH_CHECK();
+  pcfa_launch(corr_window_segments_kernel, dim3(pcfa_cdiv(nbA + nbB, 256), B), dim3(256), 0, (hipStream_t)stream,
+              (const int*)rows, H, W, P, nbA, nbB, segA, segB);
   PCFA_LAUNCH_CHECK();
   return pyramid_bwd(dpyr, fmap1, f2ext, dfmap1, dfmap2, workspace, base, B, D, H, W, num_levels, stream, segA, segB);
 }

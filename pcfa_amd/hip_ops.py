@@ -90,7 +90,7 @@ class DispatchTimer:
         "pcfa_corr_lookup_bwd": [("corr_lookup_bwd", 0)],
         "pcfa_corr_pyramid_fwd": [("corr_pyramid_gemm_fwd", 0)],
         "pcfa_corr_pyramid_bwd": [("corr_pyramid_gemm_dfmap1", 0), ("corr_pyramid_gemm_df2ext", 2)],
-        "pcfa_corr_pyramid_bwd_windows": [("corr_pyramid_gemm_dfmap1", 1), ("corr_pyramid_gemm_df2ext", 3)],
+        "pcfa_corr_pyramid_bwd_windows": [("corr_pyramid_gemm_dfmap1", 2), ("corr_pyramid_gemm_df2ext", 4)],
         "pcfa_corr_f2ext_fwd": [("corr_f2ext_fwd", 0)],
         "pcfa_spatial_corr_fwd": [("spatial_corr_fwd", 0)],
         "pcfa_spatial_corr_bwd": [("spatial_corr_bwd_in1", 0), ("spatial_corr_bwd_in2", 1)],
