@@ -247,8 +247,14 @@ def kernel_table(timings, hf, wf, hp, wp, dim=256, levels=4, radius=4):
         "gru_gates_fwd": ("hbm", 8 * q * 128 * 4),
         "gru_update_fwd": ("hbm", 6 * q * 128 * 4),
     }
-    return [_row(label, work[label][0], work[label][1], us, n) for label, (us, n) in sorted(timings.items())
-            if label in work]
+    notes = {
+        "corr_pyramid_gemm_dfmap1": "algorithmic = the dense product the reference's autograd runs; the kernel skips the "
+                                    "slab columns no lookup window touched (exact zeros of dpyr), so `achieved` is NOT "
+                                    "the matrix pipe's rate and may exceed the peak",
+        "corr_pyramid_gemm_df2ext": "as corr_pyramid_gemm_dfmap1 (query rows no window reaches are skipped)",
+    }
+    return [_row(label, work[label][0], work[label][1], us, n, notes.get(label))
+            for label, (us, n) in sorted(timings.items()) if label in work]
 
 
 PWC_LEVEL_CHANNELS = {2: 32, 3: 64, 4: 96, 5: 128, 6: 196}  # models/PWCNet/PWCNet.py:76-93

@@ -26,6 +26,7 @@
 // 24 MFMAs per wave and chunk, one barrier per chunk.  Group 1's sums meet group 0's in the epilogue's LDS image.
 #include "common.hpp"
 #include "conv3x3_f43.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -38,8 +39,8 @@ constexpr int PR = 4 * TRB + 2;       // 10 patch rows
 constexpr int NPIECE = 4 * TCB / 4 + 2;   // 18 16-B pieces per patch row: global columns x0-4 .. x0+67 (LDS 1 .. 72)
 constexpr int PCP = 80;               // LDS row stride in floats (multiple of 16: the b128 operand reads are conflict-free)
 constexpr int RAW = KC * PR * PCP;    // 6400 floats per buffer
-constexpr int NW = 6, NG = 2;         // transform rows (waves per group), channel groups
-constexpr int NTG = 64 * NW, NT = NTG * NG;   // 384 threads per group, 768 per workgroup
+constexpr int NW = 6, NG = 2;         // transform rows (waves per group), channel groups (NGT <= NG per instance)
+constexpr int NTG = 64 * NW;          // 384 threads per group (768 per workgroup with two groups)
 constexpr int RAW_LOADS = (KC * PR * NPIECE + NTG - 1) / NTG;   // 4 pieces per thread and chunk
 constexpr int MS = TB + 1;
 constexpr int EPI = NW * 4 * 16 * MS;  // epilogue image [6 rows][4 output columns][16 channels][MS]
@@ -90,15 +91,18 @@ __global__ void f43_pack_kernel(const float* __restrict__ w, float* __restrict__
 }
 
 // ksplit > 1: `out` is the workspace [ksplit][B][N][H][W] (partials, no bias / activation); ksplit == 1: the result.
-template <int ACT, bool PARTIAL>
-__global__ __launch_bounds__(NT) void conv3x3_f43_kernel(
+// NGT = channel groups inside the workgroup (2: twelve waves, three per SIMD, 168 registers; 1: six waves, 2-2-1-1
+// over the SIMDs but 256 registers, so the U operands can run UA = 2 channel pairs ahead).
+template <int ACT, bool PARTIAL, int NGT = 2, int UA = 1>
+__global__ __launch_bounds__(NTG * NGT) void conv3x3_f43_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
     const float* __restrict__ mask, const float* __restrict__ addend, float* __restrict__ out, int K, int N, int H,
     int W, int blocks_x, int ksplit, int B, float slope) {
   __shared__ __attribute__((aligned(16))) float smem[LDSF];
   const int tid = threadIdx.x, lane = tid & 63;
+  constexpr int NT = NTG * NGT;
   const int wv12 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wv12 >= NW ? 1 : 0, wave = wv12 - grp * NW;      // channel group, transform row
+  const int grp = (NGT > 1 && wv12 >= NW) ? 1 : 0, wave = wv12 - grp * NW;      // channel group, transform row
   const int gt = tid - grp * NTG;                                   // thread index inside the group
   const int l31 = lane & 31, lh = lane >> 5;
   const int by = blockIdx.x / blocks_x, bx = blockIdx.x - by * blocks_x;
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(NT) void conv3x3_f43_kernel(
   const int cb = (int)((long long)nchunk * ks / ksplit), ce = (int)((long long)nchunk * (ks + 1) / ksplit);
   // this group's chunks: cb + grp, cb + grp + 2, ...; both groups run the same number of iterations (the shorter one
   // repeats its last chunk into a dead accumulator-free pass: see `live` below) so that the barriers match
-  const int niter = (ce - cb + 1) / 2;
-  const int nmine = (ce - cb - grp + 1) / 2;
+  const int niter = (ce - cb + NGT - 1) / NGT;
+  const int nmine = (ce - cb - grp + NGT - 1) / NGT;
 
   // ---- staging: piece e = gt + NTG i of the chunk's patch: (channel, row, piece column) ----
   unsigned psrc[RAW_LOADS];
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(NT) void conv3x3_f43_kernel(
   }
   const bool kfull = (K % KC) == 0;
   // always a chunk of this workgroup's range (a group that has run out repeats one; `live` keeps it out of the sums)
-  auto chunk_of = [&](int it) { return min(cb + grp + 2 * max(min(it, nmine - 1), 0), ce - 1); };
+  auto chunk_of = [&](int it) { return min(cb + grp + NGT * max(min(it, nmine - 1), 0), ce - 1); };
   auto load_raw_half = [&](int c, int h, float4 (&rr)[2]) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -251,11 +255,13 @@ __global__ __launch_bounds__(NT) void conv3x3_f43_kernel(
       store_raw_half(chunk_of(0), 0, h, rh);
     }
   }
-  auto upair = [&](int it, int kpi) {   // pair kpi (may run past 3: the following chunk) of iteration it
+  auto upair = [&](int it, int kpi) {   // pair kpi (may run past 3: the following chunks) of iteration it
     const int itn = it + (kpi >> 2);
     return load_u(chunk_of(itn), kpi & 3);
   };
-  UPair u0 = upair(0, 0);
+  UPair uq[UA + 1];
+#pragma unroll
+  for (int a = 0; a < UA; ++a) uq[a] = upair(0, a);
   __syncthreads();
   for (int it = 0; it < niter; ++it) {
     const int cn = chunk_of(it + 1);
@@ -265,9 +271,10 @@ __global__ __launch_bounds__(NT) void conv3x3_f43_kernel(
     float4 rh[2];
 #pragma unroll
     for (int kpi = 0; kpi < KC / 2; ++kpi) {
-      const UPair u1 = (PCFA_F43_DBG & 4) ? u0 : upair(it, kpi + 1);
+      uq[UA] = (PCFA_F43_DBG & 4) ? uq[0] : upair(it, kpi + UA);
       if (more && (kpi & 1) == 0) load_raw_half(cn, kpi >> 1, rh);
       __builtin_amdgcn_sched_barrier(0);
+      const UPair u0 = uq[0];
       if (live) {
         float v[6];
         if (PCFA_F43_DBG & 2) {
@@ -290,7 +297,8 @@ __global__ __launch_bounds__(NT) void conv3x3_f43_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
       if (more && (kpi & 1) == 1) store_raw_half(cn, (it + 1) & 1, kpi >> 1, rh);
-      u0 = u1;
+#pragma unroll
+      for (int a = 0; a < UA; ++a) uq[a] = uq[a + 1];
     }
     __syncthreads();
   }
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(NT) void conv3x3_f43_kernel(
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    for (int g = 0; g < NGT; ++g) {
       if (grp == g && (l31 >> 4) == pass) {
         const int cl = l31 & 15;
 #pragma unroll
@@ -468,11 +476,16 @@ int pcfa_f43_run(const float* x, const float* packed, const float* bias, const f
     return PCFA_ERR_UNSUPPORTED;
   const int ksplit = pcfa_f43_ksplit(B, K, N, H, W);
   const int blocks_x = pcfa_cdiv(W, 4 * TCB), blocks_y = pcfa_cdiv(H, 4 * TRB);
-  dim3 grid((unsigned)(blocks_x * blocks_y), (unsigned)pcfa_cdiv(N, 32), (unsigned)(B * ksplit)), block(NT);
+  static const int six = getenv("PCFA_F43_WAVES") ? atoi(getenv("PCFA_F43_WAVES")) == 6 : 0;   // dev A/B (tools/dev)
+  dim3 grid((unsigned)(blocks_x * blocks_y), (unsigned)pcfa_cdiv(N, 32), (unsigned)(B * ksplit)), block(six ? NTG : 2 * NTG);
   if (ksplit == 1) {
-#define PCFA_F43_DIRECT(A_)                                                                                       \
-  pcfa_launch(conv3x3_f43_kernel<A_, false>, grid, block, 0, s, x, packed, bias, mask, addend, out, K, N, H, W, \
-              blocks_x, 1, B, slope)
+#define PCFA_F43_DIRECT(A_)                                                                                          \
+  do {                                                                                                               \
+    if (six) pcfa_launch(conv3x3_f43_kernel<A_, false, 1, 2>, grid, block, 0, s, x, packed, bias, mask, addend, out, \
+                         K, N, H, W, blocks_x, 1, B, slope);                                                         \
+    else pcfa_launch(conv3x3_f43_kernel<A_, false>, grid, block, 0, s, x, packed, bias, mask, addend, out, K, N, H,  \
+                     W, blocks_x, 1, B, slope);                                                                      \
+  } while (0)
     if (act == 1) PCFA_F43_DIRECT(1); else if (act == 2) PCFA_F43_DIRECT(2); else PCFA_F43_DIRECT(0);
 #undef PCFA_F43_DIRECT
     PCFA_LAUNCH_CHECK();
@@ -481,8 +494,12 @@ int pcfa_f43_run(const float* x, const float* packed, const float* bias, const f
   const size_t need = (size_t)ksplit * B * N * H * W * sizeof(float);
   if (!workspace || workspace_bytes < need || !aligned16(workspace)) return PCFA_ERR_INVALID_ARG;
   float* part = (float*)workspace;
-  pcfa_launch(conv3x3_f43_kernel<0, true>, grid, block, 0, s, x, packed, (const float*)nullptr, (const float*)nullptr,
-              (const float*)nullptr, part, K, N, H, W, blocks_x, ksplit, B, 0.f);
+  if (six)
+    pcfa_launch(conv3x3_f43_kernel<0, true, 1, 2>, grid, block, 0, s, x, packed, (const float*)nullptr,
+                (const float*)nullptr, (const float*)nullptr, part, K, N, H, W, blocks_x, ksplit, B, 0.f);
+  else
+    pcfa_launch(conv3x3_f43_kernel<0, true>, grid, block, 0, s, x, packed, (const float*)nullptr, (const float*)nullptr,
+                (const float*)nullptr, part, K, N, H, W, blocks_x, ksplit, B, 0.f);
   PCFA_LAUNCH_CHECK();
   const long long total4 = (long long)B * N * H * W / 4, plane4 = (long long)H * W / 4;
   const dim3 fg((unsigned)min((total4 + 255) / 256, 2048LL)), fb(256);
