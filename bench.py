@@ -87,10 +87,10 @@ def parse():
 # --------------------------------------------------------------------------------------------------------------
 # the product objects under test
 # --------------------------------------------------------------------------------------------------------------
-def attack_args(net, boxconstraint="change_of_variables", joint=False, universal=False, steps=1):
+def attack_args(net, boxconstraint="change_of_variables", joint=False, universal=False, steps=1, target="zero"):
     """BASELINE config 2 flags (attack_PCFA.py CLI defaults): delta_bound 0.005, zero target, AEE."""
     return Namespace(net=net, steps=steps, joint_perturbation=joint, universal_perturbation=universal,
-                     boxconstraint=boxconstraint, delta_bound=0.005, mu=-1., target="zero", custom_target_path="",
+                     boxconstraint=boxconstraint, delta_bound=0.005, mu=-1., target=target, custom_target_path="",
                      loss="aee", save_frequency=1, small_save=False, no_save=True, unregistered_artifacts=True,
                      weights="random:1234", batch_size=1, epochs=1)
 
@@ -109,13 +109,13 @@ def load_model(net, device, cov):
 
 
 def AttackStepper(net, h, w, device, seed, boxconstraint="change_of_variables", use_graph=False, model=None,
-                  joint=False):
+                  joint=False, target="zero"):
     """`pcfa_amd.attack_PCFA.PairAttack` on one synthetic pair (what pcfa_attack builds per pair), graph off unless
     asked: call `.enable_graph()` -- exactly what pcfa_attack does on the GPU."""
     from pcfa_amd import attack_PCFA
     from pcfa_amd.helper_functions import datasets
     cov = boxconstraint == "change_of_variables"
-    args = attack_args(net, boxconstraint, joint=joint)
+    args = attack_args(net, boxconstraint, joint=joint, target=target)
     if model is None:
         model = load_model(net, device, cov)
     i1, i2, _ = datasets.synthetic_pair(seed, h, w)

@@ -5,7 +5,9 @@ L-BFGS(max_iter=10) on one synthetic 436x1024 pair, RAFT, change of variables, z
 port (the same host code with the oracle operators and torch.optim.LBFGS) at TWO host thread counts.  The port's own
 spread between the two thread counts is the noise floor of the comparison: an un-damped L-BFGS attack
 amplifies last-bit differences, so the bar for the best-iterate results (aee_adv_tgt_min, aee_adv_init at the best
-iterate, ||delta|| of the best iterate) is  |gpu - port| <= max(floor, 3 x |port_a - port_b|).
+iterate, ||delta|| of the best iterate) is  |gpu - port| <= max(floor, 3 x |port_a - port_b|, 3 x |gpu - gpu_rerun|):
+the GPU's own run-to-run spread is reported and counted as noise (RAFT: bit-reproducible; PWC-Net: the warp
+backward's atomics make two GPU runs of 20 steps end 3 % apart).
 
     python tools/schedule_parity.py [--steps 20] [--threads 16,8] [--size 436x1024] [--net RAFT] [--out FILE.json]
 Prints one JSON object; exit code 1 when the bar is missed.
@@ -24,14 +26,14 @@ import bench  # noqa: E402
 FLOORS = {"aee_adv_tgt_min": 1e-3, "aee_adv_init_at_min": 1e-3, "l2_delta_min": 1e-5}
 
 
-def run(net, h, w, steps, device, threads=None, progress=None):
+def run(net, h, w, steps, device, threads=None, progress=None, box="change_of_variables", joint=False, target="zero"):
     from pcfa_amd import ops
     t0 = time.perf_counter()
     if device.type == "cpu":
         from oracle import ops as oracle_ops
         torch.set_num_threads(threads)
         with ops.override_for_testing(oracle_ops):
-            st = bench.AttackStepper(net, h, w, device, seed=0)
+            st = bench.AttackStepper(net, h, w, device, seed=0, boxconstraint=box, joint=joint, target=target)
             hist = []
             for k in range(steps):
                 hist.append(st.step())
@@ -40,7 +42,7 @@ def run(net, h, w, steps, device, threads=None, progress=None):
                           file=sys.stderr, flush=True)
             res = st.result()
     else:
-        st = bench.AttackStepper(net, h, w, device, seed=0, use_graph=True)
+        st = bench.AttackStepper(net, h, w, device, seed=0, use_graph=True, boxconstraint=box, joint=joint, target=target)
         hist = [st.step() for _ in range(steps)]
         res = st.result()
     return {"per_step": [dict(zip(("aee_adv_tgt", "aee_adv_init", "l2_delta"), s)) for s in hist],
@@ -56,23 +58,31 @@ def main():
     ap.add_argument("--size", default="436x1024")
     ap.add_argument("--net", default="RAFT")
     ap.add_argument("--out", default="")
+    ap.add_argument("--box", default="change_of_variables", choices=["change_of_variables", "clipping"])
+    ap.add_argument("--joint", action="store_true", help="--joint_perturbation (needs --box clipping)")
+    ap.add_argument("--target", default="zero", choices=["zero", "neg_flow"])
     a = ap.parse_args()
+    kw = dict(box=a.box, joint=a.joint, target=a.target)
     h, w = (int(v) for v in a.size.split("x"))
     ta, tb = (int(v) for v in a.threads.split(","))
-    gpu = run(a.net, h, w, a.steps, torch.device("cuda", 0))
-    gpu2 = run(a.net, h, w, a.steps, torch.device("cuda", 0))       # the GPU's own run-to-run spread (MIOpen atomics)
-    pa = run(a.net, h, w, a.steps, torch.device("cpu"), ta, progress="port[%d threads]" % ta)
-    pb = run(a.net, h, w, a.steps, torch.device("cpu"), tb, progress="port[%d threads]" % tb)
+    gpu = run(a.net, h, w, a.steps, torch.device("cuda", 0), **kw)
+    gpu2 = run(a.net, h, w, a.steps, torch.device("cuda", 0), **kw)   # the GPU's own run-to-run spread (MIOpen atomics)
+    pa = run(a.net, h, w, a.steps, torch.device("cpu"), ta, progress="port[%d threads]" % ta, **kw)
+    pb = run(a.net, h, w, a.steps, torch.device("cpu"), tb, progress="port[%d threads]" % tb, **kw)
     rows, ok = {}, True
     for k, floor in FLOORS.items():
-        spread = abs(pa[k] - pb[k])
-        tol = max(floor, 3 * spread)
+        spread, own = abs(pa[k] - pb[k]), abs(gpu[k] - gpu2[k])
+        # the GPU's own run-to-run spread counts as noise too: RAFT's path is bit-reproducible (own = 0), PWC-Net's
+        # warp backward scatters with fp32 atomics (as grid_sample's backward does) and is not
+        tol = max(floor, 3 * spread, 3 * own)
         diff = abs(gpu[k] - pa[k])
         rows[k] = {"gpu": gpu[k], "gpu_rerun": gpu2[k], "port_a": pa[k], "port_b": pb[k], "port_spread": spread,
-                   "gpu_minus_port_a": gpu[k] - pa[k], "tolerance": tol, "ok": diff <= tol}
+                   "gpu_spread": own, "gpu_minus_port_a": gpu[k] - pa[k], "tolerance": tol, "ok": diff <= tol}
         ok = ok and diff <= tol
-    out = {"what": "best-iterate results of a %d-step PCFA attack, %s %dx%d, GPU vs CPU port" % (a.steps, a.net, h, w),
-           "rule": "|gpu - port_a| <= max(floor, 3 x |port_a - port_b|) (SURVEY D10)", "ok": ok, "metrics": rows,
+    out = {"what": "best-iterate results of a %d-step PCFA attack, %s %dx%d (%s%s, %s target), GPU vs CPU port"
+                   % (a.steps, a.net, h, w, a.box, ", joint perturbation" if a.joint else "", a.target),
+           "rule": "|gpu - port_a| <= max(floor, 3 x |port_a - port_b|, 3 x |gpu - gpu_rerun|) (SURVEY D10)", "ok": ok,
+           "gpu_bit_reproducible": all(r["gpu_spread"] == 0.0 for r in rows.values()), "metrics": rows,
            "gpu": gpu, "gpu_rerun": gpu2, "port_a": pa, "port_b": pb}
     txt = json.dumps(out)
     if a.out:
