@@ -299,6 +299,7 @@ TRACED = {  # kernel-name fragment -> label
     "gru_gates_fwd_kernel": "gru_gates_fwd", "gru_update_fwd_kernel": "gru_update_fwd",
     "scorr9_fwd_kernel": "spatial_corr_fwd", "scorr9_bwd_kernel": "spatial_corr_bwd",
     "pwc_warp_fwd_kernel": "pwc_warp_fwd", "pwc_warp_bwd_kernel": "pwc_warp_bwd",
+    "pwc_warp_bwd_det_kernel": "pwc_warp_bwd",
     # the optimiser (pcfa_amd/csrc/lbfgs_gram.hip, lbfgs.hip)
     "gram_pass_kernel": "lbfgs_gram_pass", "gram_direction_kernel": "lbfgs_gram_direction",
     "gram_reduce_kernel": "lbfgs_small", "gram_coeff_kernel": "lbfgs_gram_coeff",

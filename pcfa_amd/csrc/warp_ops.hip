@@ -150,6 +150,99 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_kernel(const float* __restri
   }
 }
 
+// Deterministic variant of the scatter: contributions are added as 2^-40 fixed-point int64 (integer adds commute and
+// associate, so the order in which the atomics land cannot change the sum: two runs give the same bits), the flow
+// gradient's channel groups write their partials side by side.  wfinish converts / adds in index order.  Range
+// +-8.4e6, resolution 9e-13 per addend (fp32 keeps 6e-8 relative: finer only below 1.5e-5).
+constexpr double WARP_FIX = 1099511627776.0;   // 2^40
+
+__device__ __forceinline__ void fix_add(long long* p, float v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * WARP_FIX));
+}
+
+__global__ __launch_bounds__(256) void pwc_warp_bwd_det_kernel(const float* __restrict__ x, const float* __restrict__ flo,
+                                                              const float* __restrict__ gout, long long* __restrict__ gxi,
+                                                              float* __restrict__ gfpart, int C, int H, int W,
+                                                              float mask_thresh) {
+  const long long plane = (long long)H * W;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const int b = blockIdx.z, G = gridDim.y, B = gridDim.z;
+  const int py = (int)(p / W), px = (int)(p % W);
+  const float* fb = flo + (size_t)b * 2 * plane;
+  float* gf = gfpart + ((size_t)blockIdx.y * B + b) * 2 * plane;   // this channel group's partial flow gradient
+  const float ix = warp_coord((float)px, fb[p], W), iy = warp_coord((float)py, fb[plane + p], H);
+  const WarpTaps t = warp_taps(ix, iy, H, W);
+  const float ex = (float)(t.x0 + 1) - ix, ey = (float)(t.y0 + 1) - iy;
+  const float nw = ex * ey, ne = t.wx1 * ey, sw = ex * t.wy1, se = t.wx1 * t.wy1;
+  const bool bnw = t.vx0 && t.vy0, bne = t.vx1 && t.vy0, bsw = t.vx0 && t.vy1, bse = t.vx1 && t.vy1;
+  float msum = 0.f;
+  if (bnw) msum += nw;
+  if (bne) msum += ne;
+  if (bsw) msum += sw;
+  if (bse) msum += se;
+  if (!(msum >= mask_thresh)) {   // output * 0: no gradient to either input
+    gf[p] = 0.f;
+    gf[plane + p] = 0.f;
+    return;
+  }
+  const int onw = bnw ? t.y0 * W + t.x0 : 0, one = bne ? t.y0 * W + t.x0 + 1 : 0;
+  const int osw = bsw ? (t.y0 + 1) * W + t.x0 : 0, ose = bse ? (t.y0 + 1) * W + t.x0 + 1 : 0;
+  const float* xb = x + (size_t)b * C * plane;
+  long long* gb = gxi + (size_t)b * C * plane;
+  const float* go = gout + (size_t)b * C * plane + p;
+  float gix = 0.f, giy = 0.f;
+  for (int c = blockIdx.y; c < C; c += G) {
+    const float g = go[(size_t)c * plane];
+    const float* xc = xb + (size_t)c * plane;
+    long long* gc = gb + (size_t)c * plane;
+    const float vnw = xc[onw], vne = xc[one], vsw = xc[osw], vse = xc[ose];
+    if (bnw) {
+      fix_add(gc + onw, nw * g);
+      gix -= vnw * ey * g;
+      giy -= vnw * ex * g;
+    }
+    if (bne) {
+      fix_add(gc + one, ne * g);
+      gix += vne * ey * g;
+      giy -= vne * t.wx1 * g;
+    }
+    if (bsw) {
+      fix_add(gc + osw, sw * g);
+      gix -= vsw * t.wy1 * g;
+      giy += vsw * ex * g;
+    }
+    if (bse) {
+      fix_add(gc + ose, se * g);
+      gix += vse * t.wy1 * g;
+      giy += vse * t.wx1 * g;
+    }
+  }
+  gf[p] = 2.0f * ((0.5f * (float)W * gix) / (float)max(W - 1, 1));
+  gf[plane + p] = 2.0f * ((0.5f * (float)H * giy) / (float)max(H - 1, 1));
+}
+
+__global__ void pwc_warp_finish_kernel(const long long* __restrict__ gxi, const float* __restrict__ gfpart,
+                                       float* __restrict__ gx, float* __restrict__ gflo, long long nx, long long nf,
+                                       int G) {
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx + nf; i += step) {
+    if (i < nx) {
+      gx[i] = (float)((double)gxi[i] * (1.0 / WARP_FIX));
+    } else {
+      const long long j = i - nx;
+      float s = gfpart[j];
+      for (int g = 1; g < G; ++g) s += gfpart[j + (long long)g * nf];   // channel groups in index order
+      gflo[j] = s;
+    }
+  }
+}
+
+__global__ void zero_ll_kernel(long long* __restrict__ a, long long n) {
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) a[i] = 0;
+}
+
 __global__ void zero2_kernel(float* __restrict__ a, long long na, float* __restrict__ b, long long nb) {
   const long long step = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += step) {
@@ -172,6 +265,36 @@ extern "C" int pcfa_pwc_warp_fwd(const float* x, const float* flo, float* out, i
   const long long plane = (long long)H * W;
   dim3 grid(pcfa_cdiv(plane, 256), channel_groups(plane, C), B);
   pcfa_launch(pwc_warp_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, flo, out, C, H, W, mask_threshold);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" size_t pcfa_pwc_warp_bwd_det_workspace_bytes(int B, int C, int H, int W) {
+  if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
+  const long long plane = (long long)H * W;
+  return (size_t)B * C * plane * sizeof(long long) + (size_t)channel_groups(plane, C) * B * 2 * plane * sizeof(float);
+}
+
+extern "C" int pcfa_pwc_warp_bwd_det(const float* x, const float* flo, const float* grad_out, float* grad_x,
+                                     float* grad_flo, void* workspace, size_t workspace_bytes, int B, int C, int H,
+                                     int W, float mask_threshold, void* stream) {
+  if (!x || !flo || !grad_out || !grad_x || !grad_flo || !workspace || B < 1 || C < 1 || H < 1 || W < 1)
+    return PCFA_ERR_INVALID_ARG;
+  if (workspace_bytes < pcfa_pwc_warp_bwd_det_workspace_bytes(B, C, H, W)) return PCFA_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(workspace) & 7) return PCFA_ERR_INVALID_ARG;
+  const long long plane = (long long)H * W;
+  hipStream_t s = (hipStream_t)stream;
+  const long long nx = (long long)B * C * plane, nf = (long long)B * 2 * plane;
+  const int G = channel_groups(plane, C);
+  long long* gxi = (long long*)workspace;
+  float* gfpart = (float*)(gxi + nx);
+  pcfa_launch(zero_ll_kernel, dim3((int)min((nx + 255) / 256, 4096LL)), dim3(256), 0, s, gxi, nx);
+  PCFA_LAUNCH_CHECK();
+  dim3 grid(pcfa_cdiv(plane, 256), G, B);
+  pcfa_launch(pwc_warp_bwd_det_kernel, grid, dim3(256), 0, s, x, flo, grad_out, gxi, gfpart, C, H, W, mask_threshold);
+  PCFA_LAUNCH_CHECK();
+  pcfa_launch(pwc_warp_finish_kernel, dim3((int)min((nx + nf + 255) / 256, 4096LL)), dim3(256), 0, s,
+              (const long long*)gxi, (const float*)gfpart, grad_x, grad_flo, nx, nf, G);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }

@@ -110,6 +110,7 @@ class DispatchTimer:
         "pcfa_conv_fewin_fwd": [("conv_fewin_fwd", 0)],
         "pcfa_pwc_warp_fwd": [("pwc_warp_fwd", 0)],
         "pcfa_pwc_warp_bwd": [("pwc_warp_bwd", 1)],
+        "pcfa_pwc_warp_bwd_det": [("pwc_warp_bwd", 1)],
         "pcfa_conv3x3_fewout_fwd": [("conv3x3_fewout_fwd", 0)],
         "pcfa_conv3x3_fewout_bwd": [("conv3x3_fewout_bwd", 0)],
         "pcfa_instnorm_fwd": [("instnorm_stats_fwd", 0), ("instnorm_apply_fwd", 1)],
@@ -763,6 +764,9 @@ def conv_fewin(x, weight, bias=None, relu=False):
     return out
 
 
+WARP_BWD_DETERMINISTIC = True   # fixed-point scatter (bit-reproducible); False: hardware fp32 atomics
+
+
 class _PwcWarp(torch.autograd.Function):
     """PWCDCNet.warp (models/PWCNet/PWCNet.py:166-206) on pcfa_pwc_warp_fwd/bwd."""
 
@@ -785,7 +789,14 @@ class _PwcWarp(torch.autograd.Function):
         x, flo = ctx.saved_tensors
         g = g.contiguous()
         gx, gf = torch.empty_like(x), torch.empty_like(flo)
-        _call("pcfa_pwc_warp_bwd", _ptr(x), _ptr(flo), _ptr(g), _ptr(gx), _ptr(gf), *ctx.params)
+        if WARP_BWD_DETERMINISTIC:
+            B, C, H, W, thr = ctx.params
+            nws = int(_hip.load().pcfa_pwc_warp_bwd_det_workspace_bytes(B, C, H, W))
+            ws = torch.empty((nws + 7) // 8, device=x.device, dtype=torch.int64)
+            _call("pcfa_pwc_warp_bwd_det", _ptr(x), _ptr(flo), _ptr(g), _ptr(gx), _ptr(gf), _ptr(ws), nws, B, C, H, W,
+                  thr)
+        else:
+            _call("pcfa_pwc_warp_bwd", _ptr(x), _ptr(flo), _ptr(g), _ptr(gx), _ptr(gf), *ctx.params)
         return gx, gf, None
 
 

@@ -673,6 +673,20 @@ def test_pwc_warp_vs_oracle(oracle_ops, shape, scale):
     assert max_abs(got, want) <= 2e-6 * float(x.detach().abs().max())
     got.backward(go.to(DEV))
     assert rel_l2(xg.grad, x.grad) < 2e-5 and rel_l2(fg.grad, flo.grad) < 2e-5
+    # the default backward scatters 2^-40 fixed-point values (integer adds): bit-reproducible from run to run, and equal
+    # to the fp32-atomics form (pcfa_pwc_warp_bwd) up to the rounding of the addends
+    g1x, g1f = xg.grad.clone(), fg.grad.clone()
+    for _ in range(2):
+        xg.grad = fg.grad = None
+        hip_ops.pwc_warp(xg, fg).backward(go.to(DEV))
+        assert torch.equal(xg.grad, g1x) and torch.equal(fg.grad, g1f)
+    hip_ops.WARP_BWD_DETERMINISTIC = False
+    try:
+        xg.grad = fg.grad = None
+        hip_ops.pwc_warp(xg, fg).backward(go.to(DEV))
+        assert rel_l2(xg.grad, g1x) < 1e-6 and rel_l2(fg.grad, g1f) < 1e-6
+    finally:
+        hip_ops.WARP_BWD_DETERMINISTIC = True
     # zero flow: the align_corners mismatch of the original code samples at x * W / (W - 1) - 0.5, not at x
     ident = hip_ops.pwc_warp(xg.detach(), torch.zeros_like(fg))
     assert max_abs(ident, oracle_ops.pwc_warp(x.detach(), torch.zeros_like(flo))) <= 2e-6 * float(x.detach().abs().max())
