@@ -481,6 +481,19 @@ PCFA_API int pcfa_conv_fewin_pack(const float* w, float* packed, int Cin, int N,
 PCFA_API int pcfa_conv_fewin_packed_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int Cin,
                                int N, int H, int W, int ksize, int relu, void* stream);
 
+/* act(conv2d(x, w, bias, stride=2, padding=ksize/2)) for a frozen weight on the fp32 matrix cores: the encoders' stem
+ * Conv2d(3, 64, 7, stride=2, padding=3) (models/raft/extractor.py:118, models/gma/extractor.py:118) and the 3x3 / stride-2
+ * first convolution of the down-sampling residual blocks (extractor.py:23-58 with stride=2).  x: [B][Cin][H][W],
+ * w: [N][Cin][k][k], out: [B][N][Ho][Wo] with Ho = (H + 2 (k/2) - k) / 2 + 1.  pcfa_conv_s2_supported: (Cin, k) = (3, 7) or
+ * k = 3, W % 4 == 0, 16-B aligned x -- anything else is PCFA_ERR_UNSUPPORTED (the caller keeps the library convolution).
+ * packed: pcfa_conv_s2_packed_floats(Cin, N, ksize) floats written once by pcfa_conv_s2_pack (MFMA operand order).
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(slope). */
+PCFA_API int pcfa_conv_s2_supported(int Cin, int N, int ksize, int H, int W);
+PCFA_API long long pcfa_conv_s2_packed_floats(int Cin, int N, int ksize);
+PCFA_API int pcfa_conv_s2_pack(const float* w, float* packed, int Cin, int N, int ksize, void* stream);
+PCFA_API int pcfa_conv_s2_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int Cin, int N,
+                              int H, int W, int ksize, int act, float slope, void* stream);
+
 /* PWC-Net's backward warp (models/PWCNet/PWCNet.py:166-206) as one pass per direction:
  *   out = grid_sample(x, normalise(meshgrid + flo)) * (grid_sample(ones, ...) >= mask_threshold)
  * bilinear, zero padding, align_corners = False, the reference's fp32 coordinate arithmetic (normalise by W-1, then

@@ -509,6 +509,20 @@ def conv_fewin(x, weight, bias=None, relu=False):
     return F.relu(y) if relu else y
 
 
+def conv_s2_supported(x, weight):
+    N, Cin, kh, kw = weight.shape
+    return kh == kw and ((Cin, kh) == (3, 7) or kh == 3) and x.shape[3] % 4 == 0
+
+
+def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None):
+    """models/raft/extractor.py:118 (stem) and :23-58 (first convolution of a stride-2 residual block):
+    conv2d(x, w, b, stride=2, padding=k//2) followed by the activation the caller fuses."""
+    y = F.conv2d(x, weight, bias, stride=2, padding=weight.shape[-1] // 2)
+    if leaky_slope is not None:
+        return F.leaky_relu(y, leaky_slope)
+    return F.relu(y) if relu else y
+
+
 def conv3x3_cat(convs, tails=(), grad_premasked=False, mask_input_grads=False):
     """models/raft/update.py:91-101: torch.cat([relu(conv(x)) ...] + tails, dim=1).  The two flags are scheduling hints
     of the product (which kernel applies a ReLU mask); they change no value."""

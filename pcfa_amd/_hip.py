@@ -118,6 +118,10 @@ SIGNATURES = {
     "pcfa_bias_relu_fwd": (c_int, [_P, _P, _P, c_longlong, c_int, c_int, _P]),
     "pcfa_relu_bwd": (c_int, [_P, _P, _P, c_longlong, _P]),
     "pcfa_conv_fewin_packed_floats": (c_longlong, [c_int, c_int, c_int]),
+    "pcfa_conv_s2_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "pcfa_conv_s2_packed_floats": (c_longlong, [c_int, c_int, c_int]),
+    "pcfa_conv_s2_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "pcfa_conv_s2_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "pcfa_conv_fewin_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "pcfa_conv_fewin_packed_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_conv_fewin_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -805,6 +805,74 @@ def pwc_warp(x, flo, mask_threshold=0.0001):
     return _PwcWarp.apply(x, flo, mask_threshold)
 
 
+_s2_packs = {}  # id(weight) -> (weakref, version, packed)
+
+
+def _s2_packed(weight):
+    """pcfa_conv_s2_pack of a frozen [N, Cin, k, k] weight (MFMA operand order), cached per tensor version."""
+    key = id(weight)
+    hit = _s2_packs.get(key)
+    if hit is None or hit[0]() is not weight or hit[1] != weight._version:
+        lib = _hip.load()
+        N, Cin, k, _ = weight.shape
+        w = weight.detach().contiguous()
+        packed = torch.empty(int(lib.pcfa_conv_s2_packed_floats(Cin, N, k)), device=w.device, dtype=torch.float32)
+        _call("pcfa_conv_s2_pack", _ptr(w), _ptr(packed), Cin, N, k)
+        hit = (weakref.ref(weight, lambda _r, k_=key: _s2_packs.pop(k_, None)), weight._version, packed)
+        _s2_packs[key] = hit
+    return hit[2]
+
+
+def conv_s2_supported(x, weight):
+    """True when conv_s2 covers conv2d(x, weight, stride=2, padding=k//2): the 3-channel 7x7 stem or any 3x3, W % 4 == 0."""
+    N, Cin, kh, kw = weight.shape
+    return bool(x.dim() == 4 and kh == kw and x.shape[1] == Cin and not weight.requires_grad and x.is_cuda
+                and _hip.load().pcfa_conv_s2_supported(Cin, N, kh, x.shape[2], x.shape[3]))
+
+
+class _ConvS2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        _dev(x, weight, bias)
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        N, _, k, _ = weight.shape
+        Ho, Wo = (H + 2 * (k // 2) - k) // 2 + 1, (W + 2 * (k // 2) - k) // 2 + 1
+        out = torch.empty((B, N, Ho, Wo), device=x.device, dtype=torch.float32)
+        _call("pcfa_conv_s2_fwd", _ptr(x), _ptr(_s2_packed(weight)), _ptr(bias), _ptr(out), B, Cin, N, H, W, k, act,
+              float(slope))
+        ctx.act, ctx.slope, ctx.xshape = act, float(slope), tuple(x.shape)
+        ctx.save_for_backward(weight, out if act else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        weight, out = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.act:
+            gm = torch.empty_like(g)
+            if ctx.act == 1:
+                _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), g.numel())
+            else:
+                _call("pcfa_leaky_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), ctx.slope, g.numel())
+            g = gm
+        k = weight.shape[-1]
+        gx = torch.nn.grad.conv2d_input(ctx.xshape, weight, g, stride=2, padding=k // 2)
+        return gx, None, None, None, None
+
+
+def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None):
+    """act(conv2d(x, weight, bias, stride=2, padding=k//2)) for a frozen weight: the encoders' 7x7 stem and the 3x3
+    first convolution of the down-sampling residual blocks on the fp32 matrix cores (pcfa_conv_s2_fwd)."""
+    _dev(x, weight, bias)
+    if weight.requires_grad or (bias is not None and bias.requires_grad):
+        raise RuntimeError("conv_s2: frozen parameters only")
+    if not conv_s2_supported(x, weight):
+        raise ValueError("conv_s2: unsupported weight %s for input %s" % (tuple(weight.shape), tuple(x.shape)))
+    act = 2 if leaky_slope is not None else int(bool(relu))
+    return _ConvS2.apply(x, weight, bias, act, 0.0 if leaky_slope is None else leaky_slope)
+
+
 class _Conv3x3FewOut(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):

@@ -79,6 +79,8 @@ def _conv_norm(conv, norm, x, relu, cache, tag, skip=False, grad_premasked=False
             return ops.get().conv3x3(x, w, b, relu, skip=skip, grad_premasked=grad_premasked,
                                      mask_input_grad=mask_input_grad)
         assert not (skip or grad_premasked or mask_input_grad)
+        if _is_stride2(conv, x):
+            return ops.get().conv_s2(x, w, b, relu)
         if relu:
             return ops.get().bias_relu(conv._conv_forward(x, w, None), b)
         return conv._conv_forward(x, w, b)
@@ -88,6 +90,9 @@ def _conv_norm(conv, norm, x, relu, cache, tag, skip=False, grad_premasked=False
             y = ops.get().conv3x3(x, conv.weight, None, False, skip=skip)
             if skip:
                 y, xs = y
+        elif _is_stride2(conv, x):
+            assert not skip
+            y = ops.get().conv_s2(x, conv.weight, None, False)
         else:
             assert not skip
             y = conv._conv_forward(x, conv.weight, None)
@@ -97,6 +102,14 @@ def _conv_norm(conv, norm, x, relu, cache, tag, skip=False, grad_premasked=False
     assert not skip
     y = norm(conv(x))
     return F.relu(y, inplace=True) if relu else y
+
+
+def _is_stride2(conv, x):
+    """A frozen k x k / stride-2 / padding k//2 convolution ops.conv_s2 covers (the stem, the residual blocks' entry)."""
+    k = conv.kernel_size[0]
+    return (conv.kernel_size == (k, k) and conv.stride == (2, 2) and conv.padding == (k // 2, k // 2)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and ops.get().conv_s2_supported(x, conv.weight))
 
 
 def _can_skip(conv, norm):

@@ -942,6 +942,40 @@ def test_conv3x3_f43_forced():
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("shape", [
+    # (B, Cin, N, k, H, W): the stem and the two stride-2 residual-block entries at the BASELINE size, ragged / tiny ones
+    (2, 3, 64, 7, 440, 1024), (1, 64, 96, 3, 220, 512), (2, 96, 128, 3, 110, 256),
+    (1, 3, 16, 3, 20, 36), (2, 3, 64, 7, 37, 52), (1, 10, 40, 3, 9, 264), (1, 16, 32, 3, 2, 4)])
+def test_conv_s2_vs_oracle(oracle_ops, shape):
+    """extractor.py:118 and :23-58 (stride 2): forward and data gradient against the CPU restatement."""
+    B, Cin, N, k, H, W = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(N, Cin, k, k, generator=gen) / (Cin * k * k) ** .5
+    b = torch.randn(N, generator=gen)
+    for kw in (dict(relu=False), dict(relu=True), dict(leaky_slope=0.1)):
+        bias = None if kw == dict(relu=False) else b
+        xc = x.clone().requires_grad_(True)
+        want = oracle_ops.conv_s2(xc, w, bias, **kw)
+        go = torch.randn(want.shape, generator=gen)
+        want.backward(go)
+        xg = x.to(DEV).requires_grad_(True)
+        wg = w.to(DEV)
+        assert hip_ops.conv_s2_supported(xg, wg)
+        got = hip_ops.conv_s2(xg, wg, None if bias is None else bias.to(DEV), **kw)
+        got.backward(go.to(DEV))
+        assert got.shape == want.shape
+        scale = want.abs().max().item()
+        assert (got.cpu() - want).abs().max().item() <= 2e-5 * max(scale, 1.0), kw
+        flips = ((got.cpu() > 0) != (want > 0)).sum().item() if kw != dict(relu=False) else 0
+        gerr = (xg.grad.cpu() - xc.grad).norm().item() / xc.grad.norm().item()
+        assert gerr <= 2e-5 + 2 * (flips / want.numel()) ** .5, (kw, gerr, flips)
+    assert not hip_ops.conv_s2_supported(torch.zeros(1, 3, 8, 10, device=DEV), torch.zeros(4, 3, 3, 3, device=DEV))  # W % 4
+    assert not hip_ops.conv_s2_supported(torch.zeros(1, 4, 8, 12, device=DEV), torch.zeros(4, 4, 5, 5, device=DEV))
+    with pytest.raises(RuntimeError):
+        hip_ops.conv_s2(torch.zeros(1, 3, 8, 8), w[:, :3, :3, :3].contiguous())       # no CPU fallback
+
+
 def test_sepconv5_rejects_bad_operands():
     w = torch.zeros(4, 3, 1, 5, device=DEV)
     with pytest.raises(ValueError):
