@@ -493,6 +493,30 @@ PCFA_API long long pcfa_conv_s2_packed_floats(int Cin, int N, int ksize);
 PCFA_API int pcfa_conv_s2_pack(const float* w, float* packed, int Cin, int N, int ksize, void* stream);
 PCFA_API int pcfa_conv_s2_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int Cin, int N,
                               int H, int W, int ksize, int act, float slope, void* stream);
+/* Data gradient of the 3x3 / stride-2 convolution above: grad_x[B][Cin][H][W] (overwritten) from grad_out[B][N][Ho][Wo], as
+ * four stride-1 convolutions of grad_out by output parity (one MFMA per (p, q) and channel pair, nothing scattered, no
+ * layout transposes).  ksize = 3 and W % 8 == 0 (PCFA_ERR_UNSUPPORTED otherwise: the caller keeps the library
+ * gradient); packed: pcfa_conv_s2_bwd_packed_floats() floats written once by pcfa_conv_s2_bwd_pack from w[N][Cin][3][3]. */
+PCFA_API int pcfa_conv_s2_bwd_supported(int Cin, int N, int ksize, int H, int W);
+PCFA_API long long pcfa_conv_s2_bwd_packed_floats(int Cin, int N, int ksize);
+PCFA_API int pcfa_conv_s2_bwd_pack(const float* w, float* packed, int Cin, int N, int ksize, void* stream);
+PCFA_API int pcfa_conv_s2_bwd(const float* grad_out, const float* packed, float* grad_x, int B, int Cin, int N, int H, int W,
+                              int ksize, void* stream);
+/* The entry of a down-sampling residual block (models/raft/extractor.py:23-58 with stride = 2) in one launch per direction:
+ *   out   = act(conv2d(x, w,  bias,   stride=2, padding=1))     w:  [N][Cin][3][3]   (conv1)
+ *   out_d =     conv2d(x, wd, bias_d, stride=2)                 wd: [N][Cin][1][1]   (downsample[0]; its norm follows)
+ * The 1x1 convolution reads the centre tap of the 3x3 window: two more MFMAs per four input channels on operands that are
+ * already staged.  Backward: grad_x = conv1^T(grad_out) + downsample^T(grad_out_d) in the (even row, even column) parity
+ * class of pcfa_conv_s2_bwd -- the separate gradient add over x disappears.  Support as pcfa_conv_s2_supported(Cin, N, 3,
+ * H, W) / pcfa_conv_s2_bwd_supported; packed buffers from the _ds_pack / _ds_bwd_pack entry points. */
+PCFA_API long long pcfa_conv_s2_ds_packed_floats(int Cin, int N);
+PCFA_API int pcfa_conv_s2_ds_pack(const float* w, const float* wd, float* packed, int Cin, int N, void* stream);
+PCFA_API int pcfa_conv_s2_ds_fwd(const float* x, const float* packed, const float* bias, float* out, const float* bias_d,
+                                 float* out_d, int B, int Cin, int N, int H, int W, int act, float slope, void* stream);
+PCFA_API long long pcfa_conv_s2_ds_bwd_packed_floats(int Cin, int N);
+PCFA_API int pcfa_conv_s2_ds_bwd_pack(const float* w, const float* wd, float* packed, int Cin, int N, void* stream);
+PCFA_API int pcfa_conv_s2_ds_bwd(const float* grad_out, const float* grad_out_d, const float* packed, float* grad_x, int B,
+                                 int Cin, int N, int H, int W, void* stream);
 
 /* PWC-Net's backward warp (models/PWCNet/PWCNet.py:166-206) as one pass per direction:
  *   out = grid_sample(x, normalise(meshgrid + flo)) * (grid_sample(ones, ...) >= mask_threshold)

@@ -523,6 +523,17 @@ def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None):
     return F.relu(y) if relu else y
 
 
+def conv_s2_ds_supported(x, weight, weight_d):
+    N, Cin, kh, kw = weight.shape
+    return (kh, kw) == (3, 3) and tuple(weight_d.shape) == (N, Cin, 1, 1) and x.shape[3] % 8 == 0
+
+
+def conv_s2_ds(x, weight, weight_d, bias=None, bias_d=None, relu=False):
+    """models/raft/extractor.py:23-58 (stride 2): conv1 (3x3) and downsample[0] (1x1) of the block input."""
+    y = F.conv2d(x, weight, bias, stride=2, padding=1)
+    return (F.relu(y) if relu else y), F.conv2d(x, weight_d, bias_d, stride=2)
+
+
 def conv3x3_cat(convs, tails=(), grad_premasked=False, mask_input_grads=False):
     """models/raft/update.py:91-101: torch.cat([relu(conv(x)) ...] + tails, dim=1).  The two flags are scheduling hints
     of the product (which kernel applies a ReLU mask); they change no value."""

@@ -122,6 +122,16 @@ SIGNATURES = {
     "pcfa_conv_s2_packed_floats": (c_longlong, [c_int, c_int, c_int]),
     "pcfa_conv_s2_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "pcfa_conv_s2_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "pcfa_conv_s2_bwd_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "pcfa_conv_s2_bwd_packed_floats": (c_longlong, [c_int, c_int, c_int]),
+    "pcfa_conv_s2_bwd_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "pcfa_conv_s2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_conv_s2_ds_packed_floats": (c_longlong, [c_int, c_int]),
+    "pcfa_conv_s2_ds_pack": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "pcfa_conv_s2_ds_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "pcfa_conv_s2_ds_bwd_packed_floats": (c_longlong, [c_int, c_int]),
+    "pcfa_conv_s2_ds_bwd_pack": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "pcfa_conv_s2_ds_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_conv_fewin_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "pcfa_conv_fewin_packed_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_conv_fewin_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

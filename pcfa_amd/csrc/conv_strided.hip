@@ -33,8 +33,12 @@ constexpr int to32mod64(int a) { return (a % 64 <= 32) ? a + (32 - a % 64) : a +
 // KH x KW window, stride 2, padding K / 2.  CK input channels per chunk.  PAIRROW: the two k of a step are window
 // rows 2pp, 2pp + 1 of one channel (odd channel counts: the stem), else channels 2cp, 2cp + 1 of one tap.
 // WN waves side by side over 32-channel blocks (they share the staged patch), WPX over pixel groups of MB * 32.
-template <int KH_, int KW_, int CK_, bool PAIRROW_, int WN_, int WPX_, int MB_>
+// DS: the workgroup also evaluates a 1x1 / stride-2 convolution of the same input (the residual blocks' downsample,
+// extractor.py:44-46): its input pixel is the centre tap of the 3x3 window, so it costs CK / 2 more steps per chunk on
+// operands already in registers, into a second accumulator.
+template <int KH_, int KW_, int CK_, bool PAIRROW_, int WN_, int WPX_, int MB_, bool DS_ = false>
 struct S2Cfg {
+  static constexpr bool DS = DS_;
   static constexpr int KH = KH_, KW = KW_, CK = CK_, WN = WN_, MB = MB_;
   static constexpr bool PAIRROW = PAIRROW_;
   static constexpr int WP = WPX_, PXT = WP * MB * 32, NT = 64 * WN * WP;
@@ -45,15 +49,18 @@ struct S2Cfg {
   static constexpr int RS = PAIRROW ? to32mod64(ROWF) : ROWF;
   static constexpr int CHS = PAIRROW ? ROWS * RS : to32mod64(ROWS * RS);
   static constexpr int PATCH = CK * CHS;
-  static constexpr int STEPS = PAIRROW ? CK * (ROWS / 2) * KW : (CK / 2) * KH * KW;
+  static constexpr int STEPS3 = PAIRROW ? CK * (ROWS / 2) * KW : (CK / 2) * KH * KW;
+  static constexpr int STEPS = STEPS3 + (DS ? CK / 2 : 0);             // steps >= STEPS3: the 1x1 convolution's
+  static_assert(!DS || (!PAIRROW && KH == 3 && KW == 3), "the fused 1x1 rides on the 3x3 channel-pair layout");
   static constexpr int DELTA = PAIRROW ? RS : CHS;                      // LDS distance of the second k of a step
   static constexpr int NV = CK * KH * RV, NLOAD = (NV + NT - 1) / NT;   // staging: float4 pieces per chunk, per thread
   static constexpr int PRE = 4;                                        // LDS operand reads run this many steps ahead
-  static constexpr int WAVES = PAIRROW ? 2 : (WN >= 2 ? 4 : 3);                        // waves per SIMD the register budget is held to
+  static constexpr int WAVES = PAIRROW ? 2 : (WN >= 2 && !DS ? 4 : 3);                        // waves per SIMD the register budget is held to
   static_assert(PAIRROW || CK % 2 == 0, "channel pairs");
   // chunks of the K loop; even unless the layer is a single chunk (two register sets of weights alternate)
   static constexpr int nchunk(int Cin) { return PAIRROW ? 1 : rup((Cin + CK - 1) / CK, 2); }
   static constexpr int step_offset(int s) {
+    if (s >= STEPS3) return step_offset(((s - STEPS3) * KH + PAD) * KW + PADW);   // centre tap of channel pair s - STEPS3
     const int q = s % KW, qq = q + LP - PADW;
     const int col = (qq & 1) * HALF + (qq >> 1);
     if (PAIRROW) {
@@ -66,8 +73,8 @@ struct S2Cfg {
 };
 
 template <class C>
-__global__ void conv_s2_pack_kernel(const float* __restrict__ w, float* __restrict__ P, int N, int Cin, int nchunk,
-                                    long long total) {
+__global__ void conv_s2_pack_kernel(const float* __restrict__ w, const float* __restrict__ wd, float* __restrict__ P, int N,
+                                    int Cin, int nchunk, long long total) {
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(e & 63), s = (int)((e >> 6) % C::STEPS);
@@ -75,6 +82,11 @@ __global__ void conv_s2_pack_kernel(const float* __restrict__ w, float* __restri
     const int chunk = (int)(blk % nchunk), nb = (int)(blk / nchunk);
     const int n = 32 * nb + (lane & 31), lh = lane >> 5, q = s % C::KW;
     int c, p;
+    if (s >= C::STEPS3) {   // wd[N][Cin] of the fused 1x1
+      c = chunk * C::CK + 2 * (s - C::STEPS3) + lh;
+      P[e] = (n < N && c < Cin) ? wd[(long long)n * Cin + c] : 0.f;
+      continue;
+    }
     if (C::PAIRROW) {
       c = chunk * C::CK + s / ((C::ROWS / 2) * C::KW);
       p = 2 * ((s / C::KW) % (C::ROWS / 2)) + lh;
@@ -90,10 +102,10 @@ __global__ void conv_s2_pack_kernel(const float* __restrict__ w, float* __restri
 // one sequence whose next patch is always in flight under the current MFMAs, so only the first item of a workgroup
 // pays the global latency, and the single-chunk stem keeps its 84 weight registers for all rows.
 template <class C, int ACT>
-__global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WAVES, C::WAVES))) void conv_s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                          int Cin, int N, int H, int W, int Ho, int Wo, int tiles_x,
-                                                          int rpw, float slope) {
+__global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WAVES, C::WAVES))) void conv_s2_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ out,
+    const float* __restrict__ bias_d, float* __restrict__ out_d, int Cin, int N, int H, int W, int Ho, int Wo, int tiles_x,
+    int rpw, float slope) {
   __shared__ __attribute__((aligned(16))) float smem[2 * C::PATCH + C::HALF + 4];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,11 +146,14 @@ __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WAVES,
   };
   const float* pw = wp + ((long long)nb * nchunk * C::STEPS) * 64;   // wave-uniform; + lane at the loads
 
-  f32x16 acc[C::MB];
+  f32x16 acc[C::MB], accd[C::DS ? C::MB : 1];
 #pragma unroll
   for (int m = 0; m < C::MB; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      acc[m][r] = 0.f;
+      if (C::DS) accd[m][r] = 0.f;
+    }
 
   float4 ra[C::NLOAD], rb[C::NLOAD];
   unsigned oka, okb;
@@ -203,6 +218,8 @@ __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WAVES,
       for (int m = 0; m < C::MB; ++m)
         if (PCFA_S2_DBG & 1)
           acc[m][s & 15] += wcur[s] * cur[m];
+        else if (C::DS && s >= C::STEPS3)
+          accd[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[s], cur[m], accd[m], 0, 0, 0);
         else
           acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[s], cur[m], acc[m], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -229,6 +246,15 @@ __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WAVES,
           if (ox0 + (wpx * C::MB + m) * 32 + l31 < Wo && n < N) orow[loff + 32 * m] = y;
           acc[m][r] = 0.f;
         }
+        if (C::DS) {   // the 1x1 convolution's output: bias only (its normalisation follows in the caller)
+          const float bdr = bias_d != nullptr ? bias_d[min(n, N - 1)] : 0.f;
+          float* drow = out_d + (orow - out);
+#pragma unroll
+          for (int m = 0; m < C::MB; ++m) {
+            if (ox0 + (wpx * C::MB + m) * 32 + l31 < Wo && n < N) drow[loff + 32 * m] = accd[m][r] + bdr;
+            accd[m][r] = 0.f;
+          }
+        }
       }
     }
     row = nrow;
@@ -250,9 +276,10 @@ typedef S2Cfg<7, 7, 3, true, 2, 2, 2> StemCfg;    // 3 -> N, 7x7: 64 channels x 
 #ifndef PCFA_S2_CK
 #define PCFA_S2_CK 4
 #endif
-template <int WN, int MB, int WP = (WN == 1 ? 4 : WN == 2 ? 2 : 1)>
-using Res3 = S2Cfg<3, 3, PCFA_S2_CK, false, WN, WP, MB>;
-typedef Res3<4, 1> Res3Cfg;   // the weight packing does not depend on WN / MB beyond the block padding to 4
+template <int WN, int MB, bool DS = false, int WP = (WN == 1 ? 4 : WN == 2 ? 2 : 1)>
+using Res3 = S2Cfg<3, 3, PCFA_S2_CK, false, WN, WP, MB, DS>;
+typedef Res3<4, 1> Res3Cfg;        // the weight packing does not depend on WN / MB beyond the block padding to 4
+typedef Res3<4, 1, true> Res3DsCfg;
 
 template <class C>
 long long packed_floats_t(int Cin, int N) {
@@ -261,17 +288,17 @@ long long packed_floats_t(int Cin, int N) {
 }
 
 template <class C>
-int pack_t(const float* w, float* packed, int Cin, int N, hipStream_t s) {
+int pack_t(const float* w, const float* wd, float* packed, int Cin, int N, hipStream_t s) {
   const long long total = packed_floats_t<C>(Cin, N);
-  pcfa_launch(conv_s2_pack_kernel<C>, dim3((unsigned)min((total + 255) / 256, 4096LL)), dim3(256), 0, s, w, packed, N,
+  pcfa_launch(conv_s2_pack_kernel<C>, dim3((unsigned)min((total + 255) / 256, 4096LL)), dim3(256), 0, s, w, wd, packed, N,
               Cin, C::nchunk(Cin), total);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
 
 template <class C>
-int fwd_t(const float* x, const float* packed, const float* bias, float* out, int B, int Cin, int N, int H, int W, int act,
-          float slope, hipStream_t s) {
+int fwd_t(const float* x, const float* packed, const float* bias, float* out, const float* bias_d, float* out_d, int B,
+          int Cin, int N, int H, int W, int act, float slope, hipStream_t s) {
   const int Ho = (H + 2 * C::PAD - C::KH) / 2 + 1, Wo = (W + 2 * C::PADW - C::KW) / 2 + 1;
   const int tiles_x = pcfa_cdiv(Wo, C::PXT), nby = rup((N + 31) / 32, C::WN) / C::WN;
   // rows per workgroup: as many as still leave >= 6 workgroups per CU (dev override PCFA_S2_RPW)
@@ -281,12 +308,173 @@ int fwd_t(const float* x, const float* packed, const float* bias, float* out, in
   if (rpw_env > 0) rpw = rpw_env;
   dim3 grid((unsigned)(tiles_x * pcfa_cdiv(Ho, rpw)), (unsigned)nby, (unsigned)B);
 #define PCFA_S2_GO(A_)                                                                                              \
-  pcfa_launch(conv_s2_fwd_kernel<C, A_>, grid, dim3(C::NT), 0, s, x, packed, bias, out, Cin, N, H, W, Ho, Wo, tiles_x, \
-              rpw, slope)
+  pcfa_launch(conv_s2_fwd_kernel<C, A_>, grid, dim3(C::NT), 0, s, x, packed, bias, out, bias_d, out_d, Cin, N, H, W, Ho, \
+              Wo, tiles_x, rpw, slope)
   if (act == 1) PCFA_S2_GO(1); else if (act == 2) PCFA_S2_GO(2); else PCFA_S2_GO(0);
 #undef PCFA_S2_GO
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Data gradient of the 3x3 / stride-2 convolution: dx[c][y][x] = sum_n sum_pq g[n][oy][ox] w[n][c][p][q] with
+// y = 2 oy - 1 + p, x = 2 ox - 1 + q.  By output parity (a, b) = (y & 1, x & 1) it is four stride-1 convolutions of g:
+//   a = 0: p = 1 (oy = i)            a = 1: p = 0 (oy = i + 1), p = 2 (oy = i)          (y = 2 i + a; same for b, q, j)
+// so every (p, q) feeds exactly one parity class: a wave keeps the four classes of its 32 coarse pixels (two fine rows
+// x 64 fine pixels) in four accumulators and issues ONE MFMA per (channel pair, p, q) -- the same 9 MFMAs per channel
+// pair as the forward, no zero taps, nothing scattered.  The two x-classes of a pixel sit in one lane, so the epilogue
+// writes float2 (256 B per instruction and channel row).  g needs no de-interleave (stride 1 on the coarse grid).
+// Layout as the forward: channels of dx = M (WN blocks of 32 per workgroup share the patch), coarse pixels = N.
+// ---------------------------------------------------------------------------------------------------------------
+// DS: the gradient of the fused 1x1 / stride-2 convolution (dx[c][2 i][2 j] += sum_n gd[n][i][j] wd[n][c]) rides along:
+// a second patch region holds row i of gd, CK / 2 more steps per chunk feed the (0, 0) class.
+template <int WN_, int WP_, bool DS_ = false>
+struct S2BwdCfg {
+  static constexpr bool DS = DS_;
+  static constexpr int WN = WN_, WP = WP_, NT = 64 * WN * WP, CK = 4, STEPS3 = (CK / 2) * 9, STEPS = STEPS3 + (DS ? CK / 2 : 0);
+  static constexpr int PXC = 32 * WP;                       // coarse pixels per workgroup
+  static constexpr int RV = PXC / 4 + 1, RSB = 4 * RV;      // float4 per patch row (one more for ox = j + 1), row stride
+  static constexpr int CHS = 2 * RSB;                       // [channel][row i, i + 1][RSB]
+  static constexpr int PATCH = (DS ? 2 : 1) * CK * CHS;     // DS: + [channel][row i of gd, unused][RSB]
+  static constexpr int NV3 = CK * 2 * RV, NV = NV3 + (DS ? CK * RV : 0), NLOAD = (NV + NT - 1) / NT;
+  static constexpr int PRE = 4;
+  static constexpr int WAVES = 3;
+  static constexpr int step_offset(int s) {                 // LDS offset of (pair, p, q): channel 2 pair, row (p == 0), column (q == 0)
+    if (s >= STEPS3) return CK * CHS + 2 * (s - STEPS3) * CHS;
+    const int pair = s / 9, p = (s / 3) % 3, q = s % 3;
+    return 2 * pair * CHS + (p == 0 ? RSB : 0) + (q == 0 ? 1 : 0);
+  }
+  static constexpr int step_class(int s) {                  // accumulator 2 a + b
+    if (s >= STEPS3) return 0;
+    const int p = (s / 3) % 3, q = s % 3;
+    return 2 * (p == 1 ? 0 : 1) + (q == 1 ? 0 : 1);
+  }
+};
+
+// packed[cb][chunk][step][lane]: A operand of step (pair, p, q): w[n = chunk CK + 2 pair + (lane >> 5)][c = 32 cb + (lane & 31)][p][q]
+template <bool DS>
+__global__ void conv_s2_bwd_pack_kernel(const float* __restrict__ w, const float* __restrict__ wd, float* __restrict__ P,
+                                        int N, int Cin, int nchunk, long long total) {
+  constexpr int STEPS = DS ? 20 : 18, CK = 4;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(e & 63), s = (int)((e >> 6) % STEPS);
+    const long long blk = (e >> 6) / STEPS;
+    const int chunk = (int)(blk % nchunk), cb = (int)(blk / nchunk);
+    const int c = 32 * cb + (lane & 31);
+    if (s >= 18) {
+      const int n = chunk * CK + 2 * (s - 18) + (lane >> 5);
+      P[e] = (n < N && c < Cin) ? wd[(long long)n * Cin + c] : 0.f;
+      continue;
+    }
+    const int n = chunk * CK + 2 * (s / 9) + (lane >> 5), p = (s / 3) % 3, q = s % 3;
+    P[e] = (n < N && c < Cin) ? w[(((long long)n * Cin + c) * 3 + p) * 3 + q] : 0.f;
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WAVES, C::WAVES))) void conv_s2_bwd_kernel(
+    const float* __restrict__ g, const float* __restrict__ gd, const float* __restrict__ wp, float* __restrict__ dx,
+    int Cin, int N, int H, int W, int Ho, int Wo, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * C::PATCH + 4];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wv % C::WN, wpx = wv / C::WN;
+  const int i = blockIdx.x / tiles_x, j0 = (blockIdx.x - i * tiles_x) * C::PXC;   // coarse row, first coarse column
+  const int cb = blockIdx.y * C::WN + wn;
+  const int gplane = Ho * Wo;
+  g += (long long)blockIdx.z * N * gplane;
+  if (C::DS) gd += (long long)blockIdx.z * N * gplane;
+  const int nchunk = (N + C::CK - 1) / C::CK + (((N + C::CK - 1) / C::CK) & 1);   // even (two weight register sets)
+
+  auto load_patch = [&](int chunk, float4 (&rr)[C::NLOAD], unsigned& okm) {
+    okm = 0;
+#pragma unroll
+    for (int k = 0; k < C::NLOAD; ++k) {
+      const int e = min(tid + C::NT * k, C::NV - 1);
+      const bool third = C::DS && e >= C::NV3;                 // a piece of gd's row i
+      const int jj = (third ? e - C::NV3 : e) / C::RV, v = (third ? e - C::NV3 : e) - jj * C::RV;
+      const int c = third ? jj : jj >> 1, r = third ? 0 : jj & 1;
+      const int n = chunk * C::CK + c, oy = i + r, ox = j0 + 4 * v;
+      okm |= (unsigned)((int)(n < N) & (int)(oy < Ho) & (int)(ox + 3 < Wo)) << k;
+      rr[k] = *reinterpret_cast<const float4*>((third ? gd : g) +
+                                               (unsigned)(min(n, N - 1) * gplane + min(oy, Ho - 1) * Wo + min(ox, Wo - 4)));
+    }
+  };
+  auto store_patch = [&](int buf, const float4 (&rr)[C::NLOAD], unsigned okm) {
+#pragma unroll
+    for (int k = 0; k < C::NLOAD; ++k) {
+      const int e = tid + C::NT * k;
+      const bool third = C::DS && e >= C::NV3;
+      const int jj = (third ? e - C::NV3 : e) / C::RV, v = (third ? e - C::NV3 : e) - jj * C::RV;
+      const int c = third ? C::CK + jj : jj >> 1, r = third ? 0 : jj & 1;
+      const float4 t = (okm >> k & 1u) ? rr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < C::NV) *reinterpret_cast<float4*>(smem + buf * C::PATCH + c * C::CHS + r * C::RSB + 4 * v) = t;
+    }
+  };
+  const float* pw = wp + ((long long)cb * nchunk * C::STEPS) * 64;   // wave-uniform; + lane at the loads
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  float4 ra[C::NLOAD], rb[C::NLOAD];
+  unsigned oka, okb;
+  float wa[C::STEPS], wb[C::STEPS];
+  load_patch(0, ra, oka);
+#pragma unroll
+  for (int s = 0; s < C::STEPS; ++s) wa[s] = pw[s * 64 + lane];
+  store_patch(0, ra, oka);
+  __syncthreads();
+  load_patch(min(1, nchunk - 1), rb, okb);
+  const int bl = wpx * 32 + l31 + lh * C::CHS;
+
+  auto item = [&](int chunk, const float (&wcur)[C::STEPS], float (&wnext)[C::STEPS], float4 (&rload)[C::NLOAD],
+                  unsigned& okload, const float4 (&rstore)[C::NLOAD], const unsigned& okstore) {
+    const float* sp = smem + (chunk & 1) * C::PATCH + bl;
+    load_patch(min(chunk + 2, nchunk - 1), rload, okload);
+    const float* qn = pw + (long long)min(chunk + 1, nchunk - 1) * C::STEPS * 64;
+#pragma unroll
+    for (int s = 0; s < C::STEPS; ++s) wnext[s] = qn[s * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    float ring[C::PRE];
+#pragma unroll
+    for (int s = 0; s < C::PRE; ++s) ring[s] = sp[C::step_offset(s)];
+#pragma unroll
+    for (int s = 0; s < C::STEPS; ++s) {
+      const float cur = ring[s % C::PRE];
+      if (s + C::PRE < C::STEPS) ring[s % C::PRE] = sp[C::step_offset(s + C::PRE)];
+      acc[C::step_class(s)] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[s], cur, acc[C::step_class(s)], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    store_patch((chunk + 1) & 1, rstore, okstore);
+    __syncthreads();
+  };
+  for (int chunk = 0; chunk < nchunk; chunk += 2) {
+    item(chunk, wa, wb, ra, oka, rb, okb);
+    item(chunk + 1, wb, wa, rb, okb, ra, oka);
+  }
+
+  // ---- epilogue: lane = coarse pixel j, register r = channel 8 (r >> 2) + 4 lh + (r & 3); the two x-classes of a
+  //      pixel are neighbours in the row: float2 stores ----
+  const int plane = H * W;
+  float* ob = dx + ((long long)blockIdx.z * Cin + 32 * cb) * plane + 2 * (j0 + wpx * 32);
+  const int jx = j0 + wpx * 32 + l31;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int y = 2 * i + a;
+    if (y < H && 2 * jx < W) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nu = 8 * (r >> 2) + (r & 3);
+        if (32 * cb + nu + 4 * lh < Cin)
+          *reinterpret_cast<float2*>(ob + (long long)nu * plane + (unsigned)(4 * lh * plane + y * W + 2 * l31)) =
+              make_float2(acc[2 * a][r], acc[2 * a + 1][r]);
+      }
+    }
+  }
 }
 
 bool is_stem(int Cin, int ksize) { return ksize == 7 && Cin == 3; }
@@ -310,9 +498,106 @@ long long pcfa_conv_s2_packed_floats(int Cin, int N, int ksize) {
 int pcfa_conv_s2_pack(const float* w, float* packed, int Cin, int N, int ksize, void* stream) {
   if (w == nullptr || packed == nullptr) return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (is_stem(Cin, ksize)) return pack_t<StemCfg>(w, packed, Cin, N, s);
-  if (ksize == 3) return pack_t<Res3Cfg>(w, packed, Cin, N, s);
+  if (is_stem(Cin, ksize)) return pack_t<StemCfg>(w, nullptr, packed, Cin, N, s);
+  if (ksize == 3) return pack_t<Res3Cfg>(w, nullptr, packed, Cin, N, s);
   return PCFA_ERR_INVALID_ARG;
+}
+
+long long pcfa_conv_s2_ds_packed_floats(int Cin, int N) { return packed_floats_t<Res3DsCfg>(Cin, N); }
+
+int pcfa_conv_s2_ds_pack(const float* w, const float* wd, float* packed, int Cin, int N, void* stream) {
+  if (w == nullptr || wd == nullptr || packed == nullptr) return PCFA_ERR_INVALID_ARG;
+  return pack_t<Res3DsCfg>(w, wd, packed, Cin, N, (hipStream_t)stream);
+}
+
+int pcfa_conv_s2_ds_fwd(const float* x, const float* packed, const float* bias, float* out, const float* bias_d,
+                        float* out_d, int B, int Cin, int N, int H, int W, int act, float slope, void* stream) {
+  if (x == nullptr || packed == nullptr || out == nullptr || out_d == nullptr || B < 1 || act < 0 || act > 2)
+    return PCFA_ERR_INVALID_ARG;
+  if (!pcfa_conv_s2_supported(Cin, N, 3, H, W)) return PCFA_ERR_UNSUPPORTED;
+  if (((uintptr_t)x & 15) != 0) return PCFA_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = (N + 31) / 32, wn = nblk >= 4 ? 4 : nblk;
+#define PCFA_S2_RES(WN_) return fwd_t<Res3<WN_, 1, true>>(x, packed, bias, out, bias_d, out_d, B, Cin, N, H, W, act, slope, s)
+  if (wn == 4) PCFA_S2_RES(4);
+  if (wn == 3) PCFA_S2_RES(3);
+  if (wn == 2) PCFA_S2_RES(2);
+  PCFA_S2_RES(1);
+#undef PCFA_S2_RES
+}
+
+static long long s2_bwd_floats(int Cin, int N, int steps) {
+  const long long nchunk = (N + 3) / 4 + (((N + 3) / 4) & 1), nblk = rup((Cin + 31) / 32, 4);
+  return nblk * nchunk * steps * 64;
+}
+long long pcfa_conv_s2_bwd_packed_floats(int Cin, int N, int ksize) { return ksize == 3 ? s2_bwd_floats(Cin, N, 18) : 0; }
+long long pcfa_conv_s2_ds_bwd_packed_floats(int Cin, int N) { return s2_bwd_floats(Cin, N, 20); }
+
+int pcfa_conv_s2_bwd_supported(int Cin, int N, int ksize, int H, int W) {
+  if (ksize != 3 || Cin < 1 || N < 1 || H < 2 || W < 8 || W % 8 != 0) return 0;    // Wo % 4 == 0: float4 rows of g
+  if ((long long)Cin * H * W > 0x7fffffffLL || (long long)N * H * W > 0x7fffffffLL) return 0;
+  return 1;
+}
+
+int pcfa_conv_s2_bwd_pack(const float* w, float* packed, int Cin, int N, int ksize, void* stream) {
+  if (w == nullptr || packed == nullptr) return PCFA_ERR_INVALID_ARG;
+  if (ksize != 3) return PCFA_ERR_UNSUPPORTED;
+  const long long total = pcfa_conv_s2_bwd_packed_floats(Cin, N, ksize);
+  pcfa_launch(conv_s2_bwd_pack_kernel<false>, dim3((unsigned)min((total + 255) / 256, 4096LL)), dim3(256), 0,
+              (hipStream_t)stream, w, (const float*)nullptr, packed, N, Cin, (int)((N + 3) / 4 + (((N + 3) / 4) & 1)), total);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+int pcfa_conv_s2_ds_bwd_pack(const float* w, const float* wd, float* packed, int Cin, int N, void* stream) {
+  if (w == nullptr || wd == nullptr || packed == nullptr) return PCFA_ERR_INVALID_ARG;
+  const long long total = pcfa_conv_s2_ds_bwd_packed_floats(Cin, N);
+  pcfa_launch(conv_s2_bwd_pack_kernel<true>, dim3((unsigned)min((total + 255) / 256, 4096LL)), dim3(256), 0,
+              (hipStream_t)stream, w, wd, packed, N, Cin, (int)((N + 3) / 4 + (((N + 3) / 4) & 1)), total);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+static int s2_bwd_run(const float* grad_out, const float* grad_out_d, const float* packed, float* grad_x, int B, int Cin,
+                      int N, int H, int W, int ksize, void* stream) {
+  if (grad_out == nullptr || packed == nullptr || grad_x == nullptr || B < 1) return PCFA_ERR_INVALID_ARG;
+  if (!pcfa_conv_s2_bwd_supported(Cin, N, ksize, H, W)) return PCFA_ERR_UNSUPPORTED;
+  if (((uintptr_t)grad_out & 15) != 0 || ((uintptr_t)grad_out_d & 15) != 0 || ((uintptr_t)grad_x & 7) != 0)
+    return PCFA_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int Ho = (H - 1) / 2 + 1, Wo = W / 2, nblk = (Cin + 31) / 32;
+  const int rows = (H + 1) / 2;                       // coarse rows i = y >> 1
+#define PCFA_S2_BWD1(WN_, WP_, DS_)                                                                                    \
+  {                                                                                                                    \
+    typedef S2BwdCfg<WN_, WP_, DS_> C;                                                                                 \
+    const int tiles_x = pcfa_cdiv(Wo, C::PXC);                                                                         \
+    pcfa_launch(conv_s2_bwd_kernel<C>, dim3((unsigned)(tiles_x * rows), (unsigned)pcfa_cdiv(nblk, WN_), (unsigned)B),   \
+                dim3(C::NT), 0, s, grad_out, grad_out_d, packed, grad_x, Cin, N, H, W, Ho, Wo, tiles_x);               \
+    PCFA_LAUNCH_CHECK();                                                                                               \
+    return PCFA_OK;                                                                                                    \
+  }
+#define PCFA_S2_BWD(WN_, WP_)                                   \
+  {                                                             \
+    if (grad_out_d != nullptr) PCFA_S2_BWD1(WN_, WP_, true)     \
+    PCFA_S2_BWD1(WN_, WP_, false)                               \
+  }
+  if (nblk >= 4) PCFA_S2_BWD(4, 1)
+  if (nblk == 3) PCFA_S2_BWD(3, 1)
+  if (nblk == 2) PCFA_S2_BWD(2, 2)
+  PCFA_S2_BWD(1, 4)
+#undef PCFA_S2_BWD
+#undef PCFA_S2_BWD1
+}
+
+int pcfa_conv_s2_bwd(const float* grad_out, const float* packed, float* grad_x, int B, int Cin, int N, int H, int W,
+                     int ksize, void* stream) {
+  return s2_bwd_run(grad_out, nullptr, packed, grad_x, B, Cin, N, H, W, ksize, stream);
+}
+
+int pcfa_conv_s2_ds_bwd(const float* grad_out, const float* grad_out_d, const float* packed, float* grad_x, int B, int Cin,
+                        int N, int H, int W, void* stream) {
+  if (grad_out_d == nullptr) return PCFA_ERR_INVALID_ARG;
+  return s2_bwd_run(grad_out, grad_out_d, packed, grad_x, B, Cin, N, H, W, 3, stream);
 }
 
 int pcfa_conv_s2_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int Cin, int N, int H,
@@ -321,12 +606,13 @@ int pcfa_conv_s2_fwd(const float* x, const float* packed, const float* bias, flo
   if (!pcfa_conv_s2_supported(Cin, N, ksize, H, W)) return PCFA_ERR_UNSUPPORTED;
   if (((uintptr_t)x & 15) != 0) return PCFA_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (is_stem(Cin, ksize)) return fwd_t<StemCfg>(x, packed, bias, out, B, Cin, N, H, W, act, slope, s);
+  if (is_stem(Cin, ksize)) return fwd_t<StemCfg>(x, packed, bias, out, nullptr, nullptr, B, Cin, N, H, W, act, slope, s);
   // as many channel blocks per workgroup as the layer has (up to four; they share the staged patch), 32 pixels per
   // wave (64 measured 2-5 % slower at the encoder shapes, one-wave workgroups with private patches 10-70 % slower)
   static const int wn_env = getenv("PCFA_S2_WN") ? atoi(getenv("PCFA_S2_WN")) : 0;   // dev override
   const int nblk = (N + 31) / 32, wn = wn_env ? wn_env : (nblk >= 4 ? 4 : nblk);
-#define PCFA_S2_RES(WN_) return fwd_t<Res3<WN_, 1>>(x, packed, bias, out, B, Cin, N, H, W, act, slope, s)
+#define PCFA_S2_RES(WN_) \
+  return fwd_t<Res3<WN_, 1>>(x, packed, bias, out, nullptr, nullptr, B, Cin, N, H, W, act, slope, s)
   if (wn == 4) PCFA_S2_RES(4);
   if (wn == 3) PCFA_S2_RES(3);
   if (wn == 2) PCFA_S2_RES(2);

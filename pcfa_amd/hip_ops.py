@@ -823,6 +823,24 @@ def _s2_packed(weight):
     return hit[2]
 
 
+CONV_S2_BWD = True   # data gradient on pcfa_conv_s2_bwd where it applies (False: library gradient; tools/dev A/B)
+_s2_bwd_packs = {}
+
+
+def _s2_bwd_packed(weight):
+    key = id(weight)
+    hit = _s2_bwd_packs.get(key)
+    if hit is None or hit[0]() is not weight or hit[1] != weight._version:
+        lib = _hip.load()
+        N, Cin, k, _ = weight.shape
+        w = weight.detach().contiguous()
+        packed = torch.empty(int(lib.pcfa_conv_s2_bwd_packed_floats(Cin, N, k)), device=w.device, dtype=torch.float32)
+        _call("pcfa_conv_s2_bwd_pack", _ptr(w), _ptr(packed), Cin, N, k)
+        hit = (weakref.ref(weight, lambda _r, k_=key: _s2_bwd_packs.pop(k_, None)), weight._version, packed)
+        _s2_bwd_packs[key] = hit
+    return hit[2]
+
+
 def conv_s2_supported(x, weight):
     """True when conv_s2 covers conv2d(x, weight, stride=2, padding=k//2): the 3-channel 7x7 stem or any 3x3, W % 4 == 0."""
     N, Cin, kh, kw = weight.shape
@@ -856,9 +874,91 @@ class _ConvS2(torch.autograd.Function):
             else:
                 _call("pcfa_leaky_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), ctx.slope, g.numel())
             g = gm
-        k = weight.shape[-1]
-        gx = torch.nn.grad.conv2d_input(ctx.xshape, weight, g, stride=2, padding=k // 2)
+        N, Cin, k, _ = weight.shape
+        B, _, H, W = ctx.xshape
+        if CONV_S2_BWD and _hip.load().pcfa_conv_s2_bwd_supported(Cin, N, k, H, W):
+            gx = torch.empty(ctx.xshape, device=g.device, dtype=torch.float32)
+            _call("pcfa_conv_s2_bwd", _ptr(g), _ptr(_s2_bwd_packed(weight)), _ptr(gx), B, Cin, N, H, W, k)
+        else:   # the stem's gradient and ragged widths: library
+            gx = torch.nn.grad.conv2d_input(ctx.xshape, weight, g, stride=2, padding=k // 2)
         return gx, None, None, None, None
+
+
+_s2_ds_packs = {}   # (id(w), id(wd)) -> (weakref w, weakref wd, versions, fwd_packed, bwd_packed)
+
+
+def _s2_ds_packed(weight, weight_d):
+    key = (id(weight), id(weight_d))
+    hit = _s2_ds_packs.get(key)
+    ver = (weight._version, weight_d._version)
+    if hit is None or hit[0]() is not weight or hit[1]() is not weight_d or hit[2] != ver:
+        lib = _hip.load()
+        N, Cin, _, _ = weight.shape
+        w, wd = weight.detach().contiguous(), weight_d.detach().contiguous()
+        pf = torch.empty(int(lib.pcfa_conv_s2_ds_packed_floats(Cin, N)), device=w.device, dtype=torch.float32)
+        pb = torch.empty(int(lib.pcfa_conv_s2_ds_bwd_packed_floats(Cin, N)), device=w.device, dtype=torch.float32)
+        _call("pcfa_conv_s2_ds_pack", _ptr(w), _ptr(wd), _ptr(pf), Cin, N)
+        _call("pcfa_conv_s2_ds_bwd_pack", _ptr(w), _ptr(wd), _ptr(pb), Cin, N)
+        drop = lambda _r, k_=key: _s2_ds_packs.pop(k_, None)
+        hit = (weakref.ref(weight, drop), weakref.ref(weight_d, drop), ver, pf, pb)
+        _s2_ds_packs[key] = hit
+    return hit[3], hit[4]
+
+
+def conv_s2_ds_supported(x, weight, weight_d):
+    """True when conv_s2_ds covers the pair: a 3x3 and a 1x1 stride-2 convolution of the same input with equally many
+    output channels, W % 8 == 0 (both directions on the HIP kernels)."""
+    N, Cin, kh, kw = weight.shape
+    if not (x.dim() == 4 and x.is_cuda and (kh, kw) == (3, 3) and tuple(weight_d.shape) == (N, Cin, 1, 1)
+            and x.shape[1] == Cin and not weight.requires_grad and not weight_d.requires_grad):
+        return False
+    lib = _hip.load()
+    return bool(lib.pcfa_conv_s2_supported(Cin, N, 3, x.shape[2], x.shape[3])
+                and lib.pcfa_conv_s2_bwd_supported(Cin, N, 3, x.shape[2], x.shape[3]))
+
+
+class _ConvS2DS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, weight_d, bias, bias_d, act):
+        _dev(x, weight, weight_d, bias, bias_d)
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        N = weight.shape[0]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty((B, N, Ho, Wo), device=x.device, dtype=torch.float32)
+        out_d = torch.empty_like(out)
+        pf, pb = _s2_ds_packed(weight, weight_d)
+        _call("pcfa_conv_s2_ds_fwd", _ptr(x), _ptr(pf), _ptr(bias), _ptr(out), _ptr(bias_d), _ptr(out_d), B, Cin, N, H, W,
+              act, 0.0)
+        ctx.act, ctx.xshape, ctx.packed_bwd = act, tuple(x.shape), pb
+        ctx.save_for_backward(out if act else None)
+        return out, out_d
+
+    @staticmethod
+    def backward(ctx, g, gd):
+        (out,) = ctx.saved_tensors
+        B, Cin, H, W = ctx.xshape
+        g = g.contiguous()
+        gd = gd.contiguous()
+        if ctx.act:
+            gm = torch.empty_like(g)
+            _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), g.numel())
+            g = gm
+        gx = torch.empty(ctx.xshape, device=g.device, dtype=torch.float32)
+        _call("pcfa_conv_s2_ds_bwd", _ptr(g), _ptr(gd), _ptr(ctx.packed_bwd), _ptr(gx), B, Cin, g.shape[1], H, W)
+        return gx, None, None, None, None, None
+
+
+def conv_s2_ds(x, weight, weight_d, bias=None, bias_d=None, relu=False):
+    """(act(conv2d(x, weight, bias, stride=2, padding=1)), conv2d(x, weight_d, bias_d, stride=2)): conv1 and downsample[0]
+    of a stride-2 residual block (extractor.py:23-58) in one launch per direction (pcfa_conv_s2_ds_fwd / _bwd)."""
+    _dev(x, weight, weight_d, bias, bias_d)
+    if not conv_s2_ds_supported(x, weight, weight_d):
+        raise ValueError("conv_s2_ds: unsupported weights %s / %s for input %s"
+                         % (tuple(weight.shape), tuple(weight_d.shape), tuple(x.shape)))
+    if any(b is not None and b.requires_grad for b in (bias, bias_d)):
+        raise RuntimeError("conv_s2_ds: frozen parameters only")
+    return _ConvS2DS.apply(x, weight, weight_d, bias, bias_d, int(bool(relu)))
 
 
 def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None):

@@ -57,6 +57,7 @@ def _fold_batchnorm(conv, bn, cache, tag):
     return hit[1], hit[2]
 
 
+FUSED_DOWNSAMPLE = True   # conv1 + downsample[0] of a stride-2 residual block in one launch (tools/dev A/B: set False)
 _DEFER_RELU = os.environ.get("PCFA_DEFER_RELU", "1") != "0"   # A/B switch: ReLU backward fused into neighbouring kernels
 # Module-level switches, read from the environment ONCE at import (defaults for tools); code that needs another setting
 # assigns the attribute (bench.py, tests) -- nothing reads os.environ at call time.
@@ -138,7 +139,32 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
         self._fold_cache = {}
 
+    def _entry_pair(self, x):
+        """(relu(norm1(conv1(x))), norm3(downsample[0](x))) of a stride-2 block through ONE fused launch per direction
+        (ops.conv_s2_ds), or None when the fast path does not apply."""
+        conv1, convd, n1, nd = self.conv1, self.downsample[0], self.norm1, self.downsample[1]
+        o = ops.get()
+        if not (FUSED_DOWNSAMPLE and _all_frozen(self) and conv1.stride == (2, 2) and convd.stride == (2, 2)
+                and convd.kernel_size == (1, 1) and convd.padding == (0, 0) and _is_stride2(conv1, x)
+                and o.conv_s2_ds_supported(x, conv1.weight, convd.weight)):
+            return None
+        if all(isinstance(n, nn.BatchNorm2d) and not n.training and n.track_running_stats for n in (n1, nd)):
+            w1, b1 = _fold_batchnorm(conv1, n1, self._fold_cache, "1")
+            wd, bd = _fold_batchnorm(convd, nd, self._fold_cache, "d")
+            if not o.conv_s2_ds_supported(x, w1, wd):
+                return None
+            return o.conv_s2_ds(x, w1, wd, b1, bd, relu=True)
+        if all(isinstance(n, nn.InstanceNorm2d) and not n.affine and not n.track_running_stats for n in (n1, nd)):
+            y, xd = o.conv_s2_ds(x, conv1.weight, convd.weight)      # the biases cancel in the instance norms
+            return o.instance_norm_relu(y, n1.eps, True), o.instance_norm_relu(xd, nd.eps, False)
+        return None
+
     def forward(self, x):
+        pair = self._entry_pair(x) if self.downsample is not None else None
+        if pair is not None:
+            y, xd = pair
+            y = _conv_norm(self.conv2, self.norm2, y, True, self._fold_cache, "2")
+            return ops.get().add_relu(xd, y)
         if self.downsample is None and _all_frozen(self) and _can_skip(self.conv1, self.norm1):
             # the block input feeds conv1 and the residual sum: conv1's data-gradient kernel adds the residual path's
             # gradient in its epilogue (one autograd `add` over the activation less per block)

@@ -976,6 +976,35 @@ def test_conv_s2_vs_oracle(oracle_ops, shape):
         hip_ops.conv_s2(torch.zeros(1, 3, 8, 8), w[:, :3, :3, :3].contiguous())       # no CPU fallback
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96, 220, 512), (1, 96, 128, 110, 256), (1, 10, 40, 9, 264), (2, 16, 16, 6, 8)])
+def test_conv_s2_ds_vs_oracle(oracle_ops, shape):
+    """extractor.py:23-58 (stride 2): conv1 (3x3) and downsample[0] (1x1) of the block input in one launch per direction,
+    both outputs and the summed data gradient against the CPU restatement."""
+    B, Cin, N, H, W = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(N, Cin, 3, 3, generator=gen) / (Cin * 9) ** .5
+    wd = torch.randn(N, Cin, 1, 1, generator=gen) / Cin ** .5
+    b, bd = torch.randn(N, generator=gen), torch.randn(N, generator=gen)
+    for relu, bias in ((False, False), (True, True)):
+        xc = x.clone().requires_grad_(True)
+        want, want_d = oracle_ops.conv_s2_ds(xc, w, wd, b if bias else None, bd if bias else None, relu=relu)
+        go, god = torch.randn(want.shape, generator=gen), torch.randn(want.shape, generator=gen)
+        (want * go + want_d * god).sum().backward()
+        xg = x.to(DEV).requires_grad_(True)
+        assert hip_ops.conv_s2_ds_supported(xg, w.to(DEV), wd.to(DEV))
+        got, got_d = hip_ops.conv_s2_ds(xg, w.to(DEV), wd.to(DEV), b.to(DEV) if bias else None,
+                                        bd.to(DEV) if bias else None, relu=relu)
+        (got * go.to(DEV) + got_d * god.to(DEV)).sum().backward()
+        for g_, w_ in ((got, want), (got_d, want_d)):
+            assert (g_.cpu() - w_).abs().max().item() <= 2e-5 * max(w_.abs().max().item(), 1.0)
+        flips = ((got.cpu() > 0) != (want > 0)).sum().item() if relu else 0
+        gerr = (xg.grad.cpu() - xc.grad).norm().item() / xc.grad.norm().item()
+        assert gerr <= 2e-5 + 2 * (flips / want.numel()) ** .5, (relu, gerr, flips)
+    assert not hip_ops.conv_s2_ds_supported(torch.zeros(1, 8, 8, 12, device=DEV), torch.zeros(8, 8, 3, 3, device=DEV),
+                                            torch.zeros(8, 8, 1, 1, device=DEV))          # W % 8
+
+
 def test_sepconv5_rejects_bad_operands():
     w = torch.zeros(4, 3, 1, 5, device=DEV)
     with pytest.raises(ValueError):

@@ -39,5 +39,33 @@ def main():
                 print("      %7.1f us  %s" % (us, kname))
 
 
+def pair():
+    """conv1 + downsample[0] of the stride-2 blocks: fused launch against conv_s2 + library 1x1."""
+    for B, Cin, N, H, W in [(2, 64, 96, 220, 512), (1, 64, 96, 220, 512), (2, 96, 128, 110, 256), (1, 96, 128, 110, 256)]:
+        x = torch.randn(B, Cin, H, W, device=DEV, requires_grad=True)
+        w = torch.randn(N, Cin, 3, 3, device=DEV) / (Cin * 9) ** .5
+        wd = torch.randn(N, Cin, 1, 1, device=DEV) / Cin ** .5
+        go = torch.randn(B, N, H // 2, W // 2, device=DEV)
+
+        def fused():
+            x.grad = None
+            y, yd = hip_ops.conv_s2_ds(x, w, wd)
+            (y * go).sum().backward() if False else torch.autograd.backward([y, yd], [go, go])
+
+        def split():
+            x.grad = None
+            y, yd = hip_ops.conv_s2(x, w), F.conv2d(x, wd, None, stride=2)
+            torch.autograd.backward([y, yd], [go, go])
+
+        for tag, fn in (("fused", fused), ("split", split)):
+            t, parts = device_us(fn)
+            print("block entry %d->%d B%d %s fwd+bwd %7.1f us" % (Cin, N, B, tag, t))
+            for kname, us in sorted(parts.items(), key=lambda kv: -kv[1]):
+                print("      %7.1f us  %s" % (us, kname))
+
+
 if __name__ == "__main__":
+    if "--pair" in sys.argv:
+        pair()
+        sys.exit(0)
     main()
