@@ -493,10 +493,12 @@ PCFA_API long long pcfa_conv_s2_packed_floats(int Cin, int N, int ksize);
 PCFA_API int pcfa_conv_s2_pack(const float* w, float* packed, int Cin, int N, int ksize, void* stream);
 PCFA_API int pcfa_conv_s2_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int Cin, int N,
                               int H, int W, int ksize, int act, float slope, void* stream);
-/* Data gradient of the 3x3 / stride-2 convolution above: grad_x[B][Cin][H][W] (overwritten) from grad_out[B][N][Ho][Wo], as
- * four stride-1 convolutions of grad_out by output parity (one MFMA per (p, q) and channel pair, nothing scattered, no
- * layout transposes).  ksize = 3 and W % 8 == 0 (PCFA_ERR_UNSUPPORTED otherwise: the caller keeps the library
- * gradient); packed: pcfa_conv_s2_bwd_packed_floats() floats written once by pcfa_conv_s2_bwd_pack from w[N][Cin][3][3]. */
+/* Data gradient of the stride-2 convolutions above: grad_x[B][Cin][H][W] (overwritten) from grad_out[B][N][Ho][Wo].
+ * ksize = 3: four stride-1 convolutions of grad_out by output parity (one MFMA per (p, q) and channel pair, nothing
+ * scattered, no layout transposes).  (Cin, ksize) = (3, 7), the stem: a 4x4-tap convolution of grad_out onto the 12
+ * (channel, parity) rows on the 16x16x4 fp32 MFMA (the library: GEMM into a 147 x pixels matrix + col2im).
+ * W % 8 == 0 (PCFA_ERR_UNSUPPORTED otherwise: the caller keeps the library gradient); packed:
+ * pcfa_conv_s2_bwd_packed_floats() floats written once by pcfa_conv_s2_bwd_pack from w[N][Cin][k][k]. */
 PCFA_API int pcfa_conv_s2_bwd_supported(int Cin, int N, int ksize, int H, int W);
 PCFA_API long long pcfa_conv_s2_bwd_packed_floats(int Cin, int N, int ksize);
 PCFA_API int pcfa_conv_s2_bwd_pack(const float* w, float* packed, int Cin, int N, int ksize, void* stream);

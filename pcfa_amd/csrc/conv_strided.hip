@@ -477,6 +477,144 @@ __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WAVES,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Data gradient of the 7x7 / stride-2 stem (3 <- N channels).  With y = 2 i + a, x = 2 j + b:
+//   dx[c][2 i + a][2 j + b] = sum_n sum_{di, dj in -1..2} g[n][i + di][j + dj] w[n][c][a + 3 - 2 di][b + 3 - 2 dj]
+// (weights outside 0..6 are zero): a stride-1 4x4-tap convolution of g onto 12 "phase channels" (c, a, b).  Twelve rows
+// are too few for the 32x32 tiles, so this one runs on v_mfma_f32_16x16x4_f32: M = 16 = (c, a, b) + 4 idle rows,
+// N = 16 coarse pixels, K = 4 channels of g at one tap.  Its D layout puts row 4 (lane >> 4) + r in register r of a
+// lane: lane group = colour channel c, register = parity class, so a lane stores float2 (x = 2 j, 2 j + 1) for the two
+// fine rows -- no scatter, no col2im buffer (the library path: a GEMM into a 147 x pixels matrix + Col2Im2dU).
+// A wave owns 64 coarse pixels of one coarse row (four pixel blocks share each weight operand), a workgroup four rows;
+// the weight operand stream (16 taps x N / 4) is packed once in lane order and requested a chunk ahead.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct StemBwd {
+  static constexpr int CK = 8, KG = CK / 4, TAPS = 16, STEPS = KG * TAPS;   // chunk: 8 channels of g = 2 k-groups x 16 taps
+  static constexpr int MB = 4, PXC = 16 * MB, TR = 4, NT = 256;             // wave: 64 coarse pixels; workgroup: 4 coarse rows
+  static constexpr int RV = (PXC + 8) / 4, RS = 4 * RV;                     // patch row: columns j0 - 4 .. j0 + 67
+  static constexpr int PROWS = TR + 3;                                      // coarse rows i0 - 1 .. i0 + 5
+  static constexpr int CHS = (PROWS * RS + 31) / 32 * 32 + 16;              // = 16 (mod 32): the four k lanes groups of a
+  static constexpr int PATCH = CK * CHS;                                    //   ds_read_b32 half land on disjoint banks
+  static constexpr int NV = CK * PROWS * RV, NLOAD = (NV + NT - 1) / NT;
+  static constexpr int PRE = 3;
+  static constexpr int step_offset(int s) {   // (k-group, tap (di + 1) * 4 + (dj + 1)): channel 4 kg, row di + 1, column dj + 4
+    const int kg = s / TAPS, t = s % TAPS;
+    return 4 * kg * CHS + (t / 4) * RS + (t % 4) + 3;
+  }
+};
+
+// packed[chunk][step][lane]: A operand: row m = lane & 15 = 4 c + 2 a + b, k = lane >> 4: n = 8 chunk + 4 kg + k
+__global__ void conv_s2_stem_bwd_pack_kernel(const float* __restrict__ w, float* __restrict__ P, int N, long long total) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(e & 63), s = (int)((e >> 6) % StemBwd::STEPS), chunk = (int)((e >> 6) / StemBwd::STEPS);
+    const int m = lane & 15, c = m >> 2, a = (m >> 1) & 1, b = m & 1;
+    const int kg = s / 16, t = s % 16, di = t / 4 - 1, dj = t % 4 - 1;
+    const int n = 8 * chunk + 4 * kg + (lane >> 4), p = a + 3 - 2 * di, q = b + 3 - 2 * dj;
+    P[e] = (c < 3 && n < N && p >= 0 && p < 7 && q >= 0 && q < 7) ? w[(((long long)n * 3 + c) * 7 + p) * 7 + q] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(StemBwd::NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_s2_stem_bwd_kernel(
+    const float* __restrict__ g, const float* __restrict__ wp, float* __restrict__ dx, int N, int H, int W, int Ho, int Wo,
+    int tiles_x) {
+  typedef StemBwd C;
+  __shared__ __attribute__((aligned(16))) float smem[2 * C::PATCH + 4];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rblk = blockIdx.x / tiles_x, j0 = (blockIdx.x - rblk * tiles_x) * C::PXC, i0 = rblk * C::TR;
+  const int gplane = Ho * Wo;
+  g += (long long)blockIdx.z * N * gplane;
+  const int nchunk = ((N + C::CK - 1) / C::CK + 1) & ~1;   // even: two weight register sets alternate
+
+  auto load_patch = [&](int chunk, float4 (&rr)[C::NLOAD], unsigned& okm) {
+    okm = 0;
+#pragma unroll
+    for (int k = 0; k < C::NLOAD; ++k) {
+      const int e = min(tid + C::NT * k, C::NV - 1);
+      const int jj = e / C::RV, v = e - jj * C::RV, c = jj / C::PROWS, r = jj - c * C::PROWS;
+      const int n = chunk * C::CK + c, oy = i0 - 1 + r, ox = j0 - 4 + 4 * v;
+      okm |= (unsigned)((int)(n < N) & (int)(oy >= 0) & (int)(oy < Ho) & (int)(ox >= 0) & (int)(ox + 3 < Wo)) << k;
+      rr[k] = *reinterpret_cast<const float4*>(
+          g + (unsigned)(min(n, N - 1) * gplane + min(max(oy, 0), Ho - 1) * Wo + min(max(ox, 0), Wo - 4)));
+    }
+  };
+  auto store_patch = [&](int buf, const float4 (&rr)[C::NLOAD], unsigned okm) {
+#pragma unroll
+    for (int k = 0; k < C::NLOAD; ++k) {
+      const int e = tid + C::NT * k;
+      const int jj = e / C::RV, v = e - jj * C::RV, c = jj / C::PROWS, r = jj - c * C::PROWS;
+      const float4 t = (okm >> k & 1u) ? rr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < C::NV) *reinterpret_cast<float4*>(smem + buf * C::PATCH + c * C::CHS + r * C::RS + 4 * v) = t;
+    }
+  };
+
+  f32x4v acc[C::MB];
+#pragma unroll
+  for (int m = 0; m < C::MB; ++m) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[C::NLOAD], rb[C::NLOAD];
+  unsigned oka, okb;
+  float wa[C::STEPS], wb[C::STEPS];
+  load_patch(0, ra, oka);
+#pragma unroll
+  for (int s = 0; s < C::STEPS; ++s) wa[s] = wp[s * 64 + lane];
+  store_patch(0, ra, oka);
+  __syncthreads();
+  load_patch(1, rb, okb);
+  const int bl = lg * C::CHS + wv * C::RS + l15;   // k lane group -> channel, wave -> row of the tile, lane -> pixel
+
+  auto item = [&](int chunk, const float (&wcur)[C::STEPS], float (&wnext)[C::STEPS], float4 (&rload)[C::NLOAD],
+                  unsigned& okload, const float4 (&rstore)[C::NLOAD], const unsigned& okstore) {
+    const float* sp = smem + (chunk & 1) * C::PATCH + bl;
+    load_patch(min(chunk + 2, nchunk - 1), rload, okload);
+    const float* qn = wp + (long long)min(chunk + 1, nchunk - 1) * C::STEPS * 64;
+#pragma unroll
+    for (int s = 0; s < C::STEPS; ++s) wnext[s] = qn[s * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    float ring[C::PRE][C::MB];
+#pragma unroll
+    for (int s = 0; s < C::PRE; ++s)
+#pragma unroll
+      for (int m = 0; m < C::MB; ++m) ring[s][m] = sp[16 * m + C::step_offset(s)];
+#pragma unroll
+    for (int s = 0; s < C::STEPS; ++s) {
+      float cur[C::MB];
+#pragma unroll
+      for (int m = 0; m < C::MB; ++m) cur[m] = ring[s % C::PRE][m];
+      if (s + C::PRE < C::STEPS)
+#pragma unroll
+        for (int m = 0; m < C::MB; ++m) ring[s % C::PRE][m] = sp[16 * m + C::step_offset(s + C::PRE)];
+#pragma unroll
+      for (int m = 0; m < C::MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[s], cur[m], acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    store_patch((chunk + 1) & 1, rstore, okstore);
+    __syncthreads();
+  };
+  for (int chunk = 0; chunk < nchunk; chunk += 2) {
+    item(chunk, wa, wb, ra, oka, rb, okb);
+    item(chunk + 1, wb, wa, rb, okb, ra, oka);
+  }
+
+  // ---- epilogue: lane group = colour channel, register 2 a + b = parity class: float2 per fine row ----
+  const int i = i0 + wv;
+  if (lg < 3) {
+    float* ob = dx + ((long long)blockIdx.z * 3 + lg) * H * W;
+#pragma unroll
+    for (int m = 0; m < C::MB; ++m) {
+      const int j = j0 + 16 * m + l15;
+      if (2 * j < W) {
+        if (2 * i < H) *reinterpret_cast<float2*>(ob + (long long)(2 * i) * W + 2 * j) = make_float2(acc[m][0], acc[m][1]);
+        if (2 * i + 1 < H)
+          *reinterpret_cast<float2*>(ob + (long long)(2 * i + 1) * W + 2 * j) = make_float2(acc[m][2], acc[m][3]);
+      }
+    }
+  }
+}
+
 bool is_stem(int Cin, int ksize) { return ksize == 7 && Cin == 3; }
 
 }  // namespace
@@ -530,17 +668,30 @@ static long long s2_bwd_floats(int Cin, int N, int steps) {
   const long long nchunk = (N + 3) / 4 + (((N + 3) / 4) & 1), nblk = rup((Cin + 31) / 32, 4);
   return nblk * nchunk * steps * 64;
 }
-long long pcfa_conv_s2_bwd_packed_floats(int Cin, int N, int ksize) { return ksize == 3 ? s2_bwd_floats(Cin, N, 18) : 0; }
+static long long stem_bwd_floats(int N) {
+  return (long long)(((N + StemBwd::CK - 1) / StemBwd::CK + 1) & ~1) * StemBwd::STEPS * 64;
+}
+long long pcfa_conv_s2_bwd_packed_floats(int Cin, int N, int ksize) {
+  if (is_stem(Cin, ksize)) return stem_bwd_floats(N);
+  return ksize == 3 ? s2_bwd_floats(Cin, N, 18) : 0;
+}
 long long pcfa_conv_s2_ds_bwd_packed_floats(int Cin, int N) { return s2_bwd_floats(Cin, N, 20); }
 
 int pcfa_conv_s2_bwd_supported(int Cin, int N, int ksize, int H, int W) {
-  if (ksize != 3 || Cin < 1 || N < 1 || H < 2 || W < 8 || W % 8 != 0) return 0;    // Wo % 4 == 0: float4 rows of g
+  if (!(ksize == 3 || is_stem(Cin, ksize)) || Cin < 1 || N < 1 || H < 2 || W < 8 || W % 8 != 0) return 0;    // Wo % 4 == 0: float4 rows of g
   if ((long long)Cin * H * W > 0x7fffffffLL || (long long)N * H * W > 0x7fffffffLL) return 0;
   return 1;
 }
 
 int pcfa_conv_s2_bwd_pack(const float* w, float* packed, int Cin, int N, int ksize, void* stream) {
   if (w == nullptr || packed == nullptr) return PCFA_ERR_INVALID_ARG;
+  if (is_stem(Cin, ksize)) {
+    const long long total = stem_bwd_floats(N);
+    pcfa_launch(conv_s2_stem_bwd_pack_kernel, dim3((unsigned)min((total + 255) / 256, 4096LL)), dim3(256), 0,
+                (hipStream_t)stream, w, packed, N, total);
+    PCFA_LAUNCH_CHECK();
+    return PCFA_OK;
+  }
   if (ksize != 3) return PCFA_ERR_UNSUPPORTED;
   const long long total = pcfa_conv_s2_bwd_packed_floats(Cin, N, ksize);
   pcfa_launch(conv_s2_bwd_pack_kernel<false>, dim3((unsigned)min((total + 255) / 256, 4096LL)), dim3(256), 0,
@@ -591,6 +742,16 @@ static int s2_bwd_run(const float* grad_out, const float* grad_out_d, const floa
 
 int pcfa_conv_s2_bwd(const float* grad_out, const float* packed, float* grad_x, int B, int Cin, int N, int H, int W,
                      int ksize, void* stream) {
+  if (is_stem(Cin, ksize)) {
+    if (grad_out == nullptr || packed == nullptr || grad_x == nullptr || B < 1) return PCFA_ERR_INVALID_ARG;
+    if (!pcfa_conv_s2_bwd_supported(Cin, N, ksize, H, W)) return PCFA_ERR_UNSUPPORTED;
+    if (((uintptr_t)grad_out & 15) != 0 || ((uintptr_t)grad_x & 7) != 0) return PCFA_ERR_INVALID_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = W / 2, rows = (H + 1) / 2, tiles_x = pcfa_cdiv(Wo, StemBwd::PXC);
+    pcfa_launch(conv_s2_stem_bwd_kernel, dim3((unsigned)(tiles_x * pcfa_cdiv(rows, StemBwd::TR)), 1u, (unsigned)B),
+                dim3(StemBwd::NT), 0, (hipStream_t)stream, grad_out, packed, grad_x, N, H, W, Ho, Wo, tiles_x);
+    PCFA_LAUNCH_CHECK();
+    return PCFA_OK;
+  }
   return s2_bwd_run(grad_out, nullptr, packed, grad_x, B, Cin, N, H, W, ksize, stream);
 }
 
