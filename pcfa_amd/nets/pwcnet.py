@@ -17,10 +17,14 @@ import torch.nn as nn
 from .. import ops
 
 
+DILATED_AS_SUBGRIDS = (2, 4, 8, 16)   # dilations run as d*d plain 3x3 convolutions on sub-sampled grids (() = library)
+CONV_S2 = True   # stride-2 pyramid layers on ops.conv_s2 (False: library convolution; tools/dev A/B)
+
+
 class _ConvLeaky(nn.Sequential):
     """conv() of the reference (PWCNet.py:29-35): Conv2d + LeakyReLU(0.1); same parameter names ("0.weight", "0.bias").
     Frozen 3x3 / stride 1 / pad 1 instances run as ops.conv3x3 (Winograd on the fp32 matrix cores, bias and
-    LeakyReLU in the epilogue); strided and dilated ones stay on the library convolution."""
+    LeakyReLU in the epilogue), 3x3 / stride 2 ones as ops.conv_s2; dilated ones stay on the library convolution."""
 
     def forward(self, x):
         c = self[0]
@@ -28,6 +32,24 @@ class _ConvLeaky(nn.Sequential):
                 and c.out_channels >= 16 and not c.weight.requires_grad
                 and not (c.bias is not None and c.bias.requires_grad)):
             return ops.get().conv3x3(x, c.weight, c.bias, False, self[1].negative_slope)
+        d = c.dilation[0]
+        if (DILATED_AS_SUBGRIDS and d in DILATED_AS_SUBGRIDS and c.kernel_size == (3, 3) and c.stride == (1, 1)
+                and c.dilation == (d, d) and c.padding == (d, d) and c.groups == 1 and c.out_channels >= 16
+                and x.shape[-2] % d == 0 and x.shape[-1] % d == 0 and not c.weight.requires_grad
+                and not (c.bias is not None and c.bias.requires_grad)):
+            # A 3x3 convolution with dilation d (the context network, PWCNet.py:160-166) never mixes pixels of different
+            # (y mod d, x mod d): it is d*d independent plain 3x3 convolutions on the sub-sampled grids, zero padding
+            # included (H, W multiples of d).  Sub-grids go to the batch axis and run on the Winograd kernel.
+            B, C, H, W = x.shape
+            xs = x.reshape(B, C, H // d, d, W // d, d).permute(0, 3, 5, 1, 2, 4).reshape(B * d * d, C, H // d, W // d)
+            ys = ops.get().conv3x3(xs.contiguous(), c.weight, c.bias, False, self[1].negative_slope)
+            N = ys.shape[1]
+            return ys.reshape(B, d, d, N, H // d, W // d).permute(0, 3, 4, 1, 5, 2).reshape(B, N, H, W)
+        if (CONV_S2 and c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1) and c.dilation == (1, 1)
+                and c.groups == 1 and not c.weight.requires_grad and not (c.bias is not None and c.bias.requires_grad)
+                and ops.get().conv_s2_supported(x, c.weight)):
+            # the pyramid's stride-2 layers (PWCNet.py:87-104): direct fp32-MFMA kernel, bias + LeakyReLU in the epilogue
+            return ops.get().conv_s2(x, c.weight, c.bias, leaky_slope=self[1].negative_slope)
         return super().forward(x)
 
 
