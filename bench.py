@@ -242,12 +242,25 @@ def kernel_table(timings, hf, wf, hp, wp, dim=256, levels=4, radius=4):
         "corr_pyramid_gemm_fwd": ("mfma", gemm),
         "corr_pyramid_gemm_dfmap1": ("mfma", gemm),
         "corr_pyramid_gemm_df2ext": ("mfma", gemm),
+        # the encoders' stride-2 layers (csrc/conv_strided.hip): feature encoder on both images + context encoder on one
+        # = 3 images per closure; mean over the launches of a closure (B = 2 and B = 1, two layers for the block entries)
+        "conv_s2_stem_fwd": ("mfma", 1.5 * 2.0 * 147 * 64 * (hp // 2) * (wp // 2)),
+        "conv_s2_stem_bwd": ("mfma", 1.5 * 2.0 * 147 * 64 * (hp // 2) * (wp // 2)),
+        "conv_s2_block_entry_fwd": ("mfma", 0.75 * 2.0 * 10 * (64 * 96 * (hp // 4) * (wp // 4) + 96 * 128 * (hp // 8) * (wp // 8))),
+        "conv_s2_block_entry_bwd": ("mfma", 0.75 * 2.0 * 10 * (64 * 96 * (hp // 4) * (wp // 4) + 96 * 128 * (hp // 8) * (wp // 8))),
         "box_transform_fwd": ("hbm", 4 * img),
         "box_transform_bwd": ("hbm", 6 * img),
         "gru_gates_fwd": ("hbm", 8 * q * 128 * 4),
         "gru_update_fwd": ("hbm", 6 * q * 128 * 4),
     }
+    s2 = ("mean over the closure's launches (B = 2 feature encoder, B = 1 context encoder%s); 3x3 conv1 + fused 1x1 "
+          "downsample = 10 taps; the fp32 matrix pipe sustains ~1.9 GHz, i.e. ~124 of the 157.3 TFLOP/s peak")
     notes = {
+        "conv_s2_stem_fwd": "7x7 stem, 147 real of 168 issued k per pixel (window rows paired for the MFMA k = 2)",
+        "conv_s2_stem_bwd": "on the 16x16x4 MFMA: 12 of 16 rows carry (channel, parity) classes, 49 of 64 (tap, class) "
+                            "products are non-zero -- `achieved` counts the 147 real taps only",
+        "conv_s2_block_entry_fwd": s2 % ", 64->96 and 96->128",
+        "conv_s2_block_entry_bwd": s2 % ", 64->96 and 96->128",
         "corr_pyramid_gemm_dfmap1": "algorithmic = the dense product the reference's autograd runs; the kernel skips the "
                                     "slab columns no lookup window touched (exact zeros of dpyr), so `achieved` is NOT "
                                     "the matrix pipe's rate and may exceed the peak",
@@ -300,6 +313,9 @@ TRACED = {  # kernel-name fragment -> label
     "scorr9_fwd_kernel": "spatial_corr_fwd", "scorr9_bwd_kernel": "spatial_corr_bwd",
     "pwc_warp_fwd_kernel": "pwc_warp_fwd", "pwc_warp_bwd_kernel": "pwc_warp_bwd",
     "pwc_warp_bwd_det_kernel": "pwc_warp_bwd",
+    "conv_s2_fwd_kernel<(anonymous namespace)::S2Cfg<7, 7": "conv_s2_stem_fwd",
+    "conv_s2_fwd_kernel<(anonymous namespace)::S2Cfg<3, 3": "conv_s2_block_entry_fwd",
+    "conv_s2_bwd_kernel": "conv_s2_block_entry_bwd", "conv_s2_stem_bwd_kernel": "conv_s2_stem_bwd",
     # the optimiser (pcfa_amd/csrc/lbfgs_gram.hip, lbfgs.hip)
     "gram_pass_kernel": "lbfgs_gram_pass", "gram_direction_kernel": "lbfgs_gram_direction",
     "gram_reduce_kernel": "lbfgs_small", "gram_coeff_kernel": "lbfgs_gram_coeff",

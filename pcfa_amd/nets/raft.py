@@ -57,6 +57,7 @@ def _fold_batchnorm(conv, bn, cache, tag):
     return hit[1], hit[2]
 
 
+CONV_S2 = True            # stride-2 layers on ops.conv_s2 (False: library convolution; tools/dev A/B)
 FUSED_DOWNSAMPLE = True   # conv1 + downsample[0] of a stride-2 residual block in one launch (tools/dev A/B: set False)
 _DEFER_RELU = os.environ.get("PCFA_DEFER_RELU", "1") != "0"   # A/B switch: ReLU backward fused into neighbouring kernels
 # Module-level switches, read from the environment ONCE at import (defaults for tools); code that needs another setting
@@ -108,7 +109,7 @@ def _conv_norm(conv, norm, x, relu, cache, tag, skip=False, grad_premasked=False
 def _is_stride2(conv, x):
     """A frozen k x k / stride-2 / padding k//2 convolution ops.conv_s2 covers (the stem, the residual blocks' entry)."""
     k = conv.kernel_size[0]
-    return (conv.kernel_size == (k, k) and conv.stride == (2, 2) and conv.padding == (k // 2, k // 2)
+    return (CONV_S2 and conv.kernel_size == (k, k) and conv.stride == (2, 2) and conv.padding == (k // 2, k // 2)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
             and ops.get().conv_s2_supported(x, conv.weight))
 

@@ -1296,7 +1296,14 @@ def test_schedule_parity_at_baseline_size_vs_cpu_port():
     """The whole schedule at 436x1024 (BASELINE config 2): best-iterate AEE(adv, target), AEE(adv, init) and ||delta|| of
     a PCFA attack on the GPU against the CPU port, inside 3x the port's own spread between two thread counts
     (tools/schedule_parity.py).  3 steps (33 closure evaluations) here -- the 20-step run takes ten minutes
-    of host time and is committed as profiles/r03_schedule_parity_20steps.json (PCFA_SCHEDULE_PARITY_STEPS=20 runs it)."""
+    of host time and is committed under profiles/ (PCFA_SCHEDULE_PARITY_STEPS=20 runs it).
+
+    Synthetic pair 1, not bench.py's pair 0: torch.optim.LBFGS keeps a curvature pair iff y.s > 1e-10 (hard-coded), and
+    on these random-weight problems the FIRST pair has y.s = -1.5e-10 .. +5.8e-10 with |y| = 0.7 % of |g| -- the size of
+    the rounding noise of the network gradient itself (3e-3 between any two convolution back ends, the CPU port's included).
+    Pair 0 sits on that threshold (library stride-2 layers -0.7e-10: rejected; conv_s2 +1.8e-10: kept) and the two
+    branches run the fixed-step optimiser's period-3 overshoot cycle one closure apart for good; pair 1 (4.8e-10 /
+    5.8e-10) is kept by every back end.  tools/dev/first_pair_probe.py prints the numbers, DESIGN.md section 4 has them."""
     import json
     import os
     import subprocess
@@ -1304,7 +1311,7 @@ def test_schedule_parity_at_baseline_size_vs_cpu_port():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     steps = os.environ.get("PCFA_SCHEDULE_PARITY_STEPS", "3")
     r = subprocess.run([sys.executable, os.path.join(repo, "tools", "schedule_parity.py"), "--steps", steps,
-                        "--threads", "16,8"], capture_output=True, text=True, timeout=3000, env=_rank_env())
+                        "--threads", "16,8", "--seed", "1"], capture_output=True, text=True, timeout=3000, env=_rank_env())
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert lines, r.stderr[-3000:]
     out = json.loads(lines[-1])

@@ -26,14 +26,15 @@ import bench  # noqa: E402
 FLOORS = {"aee_adv_tgt_min": 1e-3, "aee_adv_init_at_min": 1e-3, "l2_delta_min": 1e-5}
 
 
-def run(net, h, w, steps, device, threads=None, progress=None, box="change_of_variables", joint=False, target="zero"):
+def run(net, h, w, steps, device, threads=None, progress=None, box="change_of_variables", joint=False, target="zero",
+        seed=0):
     from pcfa_amd import ops
     t0 = time.perf_counter()
     if device.type == "cpu":
         from oracle import ops as oracle_ops
         torch.set_num_threads(threads)
         with ops.override_for_testing(oracle_ops):
-            st = bench.AttackStepper(net, h, w, device, seed=0, boxconstraint=box, joint=joint, target=target)
+            st = bench.AttackStepper(net, h, w, device, seed=seed, boxconstraint=box, joint=joint, target=target)
             hist = []
             for k in range(steps):
                 hist.append(st.step())
@@ -42,7 +43,8 @@ def run(net, h, w, steps, device, threads=None, progress=None, box="change_of_va
                           file=sys.stderr, flush=True)
             res = st.result()
     else:
-        st = bench.AttackStepper(net, h, w, device, seed=0, use_graph=True, boxconstraint=box, joint=joint, target=target)
+        st = bench.AttackStepper(net, h, w, device, seed=seed, use_graph=True, boxconstraint=box, joint=joint,
+                                 target=target)
         hist = [st.step() for _ in range(steps)]
         res = st.result()
     return {"per_step": [dict(zip(("aee_adv_tgt", "aee_adv_init", "l2_delta"), s)) for s in hist],
@@ -61,8 +63,9 @@ def main():
     ap.add_argument("--box", default="change_of_variables", choices=["change_of_variables", "clipping"])
     ap.add_argument("--joint", action="store_true", help="--joint_perturbation (needs --box clipping)")
     ap.add_argument("--target", default="zero", choices=["zero", "neg_flow"])
+    ap.add_argument("--seed", type=int, default=0, help="synthetic pair (bench.py uses 0)")
     a = ap.parse_args()
-    kw = dict(box=a.box, joint=a.joint, target=a.target)
+    kw = dict(box=a.box, joint=a.joint, target=a.target, seed=a.seed)
     h, w = (int(v) for v in a.size.split("x"))
     ta, tb = (int(v) for v in a.threads.split(","))
     gpu = run(a.net, h, w, a.steps, torch.device("cuda", 0), **kw)
@@ -79,8 +82,8 @@ def main():
         rows[k] = {"gpu": gpu[k], "gpu_rerun": gpu2[k], "port_a": pa[k], "port_b": pb[k], "port_spread": spread,
                    "gpu_spread": own, "gpu_minus_port_a": gpu[k] - pa[k], "tolerance": tol, "ok": diff <= tol}
         ok = ok and diff <= tol
-    out = {"what": "best-iterate results of a %d-step PCFA attack, %s %dx%d (%s%s, %s target), GPU vs CPU port"
-                   % (a.steps, a.net, h, w, a.box, ", joint perturbation" if a.joint else "", a.target),
+    out = {"what": "best-iterate results of a %d-step PCFA attack, %s %dx%d (%s%s, %s target, synthetic pair %d), GPU vs "
+                   "CPU port" % (a.steps, a.net, h, w, a.box, ", joint perturbation" if a.joint else "", a.target, a.seed),
            "rule": "|gpu - port_a| <= max(floor, 3 x |port_a - port_b|, 3 x |gpu - gpu_rerun|) (SURVEY D10)", "ok": ok,
            "gpu_bit_reproducible": all(r["gpu_spread"] == 0.0 for r in rows.values()), "metrics": rows,
            "gpu": gpu, "gpu_rerun": gpu2, "port_a": pa, "port_b": pb}
