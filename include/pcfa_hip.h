@@ -274,6 +274,15 @@ PCFA_API int pcfa_box_transform_bwd(const float* image, const float* delta, cons
                            float* grad_image, float* grad_delta, int B, long long n_per_item,
                            int change_of_variables, double eps_box, float scale, void* stream);
 
+/* RAFT.forward's input normalisation `2 * (image / 255.0) - 1.0` of both images (models/raft/raft.py:88-89,
+ * models/gma/network.py:79-80) in one launch per direction: pair = [n(image1); n(image2)] ([2B][n], the feature encoder's
+ * batch), ctx = n(image1) ([B][n], the context encoder's input); backward: grad_image1 = ((grad_pair[:B] + grad_ctx) * 2) / 255,
+ * grad_image2 = (grad_pair[B:] * 2) / 255 (grad_ctx may be NULL).  Bit-identical to the torch expression on the GPU. */
+PCFA_API int pcfa_pm1_pair_fwd(const float* image1, const float* image2, float* pair, float* ctx, int B, long long n,
+                               void* stream);
+PCFA_API int pcfa_pm1_pair_bwd(const float* grad_pair, const float* grad_ctx, float* grad_image1, float* grad_image2, int B,
+                               long long n, void* stream);
+
 /* extract_deltas (attack_PCFA.py:20-29): delta = box(nw_input) - image. */
 PCFA_API int pcfa_extract_deltas_fwd(const float* nw_input, const float* image, float* delta,
                             long long n, int change_of_variables, double eps_box, void* stream);

@@ -604,6 +604,13 @@ def bias_relu(x, bias=None):
 # --------------------------------------------------------------------------- #
 # attack math
 # --------------------------------------------------------------------------- #
+def pm1_pair(image1, image2):
+    """models/raft/raft.py:88-89: image = 2 * (image / 255.0) - 1.0 for both images; (fnet batch, cnet input)."""
+    n1 = 2 * (image1 / 255.0) - 1.0
+    n2 = 2 * (image2 / 255.0) - 1.0
+    return torch.cat([n1, n2], dim=0), n1
+
+
 def box_transform(image, delta=None, change_of_variables=False, eps_box=0., scale=1.):
     """helper_functions/own_models.py:62-85 for one image tensor."""
     x = image

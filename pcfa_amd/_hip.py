@@ -63,6 +63,8 @@ SIGNATURES = {
     "pcfa_channelnorm_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_longlong, c_int, _P]),
     "pcfa_box_transform_fwd": (c_int, [_P, _P, _P, c_int, c_longlong, c_int, c_double, c_float, _P]),
     "pcfa_box_transform_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_longlong, c_int, c_double, c_float, _P]),
+    "pcfa_pm1_pair_fwd": (c_int, [_P, _P, _P, _P, c_int, c_longlong, _P]),
+    "pcfa_pm1_pair_bwd": (c_int, [_P, _P, _P, _P, c_int, c_longlong, _P]),
     "pcfa_extract_deltas_fwd": (c_int, [_P, _P, _P, c_longlong, c_int, c_double, _P]),
     "pcfa_extract_deltas_bwd": (c_int, [_P, _P, _P, c_longlong, c_int, c_double, _P]),
     "pcfa_extract_deltas_joint_fwd": (c_int, [_P, _P, _P, _P, c_longlong, _P]),

@@ -367,6 +367,53 @@ extern "C" int pcfa_box_transform_bwd(const float* image, const float* delta,
   return PCFA_OK;
 }
 
+// RAFT.forward / RAFTGMA.forward normalise both images with `2 * (image / 255.0) - 1.0` (models/raft/raft.py:88-89,
+// models/gma/network.py:79-80): three elementwise launches per image, two more each in the backward and the gradient sums
+// of image 1 (feature AND context encoder read it).  One launch per direction instead: pair = [n(image1); n(image2)]
+// for the feature encoder, ctx = n(image1) once more for the context encoder.  Same fp32 operations in the same order
+// as the three torch kernels on the GPU (a tensor divided by a host scalar is multiplied by the rounded reciprocal
+// there), so the result is bit-identical.
+__global__ void pm1_pair_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ pair,
+                                    float* __restrict__ ctx, long long n, int B) {
+  const float inv = 1.0f / 255.0f;
+  const long long nb = (long long)n * B;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += (long long)gridDim.x * blockDim.x) {
+    const float ya = 2.0f * (a[i] * inv) - 1.0f, yb = 2.0f * (b[i] * inv) - 1.0f;
+    pair[i] = ya;
+    pair[nb + i] = yb;
+    ctx[i] = ya;
+  }
+}
+
+__global__ void pm1_pair_bwd_kernel(const float* __restrict__ gpair, const float* __restrict__ gctx, float* __restrict__ ga,
+                                    float* __restrict__ gb, long long n, int B) {
+  const float inv = 1.0f / 255.0f;
+  const long long nb = (long long)n * B;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += (long long)gridDim.x * blockDim.x) {
+    const float g1 = gctx != nullptr ? gpair[i] + gctx[i] : gpair[i];   // autograd's sum of the two uses of n(image1)
+    ga[i] = (g1 * 2.0f) * inv;
+    gb[i] = (gpair[nb + i] * 2.0f) * inv;
+  }
+}
+
+extern "C" int pcfa_pm1_pair_fwd(const float* image1, const float* image2, float* pair, float* ctx, int B, long long n,
+                                 void* stream) {
+  if (!image1 || !image2 || !pair || !ctx || B < 1 || n < 1) return PCFA_ERR_INVALID_ARG;
+  pcfa_launch(pm1_pair_fwd_kernel, dim3(ew_blocks((long long)B * n)), dim3(256), 0, (hipStream_t)stream, image1, image2,
+              pair, ctx, n, B);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_pm1_pair_bwd(const float* grad_pair, const float* grad_ctx, float* grad_image1, float* grad_image2,
+                                 int B, long long n, void* stream) {
+  if (!grad_pair || !grad_image1 || !grad_image2 || B < 1 || n < 1) return PCFA_ERR_INVALID_ARG;
+  pcfa_launch(pm1_pair_bwd_kernel, dim3(ew_blocks((long long)B * n)), dim3(256), 0, (hipStream_t)stream, grad_pair,
+              grad_ctx, grad_image1, grad_image2, n, B);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
 extern "C" int pcfa_extract_deltas_fwd(const float* nw_input, const float* image, float* delta,
                                        long long n, int cov, double eps_box, void* stream) {
   if (!nw_input || !image || !delta || n < 1) return PCFA_ERR_INVALID_ARG;

@@ -1767,6 +1767,42 @@ def bias_relu(x, bias=None):
 # --------------------------------------------------------------------------- #
 # attack math
 # --------------------------------------------------------------------------- #
+class _Pm1Pair(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image1, image2):
+        _dev(image1, image2)
+        if image1.shape != image2.shape:
+            raise ValueError("pm1_pair: shapes differ: %s vs %s" % (tuple(image1.shape), tuple(image2.shape)))
+        a, b = image1.contiguous(), image2.contiguous()
+        B = a.shape[0]
+        n = a.numel() // B
+        pair = torch.empty((2 * B,) + tuple(a.shape[1:]), device=a.device, dtype=torch.float32)
+        cx = torch.empty_like(a)
+        _call("pcfa_pm1_pair_fwd", _ptr(a), _ptr(b), _ptr(pair), _ptr(cx), B, n)
+        ctx.set_materialize_grads(False)    # an unused output hands None to the backward, not a zero tensor
+        ctx.dims = (B, n)
+        return pair, cx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gpair, gctx):
+        B, n = ctx.dims
+        if gpair is None:
+            gpair = torch.zeros((2 * B, n), device=gctx.device, dtype=torch.float32)
+        gpair = gpair.contiguous()
+        gctx = None if gctx is None else gctx.contiguous()
+        ga = torch.empty((B,) + tuple(gpair.shape[1:]), device=gpair.device, dtype=torch.float32)
+        gb = torch.empty_like(ga)
+        _call("pcfa_pm1_pair_bwd", _ptr(gpair), _ptr(gctx), _ptr(ga), _ptr(gb), B, n)
+        return ga, gb
+
+
+def pm1_pair(image1, image2):
+    """(cat([n(image1), n(image2)]), n(image1)) with n(x) = 2 * (x / 255.0) - 1.0 (raft.py:88-89): the feature encoder's
+    batch and the context encoder's input in one launch per direction."""
+    return _Pm1Pair.apply(image1, image2)
+
+
 class _BoxTransform(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, delta, cov, eps_box, scale):

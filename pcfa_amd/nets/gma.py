@@ -184,11 +184,11 @@ class RAFTGMA(nn.Module):
                 m.eval()
 
     def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
-        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
-        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        # both images normalised in one launch: the feature encoder's batch of two and the context encoder's input
+        images12, image1 = ops.get().pm1_pair(image1, image2)
         hdim, cdim = self.hidden_dim, self.context_dim
 
-        fmap1, fmap2 = self.fnet([image1, image2])
+        fmap1, fmap2 = self.fnet(images12, split=image1.shape[0])
         corr_fn = ops.get().CorrBlock(fmap1.float(), fmap2.float(), num_levels=4, radius=self.args.corr_radius)
 
         net, inp = torch.split(self.cnet(image1), [hdim, cdim], dim=1)

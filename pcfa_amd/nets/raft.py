@@ -215,9 +215,13 @@ class BasicEncoder(nn.Module):
         return nn.Sequential(ResidualBlock(cin, cout, self.norm_fn, stride=stride),
                              ResidualBlock(cout, cout, self.norm_fn, stride=1))
 
-    def forward(self, x):
-        pair = isinstance(x, (tuple, list))
-        if pair:
+    def forward(self, x, split=None):
+        """x: a tensor, a pair of equally shaped tensors (run as one batch, results split again), or with `split` = n a
+        batch that already holds both images ([:n], [n:])."""
+        pair = isinstance(x, (tuple, list)) or split is not None
+        if split is not None:
+            n = split
+        elif pair:
             n = x[0].shape[0]
             x = torch.cat(x, dim=0)
         x = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1")
@@ -499,11 +503,11 @@ class RAFT(nn.Module):
                 m.eval()
 
     def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=False):
-        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
-        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        # both images normalised in one launch: the feature encoder's batch of two and the context encoder's input
+        images12, image1 = ops.get().pm1_pair(image1, image2)
         hdim, cdim = self.hidden_dim, self.context_dim
 
-        fmap1, fmap2 = self.fnet([image1, image2])
+        fmap1, fmap2 = self.fnet(images12, split=image1.shape[0])
         corr_fn = ops.get().CorrBlock(fmap1.float(), fmap2.float(), num_levels=self.args["corr_levels"],
                                       radius=self.args["corr_radius"])
 

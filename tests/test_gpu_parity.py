@@ -1005,6 +1005,29 @@ def test_conv_s2_ds_vs_oracle(oracle_ops, shape):
                                             torch.zeros(8, 8, 1, 1, device=DEV))          # W % 8
 
 
+def test_pm1_pair_is_bit_identical_to_the_torch_expression():
+    """raft.py:88-89 `2 * (image / 255.0) - 1.0` for both images + the gradient sum of image 1's two uses, one launch each."""
+    gen = torch.Generator().manual_seed(5)
+    for shape in ((1, 3, 440, 1024), (2, 3, 37, 53)):
+        a = (255 * torch.rand(shape, generator=gen)).to(DEV).requires_grad_(True)
+        b = (255 * torch.rand(shape, generator=gen)).to(DEV).requires_grad_(True)
+        gp = torch.randn((2 * shape[0],) + shape[1:], generator=gen).to(DEV)
+        gc = torch.randn(shape, generator=gen).to(DEV)
+        n1, n2 = 2 * (a / 255.0) - 1.0, 2 * (b / 255.0) - 1.0
+        torch.autograd.backward([torch.cat([n1, n2], 0), n1], [gp, gc])
+        want = (torch.cat([n1, n2], 0).detach(), n1.detach(), a.grad.clone(), b.grad.clone())
+        a.grad = b.grad = None
+        pair, cx = hip_ops.pm1_pair(a, b)
+        torch.autograd.backward([pair, cx], [gp, gc])
+        for got, w in zip((pair.detach(), cx.detach(), a.grad, b.grad), want):
+            assert torch.equal(got, w)
+        a.grad = b.grad = None
+        pair, cx = hip_ops.pm1_pair(a, b)          # the context encoder's copy unused: its gradient is absent
+        pair.backward(gp)
+        n1, n2 = 2 * (a.detach().requires_grad_(True) / 255.0) - 1.0, None
+        assert torch.equal(a.grad, (gp[:shape[0]] * 2) / 255.0)
+
+
 def test_sepconv5_rejects_bad_operands():
     w = torch.zeros(4, 3, 1, 5, device=DEV)
     with pytest.raises(ValueError):

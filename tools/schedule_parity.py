@@ -64,14 +64,35 @@ def main():
     ap.add_argument("--joint", action="store_true", help="--joint_perturbation (needs --box clipping)")
     ap.add_argument("--target", default="zero", choices=["zero", "neg_flow"])
     ap.add_argument("--seed", type=int, default=0, help="synthetic pair (bench.py uses 0)")
+    ap.add_argument("--part", default="", choices=["", "gpu", "port_a", "port_b"],
+                    help="run only this leg and write it to --out (a 20-step port leg alone takes ~11 minutes)")
+    ap.add_argument("--merge", nargs=3, metavar=("GPU.json", "PORT_A.json", "PORT_B.json"),
+                    help="apply the rule to three --part records")
     a = ap.parse_args()
     kw = dict(box=a.box, joint=a.joint, target=a.target, seed=a.seed)
     h, w = (int(v) for v in a.size.split("x"))
     ta, tb = (int(v) for v in a.threads.split(","))
-    gpu = run(a.net, h, w, a.steps, torch.device("cuda", 0), **kw)
-    gpu2 = run(a.net, h, w, a.steps, torch.device("cuda", 0), **kw)   # the GPU's own run-to-run spread (MIOpen atomics)
-    pa = run(a.net, h, w, a.steps, torch.device("cpu"), ta, progress="port[%d threads]" % ta, **kw)
-    pb = run(a.net, h, w, a.steps, torch.device("cpu"), tb, progress="port[%d threads]" % tb, **kw)
+    if a.part:
+        if a.part == "gpu":
+            rec = {"gpu": run(a.net, h, w, a.steps, torch.device("cuda", 0), **kw),
+                   "gpu_rerun": run(a.net, h, w, a.steps, torch.device("cuda", 0), **kw)}
+        else:
+            t = ta if a.part == "port_a" else tb
+            rec = {a.part: run(a.net, h, w, a.steps, torch.device("cpu"), t, progress="port[%d threads]" % t, **kw)}
+        rec["args"] = vars(a)
+        with open(a.out, "w") as f:
+            f.write(json.dumps(rec) + "\n")
+        return
+    if a.merge:
+        recs = [json.load(open(f)) for f in a.merge]
+        for r in recs[1:]:   # the legs must describe the same run
+            assert all(r["args"][k] == recs[0]["args"][k] for k in ("steps", "size", "net", "box", "joint", "target", "seed"))
+        gpu, gpu2, pa, pb = recs[0]["gpu"], recs[0]["gpu_rerun"], recs[1]["port_a"], recs[2]["port_b"]
+    else:
+        gpu = run(a.net, h, w, a.steps, torch.device("cuda", 0), **kw)
+        gpu2 = run(a.net, h, w, a.steps, torch.device("cuda", 0), **kw)   # the GPU's own run-to-run spread (MIOpen atomics)
+        pa = run(a.net, h, w, a.steps, torch.device("cpu"), ta, progress="port[%d threads]" % ta, **kw)
+        pb = run(a.net, h, w, a.steps, torch.device("cpu"), tb, progress="port[%d threads]" % tb, **kw)
     rows, ok = {}, True
     for k, floor in FLOORS.items():
         spread, own = abs(pa[k] - pb[k]), abs(gpu[k] - gpu2[k])
