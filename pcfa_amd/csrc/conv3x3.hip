@@ -544,6 +544,16 @@ static bool use_f43(int B, int K, int N, int H, int W) {
   }();
   if (!pcfa_f43_supported(B, K, N, H, W)) return false;
   if (forced) return forced == 43;
+  // Single images with many input channels (PWC-Net's dense decoder blocks, PWCNet.py:110-158: 117..629 -> 128..32 at
+  // 96x320 .. 6x20): the F(2x2,3x3) kernel has no channel split, so a small map is a handful of workgroups each
+  // walking the whole K (81 us at 533 -> 64 on 24x80); F(4x4,3x3) splits K over workgroups (27 us).  Thresholds from
+  // tools/dev/conv3x3_shapes_ab.py (every conv3x3 shape of a PWC-Net closure, both algorithms): -1.0 ms per closure.
+  if (B == 1) {
+    const long long px = (long long)H * W;
+    if (px <= 4096 && K >= 176) return true;
+    if (px > 4096 && px <= 16384 && K >= 384) return true;
+    if (px >= 16384 && px < 100000 && (long long)K * N >= 15000) return true;
+  }
   if (H < 24 || W < 64 || K < 16) return false;
   // channel-split path: every split is one more partial output to write and re-read (and 256->192, three splits, is
   // already paired with convf2 in one F(2x2,3x3) launch that fills its tail: 57 us for both against 42 + 19)

@@ -886,7 +886,9 @@ def test_gru_step_vs_oracle(oracle_ops, shape):
     (2, 5, 7, 9, 21), (1, 12, 70, 3, 5), (1, 3, 2, 1, 1), (2, 64, 64, 40, 48),
     # F(4x4,3x3) without the channel split (enough tiles), ragged tile rows / partial column blocks / odd channel counts
     (2, 64, 64, 220, 512), (1, 21, 37, 30, 68), (1, 96, 96, 110, 256), (1, 126, 256, 55, 128), (1, 565, 128, 24, 80),
-    (1, 192, 256, 55, 128)])
+    (1, 192, 256, 55, 128),
+    # PWC-Net's dense decoder blocks (PWCNet.py:110-158): many input channels on one image, maps from 96x320 to 6x20
+    (1, 245, 128, 96, 320), (1, 501, 64, 48, 160), (1, 196, 196, 6, 20)])
 @pytest.mark.parametrize("relu", [False, True, 0.1])
 def test_conv3x3_winograd_vs_oracle(oracle_ops, shape, relu):
     """Winograd on fp32 MFMA against conv2d: forward (+bias, +ReLU / LeakyReLU) and data gradient, once with the
@@ -901,7 +903,8 @@ def test_conv3x3_winograd_vs_oracle(oracle_ops, shape, relu):
     if os.environ.get("PCFA_CONV3X3_ALGO") == "f43":
         assert f43 == (W % 4 == 0 and W >= 8)
     elif "PCFA_CONV3X3_ALGO" not in os.environ:
-        assert f43 == (shape in ((1, 192, 256, 55, 128), (2, 64, 64, 220, 512)))
+        assert f43 == (shape in ((1, 192, 256, 55, 128), (2, 64, 64, 220, 512), (1, 565, 128, 24, 80),
+                                 (1, 245, 128, 96, 320), (1, 501, 64, 48, 160), (1, 196, 196, 6, 20)))
     tol = 1.5e-5 if f43 else 5e-6
     gen = torch.Generator().manual_seed(3 + Cin + W)
     x = torch.randn(B, Cin, H, W, generator=gen)
@@ -922,7 +925,8 @@ def test_conv3x3_winograd_vs_oracle(oracle_ops, shape, relu):
     # 14.4 M outputs at 220x512 -> 1.0e-3); the convolution's own backward error is the relu=False case of this test
     flips = int(((got.detach().cpu() > 0) != (want.detach() > 0)).sum())
     assert flips <= max(4, 4e-6 * want.numel()), flips
-    gtol = tol if relu is False else tol + 2.0 * (flips / want.numel()) ** .5
+    # a flipped mask bit moves the gradient by |grad_out| at that output (N(0,1): up to ~4.5 in a few million draws)
+    gtol = tol if relu is False else tol + 5.0 * (flips / want.numel()) ** .5
     assert rel_l2(gx.grad, cx.grad) < gtol, (rel_l2(gx.grad, cx.grad), flips)
     got2 = hip_ops.conv3x3(gx.detach(), w.to(DEV), b.to(DEV), **act)
     assert torch.equal(got2, got.detach())          # no atomics anywhere, split or not: bitwise reproducible
