@@ -559,7 +559,9 @@ static bool use_f43(int B, int K, int N, int H, int W) {
   // already paired with convf2 in one F(2x2,3x3) launch that fills its tail: 57 us for both against 42 + 19)
   const int ks = pcfa_f43_ksplit(B, K, N, H, W);
   if (ks > 1) return ks == 2 && (long long)K * N >= 192LL * 256;
-  return (long long)H * W >= 100000;                                              // enough tiles: large maps only
+  // enough tiles without a split: large maps only.  (96->96 at 110x256, batch 2, looks like a candidate back to back --
+  // 70.5 -> 44.1 us -- but takes 68 us inside a closure, where its 21 MB input is not already in the caches: measured, left.)
+  return (long long)H * W >= 100000;
 }
 
 extern "C" int pcfa_conv3x3_algo(int B, int K, int N, int H, int W) {

@@ -886,7 +886,7 @@ def test_gru_step_vs_oracle(oracle_ops, shape):
     (2, 5, 7, 9, 21), (1, 12, 70, 3, 5), (1, 3, 2, 1, 1), (2, 64, 64, 40, 48),
     # F(4x4,3x3) without the channel split (enough tiles), ragged tile rows / partial column blocks / odd channel counts
     (2, 64, 64, 220, 512), (1, 21, 37, 30, 68), (1, 96, 96, 110, 256), (1, 126, 256, 55, 128), (1, 565, 128, 24, 80),
-    (1, 192, 256, 55, 128),
+    (1, 192, 256, 55, 128), (2, 96, 96, 110, 256),
     # PWC-Net's dense decoder blocks (PWCNet.py:110-158): many input channels on one image, maps from 96x320 to 6x20
     (1, 245, 128, 96, 320), (1, 501, 64, 48, 160), (1, 196, 196, 6, 20)])
 @pytest.mark.parametrize("relu", [False, True, 0.1])
