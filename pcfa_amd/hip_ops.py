@@ -1155,10 +1155,26 @@ def _conv3x3_packed(weight):
 _CONV_WS = {}   # device index -> scratch of pcfa_conv3x3_run (split-K partial outputs of the F(4x4,3x3) path)
 
 
-def _conv_workspace(device, nbytes):
-    """One scratch buffer per device, grown on demand OUTSIDE graph captures (every capture in this package follows
-    eager warm-up calls of the same shapes); the convolutions of one closure are stream-ordered on one stream."""
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """The second stream of `device` on which nets/raft.py runs the context encoder beside the feature encoder (one per
+    device, created on first use); scratch buffers are kept per (device, main | side)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(idx)
+    if s is None:
+        s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device)
+    return s
+
+
+def _conv_workspace(device, nbytes):
+    """One scratch buffer per (device, stream), grown on demand OUTSIDE graph captures (every capture in this package
+    follows eager warm-up calls of the same shapes); convolutions are stream-ordered per stream, and two streams (the
+    encoders running side by side, nets/raft.py) never share a buffer."""
+    dev_idx = device.index if device.index is not None else torch.cuda.current_device()
+    side = _SIDE_STREAMS.get(dev_idx)
+    idx = (dev_idx, side is not None and torch.cuda.current_stream(device) == side)
     ws = _CONV_WS.get(idx)
     if ws is None or ws.numel() * 4 < nbytes:
         if torch.cuda.is_current_stream_capturing():

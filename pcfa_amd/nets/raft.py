@@ -57,6 +57,11 @@ def _fold_batchnorm(conv, bn, cache, tag):
     return hit[1], hit[2]
 
 
+# Opt-in (PCFA_OVERLAP_ENCODERS=1, read once): the context encoder on a second stream beside the feature encoder.
+# Measured 13.10 -> 12.95 ms per captured closure -- and one hard failure: with several closures captured in one process
+# (per-shape graph reuse, tests/test_gpu_parity.py::test_pair_graph_reuse_equals_fresh_capture) a replay of a two-branch
+# graph crashed inside hipGraphLaunch.  Off until that is understood; the single-stream capture is the product path.
+OVERLAP_ENCODERS = os.environ.get("PCFA_OVERLAP_ENCODERS", "0") == "1"
 CONV_S2 = True            # stride-2 layers on ops.conv_s2 (False: library convolution; tools/dev A/B)
 FUSED_DOWNSAMPLE = True   # conv1 + downsample[0] of a stride-2 residual block in one launch (tools/dev A/B: set False)
 _DEFER_RELU = os.environ.get("PCFA_DEFER_RELU", "1") != "0"   # A/B switch: ReLU backward fused into neighbouring kernels
@@ -507,11 +512,26 @@ class RAFT(nn.Module):
         images12, image1 = ops.get().pm1_pair(image1, image2)
         hdim, cdim = self.hidden_dim, self.context_dim
 
+        side = None
+        if OVERLAP_ENCODERS and image1.is_cuda and hasattr(ops.get(), "side_stream"):
+            # the context encoder (one image) runs beside the feature encoder (two images): independent until the GRU,
+            # and their small-map layers each leave most of the chip idle.  A second stream forks here and joins below;
+            # under capture it becomes a parallel branch of the hipGraph, autograd runs each branch's backward on its
+            # forward stream.
+            main = torch.cuda.current_stream()
+            side = ops.get().side_stream(image1.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                cnet_out = self.cnet(image1)
         fmap1, fmap2 = self.fnet(images12, split=image1.shape[0])
         corr_fn = ops.get().CorrBlock(fmap1.float(), fmap2.float(), num_levels=self.args["corr_levels"],
                                       radius=self.args["corr_radius"])
+        if side is not None:
+            main.wait_stream(side)
+        else:
+            cnet_out = self.cnet(image1)
 
-        net, inp = torch.split(self.cnet(image1), [hdim, cdim], dim=1)
+        net, inp = torch.split(cnet_out, [hdim, cdim], dim=1)
         net, inp = torch.tanh(net), torch.relu(inp)
 
         N, _, H, W = image1.shape

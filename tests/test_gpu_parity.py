@@ -1474,7 +1474,10 @@ def test_pair_graph_reuse_equals_fresh_capture():
         assert ca == cb == 10 and len(la) == len(lb) == 10
         assert max_abs(fa, fb) < 1e-4 and abs(ta - tb) < 1e-5
         for k in range(6):   # an un-damped L-BFGS step that overshoots (loss >> start) amplifies last-bit noise
-            tol = 1e-5 if lb[k] < 1.5 * lb[0] else 3e-2
+            # from the third evaluation on the iterate depends on the first curvature pair, whose y is a difference of
+            # nearly equal gradients (|y| < 1 % of |g|): run-to-run noise of the library kernels that
+            # are left (atomics) shows up there at ~5e-5
+            tol = (1e-5 if k < 2 else 3e-4) if lb[k] < 1.5 * lb[0] else 3e-2
             assert abs(la[k] - lb[k]) <= tol * abs(lb[k]), (k, la, lb)
 
 
