@@ -1387,9 +1387,10 @@ class _DenseBlock(torch.autograd.Function):
             gm = torch.empty((1, n, H, W), device=g.device, dtype=torch.float32)
             _call("pcfa_leaky_relu_bwd", _ptr_off(buf, (start - n) * plane), _ptr_off(gb, (start - n) * plane), _ptr(gm),
                   ctx.slope, n * plane)
-            gin = torch.empty((1, k, H, W), device=g.device, dtype=torch.float32)
-            _conv3x3_run(g.device, _ptr(gm), bwd, None, None, None, _ptr(gin), 1, n, k, H, W)
-            gb[:, start:].add_(gin)
+            # the layer's input gradient is added to the running gradient in the convolution's epilogue, in place (every
+            # output element reads its own addend): no separate gradient tensor, no add launch
+            dst = _ptr_off(gb, start * plane)
+            _conv3x3_run(g.device, _ptr(gm), bwd, None, None, dst, dst, 1, n, k, H, W)
         return (gb[:, total - K0:], None) + (None,) * (2 * len(ctx.packs))
 
 
