@@ -54,7 +54,10 @@ struct S2Cfg {
   static_assert(!DS || (!PAIRROW && KH == 3 && KW == 3), "the fused 1x1 rides on the 3x3 channel-pair layout");
   static constexpr int DELTA = PAIRROW ? RS : CHS;                      // LDS distance of the second k of a step
   static constexpr int NV = CK * KH * RV, NLOAD = (NV + NT - 1) / NT;   // staging: float4 pieces per chunk, per thread
-  static constexpr int PRE = 4;                                        // LDS operand reads run this many steps ahead
+#ifndef PCFA_S2_PRE
+#define PCFA_S2_PRE 4
+#endif
+  static constexpr int PRE = PCFA_S2_PRE;                              // LDS operand reads run this many steps ahead
   static constexpr int WAVES = PAIRROW ? 2 : (WN >= 2 && !DS ? 4 : 3);                        // waves per SIMD the register budget is held to
   static_assert(PAIRROW || CK % 2 == 0, "channel pairs");
   // chunks of the K loop; even unless the layer is a single chunk (two register sets of weights alternate)
@@ -271,7 +274,13 @@ __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WAVES,
   }
 }
 
-typedef S2Cfg<7, 7, 3, true, 2, 2, 2> StemCfg;    // 3 -> N, 7x7: 64 channels x 128 pixels per workgroup
+#ifndef PCFA_S2_STEM_MB
+#define PCFA_S2_STEM_MB 2
+#endif
+#ifndef PCFA_S2_STEM_WN
+#define PCFA_S2_STEM_WN 2
+#endif
+typedef S2Cfg<7, 7, 3, true, PCFA_S2_STEM_WN, 4 / PCFA_S2_STEM_WN, PCFA_S2_STEM_MB> StemCfg;    // 3 -> N, 7x7: 64 channels x 128 pixels per workgroup
 // C -> N, 3x3: WN waves = WN 32-channel blocks on one patch of 32 MB pixels (1 or 2 waves along the pixels for few blocks)
 #ifndef PCFA_S2_CK
 #define PCFA_S2_CK 4
