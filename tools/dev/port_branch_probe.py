@@ -17,6 +17,8 @@ class Stop(Exception):
     pass
 
 
+NOMKLDNN = len(sys.argv) > 2 and sys.argv[2] == "nomkldnn"   # torch's native CPU convolution instead of oneDNN's
+torch.backends.mkldnn.enabled = not NOMKLDNN
 for threads in [int(v) for v in sys.argv[1].split(",")]:
     torch.set_num_threads(threads)
     with ops.override_for_testing(oracle_ops):
@@ -36,4 +38,5 @@ for threads in [int(v) for v in sys.argv[1].split(",")]:
             st.step()
         except Stop:
             pass
-    print("port threads %2d closures: %s" % (threads, ["%.6f" % v for v in losses]), flush=True)
+    print("port threads %2d %s closures: %s" % (threads, "native conv" if NOMKLDNN else "oneDNN", ["%.6f" % v for v in losses]),
+          flush=True)
