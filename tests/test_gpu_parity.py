@@ -1345,6 +1345,29 @@ def test_schedule_parity_at_baseline_size_vs_cpu_port():
     assert out["ok"] and r.returncode == 0, out["metrics"]
 
 
+@pytest.mark.parametrize("cfg", [("RAFT", "436x1024", []), ("PWCNet", "375x1242", ["--box", "clipping", "--joint"])],
+                         ids=["raft", "pwcnet"])
+def test_trajectory_closure_parity_vs_cpu_port(cfg):
+    """Closure parity ALONG a real trajectory at the BASELINE sizes: the CPU port runs two attack steps (20 closure
+    evaluations, the fixed-step optimiser's overshoot points included) and the GPU closure is evaluated at exactly
+    those iterates: loss 1e-5 relative, gradient 1e-2 relative L2 at every point (tools/trajectory_closure_parity.py).
+    Unlike end-of-attack metrics this cannot land on another branch of torch.optim.LBFGS's hard thresholds (DESIGN.md
+    section 4); 3-step records under profiles/r03_trajectory_closure_parity_*.json."""
+    import json
+    import os
+    import subprocess
+    import sys
+    net, size, extra = cfg
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "trajectory_closure_parity.py"), "--net", net, "--size",
+                        size, "--steps", "2"] + extra, capture_output=True, text=True, timeout=1500, env=_rank_env())
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stderr[-3000:]
+    out = json.loads(lines[-1])
+    assert out["ok"] and r.returncode == 0, (out["max_loss_rel"], out["max_grad_rel_l2"])
+    assert len(out["points"]) == 20
+
+
 def _rank_env():
     import os
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",
