@@ -40,3 +40,18 @@ t2, parts2 = device_us(lambda: hip_ops.sepconv5(h, m, w))
 print("sepconv5 (product, direct implicit GEMM): %.1f us" % t2)
 for k, v in parts2.items():
     print("    %.1f us %s" % (v, k[:70]))
+
+# ---- 5x1 (vertical) form ----
+wv_ = (torch.randn(N, C, 5, 1, generator=g) / (5 * C) ** .5).to(dev)
+packed_v = torch.empty(lib.wino15_packed_floats(C, N), device=dev)
+assert lib.wino15_pack(P(wv_.data_ptr()), P(packed_v.data_ptr()), C, N, P(s)) == 0     # same packing: taps along the axis
+out_v = torch.empty(1, N, H, W, device=dev)
+run_v = lambda: lib.wino51_run(P(x.data_ptr()), P(packed_v.data_ptr()), P(out_v.data_ptr()), C, N, H, W, P(s))  # noqa: E731
+assert run_v() == 0
+torch.cuda.synchronize()
+ref_v = F.conv2d(x.double(), wv_.double(), None, padding=(2, 0))
+print("5x1 F(2,5) vs fp64: max %.2e rms %.2e" % ((out_v.double() - ref_v).abs().max(), (out_v.double() - ref_v).pow(2).mean().sqrt()))
+t, _ = device_us(run_v)
+print("5x1 F(2,5) prototype (K split): %.1f us" % t)
+t2, _ = device_us(lambda: hip_ops.sepconv5(h, m, wv_))
+print("5x1 sepconv5 (product): %.1f us" % t2)

@@ -14,6 +14,7 @@ namespace {
 constexpr int CK = 8, STEPS = (CK / 2) * 6, PXT = 128, RVP = PXT / 4 + 2, RSP = 4 * RVP;   // patch row: x0 - 4 .. x0 + 131
 constexpr int CHS = RSP, PATCH = CK * CHS;
 constexpr int NV = CK * RVP, NLOAD = (NV + 255) / 256;
+constexpr int VCHS = 6 * 64, VPATCH = CK * VCHS, VNV = CK * 6 * 16, VNLOAD = (VNV + 255) / 256;   // 5x1: [ch][6 rows][64 px]
 
 __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ P, int N, int C, int nchunk, long long total) {
   const float G[6][5] = {{0.25f, 0.f, 0.f, 0.f, 0.f},
@@ -264,6 +265,133 @@ __global__ __launch_bounds__(512) void wino15_ks2_kernel(const float* __restrict
     }
   }
 }
+// The 5x1 (vertical) form: pair = output rows 2 r, 2 r + 1 at one x; lane = x, d_i = in[c][2 r - 2 + i][x] (six patch rows);
+// workgroup = one row pair x 64 pixels x 64 channels, input channels split over two wave groups as above.
+__global__ __launch_bounds__(512) void wino51_ks2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                     float* __restrict__ out, int C, int N, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float smem_all[4 * VPATCH + 4 * 32 * 64];
+  const int grp = threadIdx.x >> 8;
+  float* smem = smem_all + grp * 2 * VPATCH;
+  float* sred = smem_all + 4 * VPATCH;
+  const int tid = threadIdx.x & 255, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave inside the group
+  const int wn = wv & 1, wpx = wv >> 1;
+  const int tiles_x = W / 64;
+  const int rp = blockIdx.x / tiles_x, x0 = (blockIdx.x - rp * tiles_x) * 64;   // row pair: outputs 2 rp, 2 rp + 1
+  const int nb = blockIdx.y * 2 + wn;
+  const int plane = H * W, nchunk = C / CK / 2;   // chunks of THIS group: global chunk 2 c + grp
+
+  auto load_patch = [&](int chunk, float4 (&rr)[VNLOAD], unsigned& okm) {
+    okm = 0;
+#pragma unroll
+    for (int k = 0; k < VNLOAD; ++k) {
+      const int e = min(tid + 256 * k, VNV - 1);
+      const int c = e / 96, rem = e - c * 96, r = rem >> 4, v = rem & 15;
+      const int iy = 2 * rp - 2 + r;
+      okm |= (unsigned)((int)(iy >= 0) & (int)(iy < H)) << k;
+      rr[k] = *reinterpret_cast<const float4*>(x + (unsigned)(((2 * chunk + grp) * CK + c) * plane + min(max(iy, 0), H - 1) * W + x0 + 4 * v));
+    }
+  };
+  auto store_patch = [&](int buf, const float4 (&rr)[VNLOAD], unsigned okm) {
+#pragma unroll
+    for (int k = 0; k < VNLOAD; ++k) {
+      const int e = tid + 256 * k;
+      const int c = e / 96, rem = e - c * 96, r = rem >> 4, v = rem & 15;
+      const float4 t = (okm >> k & 1u) ? rr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < VNV) *reinterpret_cast<float4*>(smem + buf * VPATCH + c * VCHS + r * 64 + 4 * v) = t;
+    }
+  };
+  const float* pw = wp + ((long long)nb * (2 * nchunk) * STEPS) * 64;
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  float4 ra[VNLOAD], rb[VNLOAD];
+  unsigned oka, okb;
+  float wa[STEPS], wb[STEPS];
+  load_patch(0, ra, oka);
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) wa[s] = pw[((long long)grp * STEPS + s) * 64 + lane];
+  store_patch(0, ra, oka);
+  __syncthreads();
+  load_patch(min(1, nchunk - 1), rb, okb);
+  // lane: x = x0 + 32 wpx + l31, channel 2 p + lh; the six rows of the pair are 64 floats apart
+  const int bl = lh * VCHS + 32 * wpx + l31;
+
+  auto item = [&](int chunk, const float (&wcur)[STEPS], float (&wnext)[STEPS], float4 (&rload)[VNLOAD], unsigned& okload,
+                  const float4 (&rstore)[VNLOAD], const unsigned& okstore) {
+    const float* sp = smem + (chunk & 1) * VPATCH + bl;
+    load_patch(min(chunk + 2, nchunk - 1), rload, okload);
+    const float* qn = pw + (long long)(2 * min(chunk + 1, nchunk - 1) + grp) * STEPS * 64;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) wnext[s] = qn[s * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    float d[2][6];
+#pragma unroll
+    for (int h = 0; h < 6; ++h) d[0][h] = sp[64 * h];
+#pragma unroll
+    for (int p = 0; p < CK / 2; ++p) {
+      if (p + 1 < CK / 2)
+#pragma unroll
+        for (int h = 0; h < 6; ++h) d[(p + 1) & 1][h] = sp[2 * (p + 1) * VCHS + 64 * h];
+      const float d0 = d[p & 1][0], d1 = d[p & 1][1], d2 = d[p & 1][2], d3 = d[p & 1][3], d4 = d[p & 1][4], d5 = d[p & 1][5];
+      // B^T d: the row stage of the F(4x4,3x3) kernel
+      const float v0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+      const float a1 = fmaf(-4.f, d2, d4), b1 = fmaf(-4.f, d1, d3);
+      const float v1 = a1 + b1, v2 = a1 - b1;
+      const float a2 = d4 - d2, b2 = 2.f * (d3 - d1);
+      const float v3 = a2 + b2, v4 = a2 - b2;
+      const float v5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 0], v0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 1], v1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 2], v2, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 3], v3, acc[3], 0, 0, 0);
+      acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 4], v4, acc[4], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 5], v5, acc[5], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    store_patch((chunk + 1) & 1, rstore, okstore);
+    __syncthreads();
+  };
+  for (int chunk = 0; chunk < nchunk; chunk += 2) {
+    item(chunk, wa, wb, ra, oka, rb, okb);
+    item(chunk + 1, wb, wa, rb, okb, ra, oka);
+  }
+
+  // y(2j) = M0 + M1 + M2 + M3 + M4,  y(2j+1) = M1 - M2 + 2 (M3 - M4) + M5; group 1 hands its part to group 0 through LDS
+  float* ob = out + (long long)(32 * nb) * plane + (long long)(2 * rp) * W + x0 + 32 * wpx;
+  float ye[16], yo[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float s12 = acc[1][r] + acc[2][r], d12 = acc[1][r] - acc[2][r], s34 = acc[3][r] + acc[4][r],
+                d34 = acc[3][r] - acc[4][r];
+    ye[r] = acc[0][r] + s12 + s34;
+    yo[r] = fmaf(2.f, d34, d12) + acc[5][r];
+  }
+  if (grp == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sred[(wv * 32 + r) * 64 + lane] = ye[r];
+      sred[(wv * 32 + 16 + r) * 64 + lane] = yo[r];
+    }
+  }
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int nu = 8 * (r >> 2) + (r & 3);
+      const float e_ = ye[r] + sred[(wv * 32 + r) * 64 + lane], o_ = yo[r] + sred[(wv * 32 + 16 + r) * 64 + lane];
+      if (32 * nb + nu + 4 * lh < N) {
+        float* o = ob + (long long)nu * plane + (unsigned)(4 * lh * plane + l31);
+        o[0] = e_;
+        if (2 * rp + 1 < H) o[W] = o_;
+      }
+    }
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -273,6 +401,13 @@ __attribute__((visibility("default"))) long long wino15_packed_floats(int C, int
 __attribute__((visibility("default"))) int wino15_pack(const float* w, float* packed, int C, int N, void* stream) {
   const long long total = wino15_packed_floats(C, N);
   hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, packed, N, C, C / CK, total);
+  return (int)hipGetLastError();
+}
+__attribute__((visibility("default"))) int wino51_run(const float* x, const float* packed, float* out, int C, int N, int H,
+                                                      int W, void* stream) {
+  if (C % 32 != 0 || N % 64 != 0 || W % 64 != 0) return -2;
+  hipLaunchKernelGGL(wino51_ks2_kernel, dim3((unsigned)((H + 1) / 2 * (W / 64)), (unsigned)(N / 64)), dim3(512), 0,
+                     (hipStream_t)stream, x, packed, out, C, N, H, W);
   return (int)hipGetLastError();
 }
 // x [C][H][W], out [N][H][W]; C % 16 == 0, N % 64 == 0, W % 128 == 0
