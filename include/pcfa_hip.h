@@ -562,6 +562,28 @@ PCFA_API int pcfa_conv3x3_fewout_fwd(const float* x, const float* w, const float
 PCFA_API int pcfa_conv3x3_fewout_bwd(const float* grad_out, const float* w, float* grad_x, int B, int K, int N, int H,
                                      int W, void* stream);
 
+/* ConvTranspose2d(K, N, kernel_size=4, stride=2, padding=1) with N <= 4 output channels and its data gradient (frozen
+ * weights): PWC-Net's `deconv` layers -- deconv6..2 (2 -> 2 channels) and upfeat6..3 (529..661 -> 2 channels)
+ * (models/PWCNet/PWCNet.py:42-43, :107-147, used :259-304).  Same stream over the input as pcfa_conv3x3_fewout_*: the
+ * 2x2 output block of an input pixel reads the pixel's 3x3 neighbourhood.  x / grad_x: [B][K][H][W]; w: [K][N][4][4]
+ * as nn.ConvTranspose2d stores it; bias: [N] or NULL; out / grad_out: [B][N][2H][2W]; workspace:
+ * pcfa_deconv4s2_fewout_workspace_bytes() bytes (0 unless the plane is small and K large: {partial sums, reduce}).
+ * Fixed summation order (bitwise reproducible; the library chose its algorithm per process). */
+PCFA_API size_t pcfa_deconv4s2_fewout_workspace_bytes(int B, int K, int N, int H, int W);
+PCFA_API int pcfa_deconv4s2_fewout_fwd(const float* x, const float* w, const float* bias, float* out, void* workspace,
+                                       int B, int K, int N, int H, int W, void* stream);
+PCFA_API int pcfa_deconv4s2_fewout_bwd(const float* grad_out, const float* w, float* grad_x, int B, int K, int N, int H,
+                                       int W, void* stream);
+
+/* out = mul * nn.Upsample(scale_factor=factor, mode='bilinear')(in) (align_corners=False) and its backward:
+ * `20 * self.upsample(flow2)` of PWC-Net (models/PWCNet/PWCNet.py:73,321).  in / grad_in: [planes][H][W];
+ * out / grad_out: [planes][factor*H][factor*W].  The backward is a gather (ATen's scatters with fp32 atomics):
+ * bitwise reproducible. */
+PCFA_API int pcfa_upsample_bilinear_fwd(const float* in, float* out, int planes, int H, int W, int factor, float mul,
+                                        void* stream);
+PCFA_API int pcfa_upsample_bilinear_bwd(const float* grad_out, float* grad_in, int planes, int H, int W, int factor,
+                                        float mul, void* stream);
+
 /* InstanceNorm2d without affine parameters on batch statistics, fused with the ReLU that follows it: every
  * `relu(norm(conv(x)))` / `norm(conv(x))` of the feature encoder (models/raft/extractor.py:23-58 with
  * norm_fn='instance', :118-157; nn.InstanceNorm2d defaults: eps 1e-5, biased variance).

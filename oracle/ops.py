@@ -570,6 +570,16 @@ def conv3x3_fewout(x, weight, bias=None):
     return F.conv2d(x, weight, bias, stride=1, padding=1)
 
 
+def deconv4s2_fewout(x, weight, bias=None):
+    """deconv() of PWC-Net (models/PWCNet/PWCNet.py:42-43): nn.ConvTranspose2d(in, out, 4, 2, 1)."""
+    return F.conv_transpose2d(x, weight, bias, stride=2, padding=1)
+
+
+def upsample_bilinear(x, factor, mul=1.0):
+    """mul * nn.Upsample(scale_factor=factor, mode='bilinear')(x): `20 * self.upsample(flow2)` (PWCNet.py:73,321)."""
+    return mul * F.interpolate(x, scale_factor=factor, mode='bilinear', align_corners=False)
+
+
 def instance_norm_relu(x, eps=1e-5, relu=False):
     """models/raft/extractor.py:23-58: nn.InstanceNorm2d (no affine, batch statistics) then the optional ReLU."""
     y = F.instance_norm(x, eps=eps)

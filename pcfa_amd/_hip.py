@@ -144,6 +144,11 @@ SIGNATURES = {
     "pcfa_conv3x3_fewout_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "pcfa_conv3x3_fewout_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_conv3x3_fewout_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_deconv4s2_fewout_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "pcfa_deconv4s2_fewout_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_deconv4s2_fewout_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_upsample_bilinear_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "pcfa_upsample_bilinear_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "pcfa_instnorm_workspace_bytes": (c_size_t, [c_int, c_longlong]),
     "pcfa_instnorm_fwd": (c_int, [_P, _P, _P, _P, c_int, c_longlong, c_float, c_int, _P]),
     "pcfa_instnorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_longlong, c_int, _P]),

@@ -260,6 +260,160 @@ __global__ __launch_bounds__(FO_PX* FO_WAVES) void conv3x3_fewout_bwd_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(K, N <= 4, kernel 4, stride 2, padding 1) and its data gradient (frozen weights): PWC-Net's `deconv`
+// layers (models/PWCNet/PWCNet.py:42-43; deconv6..2 on the 2-channel flow and upfeat6..3 on the 529..661-channel
+// decoder output, :107-147, :259-304).  out[o][Y][X] = bias[o] + sum_{c,ky,kx} x[c][y][x] w[c][o][ky][kx] with
+// Y = 2y - 1 + ky, X = 2x - 1 + kx: the 2x2 output block of input pixel (y, x) reads the pixel's 3x3 neighbourhood,
+// four taps per output -- the same stream over the input as conv3x3_fewout (the library ran these as implicit-GEMM /
+// GEMM + Col2Im2dU / first-call "naive" kernels chosen per process).  Lane = input pixel, waves split the channels,
+// wave-uniform weights through scalar loads, partial sums meet in LDS and are added in wave order (bit-reproducible).
+// Output class (a, b) = (Y & 1, X & 1); its two row taps are (dy, ky) = (-t, 1 + 2t) for a = 0 and (1 - t, 2t) for
+// a = 1, t = 0, 1 (likewise for columns).
+template <int N>
+__global__ __launch_bounds__(FO_PX* FO_FWD_WAVES) void deconv4s2_fewout_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int K, int H, int W, int splits, int kper) {
+  __shared__ float red[FO_FWD_WAVES][4 * N][FO_PX];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nb = gridDim.y / splits;
+  const int b = blockIdx.y / splits, split = blockIdx.y - b * splits;
+  const int kbeg = split * kper, kend = min(K, kbeg + kper);
+  const long long plane = (long long)H * W;
+  const long long p = (long long)blockIdx.x * FO_PX + lane;
+  const bool live = p < plane;
+  const int y = live ? (int)(p / W) : 0, xx = live ? (int)(p % W) : 0;
+  int off[9];
+  bool ok[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = y + ky - 1, xq = xx + kx - 1;
+      ok[ky * 3 + kx] = live && yy >= 0 && yy < H && xq >= 0 && xq < W;
+      off[ky * 3 + kx] = ok[ky * 3 + kx] ? yy * W + xq : 0;
+    }
+  float acc[4][N];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int o = 0; o < N; ++o) acc[q][o] = 0.f;
+  const float* xb = x + (size_t)b * K * plane;
+  constexpr int U = 4;  // channels in flight per wave
+  for (int c0 = kbeg + wave; c0 < kend; c0 += U * FO_FWD_WAVES) {
+    float v[U][9];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * FO_FWD_WAVES;  // wave-uniform
+      const float* xc = xb + (size_t)(c < kend ? c : c0) * plane;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float t = xc[off[k]];
+        v[u][k] = ok[k] ? t : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * FO_FWD_WAVES;
+      if (c < kend) {  // uniform branch
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+          const float* wc = w + ((size_t)c * N + o) * 16;  // wave-uniform address: scalar loads
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+              for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 2; ++tx) {
+                  const int dy = a ? 1 - ty : -ty, ky = a ? 2 * ty : 1 + 2 * ty;
+                  const int dx = bb ? 1 - tx : -tx, kx = bb ? 2 * tx : 1 + 2 * tx;
+                  acc[a * 2 + bb][o] += wc[ky * 4 + kx] * v[u][(dy + 1) * 3 + dx + 1];
+                }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int o = 0; o < N; ++o) red[wave][q * N + o][lane] = acc[q][o];
+  __syncthreads();
+  const long long oplane = 4 * plane;
+  for (int e = threadIdx.x; e < 4 * N * FO_PX; e += FO_PX * FO_FWD_WAVES) {
+    const int qo = e / FO_PX, l = e % FO_PX;
+    const int q = qo / N, o = qo - q * N;
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < FO_FWD_WAVES; ++g) s += red[g][qo][l];
+    const long long pp = (long long)blockIdx.x * FO_PX + l;
+    if (pp < plane) {
+      const int py = (int)(pp / W), px = (int)(pp % W);
+      const long long oi = (long long)(2 * py + (q >> 1)) * (2 * W) + 2 * px + (q & 1);
+      if (splits > 1) out[(((size_t)split * nb + b) * N + o) * oplane + oi] = s;
+      else out[((size_t)b * N + o) * oplane + oi] = s + (bias ? bias[o] : 0.f);
+    }
+  }
+}
+
+// grad_x[c][y][x] = sum_{o,ky,kx} w[c][o][ky][kx] * grad_out[o][2y - 1 + ky][2x - 1 + kx]: a lane keeps the 16 N
+// gradient taps of its pixel in registers, waves walk the channels with scalar weights and stream grad_x.
+template <int N>
+__global__ __launch_bounds__(FO_PX* FO_WAVES) void deconv4s2_fewout_bwd_kernel(
+    const float* __restrict__ gout, const float* __restrict__ w, float* __restrict__ gx, int K, int H, int W,
+    int csplit) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y / csplit, part = blockIdx.y % csplit;
+  const long long plane = (long long)H * W;
+  const long long p = (long long)blockIdx.x * FO_PX + lane;
+  const bool live = p < plane;
+  const int y = live ? (int)(p / W) : 0, xx = live ? (int)(p % W) : 0;
+  const int OH = 2 * H, OW = 2 * W;
+  float g[N][16];
+  const float* gb = gout + (size_t)b * N * 4 * plane;
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+      const int yy = 2 * y - 1 + ky, xq = 2 * xx - 1 + kx;
+      const bool ok = live && yy >= 0 && yy < OH && xq >= 0 && xq < OW;
+      const long long o_ = ok ? (long long)yy * OW + xq : 0;
+#pragma unroll
+      for (int o = 0; o < N; ++o) {
+        const float t = gb[(size_t)o * 4 * plane + o_];
+        g[o][ky * 4 + kx] = ok ? t : 0.f;
+      }
+    }
+  float* xb = gx + (size_t)b * K * plane;
+  constexpr int U = 4;
+  const int cstep = FO_WAVES * csplit;
+  for (int c0 = part * FO_WAVES + wave; c0 < K; c0 += U * cstep) {
+    float s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * cstep;  // wave-uniform
+      s[u] = 0.f;
+      if (c < K) {
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+          const float* wc = w + ((size_t)c * N + o) * 16;  // wave-uniform address: scalar loads
+#pragma unroll
+          for (int k = 0; k < 16; ++k) s[u] += wc[k] * g[o][k];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * cstep;
+      if (c < K && live) xb[(size_t)c * plane + p] = s[u];
+    }
+  }
+}
+
 }  // namespace
 
 // Channel splits of the forward: few pixels (coarse pyramid levels: 2 workgroups at 1024 x 7 x 16) cannot fill the
@@ -336,6 +490,72 @@ extern "C" int pcfa_conv3x3_fewout_bwd(const float* grad_out, const float* w, fl
     case 2: pcfa_launch(conv3x3_fewout_bwd_kernel<2>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
     case 3: pcfa_launch(conv3x3_fewout_bwd_kernel<3>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
     default: pcfa_launch(conv3x3_fewout_bwd_kernel<4>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
+  }
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+// ---- ConvTranspose2d(K, N, 4, stride 2, padding 1), N <= 4 ------------------------------------------------------------
+static int deconv_splits(int B, int K, long long plane) {
+  const long long tiles = (long long)pcfa_cdiv(plane, FO_PX) * B;
+  long long want = (256 + tiles - 1) / tiles;
+  const long long by_k = K / 64 > 0 ? K / 64 : 1;
+  if (want > by_k) want = by_k;
+  if (want > 64) want = 64;
+  return want < 4 ? 1 : (int)want;
+}
+
+extern "C" size_t pcfa_deconv4s2_fewout_workspace_bytes(int B, int K, int N, int H, int W) {
+  if (B < 1 || K < 1 || N < 1 || N > 4 || H < 1 || W < 1) return 0;
+  const long long plane = (long long)H * W;
+  const int splits = deconv_splits(B, K, plane);
+  return splits > 1 ? (size_t)splits * B * N * 4 * plane * sizeof(float) : 0;
+}
+
+extern "C" int pcfa_deconv4s2_fewout_fwd(const float* x, const float* w, const float* bias, float* out,
+                                         void* workspace, int B, int K, int N, int H, int W, void* stream) {
+  if (!x || !w || !out || B < 1 || K < 1 || H < 1 || W < 1) return PCFA_ERR_INVALID_ARG;
+  if (N < 1 || N > 4) return PCFA_ERR_UNSUPPORTED;
+  const long long plane = (long long)H * W;
+  const int splits = deconv_splits(B, K, plane);
+  if (splits > 1 && !workspace) return PCFA_ERR_WORKSPACE;
+  const int kper = ((K + splits - 1) / splits + FO_FWD_WAVES - 1) / FO_FWD_WAVES * FO_FWD_WAVES;
+  float* dst = splits > 1 ? (float*)workspace : out;
+  dim3 grid(pcfa_cdiv(plane, FO_PX), B * splits), block(FO_PX * FO_FWD_WAVES);
+  hipStream_t s = (hipStream_t)stream;
+  switch (N) {
+    case 1: pcfa_launch(deconv4s2_fewout_fwd_kernel<1>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+    case 2: pcfa_launch(deconv4s2_fewout_fwd_kernel<2>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+    case 3: pcfa_launch(deconv4s2_fewout_fwd_kernel<3>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+    default: pcfa_launch(deconv4s2_fewout_fwd_kernel<4>, grid, block, 0, s, x, w, bias, dst, K, H, W, splits, kper); break;
+  }
+  PCFA_LAUNCH_CHECK();
+  if (splits > 1) {
+    const long long n = (long long)B * N * 4 * plane;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    pcfa_launch(fewout_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)workspace, bias, out, n,
+                4 * plane, N, splits);
+    PCFA_LAUNCH_CHECK();
+  }
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_deconv4s2_fewout_bwd(const float* grad_out, const float* w, float* grad_x, int B, int K, int N,
+                                         int H, int W, void* stream) {
+  if (!grad_out || !w || !grad_x || B < 1 || K < 1 || H < 1 || W < 1) return PCFA_ERR_INVALID_ARG;
+  if (N < 1 || N > 4) return PCFA_ERR_UNSUPPORTED;
+  const long long plane = (long long)H * W;
+  const int tiles = pcfa_cdiv(plane, FO_PX) * B;
+  int csplit = 1;
+  while (tiles * csplit < 512 && FO_WAVES * csplit * 2 <= K) csplit *= 2;
+  dim3 grid(pcfa_cdiv(plane, FO_PX), B * csplit), block(FO_PX * FO_WAVES);
+  hipStream_t s = (hipStream_t)stream;
+  switch (N) {
+    case 1: pcfa_launch(deconv4s2_fewout_bwd_kernel<1>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
+    case 2: pcfa_launch(deconv4s2_fewout_bwd_kernel<2>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
+    case 3: pcfa_launch(deconv4s2_fewout_bwd_kernel<3>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
+    default: pcfa_launch(deconv4s2_fewout_bwd_kernel<4>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
   }
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;

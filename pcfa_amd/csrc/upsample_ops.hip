@@ -193,3 +193,92 @@ extern "C" int pcfa_convex_upsample_bwd(const float* flow, const float* mask, co
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
+
+// ---- nn.Upsample(scale_factor = f, mode = 'bilinear') (align_corners = False), times a constant --------------------
+// PWC-Net's `20 * self.upsample(flow2)` (models/PWCNet/PWCNet.py:73,321; f = 4) and its backward.  The library's
+// backward (upsample_bilinear2d_backward_out_frame) scatters with fp32 atomics; here it is a gather over the <= 2f
+// output rows and columns whose interpolation window reaches the input pixel -- bit-reproducible.  Index arithmetic as
+// in ATen (area_pixel_compute_source_index): src = (1/f) * (dst + 0.5) - 0.5, clamped at 0; i1 = (int)src;
+// i1p = i1 < size - 1; l1 = src - i1; l0 = 1 - l1;  out = l0y (l0x v00 + l1x v01) + l1y (l0x v10 + l1x v11).
+namespace {
+
+struct BilinTap {
+  int i1, ip;
+  float l0, l1;
+};
+
+__device__ __forceinline__ BilinTap bilin_tap(int dst, float rscale, int size) {
+  float src = rscale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  BilinTap t;
+  t.i1 = (int)src;
+  t.ip = t.i1 < size - 1 ? 1 : 0;
+  t.l1 = src - (float)t.i1;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void upsample_bilinear_fwd_kernel(const float* __restrict__ in,
+                                                                    float* __restrict__ out, int H, int W, int f,
+                                                                    float rscale, float mul) {
+  const int OW = W * f, OH = H * f;
+  const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+  if (X >= OW) return;
+  const float* ip = in + (size_t)blockIdx.z * H * W;
+  const BilinTap ty = bilin_tap(Y, rscale, H), tx = bilin_tap(X, rscale, W);
+  const float* r0 = ip + (size_t)ty.i1 * W + tx.i1;
+  const float* r1 = r0 + (size_t)ty.ip * W;
+  const float v = ty.l0 * (tx.l0 * r0[0] + tx.l1 * r0[tx.ip]) + ty.l1 * (tx.l0 * r1[0] + tx.l1 * r1[tx.ip]);
+  out[((size_t)blockIdx.z * OH + Y) * OW + X] = mul * v;
+}
+
+__global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float* __restrict__ gout,
+                                                                    float* __restrict__ gin, int H, int W, int f,
+                                                                    float rscale, float mul) {
+  const int OW = W * f, OH = H * f;
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const float* gp = gout + (size_t)blockIdx.z * OH * OW;
+  // outputs whose window can reach input index i: f (i - 0.5) - 0.5 < dst < f (i + 1.5) - 0.5 (one of slack each side;
+  // the weight below is exact, and zero outside)
+  const int y0 = max(0, f * y - (f + 1) / 2 - 1), y1 = min(OH - 1, f * y + f + (f + 1) / 2 + 1);
+  const int x0 = max(0, f * x - (f + 1) / 2 - 1), x1 = min(OW - 1, f * x + f + (f + 1) / 2 + 1);
+  float s = 0.f;
+  for (int Y = y0; Y <= y1; ++Y) {
+    const BilinTap ty = bilin_tap(Y, rscale, H);
+    const float wy = (ty.i1 == y ? ty.l0 : 0.f) + (ty.i1 + ty.ip == y ? ty.l1 : 0.f);
+    if (wy == 0.f) continue;
+    float r = 0.f;
+    for (int X = x0; X <= x1; ++X) {
+      const BilinTap tx = bilin_tap(X, rscale, W);
+      const float wx = (tx.i1 == x ? tx.l0 : 0.f) + (tx.i1 + tx.ip == x ? tx.l1 : 0.f);
+      r += wx * gp[(size_t)Y * OW + X];
+    }
+    s += wy * r;
+  }
+  gin[((size_t)blockIdx.z * H + y) * W + x] = mul * s;
+}
+
+}  // namespace
+
+extern "C" int pcfa_upsample_bilinear_fwd(const float* in, float* out, int planes, int H, int W, int factor, float mul,
+                                          void* stream) {
+  if (!in || !out || planes < 1 || H < 1 || W < 1 || factor < 1) return PCFA_ERR_INVALID_ARG;
+  if (planes > 65535 || (long long)H * factor > 65535) return PCFA_ERR_UNSUPPORTED;
+  dim3 grid(pcfa_cdiv((long long)W * factor, 256), H * factor, planes);
+  pcfa_launch(upsample_bilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, H, W, factor,
+              1.0f / (float)factor, mul);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_upsample_bilinear_bwd(const float* grad_out, float* grad_in, int planes, int H, int W, int factor,
+                                          float mul, void* stream) {
+  if (!grad_out || !grad_in || planes < 1 || H < 1 || W < 1 || factor < 1) return PCFA_ERR_INVALID_ARG;
+  if (planes > 65535 || H > 65535) return PCFA_ERR_UNSUPPORTED;
+  dim3 grid(pcfa_cdiv(W, 256), H, planes);
+  pcfa_launch(upsample_bilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, grad_out, grad_in, H, W, factor,
+              1.0f / (float)factor, mul);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}

@@ -1012,6 +1012,72 @@ def conv3x3_fewout(x, weight, bias=None):
     return _Conv3x3FewOut.apply(x, weight, bias)
 
 
+class _Deconv4s2FewOut(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _dev(x, weight, bias)
+        if weight.dim() != 4 or tuple(weight.shape[2:]) != (4, 4) or not 1 <= weight.shape[1] <= 4:
+            raise ValueError("deconv4s2_fewout expects a [K, N<=4, 4, 4] ConvTranspose2d weight, got %s"
+                             % (tuple(weight.shape),))
+        x = x.contiguous()
+        B, K, H, W = x.shape
+        N = weight.shape[1]
+        if weight.shape[0] != K:
+            raise ValueError("deconv4s2_fewout: input %s does not match weight %s" % (tuple(x.shape), tuple(weight.shape)))
+        w = weight.detach().contiguous()
+        out = torch.empty((B, N, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        nws = int(_hip.load().pcfa_deconv4s2_fewout_workspace_bytes(B, K, N, H, W))
+        ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32) if nws else None
+        _call("pcfa_deconv4s2_fewout_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), B, K, N, H, W)
+        ctx.save_for_backward(w)
+        ctx.dims = (B, K, N, H, W)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise RuntimeError("deconv4s2_fewout is the frozen-weight path: no weight / bias gradient")
+        (w,) = ctx.saved_tensors
+        B, K, N, H, W = ctx.dims
+        g = g.contiguous()
+        gx = torch.empty((B, K, H, W), device=g.device, dtype=torch.float32)
+        _call("pcfa_deconv4s2_fewout_bwd", _ptr(g), _ptr(w), _ptr(gx), B, K, N, H, W)
+        return gx, None, None
+
+
+def deconv4s2_fewout(x, weight, bias=None):
+    """conv_transpose2d(x, weight, bias, stride=2, padding=1) for a frozen 4x4 weight with at most 4 output channels:
+    PWC-Net's deconv / upfeat layers (PWCNet.py:42-43) as a streaming kernel with a fixed summation order."""
+    return _Deconv4s2FewOut.apply(x, weight, bias)
+
+
+class _UpsampleBilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, factor, mul):
+        _dev(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty((B, C, factor * H, factor * W), device=x.device, dtype=torch.float32)
+        _call("pcfa_upsample_bilinear_fwd", _ptr(x), _ptr(out), B * C, H, W, int(factor), float(mul))
+        ctx.dims = (B, C, H, W, int(factor), float(mul))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        B, C, H, W, factor, mul = ctx.dims
+        g = g.contiguous()
+        gx = torch.empty((B, C, H, W), device=g.device, dtype=torch.float32)
+        _call("pcfa_upsample_bilinear_bwd", _ptr(g), _ptr(gx), B * C, H, W, factor, mul)
+        return gx, None, None
+
+
+def upsample_bilinear(x, factor, mul=1.0):
+    """mul * nn.Upsample(scale_factor=factor, mode='bilinear')(x) (PWCNet.py:73,321); gather backward (no atomics)."""
+    return _UpsampleBilinear.apply(x, int(factor), float(mul))
+
+
 class _InstNormRelu(torch.autograd.Function):
     """relu?(F.instance_norm(x, eps=eps)) on pcfa_instnorm_fwd/bwd (two streaming launches per direction)."""
 

@@ -19,6 +19,7 @@ from .. import ops
 
 DILATED_AS_SUBGRIDS = (2, 4, 8, 16)   # dilations run as d*d plain 3x3 convolutions on sub-sampled grids (() = library)
 CONV_S2 = True   # stride-2 pyramid layers on ops.conv_s2 (False: library convolution; tools/dev A/B)
+DECONV_FEWOUT = True   # deconv / upfeat layers and the final x4 upsampling on own kernels (False: library; A/B)
 
 
 class _ConvLeaky(nn.Sequential):
@@ -74,8 +75,22 @@ def predict_flow(in_planes):
     return _PredictFlow(int(in_planes), 2, kernel_size=3, stride=1, padding=1, bias=True)
 
 
+class _Deconv(nn.ConvTranspose2d):
+    """deconv() of the reference (PWCNet.py:42-43).  Frozen 4x4 / stride 2 / pad 1 instances with at most 4 output
+    channels (every one PWC-Net has) stream through ops.deconv4s2_fewout: fixed summation order, where the library
+    picks implicit-GEMM / GEMM + col2im / first-call fallback kernels per process; parameter names unchanged."""
+
+    def forward(self, x):
+        if (self.kernel_size == (4, 4) and self.stride == (2, 2) and self.padding == (1, 1)
+                and self.output_padding == (0, 0) and self.dilation == (1, 1) and self.groups == 1
+                and self.out_channels <= 4 and DECONV_FEWOUT
+                and not (self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad))):
+            return ops.get().deconv4s2_fewout(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def deconv(in_planes, out_planes, kernel_size=4, stride=2, padding=1):
-    return nn.ConvTranspose2d(int(in_planes), int(out_planes), kernel_size, stride, padding, bias=True)
+    return _Deconv(int(in_planes), int(out_planes), kernel_size, stride, padding, bias=True)
 
 
 def correlate(input1, input2):
@@ -182,6 +197,8 @@ class PWCDCNet(nn.Module):
         x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(x))))
         flow2 = flows[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))
 
+        if DECONV_FEWOUT and not self.training:
+            return ops.get().upsample_bilinear(flow2, 4, 20.0)   # 20 * self.upsample(flow2), gather backward
         flow2 = 20 * self.upsample(flow2)
         if self.training:
             return (flow2,) + tuple(20 * self.upsample(flows[l]) for l in (3, 4, 5, 6))

@@ -721,6 +721,56 @@ def test_conv3x3_fewout_vs_oracle(oracle_ops, shape, n):
         hip_ops.conv3x3_fewout(xg.detach(), torch.zeros(5, K, 3, 3, device=DEV))
 
 
+@pytest.mark.parametrize("shape,n", [((1, 597, 48, 160), 2), ((1, 2, 48, 160), 2), ((1, 529, 6, 20), 2),
+                                     ((1, 661, 12, 40), 2), ((2, 37, 9, 13), 2), ((1, 5, 3, 70), 1), ((2, 16, 17, 5), 3),
+                                     ((1, 64, 24, 40), 4), ((1, 1024, 1, 2), 2), ((2, 9, 1, 1), 2), ((1, 6, 3, 1), 2)])
+def test_deconv4s2_fewout_vs_oracle(oracle_ops, shape, n):
+    """PWC-Net's deconv / upfeat layers (PWCNet.py:42-43: ConvTranspose2d(K, 2, 4, 2, 1)) at the KITTI level shapes,
+    ragged sizes, 1..4 output channels, with and without bias, small planes with split channel sums.  Tolerance:
+    summation order over 4K products per output; bit-reproducible."""
+    gen = torch.Generator().manual_seed(shape[1] + 7 * n)
+    B, K, H, W = shape
+    x = torch.randn(*shape, generator=gen).requires_grad_(True)
+    w = torch.randn(K, n, 4, 4, generator=gen) / (2 * K ** 0.5)
+    bias = torch.randn(n, generator=gen) if K % 2 else None
+    want = oracle_ops.deconv4s2_fewout(x, w, bias)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.deconv4s2_fewout(xg, w.to(DEV), None if bias is None else bias.to(DEV))
+    assert got.shape == want.shape == (B, n, 2 * H, 2 * W)
+    assert max_abs(got, want) <= 2e-6 * (4 * K) ** 0.5 * float(want.detach().abs().max())
+    got.backward(go.to(DEV))
+    assert rel_l2(xg.grad, x.grad) < 1e-5
+    xg2 = x.detach().to(DEV).requires_grad_(True)
+    got2 = hip_ops.deconv4s2_fewout(xg2, w.to(DEV), None if bias is None else bias.to(DEV))
+    got2.backward(go.to(DEV))
+    assert torch.equal(got2, got) and torch.equal(xg2.grad, xg.grad)
+    with pytest.raises(ValueError):
+        hip_ops.deconv4s2_fewout(xg.detach(), torch.zeros(K, 5, 4, 4, device=DEV))
+
+
+@pytest.mark.parametrize("shape,factor", [((1, 2, 96, 320), 4), ((2, 2, 7, 5), 4), ((1, 3, 1, 9), 4), ((1, 1, 6, 1), 2),
+                                          ((1, 2, 5, 300), 3), ((1, 2, 112, 256), 4)])
+def test_upsample_bilinear_vs_oracle(oracle_ops, shape, factor):
+    """`20 * self.upsample(flow2)` (PWCNet.py:73,321) and its backward as a gather: forward to 4 ulp of the output
+    range, gradient to 1e-6 relative L2 against autograd of F.interpolate; bit-reproducible."""
+    gen = torch.Generator().manual_seed(shape[2] * shape[3] + factor)
+    x = torch.randn(*shape, generator=gen).requires_grad_(True)
+    want = oracle_ops.upsample_bilinear(x, factor, 20.0)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    got = hip_ops.upsample_bilinear(xg, factor, 20.0)
+    assert got.shape == want.shape
+    assert max_abs(got, want) <= 5e-7 * float(want.detach().abs().max())
+    got.backward(go.to(DEV))
+    assert rel_l2(xg.grad, x.grad) < 1e-6
+    xg2 = x.detach().to(DEV).requires_grad_(True)
+    hip_ops.upsample_bilinear(xg2, factor, 20.0).backward(go.to(DEV))
+    assert torch.equal(xg2.grad, xg.grad)
+
+
 @pytest.mark.parametrize("shape,n,k", [((1, 2, 55, 128), 128, 7), ((2, 2, 9, 13), 5, 7), ((1, 1, 7, 20), 16, 7),
                                        ((1, 2, 11, 6), 9, 5), ((1, 2, 4, 3), 3, 3), ((1, 2, 3, 130), 64, 7)])
 def test_conv_fewin_vs_oracle(oracle_ops, shape, n, k):
@@ -1814,3 +1864,28 @@ def test_universal_artifacts_round_trip_through_evaluate_on_gpu(tmp_path):
     ev2 = evaluate_PCFA.eval_l2_universal(_f3_cli(net="RAFT", universal_perturbation=True, synthetic_size=size,
                                                   perturbation_sourcefolder=run_dir, origin_net="SpyNet"))
     assert len(ev2) == 2 and np.isfinite(ev2[1]["epoch_aee_pred-predadv"])
+
+
+# --------------------------------------------------------------------------- process-to-process reproducibility
+@pytest.mark.parametrize("net,size,extra,seeds,steps", [
+    ("PWCNet", "375x1242", ["--box", "clipping", "--joint"], "0,1,2,3", 20),
+    ("RAFT", "436x1024", ["--box", "change_of_variables"], "0", 4)])
+def test_fresh_processes_are_bit_identical(net, size, extra, seeds, steps):
+    """two FRESH processes (children of this test, started one after the other; the parent of
+    the children never touches the GPU itself) run the captured-graph attack on the same synthetic pairs and must
+    agree bit for bit -- every operator output and gradient of one recorded eager closure, the loss of every closure
+    evaluation, every per-step metric and the best-iterate results (tools/process_repro.py).  PWC-Net at BASELINE
+    config 4's shape on pairs 0-3 (r03: 38.92 vs 40.41 between two processes while the library still ran the
+    transposed convolutions and the bilinear up-sampling backward), RAFT at config 2's shape."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "process_repro.py"), "--net", net, "--size", size,
+                        "--steps", str(steps), "--procs", "2", "--seeds", seeds] + extra,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode in (0, 1), p.stderr[-3000:]
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rec["identical"], rec["first_difference"]
+    assert all(pr["graphed"] for run in rec["per_process"] for pr in run)
