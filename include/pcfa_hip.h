@@ -363,6 +363,16 @@ PCFA_API int pcfa_gru_update_bwd(const float* z, const float* q, const float* h,
  *
  * pcfa_sepconv5_pack_weights: w [Cout][Cin][5] (the Conv2d weight, either orientation, flattened) ->
  * fwd_packed [5][Cin][Cout] and/or bwd_packed [5][Cout][Cin] (either may be NULL). */
+/* Floats of one packing: the direct operand order [5][Cin][Cout] followed, where the shape is eligible (Cin % 8 == 0),
+ * by the Winograd-domain weights of the F(2,5) kernel (csrc/sepconv5_wino.hip: 6 points, MFMA operand order).
+ * fwd_packed must hold pcfa_sepconv5_packed_floats(Cout, Cin) floats, bwd_packed (the operator with the channel roles
+ * swapped) pcfa_sepconv5_packed_floats(Cin, Cout); every pcfa_sepconv5_* launch reads buffers of that length. */
+PCFA_API long long pcfa_sepconv5_packed_floats(int Cout, int Cin);
+/* Process-wide algorithm switch of every pcfa_sepconv5_* launch: 1 = 1-D Winograd F(2,5) where the shape is eligible
+ * (default; PCFA_SEPCONV_WINO=0 in the environment starts with 0), 0 = the direct implicit GEMM everywhere, negative =
+ * query only.  Returns the previous setting.  Eligible: Cin % 32 == 0 (% 64 for narrow grids), Cout % 32 == 0,
+ * W % 128 == 0 (1x5) / W % 64 == 0 (5x1), 16-B aligned tensors. */
+PCFA_API int pcfa_sepconv5_algo(int use_winograd);
 PCFA_API int pcfa_sepconv5_pack_weights(const float* w, float* fwd_packed, float* bwd_packed, int Cout, int Cin,
                                void* stream);
 PCFA_API int pcfa_sepconv5_fwd(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,

@@ -78,6 +78,8 @@ SIGNATURES = {
     "pcfa_gru_gates_bwd": (c_int, [_P] * 8 + [c_longlong, _P]),
     "pcfa_gru_update_fwd": (c_int, [_P] * 7 + [c_longlong, c_int, c_int, _P]),
     "pcfa_gru_update_bwd": (c_int, [_P] * 7 + [c_longlong, _P]),
+    "pcfa_sepconv5_packed_floats": (c_longlong, [c_int, c_int]),
+    "pcfa_sepconv5_algo": (c_int, [c_int]),
     "pcfa_sepconv5_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "pcfa_sepconv5_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_sepconv5_fwd_split": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int,

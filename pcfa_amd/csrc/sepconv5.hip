@@ -16,7 +16,7 @@
 // before its MFMAs (ring of four register sets): with one or two workgroups per CU nothing else hides the
 // L2/HBM latency.
 #include <cstdlib>
-#include "common.hpp"
+#include "sepconv5.hpp"
 
 #ifndef PCFA_SC5_PRE
 #define PCFA_SC5_PRE 4   // LDS operand reads issued this many MFMAs ahead of their use
@@ -42,50 +42,7 @@ constexpr int B_TILE_V = KC * TAPS * BV_ROW;
 constexpr int BV_VEC = B_TILE_V / 4;
 constexpr int BV_REGS = (BV_VEC + 255) / 256;
 
-struct Operand {
-  const float* a;
-  const float* b;
-  int Ca, Cin;
-};
-
-// Output channels [0, Ca) go to `a`, the rest to `b` (b may be null when Ca == Cout); acc_*: add to what is there
-// (the data gradient of a convolution whose input feeds several consumers accumulates in place instead of being
-// summed by separate elementwise kernels).
-struct OutSplit {
-  float* a;
-  float* b;
-  int Ca;
-  int acc_a, acc_b;
-  const float* mask_b;   // optional, shape of `b`: channels < mask_cb of the b part are zeroed where mask_b <= 0
-  int mask_cb;           // (the deferred ReLU backward of whoever produced the b operand of the forward)
-};
-
-// Fused SepConvGRU epilogues (models/raft/update.py:45-60): the arithmetic of pcfa_gru_gates_fwd / _update_fwd and of
-// their backward counterparts applied to the accumulators, so the pre-activations (forward) and the intermediate
-// gradients (backward) never reach memory and the elementwise launches between the convolutions disappear.
-// All tensors [B][.][H][W]; C % 32 == 0 (a wave's 32 channels are all z or all r, all a-part or all b-part).
-//   mode 1, Cout = 2C: m <  C: z[m] = sigmoid(acc + add[m]);  m >= C: r = sigmoid(acc + add[m]), rh = r * h
-//           in: p0 = add [B][2C], p1 = h;  out: o0 = z, o1 = r, o2 = r * h
-//   mode 2, Cout =  C: q = tanh(acc + add[m]),  hnew = (1 - z) * h + z * q
-//           in: p0 = add [B][C], p1 = h, p2 = z;  out: o0 = q, o1 = hnew
-//   mode 3 (data gradient of the q convolution, a-part = d(r h)): pcfa_gru_gates_bwd_acc on acc = drh:
-//           dzc = dz (1 - z) z,  drc = (drh h)(1 - r) r,  dh = dh_in + drh r
-//           in: p0 = z, p1 = r, p2 = h, p3 = dz, p4 = dh_in;  out: o0 = dzr[:, :C], o1 = dzr[:, C:] ([B][2C]), o2 = dh
-//   mode 4 (data gradient of the z|r convolution, a-part = dh): g = dh_acc + acc is the gradient of the PREVIOUS
-//           half-step's output, whose pcfa_gru_update_bwd follows at once:  dz = g q - g h,  dqc = (g z)(1 - q q),
-//           dh = g (1 - z)      in: p0 = dh_acc, p1 = z, p2 = q, p3 = h (previous half);  out: o0 = dz, o1 = dqc, o2 = dh
-// Modes 3 / 4 leave the b-part (the motion-feature gradient) to OutSplit; their a-part output pointer is unused.
-struct GruEpi {
-  int mode, C;
-  const float* p0;
-  const float* p1;
-  const float* p2;
-  const float* p3;
-  const float* p4;
-  float* o0;
-  float* o1;
-  float* o2;
-};
+using namespace pcfa_sc5;   // Operand, OutSplit, GruEpi (sepconv5.hpp)
 
 __device__ __forceinline__ float sc5_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }   // as gru_math.hip
 
@@ -491,6 +448,13 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+extern "C" int pcfa_sepconv5_algo(int use_winograd) { return sc5_wino_enabled(use_winograd); }
+
+extern "C" long long pcfa_sepconv5_packed_floats(int Cout, int Cin) {
+  if (Cout < 1 || Cin < 1) return 0;
+  return (long long)Cout * Cin * TAPS + sc5_wino_packed_floats(Cout, Cin);
+}
+
 extern "C" int pcfa_sepconv5_pack_weights(const float* w, float* fwd_packed, float* bwd_packed, int Cout,
                                           int Cin, void* stream) {
   if (!w || (!fwd_packed && !bwd_packed) || Cout < 1 || Cin < 1) return PCFA_ERR_INVALID_ARG;
@@ -498,6 +462,15 @@ extern "C" int pcfa_sepconv5_pack_weights(const float* w, float* fwd_packed, flo
   pcfa_launch(sepconv5_pack_kernel, dim3((unsigned)min((n + 255) / 256, (long long)1024)), dim3(256), 0,
               (hipStream_t)stream, w, fwd_packed, bwd_packed, Cout, Cin);
   PCFA_LAUNCH_CHECK();
+  // the Winograd-domain weights of sepconv5_wino.hip follow the direct packing (nothing when the shape is not eligible)
+  if (fwd_packed) {
+    const int e = sc5_wino_pack(w, fwd_packed + n, Cout, Cin, 0, (hipStream_t)stream);
+    if (e != PCFA_OK) return e;
+  }
+  if (bwd_packed) {
+    const int e = sc5_wino_pack(w, bwd_packed + n, Cin, Cout, 1, (hipStream_t)stream);
+    if (e != PCFA_OK) return e;
+  }
   return PCFA_OK;
 }
 
@@ -581,6 +554,11 @@ static int sepconv5_launch(const float* in_a, int Ca, const float* in_b, int Cb,
   const long long gx = (long long)tiles_x * H;
   if (gx > 0x7fffffffLL || B > 65535 || pcfa_cdiv(Cout, TM) > 65535) return PCFA_ERR_UNSUPPORTED;
   Operand in{in_a, Cb > 0 ? in_b : nullptr, Ca, Ca + Cb};
+  {   // 1-D Winograd F(2,5) where the shape allows it (sepconv5_wino.hip); its weights sit behind the direct packing
+    const float* w_wino = sc5_wino_packed_floats(Cout, Ca + Cb) > 0 ? w_packed + (long long)TAPS * (Ca + Cb) * Cout : nullptr;
+    const int e = sc5_wino_launch(in, w_wino, out, B, Cout, H, W, vertical, (hipStream_t)stream, epi);
+    if (e != PCFA_SC5_NOT_ELIGIBLE) return e;
+  }
   const int vec_w = (Cout % 4 == 0) && aligned16(w_packed);
   const int vec_x = (W % 4 == 0) && aligned16(in_a) && (Cb == 0 || aligned16(in_b));
   dim3 grid((unsigned)gx, pcfa_cdiv(Cout, TM), B), block(256);

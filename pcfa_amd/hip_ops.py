@@ -1157,8 +1157,9 @@ def _sepconv5_packed(weight):
     if hit is None or hit[0]() is not weight or hit[1] != weight._version:
         cout, cin = weight.shape[:2]
         w = weight.detach().contiguous()
-        fwd = torch.empty((5, cin, cout), device=w.device, dtype=torch.float32)
-        bwd = torch.empty((5, cout, cin), device=w.device, dtype=torch.float32)
+        lib = _hip.load()   # direct order + Winograd-domain weights (csrc/sepconv5_wino.hip)
+        fwd = torch.empty(int(lib.pcfa_sepconv5_packed_floats(cout, cin)), device=w.device, dtype=torch.float32)
+        bwd = torch.empty(int(lib.pcfa_sepconv5_packed_floats(cin, cout)), device=w.device, dtype=torch.float32)
         _call("pcfa_sepconv5_pack_weights", _ptr(w), _ptr(fwd), _ptr(bwd), cout, cin)
         hit = (weakref.ref(weight, lambda _r, k=key: _sepconv_packs.pop(k, None)), weight._version, fwd, bwd)
         _sepconv_packs[key] = hit

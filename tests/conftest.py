@@ -28,3 +28,17 @@ def pytest_collection_modifyitems(config, items):
 def oracle_ops():
     from oracle import ops as o
     return o
+
+
+@pytest.fixture
+def sepconv5_algo():
+    """select("winograd" | "direct"): the process-wide switch of the SepConvGRU convolutions (pcfa_sepconv5_algo),
+    restored after the test."""
+    from pcfa_amd import _hip
+    lib = _hip.load()
+    prev = lib.pcfa_sepconv5_algo(-1)
+
+    def select(name):
+        lib.pcfa_sepconv5_algo({"winograd": 1, "direct": 0}[name])
+    yield select
+    lib.pcfa_sepconv5_algo(prev)

@@ -878,10 +878,15 @@ def test_attack_math_vs_reference_golden():
     (1, 128, 128, 256, 55, 128), (1, 128, 128, 128, 55, 128), (1, 128, 256, 128, 55, 128),
     (2, 5, 6, 7, 9, 70), (1, 12, 0, 66, 6, 3), (1, 3, 2, 4, 1, 1)])
 @pytest.mark.parametrize("vertical", [False, True])
-def test_sepconv5_vs_oracle(oracle_ops, shape, vertical):
-    """SepConvGRU (1,5)/(5,1) gate convolutions (update.py:36-60) as implicit MFMA GEMM over [a | b]: exact fp32
-    products, different summation order than conv2d -> 2e-6 relative L2 forward and data gradients."""
+@pytest.mark.parametrize("algo", ["winograd", "direct"])
+def test_sepconv5_vs_oracle(oracle_ops, sepconv5_algo, shape, vertical, algo):
+    """SepConvGRU (1,5)/(5,1) gate convolutions (update.py:36-60) over [a | b].  direct: implicit MFMA GEMM, exact fp32
+    products, different summation order than conv2d -> 2e-6 relative L2 forward and data gradients.  winograd: 1-D
+    F(2,5) where the shape is eligible (the 55x128 shapes; the direct kernel elsewhere): transform constants up to 5,
+    1.0e-6 rms against fp64 -> 5e-6 relative L2."""
     B, Ca, Cb, Cout, H, W = shape
+    sepconv5_algo(algo)
+    tol = 5e-6 if algo == "winograd" else 2e-6
     gen = torch.Generator().manual_seed(31 + Ca + W)
     a = torch.randn(B, Ca, H, W, generator=gen)
     b = torch.randn(B, Cb, H, W, generator=gen) if Cb else None
@@ -895,19 +900,24 @@ def test_sepconv5_vs_oracle(oracle_ops, shape, vertical):
     gb = None if b is None else b.clone().to(DEV).requires_grad_(True)
     got = hip_ops.sepconv5(ga, gb, w.to(DEV))
     assert got.shape == want.shape
-    assert rel_l2(got, want) < 2e-6
+    assert rel_l2(got, want) < tol, rel_l2(got, want)
     got.backward(go.to(DEV))
-    assert rel_l2(ga.grad, ca.grad) < 2e-6
+    assert rel_l2(ga.grad, ca.grad) < tol
     if b is not None:
-        assert rel_l2(gb.grad, cb.grad) < 2e-6
+        assert rel_l2(gb.grad, cb.grad) < tol
 
 
-@pytest.mark.parametrize("shape", [(1, 128, 128, 55, 128), (2, 8, 12, 9, 70), (1, 128, 256, 16, 24)])
-def test_gru_step_vs_oracle(oracle_ops, shape):
+@pytest.mark.parametrize("shape", [(1, 128, 128, 55, 128), (2, 8, 12, 9, 70), (1, 128, 256, 16, 24), (2, 128, 128, 17, 128),
+                                   (1, 64, 64, 6, 256)])
+@pytest.mark.parametrize("algo", ["winograd", "direct"])
+def test_gru_step_vs_oracle(oracle_ops, sepconv5_algo, shape, algo):
     """The fused SepConvGRU update (one autograd node, gradients of h / motion features accumulated inside the
     kernels) against the oracle's composition of the same operators under autograd: values and every gradient
-    (h, rest, the four hoisted context parts) to 5e-6 relative L2 -- only the order of a few additions differs."""
+    (h, rest, the four hoisted context parts) to 5e-6 relative L2 -- only the order of a few additions differs --
+    with the direct kernels, 1.5e-5 with the F(2,5) Winograd kernels (all four fused epilogues, both orientations,
+    odd height = a row pair with one row, batch 2, the 32-channel x 4-group tile at 64 channels)."""
     B, C, Cr, H, W = shape
+    sepconv5_algo(algo)
     gen = torch.Generator().manual_seed(7 + C + W)
     rnd = lambda *s: torch.randn(*s, generator=gen)  # noqa: E731
     h, rest = torch.tanh(rnd(B, C, H, W)), rnd(B, Cr, H, W)
@@ -927,7 +937,9 @@ def test_gru_step_vs_oracle(oracle_ops, shape):
 
     want, got = run(oracle_ops, "cpu"), run(hip_ops, DEV)
     for w_, g_ in zip(want, got):
-        assert rel_l2(g_, w_) < 5e-6
+        assert rel_l2(g_, w_) < (1.5e-5 if algo == "winograd" else 5e-6), rel_l2(g_, w_)
+    again = run(hip_ops, DEV)
+    assert all(torch.equal(x, y) for x, y in zip(got, again))   # fixed summation order
 
 
 @pytest.mark.parametrize("shape", [
