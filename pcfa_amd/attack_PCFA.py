@@ -21,6 +21,7 @@ is data parallel over the batch with ONE all-reduce of d(loss)/d(delta) per clos
 (`attack_l2_universal`), see pcfa_amd/sharding.py.
 """
 import os
+import weakref
 import time
 
 import numpy as np
@@ -86,6 +87,25 @@ class _PairGraphs:
         self.params, self.target, self.optimizer = st.params, st.target, st.optimizer
         self.graphed, self.repredict = st.graphed, st.repredict
         self.pairs = 1
+        self.owner = weakref.ref(st)   # the ONE live PairAttack of this key; retired when the next pair adopts the set
+
+    def retire_owner(self):
+        st = self.owner()
+        if st is not None:
+            st._retire()
+
+
+MAX_CACHED_SHAPES = 2   # graph sets kept per model (LRU): each pins a closure graph pool + a 2 x 101 x n L-BFGS history
+
+
+def _cache_put(cache, key, kept):
+    cache.pop(key, None)
+    cache[key] = kept                      # dicts keep insertion order: the last entry is the most recently used
+    while len(cache) > MAX_CACHED_SHAPES:
+        old_key = next(iter(cache))
+        old = cache.pop(old_key)
+        old.retire_owner()                 # its PairAttack must not replay graphs whose buffers are about to go
+        old.graphed = old.repredict = old.optimizer = None
 
 
 def _graph_cache(model):
@@ -137,9 +157,14 @@ class PairAttack:
         kept = _graph_cache(model).get(self.graph_key) if (use_graph and reuse_graphs and not share_forward) else None
         self.graphed = self.repredict = None
         self.graphs_reused = kept is not None
+        self.retired = False
 
         if kept is not None:
-            # same shape and flags as an earlier pair: its static buffers, graphs and optimiser, refilled
+            # same shape and flags as an earlier pair: its static buffers, graphs and optimiser, refilled.  The earlier
+            # PairAttack (if still alive) is retired first: its variables, target and optimiser state are this pair's now.
+            kept.retire_owner()
+            kept.owner = weakref.ref(self)
+            _cache_put(_graph_cache(model), self.graph_key, kept)   # most recently used
             with torch.no_grad():
                 kept.image1.copy_(image1)
                 kept.image2.copy_(image2)
@@ -294,13 +319,26 @@ class PairAttack:
             self.graphed = GraphedClosure(self.closure_body, self.params, grad_sink=sink() if sink else None)
             self.repredict = GraphedForward(self._repredict_body, self.device)
             if self.reuse_graphs and hasattr(self.optimizer, "reset"):
-                _graph_cache(self.model)[self.graph_key] = _PairGraphs(self)   # the next pair of this shape adopts them
+                _cache_put(_graph_cache(self.model), self.graph_key, _PairGraphs(self))   # the next pair of this shape adopts them
         except Exception as e:  # noqa: BLE001 -- the eager closure launches the same kernels in the same order
             import logging as pylog
             pylog.warning("hipGraph capture of the closure failed (%r): launching eagerly", e)
             self.graphed = self.repredict = None
 
+    def _retire(self):
+        """A later pair of the same shape took over this pair's static buffers, graphs and optimiser (or the set was
+        evicted from the per-model cache): results recorded so far stay readable, further evaluation raises."""
+        self.retired = True
+        self.graphed = self.repredict = None
+
+    def _check_live(self):
+        if self.retired:
+            raise RuntimeError("this PairAttack was retired: a later pair of the same shape adopted its static buffers, "
+                               "graphs and optimiser (one live PairAttack per shape and model; reuse_graphs=False keeps "
+                               "pairs independent)")
+
     def closure(self):
+        self._check_live()
         self.closures += 1
         if self.graphed is not None:
             return self.graphed()
@@ -309,6 +347,7 @@ class PairAttack:
 
     # ---- one `--steps` iteration (attack_PCFA.py:155-247) -------------------------------------------------------
     def step(self):
+        self._check_live()
         args = self.args
         steps = self.steps_done
         curr_step = self.batch * args.steps + steps
@@ -550,12 +589,16 @@ class UniversalAttack:
             image1 = image1 / 255.
             image2 = image2 / 255.
         padder, [image1, image2] = ownutilities.preprocess_img(self.args.net, image1, image2)
-        st = self.states.get(tuple(image1.shape))
+        key = tuple(image1.shape)
+        st = self.states.pop(key, None)
         if st is None:
-            st = self.states[tuple(image1.shape)] = _UniversalBatchState(image1, image2, padder)
+            st = _UniversalBatchState(image1, image2, padder)
         else:
             st.image1.copy_(image1)
             st.image2.copy_(image2)
+        self.states[key] = st                              # most recently used last
+        while len(self.states) > MAX_CACHED_SHAPES:        # every state pins a closure graph pool: keep the newest
+            self.states.pop(next(iter(self.states)))
         self.st = st
         with torch.no_grad():
             self.flow_pred_init = self.predict(perturbed=False).detach().clone()

@@ -1220,6 +1220,7 @@ def _conv3x3_packed(weight):
 
 
 _CONV_WS = {}   # device index -> scratch of pcfa_conv3x3_run (split-K partial outputs of the F(4x4,3x3) path)
+_CONV_WS_RETIRED = []   # superseded (smaller) scratch buffers: kept alive for the graphs that captured their address
 
 
 _SIDE_STREAMS = {}
@@ -1247,6 +1248,11 @@ def _conv_workspace(device, nbytes):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("conv3x3 workspace would have to grow inside a graph capture (no eager warm-up of this "
                                "shape ran before it)")
+        if ws is not None:
+            # never free a scratch buffer a captured hipGraph may have baked in (pcfa_conv3x3_run's split-K partials):
+            # graphs are kept across pairs (attack_PCFA._PairGraphs), and a replay after the buffer grew for another
+            # shape would write into memory the allocator has handed to someone else
+            _CONV_WS_RETIRED.append(ws)
         ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
         _CONV_WS[idx] = ws
     return ws

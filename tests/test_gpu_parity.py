@@ -1553,6 +1553,22 @@ def test_pair_graph_reuse_equals_fresh_capture():
 
     reused, n_kept = run(True)
     fresh, n_none = run(False)
+    # the donor of an adopted graph set is retired (its variables / optimiser are the new pair's now), and
+    # the per-model cache is bounded (LRU of attack_PCFA.MAX_CACHED_SHAPES shapes)
+    model = closure_util.load_model("RAFT", True, dev)
+    model._pcfa_pair_graphs.clear()
+    sts = []
+    for seed, (h, w) in ((0, (128, 160)), (1, (128, 160)), (2, (136, 168)), (3, (144, 176))):
+        i1, i2, _ = datasets.synthetic_pair(seed, h, w)
+        sts.append(attack_PCFA.PairAttack(model, i1[None], i2[None], None, seed, attack_PCFA.EPS_BOX, dev, False, mu, args,
+                                          use_graph=True, reuse_graphs=True))
+    assert sts[0].retired and sts[0].graphed is None            # adopted by the second pair
+    with pytest.raises(RuntimeError, match="retired"):
+        sts[0].step()
+    assert sts[1].retired and not sts[2].retired and not sts[3].retired   # three shapes, two kept: the oldest is evicted
+    assert len(model._pcfa_pair_graphs) == attack_PCFA.MAX_CACHED_SHAPES == 2
+    sts[3].step()
+    model._pcfa_pair_graphs.clear()
     assert [r[0] for r in reused] == [False, True, False, True] and n_kept == 2       # two shapes, two graph sets
     assert not any(r[0] for r in fresh) and n_none == 0
     for (_, la, fa, ca, ta), (_, lb, fb, cb, tb) in zip(reused, fresh):
@@ -1901,3 +1917,16 @@ def test_fresh_processes_are_bit_identical(net, size, extra, seeds, steps):
     rec = json.loads(p.stdout.strip().splitlines()[-1])
     assert rec["identical"], rec["first_difference"]
     assert all(pr["graphed"] for run in rec["per_process"] for pr in run)
+
+
+def test_conv_workspace_never_frees_a_captured_buffer():
+    """the split-K scratch of pcfa_conv3x3_run is baked into captured hipGraphs that outlive the pair
+    (attack_PCFA._PairGraphs); when a larger shape makes it grow, the old buffer must stay allocated."""
+    dev = torch.device(DEV)
+    a = hip_ops._conv_workspace(dev, 1 << 20)
+    pa = a.data_ptr()
+    n = a.numel() * 4
+    b = hip_ops._conv_workspace(dev, 4 * n)
+    assert b.data_ptr() != pa and b.numel() * 4 >= 4 * n
+    assert any(t.data_ptr() == pa for t in hip_ops._CONV_WS_RETIRED)
+    assert hip_ops._conv_workspace(dev, n) is b                # a smaller request keeps the current buffer
