@@ -549,11 +549,12 @@ PCFA_API int pcfa_pwc_warp_fwd(const float* x, const float* flo, float* out, int
                                float mask_threshold, void* stream);
 PCFA_API int pcfa_pwc_warp_bwd(const float* x, const float* flo, const float* grad_out, float* grad_x,
                                float* grad_flo, int B, int C, int H, int W, float mask_threshold, void* stream);
-/* The same backward, bit-reproducible: the scatter adds 2^-40 fixed-point int64 values (integer adds commute, so the
+/* The same backward, bit-reproducible: the scatter adds fixed-point int64 values (integer adds commute, so the
  * order in which the atomics land does not matter) and the flow gradient's channel groups are summed in index order;
  * grid_sampler_2d_backward (and pcfa_pwc_warp_bwd) add fp32 values in whatever order the hardware serves them, which
  * made two 20-step PWC-Net attacks on the same pair end 3 % apart (profiles/r03_schedule_parity_pwcnet_20steps.json).
- * Range +-8.4e6, resolution 9e-13 per addend.  workspace >= pcfa_pwc_warp_bwd_det_workspace_bytes(), 8-B aligned. */
+ * The fixed point is scaled per call to max|grad_out| (40 bits below its leading power of two, room for 2^22 addends
+ * of maximal size).  workspace >= pcfa_pwc_warp_bwd_det_workspace_bytes(), 8-B aligned.  {clear + max, scatter, finish} */
 PCFA_API size_t pcfa_pwc_warp_bwd_det_workspace_bytes(int B, int C, int H, int W);
 PCFA_API int pcfa_pwc_warp_bwd_det(const float* x, const float* flo, const float* grad_out, float* grad_x,
                           float* grad_flo, void* workspace, size_t workspace_bytes, int B, int C, int H, int W,

@@ -815,7 +815,8 @@ extern "C" int pcfa_corr_pyramid_bwd_windows(const float* dpyr, const float* fma
   const size_t base = (pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, num_levels) + 15) & ~(size_t)15;
   const long long Q = (long long)H * W;
   const bool fast = Q % 4 == 0 && aligned16(f2ext) && aligned16(dpyr) && aligned16(fmap1) && Q >= 4;
-  if (!coords || n_coords < 1 || n_coords > MAX_COORDS || !fast || H > 65535)   // no window information:
+  // (a segment record holds four levels' ranges: deeper pyramids take the dense products)
+  if (!coords || n_coords < 1 || n_coords > MAX_COORDS || !fast || H > 65535 || num_levels > 4)   // no window information:
     return pyramid_bwd(dpyr, fmap1, f2ext, dfmap1, dfmap2, workspace, workspace_bytes, B, D, H, W, num_levels, stream,
                        nullptr, nullptr);                                                   // the dense products
   if (workspace_bytes < pcfa_corr_pyramid_bwd_windows_workspace_bytes(B, D, H, W, num_levels)) return PCFA_ERR_WORKSPACE;

@@ -150,20 +150,45 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_kernel(const float* __restri
   }
 }
 
-// Deterministic variant of the scatter: contributions are added as 2^-40 fixed-point int64 (integer adds commute and
+// Deterministic variant of the scatter: contributions are added as fixed-point int64 (integer adds commute and
 // associate, so the order in which the atomics land cannot change the sum: two runs give the same bits), the flow
-// gradient's channel groups write their partials side by side.  wfinish converts / adds in index order.  Range
-// +-8.4e6, resolution 9e-13 per addend (fp32 keeps 6e-8 relative: finer only below 1.5e-5).
-constexpr double WARP_FIX = 1099511627776.0;   // 2^40
+// gradient's channel groups write their partials side by side.  wfinish converts / adds in index order.
+// The fixed point is scaled PER CALL: with m = max|grad_out| (found by the kernel that clears the accumulators: block
+// maxima, re-reduced by every consumer block -- a maximum does not depend on the order either) the unit is
+// 2^(floor(log2 m) - 40), i.e. every addend keeps 40 bits below the largest gradient of the call (fp32 keeps 24 below
+// each value: values down to 1.5e-5 of the maximum are resolved as finely as fp32 resolves them, whatever the
+// absolute scale -- AEE / npix-scaled gradients of 1e-9 included), and 2^22 addends of maximal size fit an int64.
+constexpr int WARP_FIX_BITS = 40;
+constexpr int WARP_BMAX = 4096;   // block maxima of |grad_out| (one per block of the clearing kernel)
 
-__device__ __forceinline__ void fix_add(long long* p, float v) {
-  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * WARP_FIX));
+__device__ __forceinline__ float block_max_256(float m, float* red) {   // 256 threads, result on every thread
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return m;
+}
+
+// 2^shift = the fixed-point scale of this call (uniform over the grid: every block reduces the same block maxima)
+__device__ __forceinline__ int warp_fix_shift(const float* __restrict__ bmax, int nblk, float* red) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) m = fmaxf(m, bmax[i]);
+  m = block_max_256(m, red);
+  return (m > 0.f && m < 3.0e38f) ? WARP_FIX_BITS - ilogbf(m) : WARP_FIX_BITS;
+}
+
+__device__ __forceinline__ void fix_add(long long* p, float v, double scale) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * scale));
 }
 
 __global__ __launch_bounds__(256) void pwc_warp_bwd_det_kernel(const float* __restrict__ x, const float* __restrict__ flo,
                                                               const float* __restrict__ gout, long long* __restrict__ gxi,
-                                                              float* __restrict__ gfpart, int C, int H, int W,
-                                                              float mask_thresh) {
+                                                              float* __restrict__ gfpart, const float* __restrict__ bmax,
+                                                              int nblk, int C, int H, int W, float mask_thresh) {
+  __shared__ float red[4];
+  const double scale = ldexp(1.0, warp_fix_shift(bmax, nblk, red));
   const long long plane = (long long)H * W;
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= plane) return;
@@ -198,22 +223,22 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_det_kernel(const float* __re
     long long* gc = gb + (size_t)c * plane;
     const float vnw = xc[onw], vne = xc[one], vsw = xc[osw], vse = xc[ose];
     if (bnw) {
-      fix_add(gc + onw, nw * g);
+      fix_add(gc + onw, nw * g, scale);
       gix -= vnw * ey * g;
       giy -= vnw * ex * g;
     }
     if (bne) {
-      fix_add(gc + one, ne * g);
+      fix_add(gc + one, ne * g, scale);
       gix += vne * ey * g;
       giy -= vne * t.wx1 * g;
     }
     if (bsw) {
-      fix_add(gc + osw, sw * g);
+      fix_add(gc + osw, sw * g, scale);
       gix -= vsw * t.wy1 * g;
       giy += vsw * ex * g;
     }
     if (bse) {
-      fix_add(gc + ose, se * g);
+      fix_add(gc + ose, se * g, scale);
       gix += vse * t.wy1 * g;
       giy += vse * t.wx1 * g;
     }
@@ -222,13 +247,17 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_det_kernel(const float* __re
   gf[plane + p] = 2.0f * ((0.5f * (float)H * giy) / (float)max(H - 1, 1));
 }
 
-__global__ void pwc_warp_finish_kernel(const long long* __restrict__ gxi, const float* __restrict__ gfpart,
-                                       float* __restrict__ gx, float* __restrict__ gflo, long long nx, long long nf,
-                                       int G) {
+__global__ __launch_bounds__(256) void pwc_warp_finish_kernel(const long long* __restrict__ gxi,
+                                                              const float* __restrict__ gfpart,
+                                                              const float* __restrict__ bmax, int nblk,
+                                                              float* __restrict__ gx, float* __restrict__ gflo,
+                                                              long long nx, long long nf, int G) {
+  __shared__ float red[4];
+  const double inv = ldexp(1.0, -warp_fix_shift(bmax, nblk, red));
   const long long step = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx + nf; i += step) {
     if (i < nx) {
-      gx[i] = (float)((double)gxi[i] * (1.0 / WARP_FIX));
+      gx[i] = (float)((double)gxi[i] * inv);
     } else {
       const long long j = i - nx;
       float s = gfpart[j];
@@ -238,9 +267,18 @@ __global__ void pwc_warp_finish_kernel(const long long* __restrict__ gxi, const 
   }
 }
 
-__global__ void zero_ll_kernel(long long* __restrict__ a, long long n) {
+// clears the accumulators and leaves max|g| of this block's share of grad_out (same element count) in bmax[blockIdx.x]
+__global__ __launch_bounds__(256) void zero_ll_max_kernel(long long* __restrict__ a, const float* __restrict__ g,
+                                                          float* __restrict__ bmax, long long n) {
+  __shared__ float red[4];
   const long long step = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) a[i] = 0;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    a[i] = 0;
+    m = fmaxf(m, fabsf(g[i]));
+  }
+  m = block_max_256(m, red);
+  if (threadIdx.x == 0) bmax[blockIdx.x] = m;
 }
 
 __global__ void zero2_kernel(float* __restrict__ a, long long na, float* __restrict__ b, long long nb) {
@@ -272,7 +310,8 @@ extern "C" int pcfa_pwc_warp_fwd(const float* x, const float* flo, float* out, i
 extern "C" size_t pcfa_pwc_warp_bwd_det_workspace_bytes(int B, int C, int H, int W) {
   if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
   const long long plane = (long long)H * W;
-  return (size_t)B * C * plane * sizeof(long long) + (size_t)channel_groups(plane, C) * B * 2 * plane * sizeof(float);
+  return (size_t)B * C * plane * sizeof(long long) + (size_t)channel_groups(plane, C) * B * 2 * plane * sizeof(float) +
+         WARP_BMAX * sizeof(float);
 }
 
 extern "C" int pcfa_pwc_warp_bwd_det(const float* x, const float* flo, const float* grad_out, float* grad_x,
@@ -288,13 +327,16 @@ extern "C" int pcfa_pwc_warp_bwd_det(const float* x, const float* flo, const flo
   const int G = channel_groups(plane, C);
   long long* gxi = (long long*)workspace;
   float* gfpart = (float*)(gxi + nx);
-  pcfa_launch(zero_ll_kernel, dim3((int)min((nx + 255) / 256, 4096LL)), dim3(256), 0, s, gxi, nx);
+  float* bmax = gfpart + (size_t)G * nf;
+  const int nblk = (int)min((nx + 255) / 256, (long long)WARP_BMAX);
+  pcfa_launch(zero_ll_max_kernel, dim3(nblk), dim3(256), 0, s, gxi, grad_out, bmax, nx);
   PCFA_LAUNCH_CHECK();
   dim3 grid(pcfa_cdiv(plane, 256), G, B);
-  pcfa_launch(pwc_warp_bwd_det_kernel, grid, dim3(256), 0, s, x, flo, grad_out, gxi, gfpart, C, H, W, mask_threshold);
+  pcfa_launch(pwc_warp_bwd_det_kernel, grid, dim3(256), 0, s, x, flo, grad_out, gxi, gfpart, (const float*)bmax, nblk, C,
+              H, W, mask_threshold);
   PCFA_LAUNCH_CHECK();
   pcfa_launch(pwc_warp_finish_kernel, dim3((int)min((nx + nf + 255) / 256, 4096LL)), dim3(256), 0, s,
-              (const long long*)gxi, (const float*)gfpart, grad_x, grad_flo, nx, nf, G);
+              (const long long*)gxi, (const float*)gfpart, (const float*)bmax, nblk, grad_x, grad_flo, nx, nf, G);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }

@@ -249,12 +249,19 @@ class _CorrBuild(torch.autograd.Function):
         df1 = torch.empty_like(f1)
         df2 = torch.empty_like(f1)
         # the coordinates of every lookup that accumulated into dpyr: the products skip what no window touched
-        cs = st.coords_bwd if (st.coords_bwd and len(st.coords_bwd) <= 32 and PYRAMID_BWD_WINDOWS) else []
-        nbytes = lib.pcfa_corr_pyramid_bwd_windows_workspace_bytes(B, D, H, W, st.L)
-        ws = torch.empty((nbytes + 3) // 4, device=f1.device, dtype=torch.float32)
-        ptrs = (ctypes.c_void_p * max(len(cs), 1))(*[c.data_ptr() for c in cs])
-        _call("pcfa_corr_pyramid_bwd_windows", _ptr(st.dpyr), _ptr(f1), _ptr(st.f2ext), _ptr(df1), _ptr(df2), _ptr(ws),
-              ctypes.c_size_t(nbytes), ptrs, len(cs), st.r, B, D, H, W, st.L)
+        # (the per-block segment record of corr_window_segments_kernel holds four levels: more levels -> dense products)
+        cs = st.coords_bwd if (st.coords_bwd and len(st.coords_bwd) <= 32 and PYRAMID_BWD_WINDOWS and st.L <= 4) else []
+        if cs:
+            nbytes = lib.pcfa_corr_pyramid_bwd_windows_workspace_bytes(B, D, H, W, st.L)
+            ws = torch.empty((nbytes + 3) // 4, device=f1.device, dtype=torch.float32)
+            ptrs = (ctypes.c_void_p * len(cs))(*[c.data_ptr() for c in cs])
+            _call("pcfa_corr_pyramid_bwd_windows", _ptr(st.dpyr), _ptr(f1), _ptr(st.f2ext), _ptr(df1), _ptr(df2), _ptr(ws),
+                  ctypes.c_size_t(nbytes), ptrs, len(cs), st.r, B, D, H, W, st.L)
+        else:   # the dense products under their own entry point (and their own launch indices in DispatchTimer's plan)
+            nbytes = lib.pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, st.L)
+            ws = torch.empty((nbytes + 3) // 4, device=f1.device, dtype=torch.float32)
+            _call("pcfa_corr_pyramid_bwd", _ptr(st.dpyr), _ptr(f1), _ptr(st.f2ext), _ptr(df1), _ptr(df2), _ptr(ws),
+                  ctypes.c_size_t(nbytes), B, D, H, W, st.L)
         st.dpyr = None
         st.token_grad = None
         st.coords_bwd = None
@@ -1870,18 +1877,20 @@ class _Pm1Pair(torch.autograd.Function):
         cx = torch.empty_like(a)
         _call("pcfa_pm1_pair_fwd", _ptr(a), _ptr(b), _ptr(pair), _ptr(cx), B, n)
         ctx.set_materialize_grads(False)    # an unused output hands None to the backward, not a zero tensor
-        ctx.dims = (B, n)
+        ctx.dims = (B, n, tuple(a.shape))
         return pair, cx
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gpair, gctx):
-        B, n = ctx.dims
-        if gpair is None:
-            gpair = torch.zeros((2 * B, n), device=gctx.device, dtype=torch.float32)
+        B, n, shape = ctx.dims
+        if gpair is None and gctx is None:
+            return None, None
+        if gpair is None:   # only the context-encoder branch carries gradient
+            gpair = torch.zeros((2 * B,) + shape[1:], device=gctx.device, dtype=torch.float32)
         gpair = gpair.contiguous()
         gctx = None if gctx is None else gctx.contiguous()
-        ga = torch.empty((B,) + tuple(gpair.shape[1:]), device=gpair.device, dtype=torch.float32)
+        ga = torch.empty(shape, device=gpair.device, dtype=torch.float32)
         gb = torch.empty_like(ga)
         _call("pcfa_pm1_pair_bwd", _ptr(gpair), _ptr(gctx), _ptr(ga), _ptr(gb), B, n)
         return ga, gb

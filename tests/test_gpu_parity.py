@@ -77,10 +77,12 @@ def test_corr_block_vs_oracle(oracle_ops, shape):
     assert rel_l2(f2g.grad, f2c.grad) < 2e-5
 
 
-@pytest.mark.parametrize("levels,radius", [(4, 3), (3, 2), (2, 1), (1, 4)])
+@pytest.mark.parametrize("levels,radius", [(4, 3), (3, 2), (2, 1), (1, 4), (5, 2)])
 def test_corr_block_other_radii_and_levels(oracle_ops, levels, radius):
-    """The kernels are instantiated for radius 1..4 and any level count <= 8 (RAFT-small uses r = 3)."""
-    B, D, H, W = 1, 48, 18, 27
+    """The kernels are instantiated for radius 1..4 and any level count <= 8 (RAFT-small uses r = 3).  Five levels
+    (ADVICE r03): the window-segment records of the sparse backward hold four levels, deeper pyramids take the dense
+    products -- gradients must still match."""
+    B, D, H, W = (1, 48, 18, 27) if levels <= 4 else (1, 48, 36, 56)
     gen = torch.Generator().manual_seed(levels * 10 + radius)
     f1c = torch.randn(B, D, H, W, generator=gen).requires_grad_(True)
     f2c = torch.randn(B, D, H, W, generator=gen).requires_grad_(True)
@@ -673,7 +675,7 @@ def test_pwc_warp_vs_oracle(oracle_ops, shape, scale):
     assert max_abs(got, want) <= 2e-6 * float(x.detach().abs().max())
     got.backward(go.to(DEV))
     assert rel_l2(xg.grad, x.grad) < 2e-5 and rel_l2(fg.grad, flo.grad) < 2e-5
-    # the default backward scatters 2^-40 fixed-point values (integer adds): bit-reproducible from run to run, and equal
+    # the default backward scatters fixed-point values (integer adds): bit-reproducible from run to run, and equal
     # to the fp32-atomics form (pcfa_pwc_warp_bwd) up to the rounding of the addends
     g1x, g1f = xg.grad.clone(), fg.grad.clone()
     for _ in range(2):
@@ -687,6 +689,14 @@ def test_pwc_warp_vs_oracle(oracle_ops, shape, scale):
         assert rel_l2(xg.grad, g1x) < 1e-6 and rel_l2(fg.grad, g1f) < 1e-6
     finally:
         hip_ops.WARP_BWD_DETERMINISTIC = True
+    # the fixed point is scaled per call, so gradients of any absolute size keep fp32's resolution -- the
+    # AEE / npix-scaled gradients of the deep PWC levels (1e-9) and huge ones alike (an absolute 2^-40 unit flushed
+    # addends below 4.5e-13 and overflowed above 8.4e6)
+    for mag in (1e-9, 1e9):
+        xg.grad = fg.grad = None
+        hip_ops.pwc_warp(xg, fg).backward((mag * go).to(DEV))
+        assert rel_l2(xg.grad / mag, x.grad) < 2e-5 and rel_l2(fg.grad / mag, flo.grad) < 2e-5, mag
+        assert rel_l2(xg.grad / mag, g1x) < 1e-6
     # zero flow: the align_corners mismatch of the original code samples at x * W / (W - 1) - 0.5, not at x
     ident = hip_ops.pwc_warp(xg.detach(), torch.zeros_like(fg))
     assert max_abs(ident, oracle_ops.pwc_warp(x.detach(), torch.zeros_like(flo))) <= 2e-6 * float(x.detach().abs().max())
