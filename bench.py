@@ -316,6 +316,11 @@ TRACED = {  # kernel-name fragment -> label
     "conv_s2_fwd_kernel<(anonymous namespace)::S2Cfg<7, 7": "conv_s2_stem_fwd",
     "conv_s2_fwd_kernel<(anonymous namespace)::S2Cfg<3, 3": "conv_s2_block_entry_fwd",
     "conv_s2_bwd_kernel": "conv_s2_block_entry_bwd", "conv_s2_stem_bwd_kernel": "conv_s2_stem_bwd",
+    # the kernels that own the step: family rows from hip_ops' work recorder (family_rows below)
+    "conv3x3_winograd_kernel": "conv3x3_winograd", "conv3x3_f43_kernel": "conv3x3_f43", "f43_finish_kernel": "conv3x3_f43",
+    "sc5_wino_kernel": "sepconv5_winograd", "sepconv5_kernel": "sepconv5_direct",
+    "instnorm_stats_kernel<false>": "instnorm_fwd", "instnorm_apply_kernel<false>": "instnorm_fwd",
+    "instnorm_stats_kernel<true>": "instnorm_bwd", "instnorm_apply_kernel<true>": "instnorm_bwd",
     # the optimiser (pcfa_amd/csrc/lbfgs_gram.hip, lbfgs.hip)
     "gram_pass_kernel": "lbfgs_gram_pass", "gram_direction_kernel": "lbfgs_gram_direction",
     "gram_reduce_kernel": "lbfgs_small", "gram_coeff_kernel": "lbfgs_gram_coeff",
@@ -358,16 +363,130 @@ def graph_replay_kernel_times(st):
         st.step()
         torch.cuda.synchronize()
     acc = {}
+    total = covered = 0.0
+    launches = 0
     for ev in prof.events():
         if ev.device_type != DeviceType.CUDA:
             continue
+        us = ev.time_range.elapsed_us()
+        total += us
+        launches += 1
         for frag, label in TRACED.items():
             if frag in ev.name:
                 a = acc.setdefault(label, [0.0, 0])
-                a[0] += ev.time_range.elapsed_us()
+                a[0] += us
                 a[1] += 1
+                covered += us
                 break
+    graph_replay_kernel_times.coverage = {"device_ms_per_step": total * 1e-3, "launches_per_step": launches,
+                                          "in_kernel_rows_ms": covered * 1e-3, "frac": covered / total if total else None,
+                                          "note": "device time of the traced attack step (10 closure replays + re-prediction "
+                                                  "+ optimiser) that belongs to kernels with a roofline row in `kernels` / "
+                                                  "`kernel_families` / `lbfgs`"}
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items() if v[1]}
+
+
+FAMILY_NOTES = {
+    "conv3x3_winograd": "Winograd F(2x2,3x3): every 3x3 / stride-1 convolution and data gradient that the policy leaves on it; "
+                        "issued = direct-form flop / 2.25",
+    "conv3x3_f43": "Winograd F(4x4,3x3) incl. its split-K finish launches; issued = direct-form flop / 4 "
+                   "(fp32 rounding 2e-6 relative per layer against 3.5e-7 for F(2x2,3x3))",
+    "sepconv5_winograd": "SepConvGRU gate convolutions + fused GRU epilogues as 1-D Winograd F(2,5); issued = direct-form flop x 0.6",
+    "sepconv5_direct": "SepConvGRU gate convolutions, direct implicit GEMM (shapes the Winograd kernel does not take)",
+    "corr_pyramid_gemm_dfmap1": "sparse product over the K segments the lookup windows touched: issued = executed MFMA flop "
+                                "(segments x 128-wide blocks, read back from the kernel's own segment table), direct = the "
+                                "dense product the reference's autograd runs",
+    "corr_pyramid_gemm_df2ext": "as corr_pyramid_gemm_dfmap1 (K = hull of the query rows that reach the block's tile rows)",
+    "instnorm_fwd": "statistics + apply launches together; algorithmic bytes = x in + y out",
+    "instnorm_bwd": "statistics + apply launches together; algorithmic bytes = x + grad_out in + grad_x out",
+}
+
+
+def family_rows(traced, work):
+    """Roofline rows per kernel FAMILY of one attack step: work from hip_ops' recorder (one eagerly launched step: the
+    same launches as a replayed one), device time from the graph-replay trace.  MFMA families report the flop the matrix
+    cores actually issue (direct-form flop / the Winograd saving; executed segments for the windowed pyramid products)
+    against the fp32 matrix peak, next to the direct-form equivalent."""
+    rows = []
+    for fam, (direct, issued, calls) in sorted(work.items()):
+        if fam not in traced:
+            continue
+        us, n = traced[fam]
+        tot_us = us * n
+        if fam.startswith("instnorm"):
+            ach = direct / (tot_us * 1e-6) / 1e9
+            rows.append({"kernel": fam, "bound": "hbm", "calls_per_step": calls, "launches_per_step": n,
+                         "bytes_per_step": direct, "device_us_per_step": round(tot_us, 1), "achieved": round(ach, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "note": FAMILY_NOTES.get(fam)})
+            continue
+        ach = issued / (tot_us * 1e-6) / 1e12
+        rows.append({"kernel": fam, "bound": "mfma", "calls_per_step": calls, "launches_per_step": n,
+                     "direct_gflop_per_step": round(direct * 1e-9, 2), "issued_gflop_per_step": round(issued * 1e-9, 2),
+                     "device_us_per_step": round(tot_us, 1), "mean_launch_us": round(us, 2),
+                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                     "direct_equivalent_tflops": round(direct / (tot_us * 1e-6) / 1e12, 2), "note": FAMILY_NOTES.get(fam)})
+    return rows
+
+
+def calibration(dev):
+    """What THIS box sustains, measured once per bench run (< 50 ms): a register-only fp32-MFMA loop (the matrix roof:
+    no memory, no LDS, pseudo-random operands) and a float4 copy stream (the achievable HBM rate), next to the data-sheet
+    peaks every `frac` in this line is taken against."""
+    from pcfa_amd import _hip
+    lib = _hip.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    scratch = torch.zeros(64, device=dev)
+    n = 1 << 27   # 512 MiB in, 512 MiB out: beyond the 256 MB Infinity Cache
+    src = torch.empty(n, device=dev).normal_()
+    dst = torch.empty_like(src)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    flop = [0]
+
+    def mfma():
+        flop[0] = lib.pcfa_calib_mfma_f32(scratch.data_ptr(), 2048, 1000, stream)
+    t_m = timed(mfma, 3)
+    t_c = timed(lambda: _hip.check(lib.pcfa_calib_copy(src.data_ptr(), dst.data_ptr(), n, stream), "pcfa_calib_copy"), 3)
+    del src, dst
+    tf = flop[0] / t_m / 1e12
+    return {"mfma_f32_tflops": round(tf, 1), "mfma_f32_frac_of_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 3),
+            "mfma_implied_clock_ghz": round(tf * 1e12 / (256 * 256) / 1e9, 3),
+            "copy_GBs": round(2 * 4 * n / t_c / 1e9, 1), "copy_frac_of_peak": round(2 * 4 * n / t_c / 1e9 / HBM_PEAK_GBS, 3),
+            "how": "pcfa_calib_mfma_f32: 2048 workgroups x 4 waves x 1000 x 4 independent v_mfma_f32_32x32x2_f32 from registers "
+                   "(8 waves per SIMD resident), %.2f ms per launch; pcfa_calib_copy: float4 grid-stride copy of 512 MiB, "
+                   "%.2f ms per launch; event brackets around 3 launches after one warm-up" % (t_m * 1e3, t_c * 1e3),
+            "peaks_used": {"mfma_f32_tflops": MFMA_F32_PEAK_TFLOPS, "hbm_GBs": HBM_PEAK_GBS}}
+
+
+def schedule_parity_record():
+    """The committed end-of-attack parity matrix (tools/parity_matrix.py -> profiles/r04_schedule_parity_matrix.json):
+    pairs inside the tolerance per config, for the reader of the bench line (bench.py times synthetic pair `rank`)."""
+    path = os.path.join(REPO, "profiles", "r04_schedule_parity_matrix.json")
+    try:
+        m = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    rec = {"file": "profiles/r04_schedule_parity_matrix.json", "rule": m.get("rule")}
+    for cfg in m.get("configs", []):
+        key = "%s_%dsteps" % (cfg["net"].lower(), cfg["steps"])
+        rec[key] = {"pairs_ok": cfg["pairs_ok"], "pairs_total": cfg["pairs_total"],
+                    "pairs_ok_per_metric": cfg.get("pairs_ok_per_metric"),
+                    "bench_pair_0_inside": next((r.get("inside_all") for r in cfg["pairs"] if r["pair"] == 0), None)}
+        if cfg["net"] == "RAFT" and cfg["steps"] == 20:
+            rec["pairs_ok"], rec["pairs_total"] = cfg["pairs_ok"], cfg["pairs_total"]
+    return rec
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -631,6 +750,7 @@ def main():
         except Exception as e:  # the tracer is an extra: fall back to the eager hipEvent figures
             print("graph-replay kernel trace unavailable: %r" % (e,), file=sys.stderr)
     lbfgs_history = st.optimizer.history_count() if hasattr(st.optimizer, "history_count") else None
+    work = None
     if use_graph and corr_net:
         # dispatch-attached events cannot ride inside a captured graph: time the kernels on the same data in one
         # extra, eagerly launched step right after the timed region -- with the lookup -> convc1 fusion switched OFF,
@@ -639,8 +759,11 @@ def main():
         from pcfa_amd.nets import raft as raft_net
         raft_net.FUSED_LOOKUP = False
         hip_ops.set_dispatch_timer(prof)
+        work = {}
+        hip_ops.set_work_recorder(work)     # flop / bytes per kernel family of this step (family_rows)
         st.step()
         torch.cuda.synchronize()
+        hip_ops.set_work_recorder(None)
         hip_ops.set_dispatch_timer(None)
         raft_net.FUSED_LOOKUP = True
 
@@ -710,6 +833,9 @@ def main():
             how_eager = ("hipEvents on the dispatch packet (hipExtLaunchKernel), every launch of one eagerly launched "
                          "step with the lookup -> convc1 fusion switched off")
             out["kernels"] = kernel_table(traced if traced else timings, hf, wf, hp, wp)
+            if traced and work:
+                out["kernel_families"] = family_rows(traced, work)
+                out["kernel_rows_cover"] = getattr(graph_replay_kernel_times, "coverage", None)
             unfused = {"kernel": "corr_lookup_fwd_kernel<4> (un-fused lookup, models/raft/corr.py:29-50)", "bound": "hbm",
                        "bytes_per_launch": nbytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "traffic": lookup_traffic("corr_lookup_fwd"), "event_bracket_overhead_us": event_overhead_us()}
@@ -757,6 +883,14 @@ def main():
                                    "frac": r0["frac"], "traffic": None, "bytes_per_launch": r0["per_launch"],
                                    "mean_launch_us": r0["mean_launch_us"], "launches_timed": r0["launches_timed"],
                                    "timing": "dispatch timestamps inside the hipGraph replays (HIP activity tracer)"}
+        if world == 1:
+            try:
+                out["calibration"] = calibration(dev)
+            except Exception as e:  # noqa: BLE001 -- informational
+                out["calibration"] = {"error": repr(e)}
+        sp = schedule_parity_record()
+        if sp is not None:
+            out["schedule_parity"] = sp
         if world == 1 and use_graph and not a.no_shared_forward_leg:
             out["shared_forward_schedule"] = shared_forward_leg(a.net, h, w, dev, a.warmup, a.steps, sharding, st.model)
         if world == 1 and not a.no_cpu_baseline:

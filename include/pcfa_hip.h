@@ -62,6 +62,12 @@ PCFA_API int pcfa_timing_arm(void* start_event, void* stop_event, int nth);
 /* Launches an empty kernel on `stream`: lets a caller calibrate the fixed cost of bracketing one launch with
  * HIP events (bench.py reports it next to the per-launch timings). */
 PCFA_API int pcfa_null_launch(void* stream);
+/* Calibration of the two roofs on the box the benchmark runs on (bench.py `calibration`; nothing in the attack path
+ * calls them).  pcfa_calib_mfma_f32: `blocks` workgroups of four waves each issue `iters` x 4 independent
+ * v_mfma_f32_32x32x2_f32 from registers (no memory, no LDS); returns the flop issued (< 0 on error) -- divide by the
+ * launch's duration.  pcfa_calib_copy: dst = src as a float4 grid-stride stream (2 x 4 x n_floats bytes of traffic). */
+PCFA_API long long pcfa_calib_mfma_f32(float* scratch, int blocks, int iters, void* stream);
+PCFA_API int pcfa_calib_copy(const float* src, float* dst, long long n_floats, void* stream);
 /* Human-readable text for a return code (static storage). */
 PCFA_API const char* pcfa_status_string(int status);
 
@@ -373,6 +379,8 @@ PCFA_API long long pcfa_sepconv5_packed_floats(int Cout, int Cin);
  * query only.  Returns the previous setting.  Eligible: Cin % 32 == 0 (% 64 for narrow grids), Cout % 32 == 0,
  * W % 128 == 0 (1x5) / W % 64 == 0 (5x1), 16-B aligned tensors. */
 PCFA_API int pcfa_sepconv5_algo(int use_winograd);
+/* 1 when a launch of this shape takes the Winograd kernel under the current setting (aligned tensors assumed). */
+PCFA_API int pcfa_sepconv5_uses_winograd(int B, int Ca, int Cb, int Cout, int H, int W, int vertical);
 PCFA_API int pcfa_sepconv5_pack_weights(const float* w, float* fwd_packed, float* bwd_packed, int Cout, int Cin,
                                void* stream);
 PCFA_API int pcfa_sepconv5_fwd(const float* in_a, int Ca, const float* in_b, int Cb, const float* w_packed,

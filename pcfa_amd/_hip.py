@@ -27,6 +27,8 @@ SIGNATURES = {
     "pcfa_abi_version": (c_int, []),
     "pcfa_timing_arm": (c_int, [_P, _P, c_int]),
     "pcfa_null_launch": (c_int, [_P]),
+    "pcfa_calib_mfma_f32": (c_longlong, [_P, c_int, c_int, _P]),
+    "pcfa_calib_copy": (c_int, [_P, _P, c_longlong, _P]),
     "pcfa_status_string": (c_char_p, [c_int]),
     "pcfa_corr_slab_floats": (c_longlong, [c_int, c_int, c_int]),
     "pcfa_corr_level_offset": (c_longlong, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
@@ -80,6 +82,7 @@ SIGNATURES = {
     "pcfa_gru_update_bwd": (c_int, [_P] * 7 + [c_longlong, _P]),
     "pcfa_sepconv5_packed_floats": (c_longlong, [c_int, c_int]),
     "pcfa_sepconv5_algo": (c_int, [c_int]),
+    "pcfa_sepconv5_uses_winograd": (c_int, [c_int] * 7),
     "pcfa_sepconv5_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "pcfa_sepconv5_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_sepconv5_fwd_split": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int,

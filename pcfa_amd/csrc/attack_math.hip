@@ -330,6 +330,54 @@ extern "C" int pcfa_timing_arm(void* start_event, void* stop_event, int nth) {
   return PCFA_OK;
 }
 
+// ---- calibration kernels (bench.py `calibration`): what the chip sustains on THIS box, next to the data-sheet peaks --------
+namespace {
+typedef float calib_f32x16 __attribute__((ext_vector_type(16)));
+
+// Register-only v_mfma_f32_32x32x2_f32 loop: four independent accumulators per wave, operands from registers, pseudo-random
+// data (the matrix pipe's clock depends on what it multiplies).  4096 flop per MFMA.
+__global__ __launch_bounds__(256) void calib_mfma_f32_kernel(float* __restrict__ out, int iters) {
+  const unsigned seed = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+  float a0 = (float)(seed & 0xffff) * (1.0f / 65536.f) - 0.5f, b0 = (float)((seed >> 16) & 0xffff) * (1.0f / 65536.f) - 0.5f;
+  float a1 = b0 * 0.75f + 0.1f, b1 = a0 * 0.5f - 0.2f;
+  calib_f32x16 c0, c1, c2, c3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c0[r] = c1[r] = c2[r] = c3[r] = 0.f;
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c3, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+  if (s == 123456.789f) out[0] = s;   // keeps the loop alive; never true in practice
+}
+
+__global__ __launch_bounds__(256) void calib_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" long long pcfa_calib_mfma_f32(float* scratch, int blocks, int iters, void* stream) {
+  if (!scratch || blocks < 1 || iters < 1) return -1;
+  pcfa_launch(calib_mfma_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
+  if (hipGetLastError() != hipSuccess) return -1;
+  return (long long)blocks * 4 * iters * 4 * 4096;   // waves x iterations x MFMAs x flop
+}
+
+extern "C" int pcfa_calib_copy(const float* src, float* dst, long long n_floats, void* stream) {
+  if (!src || !dst || n_floats < 4 || n_floats % 4 != 0 || (reinterpret_cast<uintptr_t>(src) & 15) ||
+      (reinterpret_cast<uintptr_t>(dst) & 15))
+    return PCFA_ERR_INVALID_ARG;
+  pcfa_launch(calib_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst,
+              n_floats / 4);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
 extern "C" int pcfa_null_launch(void* stream) {
   pcfa_launch(null_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
   PCFA_LAUNCH_CHECK();

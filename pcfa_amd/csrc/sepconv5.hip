@@ -450,6 +450,10 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 extern "C" int pcfa_sepconv5_algo(int use_winograd) { return sc5_wino_enabled(use_winograd); }
 
+extern "C" int pcfa_sepconv5_uses_winograd(int B, int Ca, int Cb, int Cout, int H, int W, int vertical) {
+  return sc5_wino_shape_ok(B, Ca + Cb, Ca, Cout, H, W, vertical) ? 1 : 0;
+}
+
 extern "C" long long pcfa_sepconv5_packed_floats(int Cout, int Cin) {
   if (Cout < 1 || Cin < 1) return 0;
   return (long long)Cout * Cin * TAPS + sc5_wino_packed_floats(Cout, Cin);

@@ -55,6 +55,7 @@ struct GruEpi {
 // not eligible), and the launcher: returns PCFA_OK after launching, PCFA_SC5_NOT_ELIGIBLE when the direct kernel must run.
 constexpr int PCFA_SC5_NOT_ELIGIBLE = -12345;
 int sc5_wino_enabled(int set);
+bool sc5_wino_shape_ok(int B, int Cin, int Ca, int Cout, int H, int W, int vertical);
 long long sc5_wino_packed_floats(int Cout, int Cin);
 int sc5_wino_pack(const float* w, float* packed, int Cout, int Cin, int transpose, hipStream_t stream);
 int sc5_wino_launch(const Operand& in, const float* w_wino, const OutSplit& out, int B, int Cout, int H, int W,

@@ -422,20 +422,29 @@ int sc5_wino_pack(const float* w, float* packed, int N, int C, int transpose, hi
   return PCFA_OK;
 }
 
+// tile shape by output width: 64 channels x 2 K-groups, or 32 channels x 4 K-groups when the grid would not fill the chip
+static bool wino_wide(int B, int Cout, int H, int W, int vertical) {
+  const long long tiles = (long long)(vertical ? (W / VPX) * ((H + 1) / 2) : (W / HPX) * H) * B;
+  return Cout % 64 == 0 && tiles * (Cout / 64) >= 200;
+}
+
+// the shape part of the eligibility rule (pointer alignment and the output split are checked per launch)
+bool sc5_wino_shape_ok(int B, int Cin, int Ca, int Cout, int H, int W, int vertical) {
+  if (!sc5_wino_enabled(-1) || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return false;
+  const int ks = wino_wide(B, Cout, H, W, vertical) ? 2 : 4;
+  if (Cout % 32 != 0 || Cin % (2 * CK * ks) != 0 || Ca % CK != 0) return false;
+  if (W % (vertical ? VPX : HPX) != 0 || B > 65535) return false;
+  return (long long)H * W <= (1LL << 30);   // 32-bit offsets inside a channel plane
+}
+
 int sc5_wino_launch(const Operand& in, const float* w_wino, const OutSplit& out, int B, int Cout, int H, int W, int vertical,
                     hipStream_t stream, const GruEpi& epi) {
-  if (!sc5_wino_enabled(-1) || !w_wino) return PCFA_SC5_NOT_ELIGIBLE;
-  // tile shape by output width: 64 channels x 2 K-groups, or 32 channels x 4 K-groups when the grid would not fill the chip
-  const long long tiles = (long long)(vertical ? (W / VPX) * ((H + 1) / 2) : (W / HPX) * H) * B;
-  const bool wide = Cout % 64 == 0 && tiles * (Cout / 64) >= 200;
-  const int ks = wide ? 2 : 4;
-  if (Cout % 32 != 0 || in.Cin % (2 * CK * ks) != 0 || in.Ca % CK != 0) return PCFA_SC5_NOT_ELIGIBLE;
-  if (W % (vertical ? VPX : HPX) != 0 || H < 1 || B > 65535) return PCFA_SC5_NOT_ELIGIBLE;
+  if (!w_wino || !sc5_wino_shape_ok(B, in.Cin, in.Ca, Cout, H, W, vertical)) return PCFA_SC5_NOT_ELIGIBLE;
+  const bool wide = wino_wide(B, Cout, H, W, vertical);
   if (!wino_aligned16(in.a) || (in.b && !wino_aligned16(in.b)) || !wino_aligned16(out.a) || (out.b && !wino_aligned16(out.b)))
     return PCFA_SC5_NOT_ELIGIBLE;
   if (out.b != nullptr && out.Ca % 32 != 0) return PCFA_SC5_NOT_ELIGIBLE;
   if (epi.mode != 0 && (epi.C % 32 != 0)) return PCFA_SC5_NOT_ELIGIBLE;
-  if ((long long)H * W > (1LL << 30)) return PCFA_SC5_NOT_ELIGIBLE;   // 32-bit offsets inside a channel plane
 #define PCFA_WINO(V, M) return wino_pick<V, M>(wide, in, w_wino, out, B, Cout, H, W, stream, epi)
   if (vertical) {
     switch (epi.mode) {

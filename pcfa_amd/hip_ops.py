@@ -176,9 +176,64 @@ def set_dispatch_timer(timer):
     _dispatch_timer = timer
 
 
+# ---- work accounting for the roofline rows of bench.py (off unless a recorder is set) -----------------------------------
+# family -> [direct-form flop (or algorithmic bytes), flop the matrix cores actually issue, calls]; the arithmetic of a
+# Winograd kernel is its direct-form flop divided by the transform's saving: F(2x2,3x3) 36 / 16, F(4x4,3x3) 144 / 36,
+# F(2,5) 10 / 6.
+_work = None
+
+
+def set_work_recorder(rec):
+    """rec: a dict that _call fills per kernel family while set (None: off)."""
+    global _work
+    _work = rec
+
+
+def _note_work(family, direct, issued):
+    e = _work.setdefault(family, [0.0, 0.0, 0])
+    e[0] += direct
+    e[1] += issued
+    e[2] += 1
+
+
+def _conv3x3_work(B, K, N, H, W):
+    direct = 2.0 * 9 * K * N * B * H * W
+    if _hip.load().pcfa_conv3x3_algo(B, K, N, H, W) == 43:
+        _note_work("conv3x3_f43", direct, direct / 4.0)
+    else:
+        _note_work("conv3x3_winograd", direct, direct / 2.25)
+
+
+def _sepconv5_work(B, Ca, Cb, Cout, H, W, vertical):
+    direct = 2.0 * 5 * (Ca + Cb) * Cout * B * H * W
+    if _hip.load().pcfa_sepconv5_uses_winograd(B, Ca, Cb, Cout, H, W, int(vertical)):
+        _note_work("sepconv5_winograd", direct, direct * 0.6)
+    else:
+        _note_work("sepconv5_direct", direct, direct)
+
+
+_WORK_TABLE = {   # entry point -> accounting of its positional arguments (the order of include/pcfa_hip.h)
+    "pcfa_conv3x3_run": lambda a: _conv3x3_work(a[6], a[7], a[8], a[9], a[10]),
+    "pcfa_conv3x3_act_fwd_pair": lambda a: (_conv3x3_work(1, a[4], a[5], a[12], a[13]),
+                                            _conv3x3_work(1, a[10], a[11], a[12], a[13])),
+    "pcfa_sepconv5_fwd": lambda a: _sepconv5_work(a[6], a[1], a[3], a[7], a[8], a[9], a[10]),
+    "pcfa_sepconv5_fwd_split": lambda a: _sepconv5_work(a[10], a[1], a[3], a[11], a[12], a[13], a[14]),
+    "pcfa_sepconv5_fwd_split_masked": lambda a: _sepconv5_work(a[12], a[1], a[3], a[13], a[14], a[15], a[16]),
+    "pcfa_sepconv5_gru_gates_fwd": lambda a: _sepconv5_work(a[9], a[1], a[3], 2 * a[1], a[10], a[11], a[12]),
+    "pcfa_sepconv5_gru_update_fwd": lambda a: _sepconv5_work(a[10], a[1], a[3], a[1], a[11], a[12], a[13]),
+    "pcfa_sepconv5_gru_gates_bwd": lambda a: _sepconv5_work(a[13], a[1], 0, a[1] + a[2], a[14], a[15], a[16]),
+    "pcfa_sepconv5_gru_update_bwd": lambda a: _sepconv5_work(a[12], 2 * a[1], 0, a[1] + a[2], a[13], a[14], a[15]),
+    # instance norm: algorithmic traffic = x in + y out (forward), x + grad_out in + grad_x out (backward)
+    "pcfa_instnorm_fwd": lambda a: _note_work("instnorm_fwd", 2.0 * a[4] * a[5] * 4, 0.0),
+    "pcfa_instnorm_bwd": lambda a: _note_work("instnorm_bwd", 3.0 * a[5] * a[6] * 4, 0.0),
+}
+
+
 def _call(name, *args):
     """Invoke C-ABI entry point `name` on torch's current stream and raise on a non-zero status."""
     fn = getattr(_hip.load(), name)
+    if _work is not None and name in _WORK_TABLE:
+        _WORK_TABLE[name](args)
     prof = _profiler
     timer = _dispatch_timer
     if timer is not None and name in timer.plan:
@@ -257,6 +312,18 @@ class _CorrBuild(torch.autograd.Function):
             ptrs = (ctypes.c_void_p * len(cs))(*[c.data_ptr() for c in cs])
             _call("pcfa_corr_pyramid_bwd_windows", _ptr(st.dpyr), _ptr(f1), _ptr(st.f2ext), _ptr(df1), _ptr(df2), _ptr(ws),
                   ctypes.c_size_t(nbytes), ptrs, len(cs), st.r, B, D, H, W, st.L)
+            if _work is not None:
+                # executed matrix work of the two sparse products: the K segments the kernels walked, read back from the
+                # workspace (csrc/corr_pyramid.hip: per 128-wide column block {count, (begin, end) x 4, pad} ints behind
+                # the split-K area; segA = blocks of dfmap1's Q columns, segB = blocks of df2ext's slab columns)
+                base = (int(lib.pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, st.L)) + 15) & ~15
+                nbA, nbB = -(-(H * W) // 128), -(-st.slab // 128)
+                seg = ws.view(torch.int32)[base // 4: base // 4 + 10 * B * (nbA + nbB)].cpu().view(-1, 10).long()
+                live = torch.arange(4)[None, :] < seg[:, :1]
+                k = ((seg[:, 2:9:2] - seg[:, 1:8:2]) * live).sum(1)
+                dense = 2.0 * B * D * (H * W) ** 2
+                _note_work("corr_pyramid_gemm_dfmap1", dense, 2.0 * D * 128 * float(k[:B * nbA].sum()))
+                _note_work("corr_pyramid_gemm_df2ext", dense, 2.0 * D * 128 * float(k[B * nbA:].sum()))
         else:   # the dense products under their own entry point (and their own launch indices in DispatchTimer's plan)
             nbytes = lib.pcfa_corr_pyramid_bwd_workspace_bytes(B, D, H, W, st.L)
             ws = torch.empty((nbytes + 3) // 4, device=f1.device, dtype=torch.float32)
