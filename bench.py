@@ -321,6 +321,9 @@ TRACED = {  # kernel-name fragment -> label
     "sc5_wino_kernel": "sepconv5_winograd", "sepconv5_kernel": "sepconv5_direct",
     "instnorm_stats_kernel<false>": "instnorm_fwd", "instnorm_apply_kernel<false>": "instnorm_fwd",
     "instnorm_stats_kernel<true>": "instnorm_bwd", "instnorm_apply_kernel<true>": "instnorm_bwd",
+    "conv3x3_fewout_fwd": "conv3x3_fewout_fwd", "conv3x3_fewout_bwd_kernel": "conv3x3_fewout_bwd",
+    "leaky_relu_bwd_kernel": "leaky_relu_bwd", "relu_bwd2_kernel": "relu_bwd2", "relu_bwd_kernel": "relu_bwd",
+    "add_relu_kernel": "add_relu_fwd", "conv_fewin_packed_fwd_kernel": "conv_fewin_fwd",
     # the optimiser (pcfa_amd/csrc/lbfgs_gram.hip, lbfgs.hip)
     "gram_pass_kernel": "lbfgs_gram_pass", "gram_direction_kernel": "lbfgs_gram_direction",
     "gram_reduce_kernel": "lbfgs_small", "gram_coeff_kernel": "lbfgs_gram_coeff",
@@ -399,6 +402,9 @@ FAMILY_NOTES = {
     "corr_pyramid_gemm_df2ext": "as corr_pyramid_gemm_dfmap1 (K = hull of the query rows that reach the block's tile rows)",
     "instnorm_fwd": "statistics + apply launches together; algorithmic bytes = x in + y out",
     "instnorm_bwd": "statistics + apply launches together; algorithmic bytes = x + grad_out in + grad_x out",
+    "conv3x3_fewout_fwd": "flow-prediction convolutions (2 output channels): the input once + the output",
+    "conv3x3_fewout_bwd": "their data gradient: grad_out + the streamed grad_x",
+    "conv_fewin_fwd": "relu(convf1(flow)): 7x7 on two input channels as an im2col-in-LDS MFMA GEMM (3.6 MB out: launch-bound)",
 }
 
 
@@ -413,7 +419,7 @@ def family_rows(traced, work):
             continue
         us, n = traced[fam]
         tot_us = us * n
-        if fam.startswith("instnorm"):
+        if issued == 0.0:   # a stream: `direct` holds its algorithmic bytes
             ach = direct / (tot_us * 1e-6) / 1e9
             rows.append({"kernel": fam, "bound": "hbm", "calls_per_step": calls, "launches_per_step": n,
                          "bytes_per_step": direct, "device_us_per_step": round(tot_us, 1), "achieved": round(ach, 1),

@@ -357,7 +357,15 @@ __global__ __launch_bounds__(256) void calib_mfma_f32_kernel(float* __restrict__
 
 __global__ __launch_bounds__(256) void calib_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
   const long long step = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) dst[i] = src[i];
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * step < n4; i += 4 * step) {   // four 16-B loads in flight per lane
+    const float4 a = src[i], b = src[i + step], c = src[i + 2 * step], d = src[i + 3 * step];
+    dst[i] = a;
+    dst[i + step] = b;
+    dst[i + 2 * step] = c;
+    dst[i + 3 * step] = d;
+  }
+  for (; i < n4; i += step) dst[i] = src[i];
 }
 }  // namespace
 
@@ -372,7 +380,7 @@ extern "C" int pcfa_calib_copy(const float* src, float* dst, long long n_floats,
   if (!src || !dst || n_floats < 4 || n_floats % 4 != 0 || (reinterpret_cast<uintptr_t>(src) & 15) ||
       (reinterpret_cast<uintptr_t>(dst) & 15))
     return PCFA_ERR_INVALID_ARG;
-  pcfa_launch(calib_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst,
+  pcfa_launch(calib_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst,
               n_floats / 4);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
