@@ -195,6 +195,22 @@ def event_overhead_us(reps=200):
     return prof.summary()["pcfa_null_launch"][0]
 
 
+def null_launch_device_us(reps=50):
+    """Device-side duration of a kernel that does nothing (dispatch timestamps of the HIP activity tracer): the floor under
+    every launch of a dependent chain."""
+    from torch.autograd import DeviceType
+    from torch.profiler import ProfilerActivity, profile
+    from pcfa_amd import hip_ops
+    hip_ops._call("pcfa_null_launch")
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(reps):
+            hip_ops._call("pcfa_null_launch")
+        torch.cuda.synchronize()
+    d = [ev.time_range.elapsed_us() for ev in prof.events() if ev.device_type == DeviceType.CUDA and "null_kernel" in ev.name]
+    return sum(d) / len(d) if d else None
+
+
 def lookup_traffic(kernel="corr_lookup_fwd"):
     """HBM bytes per launch of the lookup kernel from rocprofv3 PMC counters (collected offline by
     tools/pmc_traffic.sh with the guide's gfx950 corrections, committed under profiles/); None if absent."""
@@ -290,6 +306,23 @@ def pwc_kernel_table(timings, hp, wp):
         us, n = timings["spatial_corr_bwd"]
         rows.append(_row("spatial_corr_bwd (5 levels, both gradients per launch)", "hbm", bwd, us * 5, n // 5,
                          "per closure: 5 launches summed"))
+    # per level: the forward runs levels 6, 5, 4, 3, 2 in this order in every forward pass, the backward
+    # 2, 3, 4, 5, 6 -- the position of a launch in the traced sequence names its level
+    seqs = getattr(graph_replay_kernel_times, "sequences", {})
+    null_us = getattr(pwc_kernel_table, "null_launch_us", None)
+    for label, order, per_px in (("spatial_corr_fwd", (6, 5, 4, 3, 2), lambda c: (2 * c + 81) * 4),
+                                 ("spatial_corr_bwd", (2, 3, 4, 5, 6), lambda c: (81 + 4 * c) * 4)):
+        seq = seqs.get(label, [])
+        if len(seq) % 5 or not seq:
+            continue
+        for pos, lvl in enumerate(order):
+            d = seq[pos::5]
+            us = sum(d) / len(d)
+            nbytes = per_px(PWC_LEVEL_CHANNELS[lvl]) * (hp >> lvl) * (wp >> lvl)
+            note = "level %d: %d x %d pixels, %d channels" % (lvl, hp >> lvl, wp >> lvl, PWC_LEVEL_CHANNELS[lvl])
+            if null_us is not None and us < 2.5 * null_us:
+                note += "; floor-bound: a launch that does nothing takes %.1f us here" % null_us
+            rows.append(_row("%s level %d" % (label, lvl), "hbm", nbytes, us, len(d), note))
     if "pwc_warp_fwd" in timings:
         us, n = timings["pwc_warp_fwd"]
         w = sum((2 * PWC_LEVEL_CHANNELS[l] + 2) * (hp >> l) * (wp >> l) * 4 for l in (2, 3, 4, 5))
@@ -365,12 +398,11 @@ def graph_replay_kernel_times(st):
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
         st.step()
         torch.cuda.synchronize()
-    acc = {}
+    acc, seqs = {}, {}
     total = covered = 0.0
     launches = 0
-    for ev in prof.events():
-        if ev.device_type != DeviceType.CUDA:
-            continue
+    evs = sorted((ev for ev in prof.events() if ev.device_type == DeviceType.CUDA), key=lambda e: e.time_range.start)
+    for ev in evs:
         us = ev.time_range.elapsed_us()
         total += us
         launches += 1
@@ -380,7 +412,10 @@ def graph_replay_kernel_times(st):
                 a[0] += us
                 a[1] += 1
                 covered += us
+                if label in ("spatial_corr_fwd", "spatial_corr_bwd"):
+                    seqs.setdefault(label, []).append(us)   # launch order: per-level rows (pwc_kernel_table)
                 break
+    graph_replay_kernel_times.sequences = seqs
     graph_replay_kernel_times.coverage = {"device_ms_per_step": total * 1e-3, "launches_per_step": launches,
                                           "in_kernel_rows_ms": covered * 1e-3, "frac": covered / total if total else None,
                                           "note": "device time of the traced attack step (10 closure replays + re-prediction "
@@ -622,6 +657,10 @@ def pwcnet_leg(a, dev, sharding):
     if os.environ.get("PCFA_BENCH_NO_TRACER", "0") != "1" and st.graphed is not None:
         try:
             traced = graph_replay_kernel_times(st)
+            pwc_seq = getattr(graph_replay_kernel_times, "sequences", {})
+            pwc_kernel_table.null_launch_us = null_launch_device_us()
+            graph_replay_kernel_times.sequences = pwc_seq
+            rec["null_launch_device_us"] = pwc_kernel_table.null_launch_us
             rec["kernels"] = pwc_kernel_table(traced, st.image1.shape[-2], st.image1.shape[-1])
         except Exception as e:  # noqa: BLE001
             rec["kernels_error"] = repr(e)

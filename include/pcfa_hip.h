@@ -469,7 +469,7 @@ PCFA_API int pcfa_conv3x3_fused_bwd(const float* g, const float* packed_bwd, con
 PCFA_API int pcfa_conv3x3_masked_fwd(const float* x, const float* packed, const float* mask, float* out, int B, int K,
                             int N, int H, int W, void* stream);
 /* The general form of all of the above, with a choice of transform (pcfa_amd/csrc/conv3x3_f43.hip):
- *   out = act(bias + conv(x))  [zeroed where mask <= 0]  [+ addend]         (bias, mask, addend optional)
+ *   out = act(bias + conv(x))  [x slope where mask <= 0]  [+ addend]        (bias, mask, addend optional)
  * `packed` holds both transforms of the weights (pcfa_conv3x3_pack_weights: [F(2x2,3x3) | F(4x4,3x3)]).  Shapes where
  * it was measured faster (pcfa_conv3x3_algo: W % 4 == 0, 16-B aligned tensors, maps of >= 100k pixels, or >= 24 x 64
  * pixels with K * N >= 192 * 256) run as Winograd F(4x4,3x3) -- 36 products per 16 outputs, 1.78x fewer matrix
@@ -480,9 +480,15 @@ PCFA_API int pcfa_conv3x3_masked_fwd(const float* x, const float* packed, const 
  * adds them in index order: deterministic, no atomics. */
 PCFA_API int pcfa_conv3x3_algo(int B, int K, int N, int H, int W);   /* 23 or 43: the transform pcfa_conv3x3_run picks */
 PCFA_API size_t pcfa_conv3x3_workspace_bytes(int B, int K, int N, int H, int W);
+/* mask (act = 0 only; same shape as out) is the OUTPUT of the (Leaky)ReLU layer that produced the tensor this data
+ * gradient belongs to: the result is multiplied by 1 where mask > 0 and by `slope` elsewhere (0: ReLU, an exact zero) --
+ * that layer's activation backward, deferred into this epilogue.  mask_channels = 0: every channel, BEFORE the addend;
+ * mask_channels = m > 0: channels [0, m) only, AFTER the addend (PWC-Net's dense decoder blocks, PWCNet.py:234-323: the
+ * gradient of a block layer's output is complete once its last consumer -- the next layer's data gradient, which adds
+ * into the running gradient of the block buffer -- has run). */
 PCFA_API int pcfa_conv3x3_run(const float* x, const float* packed, const float* bias, const float* mask,
                      const float* addend, float* out, int B, int K, int N, int H, int W, int act, float slope,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     int mask_channels, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out = relu(x + bias[c]) and its backward gx = grad_out * (out > 0): the "conv -> +bias -> ReLU" tail of the
  * motion encoder / flow head convolutions (models/raft/update.py:12-16,91-101) in one pass. */

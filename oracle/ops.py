@@ -479,9 +479,12 @@ def sepconv5(a, b, weight):
     return F.conv2d(x, weight, None, padding=(weight.shape[2] // 2, weight.shape[3] // 2))
 
 
-def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None, skip=False, grad_premasked=False, mask_input_grad=False):
+def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None, skip=False, grad_premasked=False, mask_input_grad=False,
+            input_slope=0.):
     """3x3 / stride 1 / pad 1 convolution (+ bias, + ReLU or LeakyReLU): models/raft/update.py:6-16,79-101,
-    models/PWCNet/PWCNet.py:29-35.  skip: also return x (the product sums the residual path's gradient in a kernel)."""
+    models/PWCNet/PWCNet.py:29-35.  skip: also return x (the product sums the residual path's gradient in a kernel).
+    grad_premasked / mask_input_grad / input_slope: scheduling hints of the product (which kernel applies an
+    activation's backward); they change no value."""
     y = F.conv2d(x, weight, bias, stride=1, padding=1)
     if leaky_slope is not None:
         y = F.leaky_relu(y, leaky_slope)
@@ -514,7 +517,7 @@ def conv_s2_supported(x, weight):
     return kh == kw and ((Cin, kh) == (3, 7) or kh == 3) and x.shape[3] % 4 == 0
 
 
-def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None):
+def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None, grad_premasked=False):
     """models/raft/extractor.py:118 (stem) and :23-58 (first convolution of a stride-2 residual block):
     conv2d(x, w, b, stride=2, padding=k//2) followed by the activation the caller fuses."""
     y = F.conv2d(x, weight, bias, stride=2, padding=weight.shape[-1] // 2)

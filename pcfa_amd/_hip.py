@@ -107,7 +107,7 @@ SIGNATURES = {
     "pcfa_conv3x3_masked_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_conv3x3_algo": (c_int, [c_int] * 5),
     "pcfa_conv3x3_workspace_bytes": (c_size_t, [c_int] * 5),
-    "pcfa_conv3x3_run": (c_int, [_P] * 6 + [c_int] * 6 + [c_float, _P, c_size_t, _P]),
+    "pcfa_conv3x3_run": (c_int, [_P] * 6 + [c_int] * 6 + [c_float, c_int, _P, c_size_t, _P]),
     "pcfa_conv3x3_packed_floats": (c_longlong, [c_int, c_int]),
     "pcfa_conv3x3_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "pcfa_conv3x3_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

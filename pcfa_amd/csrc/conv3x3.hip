@@ -108,7 +108,8 @@ struct Second {
   const float* bias;
   float* out;
   int K, N, nb0;
-};
+  int mask_n;   // epilogue mask mode of the FIRST problem: 0 = every channel, before the addend; > 0 = channels < mask_n only,
+};              // AFTER the addend (the dense-block backward: the producer's LeakyReLU backward once its gradient is complete)
 
 // KS = 2: in-workgroup split-K for launches of at most one workgroup per CU (e.g. conv 256 -> 126 at 55x128: 224
 // workgroups, one wave per SIMD, 37 us for 17 us of MFMA work).  Two groups of four waves run the same pipeline on
@@ -156,6 +157,8 @@ __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(K
     mask = nullptr;
     addend = nullptr;
   }
+  const int mask_n = second.mask_n;
+  const float mslope = ACT == 0 ? slope : 0.f;   // data gradients run without an activation: `slope` is the mask's
   const int n0 = nby * CBT;
   if (n0 >= N) return;  // (the packing pads N to 64: a 32-channel block may lie entirely in the padding)
   const long long plane = (long long)H * W;
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(K
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int n = n0 + pass * 16 + e_cl + 8 * q;
-        if (n < N && oy < H && ox < W) {
+        if (n < N && (mask_n == 0 || n < mask_n) && oy < H && ox < W) {
           const float* mp = mask + (long long)n * plane + (long long)oy * W + ox;
           mk[q][0] = mp[0];
           if (ox + 1 < W) mk[q][1] = mp[1];
@@ -411,14 +414,17 @@ __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(K
       }
       if (n < N && oy < H && ox < W && worker) {
         const long long oo = (long long)n * plane + (long long)oy * W + ox;
-        if (mask != nullptr) {   // data gradient w.r.t. a ReLU output: the deferred ReLU backward of the producer
-          y00 = mk[q][0] > 0.f ? y00 : 0.f;
-          y01 = mk[q][1] > 0.f ? y01 : 0.f;
-          y10 = mk[q][2] > 0.f ? y10 : 0.f;
-          y11 = mk[q][3] > 0.f ? y11 : 0.f;
+        // data gradient w.r.t. a (Leaky)ReLU output: the deferred activation backward of the producer, factor 1 where its
+        // output is positive, else the producer's slope (0: ReLU, written as an exact zero)
+        auto masked = [&](float v, float m) { return m > 0.f ? v : (mslope == 0.f ? 0.f : v * mslope); };
+        if (mask != nullptr && mask_n == 0) {
+          y00 = masked(y00, mk[q][0]); y01 = masked(y01, mk[q][1]); y10 = masked(y10, mk[q][2]); y11 = masked(y11, mk[q][3]);
         }
         if (addend != nullptr) {   // the other consumer's gradient of the same tensor, summed here instead of by autograd
           y00 += ad[q][0]; y01 += ad[q][1]; y10 += ad[q][2]; y11 += ad[q][3];
+        }
+        if (mask != nullptr && mask_n > 0 && n < mask_n) {   // the gradient is complete only with the addend
+          y00 = masked(y00, mk[q][0]); y01 = masked(y01, mk[q][1]); y10 = masked(y10, mk[q][2]); y11 = masked(y11, mk[q][3]);
         }
         float* o = out + oo;
         o[0] = y00;
@@ -496,7 +502,7 @@ extern "C" int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, floa
 static int conv3x3_launch(const float* x, const float* packed, const float* bias, const float* mask, float* out, int B,
                           int K, int N, int H, int W, int act, float slope, void* stream, const float* x2 = nullptr,
                           const float* packed2 = nullptr, const float* bias2 = nullptr, float* out2 = nullptr,
-                          int K2 = 0, int N2 = 0, const float* addend = nullptr);
+                          int K2 = 0, int N2 = 0, const float* addend = nullptr, int mask_n = 0);
 
 extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K,
                                 int N, int H, int W, int relu, void* stream) {
@@ -576,22 +582,24 @@ extern "C" size_t pcfa_conv3x3_workspace_bytes(int B, int K, int N, int H, int W
 
 extern "C" int pcfa_conv3x3_run(const float* x, const float* packed, const float* bias, const float* mask,
                                 const float* addend, float* out, int B, int K, int N, int H, int W, int act,
-                                float slope, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!x || !packed || !out || B < 1 || K < 1 || N < 1 || H < 1 || W < 1 || act < 0 || act > 2)
+                                float slope, int mask_channels, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !packed || !out || B < 1 || K < 1 || N < 1 || H < 1 || W < 1 || act < 0 || act > 2 || mask_channels < 0 ||
+      mask_channels > N || (mask_channels > 0 && (!mask || act != 0)) || (mask && act == 2))
     return PCFA_ERR_INVALID_ARG;
   if (use_f43(B, K, N, H, W)) {
     const int rc = pcfa_f43_run(x, packed + f23_packed_floats(K, N), bias, mask, addend, out, B, K, N, H, W, act,
-                                slope, workspace, workspace_bytes, (hipStream_t)stream);
+                                slope, mask_channels, workspace, workspace_bytes, (hipStream_t)stream);
     if (rc != PCFA_ERR_UNSUPPORTED) return rc;   // (misaligned views fall through to the F(2x2,3x3) kernel)
   }
   return conv3x3_launch(x, packed, bias, mask, out, B, K, N, H, W, act, slope, stream, nullptr, nullptr, nullptr,
-                        nullptr, 0, 0, addend);
+                        nullptr, 0, 0, addend, mask_channels);
 }
 
 static int conv3x3_launch(const float* x, const float* packed, const float* bias, const float* mask, float* out, int B,
                           int K, int N, int H, int W, int act, float slope, void* stream, const float* x2,
-                          const float* packed2, const float* bias2, float* out2, int K2, int N2, const float* addend) {
-  if (act < 0 || act > 2) return PCFA_ERR_INVALID_ARG;
+                          const float* packed2, const float* bias2, float* out2, int K2, int N2, const float* addend,
+                          int mask_n) {
+  if (act < 0 || act > 2 || mask_n < 0 || (mask_n > 0 && (act != 0 || !mask))) return PCFA_ERR_INVALID_ARG;
   if (!x || !packed || !out || B < 1 || K < 1 || N < 1 || H < 1 || W < 1 || !aligned16(packed))
     return PCFA_ERR_INVALID_ARG;
   const int Npad = (N + CB - 1) / CB * CB;
@@ -613,7 +621,7 @@ static int conv3x3_launch(const float* x, const float* packed, const float* bias
     block.x = 512;
   }
   grid.y = Npad / 32;
-  Second second{x2, packed2, bias2, out2, K2, N2, (int)grid.y};
+  Second second{x2, packed2, bias2, out2, K2, N2, (int)grid.y, mask_n};
   if (x2 != nullptr) {
     if (mt == 2) return PCFA_ERR_UNSUPPORTED;
     grid.y += (unsigned)((N2 + CB - 1) / CB * CB / 32);

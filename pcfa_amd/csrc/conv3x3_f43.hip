@@ -97,7 +97,7 @@ template <int ACT, bool PARTIAL, int NGT = 2, int UA = 1>
 __global__ __launch_bounds__(NTG * NGT) void conv3x3_f43_kernel(
     const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias,
     const float* __restrict__ mask, const float* __restrict__ addend, float* __restrict__ out, int K, int N, int H,
-    int W, int blocks_x, int ksplit, int B, float slope) {
+    int W, int blocks_x, int ksplit, int B, float slope, int mask_n) {
   __shared__ __attribute__((aligned(16))) float smem[LDSF];
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr int NT = NTG * NGT;
@@ -371,14 +371,19 @@ __global__ __launch_bounds__(NTG * NGT) void conv3x3_f43_kernel(
                 y.x = y.x > 0.f ? y.x : y.x * slope; y.y = y.y > 0.f ? y.y : y.y * slope;
                 y.z = y.z > 0.f ? y.z : y.z * slope; y.w = y.w > 0.f ? y.w : y.w * slope;
               }
-              if (mask != nullptr) {
+              const float ms = ACT == 0 ? slope : 0.f;   // mask factor where the producer's output is not positive
+              auto masked = [&](float v, float m) { return m > 0.f ? v : (ms == 0.f ? 0.f : v * ms); };
+              if (mask != nullptr && mask_n == 0) {
                 const float4 mk = *reinterpret_cast<const float4*>(mask + oo);
-                y.x = mk.x > 0.f ? y.x : 0.f; y.y = mk.y > 0.f ? y.y : 0.f;
-                y.z = mk.z > 0.f ? y.z : 0.f; y.w = mk.w > 0.f ? y.w : 0.f;
+                y.x = masked(y.x, mk.x); y.y = masked(y.y, mk.y); y.z = masked(y.z, mk.z); y.w = masked(y.w, mk.w);
               }
               if (addend != nullptr) {
                 const float4 ad = *reinterpret_cast<const float4*>(addend + oo);
                 y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
+              }
+              if (mask != nullptr && mask_n > 0 && n < mask_n) {   // channel prefix, after the addend (conv3x3.hip)
+                const float4 mk = *reinterpret_cast<const float4*>(mask + oo);
+                y.x = masked(y.x, mk.x); y.y = masked(y.y, mk.y); y.z = masked(y.z, mk.z); y.w = masked(y.w, mk.w);
               }
             }
             *reinterpret_cast<float4*>(ob + oo) = y;
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256) void f43_finish_kernel(const float* __restrict
                                                          const float* __restrict__ mask,
                                                          const float* __restrict__ addend, float* __restrict__ out,
                                                          int ksplit, long long total4, long long plane4, int N,
-                                                         float slope) {
+                                                         float slope, int mask_n) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
     float4 y = reinterpret_cast<const float4*>(part)[i];
@@ -414,14 +419,19 @@ __global__ __launch_bounds__(256) void f43_finish_kernel(const float* __restrict
       y.x = y.x > 0.f ? y.x : y.x * slope; y.y = y.y > 0.f ? y.y : y.y * slope;
       y.z = y.z > 0.f ? y.z : y.z * slope; y.w = y.w > 0.f ? y.w : y.w * slope;
     }
-    if (mask != nullptr) {
+    const float ms = ACT == 0 ? slope : 0.f;
+    auto masked = [&](float v, float m) { return m > 0.f ? v : (ms == 0.f ? 0.f : v * ms); };
+    if (mask != nullptr && mask_n == 0) {
       const float4 mk = reinterpret_cast<const float4*>(mask)[i];
-      y.x = mk.x > 0.f ? y.x : 0.f; y.y = mk.y > 0.f ? y.y : 0.f;
-      y.z = mk.z > 0.f ? y.z : 0.f; y.w = mk.w > 0.f ? y.w : 0.f;
+      y.x = masked(y.x, mk.x); y.y = masked(y.y, mk.y); y.z = masked(y.z, mk.z); y.w = masked(y.w, mk.w);
     }
     if (addend != nullptr) {
       const float4 ad = reinterpret_cast<const float4*>(addend)[i];
       y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w;
+    }
+    if (mask != nullptr && mask_n > 0 && (int)((i / plane4) % N) < mask_n) {
+      const float4 mk = reinterpret_cast<const float4*>(mask)[i];
+      y.x = masked(y.x, mk.x); y.y = masked(y.y, mk.y); y.z = masked(y.z, mk.z); y.w = masked(y.w, mk.w);
     }
     reinterpret_cast<float4*>(out)[i] = y;
   }
@@ -468,7 +478,7 @@ size_t pcfa_f43_workspace_bytes(int B, int K, int N, int H, int W) {
 }
 
 int pcfa_f43_run(const float* x, const float* packed, const float* bias, const float* mask, const float* addend,
-                 float* out, int B, int K, int N, int H, int W, int act, float slope, void* workspace,
+                 float* out, int B, int K, int N, int H, int W, int act, float slope, int mask_n, void* workspace,
                  size_t workspace_bytes, hipStream_t s) {
   if (!pcfa_f43_supported(B, K, N, H, W)) return PCFA_ERR_UNSUPPORTED;
   if (!aligned16(x) || !aligned16(out) || !aligned16(packed) || (mask && !aligned16(mask)) ||
@@ -482,9 +492,9 @@ int pcfa_f43_run(const float* x, const float* packed, const float* bias, const f
 #define PCFA_F43_DIRECT(A_)                                                                                          \
   do {                                                                                                               \
     if (six) pcfa_launch(conv3x3_f43_kernel<A_, false, 1, 2>, grid, block, 0, s, x, packed, bias, mask, addend, out, \
-                         K, N, H, W, blocks_x, 1, B, slope);                                                         \
+                         K, N, H, W, blocks_x, 1, B, slope, mask_n);                                                 \
     else pcfa_launch(conv3x3_f43_kernel<A_, false>, grid, block, 0, s, x, packed, bias, mask, addend, out, K, N, H,  \
-                     W, blocks_x, 1, B, slope);                                                                      \
+                     W, blocks_x, 1, B, slope, mask_n);                                                              \
   } while (0)
     if (act == 1) PCFA_F43_DIRECT(1); else if (act == 2) PCFA_F43_DIRECT(2); else PCFA_F43_DIRECT(0);
 #undef PCFA_F43_DIRECT
@@ -496,15 +506,15 @@ int pcfa_f43_run(const float* x, const float* packed, const float* bias, const f
   float* part = (float*)workspace;
   if (six)
     pcfa_launch(conv3x3_f43_kernel<0, true, 1, 2>, grid, block, 0, s, x, packed, (const float*)nullptr,
-                (const float*)nullptr, (const float*)nullptr, part, K, N, H, W, blocks_x, ksplit, B, 0.f);
+                (const float*)nullptr, (const float*)nullptr, part, K, N, H, W, blocks_x, ksplit, B, 0.f, 0);
   else
     pcfa_launch(conv3x3_f43_kernel<0, true>, grid, block, 0, s, x, packed, (const float*)nullptr, (const float*)nullptr,
-                (const float*)nullptr, part, K, N, H, W, blocks_x, ksplit, B, 0.f);
+                (const float*)nullptr, part, K, N, H, W, blocks_x, ksplit, B, 0.f, 0);
   PCFA_LAUNCH_CHECK();
   const long long total4 = (long long)B * N * H * W / 4, plane4 = (long long)H * W / 4;
   const dim3 fg((unsigned)min((total4 + 255) / 256, 2048LL)), fb(256);
 #define PCFA_F43_FINISH(A_) \
-  pcfa_launch(f43_finish_kernel<A_>, fg, fb, 0, s, (const float*)part, bias, mask, addend, out, ksplit, total4, plane4, N, slope)
+  pcfa_launch(f43_finish_kernel<A_>, fg, fb, 0, s, (const float*)part, bias, mask, addend, out, ksplit, total4, plane4, N, slope, mask_n)
   if (act == 1) PCFA_F43_FINISH(1); else if (act == 2) PCFA_F43_FINISH(2); else PCFA_F43_FINISH(0);
 #undef PCFA_F43_FINISH
   PCFA_LAUNCH_CHECK();

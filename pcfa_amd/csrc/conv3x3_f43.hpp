@@ -9,5 +9,5 @@ bool pcfa_f43_supported(int B, int K, int N, int H, int W);
 int pcfa_f43_ksplit(int B, int K, int N, int H, int W);
 size_t pcfa_f43_workspace_bytes(int B, int K, int N, int H, int W);
 int pcfa_f43_run(const float* x, const float* packed, const float* bias, const float* mask, const float* addend,
-                 float* out, int B, int K, int N, int H, int W, int act, float slope, void* workspace,
+                 float* out, int B, int K, int N, int H, int W, int act, float slope, int mask_n, void* workspace,
                  size_t workspace_bytes, hipStream_t s);

@@ -931,8 +931,9 @@ def conv_s2_supported(x, weight):
 
 class _ConvS2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act, slope):
+    def forward(ctx, x, weight, bias, act, slope, grad_premasked=False):
         _dev(x, weight, bias)
+        ctx.grad_premasked = bool(grad_premasked)   # the consumer applies this layer's activation backward (conv3x3)
         x = x.contiguous()
         B, Cin, H, W = x.shape
         N, _, k, _ = weight.shape
@@ -941,14 +942,14 @@ class _ConvS2(torch.autograd.Function):
         _call("pcfa_conv_s2_fwd", _ptr(x), _ptr(_s2_packed(weight)), _ptr(bias), _ptr(out), B, Cin, N, H, W, k, act,
               float(slope))
         ctx.act, ctx.slope, ctx.xshape = act, float(slope), tuple(x.shape)
-        ctx.save_for_backward(weight, out if act else None)
+        ctx.save_for_backward(weight, out if (act and not ctx.grad_premasked) else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
         weight, out = ctx.saved_tensors
         g = g.contiguous()
-        if ctx.act:
+        if ctx.act and not ctx.grad_premasked:
             gm = torch.empty_like(g)
             if ctx.act == 1:
                 _call("pcfa_relu_bwd", _ptr(out), _ptr(g), _ptr(gm), g.numel())
@@ -962,7 +963,7 @@ class _ConvS2(torch.autograd.Function):
             _call("pcfa_conv_s2_bwd", _ptr(g), _ptr(_s2_bwd_packed(weight)), _ptr(gx), B, Cin, N, H, W, k)
         else:   # the stem's gradient and ragged widths: library
             gx = torch.nn.grad.conv2d_input(ctx.xshape, weight, g, stride=2, padding=k // 2)
-        return gx, None, None, None, None
+        return gx, None, None, None, None, None
 
 
 _s2_ds_packs = {}   # (id(w), id(wd)) -> (weakref w, weakref wd, versions, fwd_packed, bwd_packed)
@@ -1042,7 +1043,7 @@ def conv_s2_ds(x, weight, weight_d, bias=None, bias_d=None, relu=False):
     return _ConvS2DS.apply(x, weight, weight_d, bias, bias_d, int(bool(relu)))
 
 
-def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None):
+def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None, grad_premasked=False):
     """act(conv2d(x, weight, bias, stride=2, padding=k//2)) for a frozen weight: the encoders' 7x7 stem and the 3x3
     first convolution of the down-sampling residual blocks on the fp32 matrix cores (pcfa_conv_s2_fwd)."""
     _dev(x, weight, bias)
@@ -1051,7 +1052,9 @@ def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None):
     if not conv_s2_supported(x, weight):
         raise ValueError("conv_s2: unsupported weight %s for input %s" % (tuple(weight.shape), tuple(x.shape)))
     act = 2 if leaky_slope is not None else int(bool(relu))
-    return _ConvS2.apply(x, weight, bias, act, 0.0 if leaky_slope is None else leaky_slope)
+    if grad_premasked and not act:
+        raise ValueError("conv_s2: grad_premasked needs an activation")
+    return _ConvS2.apply(x, weight, bias, act, 0.0 if leaky_slope is None else leaky_slope, bool(grad_premasked))
 
 
 class _Conv3x3FewOut(torch.autograd.Function):
@@ -1339,21 +1342,24 @@ def _conv_workspace(device, nbytes):
     return ws
 
 
-def _conv3x3_run(device, x_ptr, packed, bias_ptr, mask_ptr, addend_ptr, out_ptr, B, K, N, H, W, act=0, slope=0.):
+def _conv3x3_run(device, x_ptr, packed, bias_ptr, mask_ptr, addend_ptr, out_ptr, B, K, N, H, W, act=0, slope=0.,
+                 mask_channels=0):
     """out = act(bias + conv3x3(x)) [masked] [+ addend] through pcfa_conv3x3_run (the library picks F(4x4,3x3) or
-    F(2x2,3x3) per shape); pointers are raw device addresses (or None)."""
+    F(2x2,3x3) per shape); pointers are raw device addresses (or None).  With a mask (act = 0) `slope` is the factor where
+    the mask is not positive; mask_channels > 0: only that channel prefix, after the addend (include/pcfa_hip.h)."""
     nws = int(_hip.load().pcfa_conv3x3_workspace_bytes(B, K, N, H, W))
     ws = _conv_workspace(device, nws) if nws else None
     _call("pcfa_conv3x3_run", x_ptr, _ptr(packed), bias_ptr, mask_ptr, addend_ptr, out_ptr, B, K, N, H, W, int(act),
-          float(slope), _ptr(ws), nws)
+          float(slope), int(mask_channels), _ptr(ws), nws)
 
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, slope=None, skip=False, flags=0):
+    def forward(ctx, x, weight, bias, relu, slope=None, skip=False, flags=0, input_slope=0.):
         _dev(x, weight, bias)
         ctx.skip = bool(skip)
         ctx.grad_premasked, ctx.mask_input_grad = bool(flags & 1), bool(flags & 2)
+        ctx.input_slope = float(input_slope)   # slope of the (Leaky)ReLU that produced x (mask_input_grad; 0 = ReLU)
         ctx.set_materialize_grads(False)
         if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.dtype != torch.float32:
             raise ValueError("conv3x3 expects a float32 3x3 Conv2d weight, got %s" % (tuple(weight.shape),))
@@ -1367,8 +1373,8 @@ class _Conv3x3(torch.autograd.Function):
         act = 2 if slope is not None else int(bool(relu))
         _conv3x3_run(x.device, _ptr(x), fwd, _ptr(bias), None, None, _ptr(out), B, K, N, H, W, act, float(slope or 0.))
         ctx.bwd, ctx.dims, ctx.act, ctx.slope = bwd, (B, K, N, H, W), act, float(slope or 0.)
-        if ctx.grad_premasked and act != 1:
-            raise ValueError("conv3x3: grad_premasked needs relu=True")
+        if ctx.grad_premasked and not act:
+            raise ValueError("conv3x3: grad_premasked needs an activation (relu=True or leaky_slope)")
         ctx.save_for_backward(*(([out] if act and not ctx.grad_premasked else []) + ([x] if ctx.mask_input_grad else [])))
         if ctx.skip:
             return out, x.view_as(x)   # the alias feeds the residual path: its gradient is summed in the epilogue below
@@ -1380,7 +1386,7 @@ class _Conv3x3(torch.autograd.Function):
             raise RuntimeError("conv3x3 is the frozen-weight path: no weight / bias gradient")
         B, K, N, H, W = ctx.dims
         if g is None:
-            return (None if g_skip is None else g_skip), None, None, None, None, None, None
+            return (None if g_skip is None else g_skip), None, None, None, None, None, None, None
         g = g.contiguous()
         if ctx.act and not ctx.grad_premasked:
             out = ctx.saved_tensors[0]
@@ -1392,12 +1398,13 @@ class _Conv3x3(torch.autograd.Function):
             g = gm
         gin = torch.empty((B, K, H, W), device=g.device, dtype=torch.float32)
         if g_skip is not None or ctx.mask_input_grad:
-            xin = ctx.saved_tensors[-1] if ctx.mask_input_grad else None   # = a ReLU output: [xin > 0] is its mask
+            xin = ctx.saved_tensors[-1] if ctx.mask_input_grad else None   # = a (Leaky)ReLU output: [xin > 0] is its mask
             _conv3x3_run(g.device, _ptr(g), ctx.bwd, None, _ptr(xin),
-                         _ptr(None if g_skip is None else g_skip.contiguous()), _ptr(gin), B, N, K, H, W)
+                         _ptr(None if g_skip is None else g_skip.contiguous()), _ptr(gin), B, N, K, H, W,
+                         slope=ctx.input_slope if ctx.mask_input_grad else 0.)
         else:
             _conv3x3_run(g.device, _ptr(g), ctx.bwd, None, None, None, _ptr(gin), B, N, K, H, W)
-        return gin, None, None, None, None, None, None
+        return gin, None, None, None, None, None, None, None
 
 
 _PAIR_LAUNCH = os.environ.get("PCFA_CONV3X3_PAIR", "1") != "0"   # A/B switch (tools/dev)
@@ -1494,6 +1501,9 @@ def conv3x3_cat(convs, tails=(), grad_premasked=False, mask_input_grads=False):
     return _Conv3x3Cat.apply(len(convs), int(bool(grad_premasked)) | 2 * int(bool(mask_input_grads)), *flat, *tails)
 
 
+DENSE_BLOCK_FUSED_MASKS = True   # False: one pcfa_leaky_relu_bwd launch per layer (A/B in tools, parity tests)
+
+
 class _DenseBlock(torch.autograd.Function):
     """x_{i+1} = cat(leaky_relu(conv3x3_i(x_i)), x_i) for i = 0..n-1 (PWC-Net's DenseNet decoders, PWCNet.py:234-323)
     written into ONE pre-allocated buffer: every convolution reads the channel suffix it needs in place and writes
@@ -1537,14 +1547,28 @@ class _DenseBlock(torch.autograd.Function):
         total, K0, H, W = ctx.dims
         plane = H * W
         gb = g.contiguous().clone()  # running gradient of the buffer: every layer adds its input gradient to a suffix
-        for bwd, k, n, start in reversed(ctx.packs):
-            gm = torch.empty((1, n, H, W), device=g.device, dtype=torch.float32)
-            _call("pcfa_leaky_relu_bwd", _ptr_off(buf, (start - n) * plane), _ptr_off(gb, (start - n) * plane), _ptr(gm),
-                  ctx.slope, n * plane)
+        npk = len(ctx.packs)
+        for i in range(npk - 1, -1, -1):
+            bwd, k, n, start = ctx.packs[i]
+            if i == npk - 1 or not DENSE_BLOCK_FUSED_MASKS:
+                # LeakyReLU backward of this layer's output (the top layer's gradient arrives from outside only)
+                gm = torch.empty((1, n, H, W), device=g.device, dtype=torch.float32)
+                _call("pcfa_leaky_relu_bwd", _ptr_off(buf, (start - n) * plane), _ptr_off(gb, (start - n) * plane),
+                      _ptr(gm), ctx.slope, n * plane)
+                gm_ptr = _ptr(gm)
+            else:   # already multiplied by the layer above (below): its slot of the running gradient IS the masked gradient
+                gm_ptr = _ptr_off(gb, (start - n) * plane)
             # the layer's input gradient is added to the running gradient in the convolution's epilogue, in place (every
-            # output element reads its own addend): no separate gradient tensor, no add launch
+            # output element reads its own addend): no separate gradient tensor, no add launch.  The first channels of
+            # the suffix are the output of layer i - 1, and this is the last contribution to their gradient: its
+            # LeakyReLU backward rides in the same epilogue (mask = that layer's output in the block buffer, applied
+            # after the addend) -- 4 elementwise launches less per block.
             dst = _ptr_off(gb, start * plane)
-            _conv3x3_run(g.device, _ptr(gm), bwd, None, None, dst, dst, 1, n, k, H, W)
+            if i > 0 and DENSE_BLOCK_FUSED_MASKS:
+                _conv3x3_run(g.device, gm_ptr, bwd, None, _ptr_off(buf, start * plane), dst, dst, 1, n, k, H, W,
+                             slope=ctx.slope, mask_channels=ctx.packs[i - 1][2])
+            else:
+                _conv3x3_run(g.device, gm_ptr, bwd, None, None, dst, dst, 1, n, k, H, W)
         return (gb[:, total - K0:], None) + (None,) * (2 * len(ctx.packs))
 
 
@@ -1556,15 +1580,17 @@ def dense_block(x, layers, slope=0.1):
     return _DenseBlock.apply(x, slope, *flat)
 
 
-def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None, skip=False, grad_premasked=False, mask_input_grad=False):
+def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None, skip=False, grad_premasked=False, mask_input_grad=False,
+            input_slope=0.):
     """act(conv2d(x, weight, bias, stride=1, padding=1)) for a frozen 3x3 weight: Winograd F(2x2,3x3) on the fp32
     matrix cores with bias and ReLU (or LeakyReLU(leaky_slope)) fused into the epilogue; the data gradient runs the
     same kernel.  skip=True returns (result, x_alias): use x_alias for a residual connection around the convolution --
     the gradient arriving on it is added in the data-gradient kernel's epilogue instead of by an autograd `add`.
     grad_premasked / mask_input_grad: the deferred-ReLU contract of conv3x3_cat (the consumer of this layer's output
-    applies [output > 0] to the gradient / this layer applies [x > 0] to the gradient it returns for a ReLU-output x)."""
+    applies [output > 0] to the gradient / this layer applies [x > 0] to the gradient it returns for a ReLU-output x);
+    with LeakyReLU layers the factor where the output is not positive is the producer's slope (input_slope)."""
     return _Conv3x3.apply(x, weight, bias, relu, leaky_slope, skip,
-                          int(bool(grad_premasked)) | 2 * int(bool(mask_input_grad)))
+                          int(bool(grad_premasked)) | 2 * int(bool(mask_input_grad)), float(input_slope))
 
 
 _GRU_EPILOGUES = os.environ.get("PCFA_GRU_EPILOGUES", "1") != "0"   # A/B switch (tools/dev)

@@ -20,38 +20,90 @@ from .. import ops
 DILATED_AS_SUBGRIDS = (2, 4, 8, 16)   # dilations run as d*d plain 3x3 convolutions on sub-sampled grids (() = library)
 CONV_S2 = True   # stride-2 pyramid layers on ops.conv_s2 (False: library convolution; tools/dev A/B)
 DECONV_FEWOUT = True   # deconv / upfeat layers and the final x4 upsampling on own kernels (False: library; A/B)
+DEFER_LEAKY = True   # LeakyReLU backward of single-consumer layers in the consumer's data-gradient epilogue (A/B, tests)
 
 
 class _ConvLeaky(nn.Sequential):
     """conv() of the reference (PWCNet.py:29-35): Conv2d + LeakyReLU(0.1); same parameter names ("0.weight", "0.bias").
     Frozen 3x3 / stride 1 / pad 1 instances run as ops.conv3x3 (Winograd on the fp32 matrix cores, bias and
-    LeakyReLU in the epilogue), 3x3 / stride 2 ones as ops.conv_s2; dilated ones stay on the library convolution."""
+    LeakyReLU in the epilogue), 3x3 / stride 2 ones as ops.conv_s2, dilated ones as d*d plain convolutions on sub-grids.
 
-    def forward(self, x):
+    Chains of such layers (pyramid level: conv_a -> conv_aa -> conv_b; context network: dc_conv1 .. dc_conv6) defer the
+    LeakyReLU backward of a layer whose output has ONE consumer into that consumer's data-gradient epilogue
+    (`grad_premasked` on the producer, `mask_input_grad` on the consumer -- the contract of ops.conv3x3): the caller
+    sets the flags only where `kind()` says both sides run on the operator table."""
+
+    def _frozen(self):
         c = self[0]
-        if (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
-                and c.out_channels >= 16 and not c.weight.requires_grad
-                and not (c.bias is not None and c.bias.requires_grad)):
-            return ops.get().conv3x3(x, c.weight, c.bias, False, self[1].negative_slope)
+        return not (c.weight.requires_grad or (c.bias is not None and c.bias.requires_grad))
+
+    def kind(self, x):
+        """Which path forward(x) takes: "conv3x3" | "subgrid" | "s2" | None (the library modules)."""
+        c = self[0]
+        if not self._frozen() or c.kernel_size != (3, 3) or c.groups != 1:
+            return None
+        if c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.out_channels >= 16:
+            return "conv3x3"
         d = c.dilation[0]
-        if (DILATED_AS_SUBGRIDS and d in DILATED_AS_SUBGRIDS and c.kernel_size == (3, 3) and c.stride == (1, 1)
-                and c.dilation == (d, d) and c.padding == (d, d) and c.groups == 1 and c.out_channels >= 16
-                and x.shape[-2] % d == 0 and x.shape[-1] % d == 0 and not c.weight.requires_grad
-                and not (c.bias is not None and c.bias.requires_grad)):
-            # A 3x3 convolution with dilation d (the context network, PWCNet.py:160-166) never mixes pixels of different
-            # (y mod d, x mod d): it is d*d independent plain 3x3 convolutions on the sub-sampled grids, zero padding
-            # included (H, W multiples of d).  Sub-grids go to the batch axis and run on the Winograd kernel.
-            B, C, H, W = x.shape
-            xs = x.reshape(B, C, H // d, d, W // d, d).permute(0, 3, 5, 1, 2, 4).reshape(B * d * d, C, H // d, W // d)
-            ys = ops.get().conv3x3(xs.contiguous(), c.weight, c.bias, False, self[1].negative_slope)
-            N = ys.shape[1]
-            return ys.reshape(B, d, d, N, H // d, W // d).permute(0, 3, 4, 1, 5, 2).reshape(B, N, H, W)
-        if (CONV_S2 and c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1) and c.dilation == (1, 1)
-                and c.groups == 1 and not c.weight.requires_grad and not (c.bias is not None and c.bias.requires_grad)
+        if (DILATED_AS_SUBGRIDS and d in DILATED_AS_SUBGRIDS and c.stride == (1, 1) and c.dilation == (d, d)
+                and c.padding == (d, d) and c.out_channels >= 16 and x.shape[-2] % d == 0 and x.shape[-1] % d == 0):
+            return "subgrid"
+        if (CONV_S2 and c.stride == (2, 2) and c.padding == (1, 1) and c.dilation == (1, 1)
                 and ops.get().conv_s2_supported(x, c.weight)):
+            return "s2"
+        return None
+
+    def forward(self, x, grad_premasked=False, mask_input_grad=False):
+        c, slope = self[0], self[1].negative_slope
+        kind = self.kind(x)
+        if kind is None:
+            if grad_premasked or mask_input_grad:
+                raise RuntimeError("deferred LeakyReLU masks need the operator-table path on both sides (kind() is None)")
+            return super().forward(x)
+        kw = dict(grad_premasked=grad_premasked)
+        if kind == "s2":
             # the pyramid's stride-2 layers (PWCNet.py:87-104): direct fp32-MFMA kernel, bias + LeakyReLU in the epilogue
-            return ops.get().conv_s2(x, c.weight, c.bias, leaky_slope=self[1].negative_slope)
-        return super().forward(x)
+            if mask_input_grad:
+                raise RuntimeError("conv_s2 does not apply an input mask")
+            return ops.get().conv_s2(x, c.weight, c.bias, leaky_slope=slope, **kw)
+        kw.update(mask_input_grad=mask_input_grad, input_slope=slope if mask_input_grad else 0.)
+        if kind == "conv3x3":
+            return ops.get().conv3x3(x, c.weight, c.bias, False, slope, **kw)
+        # A 3x3 convolution with dilation d (the context network, PWCNet.py:160-166) never mixes pixels of different
+        # (y mod d, x mod d): it is d*d independent plain 3x3 convolutions on the sub-sampled grids, zero padding
+        # included (H, W multiples of d).  Sub-grids go to the batch axis and run on the Winograd kernel.
+        d = c.dilation[0]
+        B, C, H, W = x.shape
+        xs = x.reshape(B, C, H // d, d, W // d, d).permute(0, 3, 5, 1, 2, 4).reshape(B * d * d, C, H // d, W // d)
+        ys = ops.get().conv3x3(xs.contiguous(), c.weight, c.bias, False, slope, **kw)
+        N = ys.shape[1]
+        return ys.reshape(B, d, d, N, H // d, W // d).permute(0, 3, 4, 1, 5, 2).reshape(B, N, H, W)
+
+
+def _chain(layers, x, last_premasked=False):
+    """x -> layers[0] -> layers[1] -> ...: every intermediate output has exactly one consumer, so its LeakyReLU backward is
+    applied by that consumer's data-gradient kernel wherever both layers run on the operator table (and the consumer is
+    a stride-1 convolution, whose kernel has the mask epilogue)."""
+    if not DEFER_LEAKY:
+        for layer in layers:
+            x = layer(x)
+        return x
+    masked_in = False
+    for i, layer in enumerate(layers):
+        k = layer.kind(x)
+        nxt = layers[i + 1] if i + 1 < len(layers) else None
+        # the next layer's path depends on its input only through the spatial size (sub-grid divisibility), which a
+        # stride-1 / stride-2 3x3 layer fixes: decide on a shape probe
+        premask = False
+        if k is not None and nxt is not None:
+            c = layer[0]
+            ho = (x.shape[-2] - 1) // c.stride[0] + 1 if c.stride[0] == 2 else x.shape[-2]
+            wo = (x.shape[-1] - 1) // c.stride[1] + 1 if c.stride[1] == 2 else x.shape[-1]
+            probe = torch.empty((x.shape[0], c.out_channels, ho, wo), device="meta")
+            premask = nxt.kind(probe) in ("conv3x3", "subgrid")
+        x = layer(x, grad_premasked=premask, mask_input_grad=masked_in)
+        masked_in = premask
+    return x
 
 
 def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
@@ -169,9 +221,8 @@ class PWCDCNet(nn.Module):
             feats, x = [], im
             for lvl in range(1, 7):
                 first, second = ("aa", "a") if lvl == 6 else ("a", "aa")
-                x = getattr(self, "conv%d%s" % (lvl, first))(x)
-                x = getattr(self, "conv%d%s" % (lvl, second))(x)
-                x = getattr(self, "conv%db" % lvl)(x)
+                x = _chain([getattr(self, "conv%d%s" % (lvl, first)), getattr(self, "conv%d%s" % (lvl, second)),
+                            getattr(self, "conv%db" % lvl)], x)
                 feats.append(x)
             return feats
 
@@ -194,8 +245,8 @@ class PWCDCNet(nn.Module):
                 up_flow = getattr(self, "deconv%d" % lvl)(flow)
                 up_feat = getattr(self, "upfeat%d" % lvl)(x)
 
-        x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(x))))
-        flow2 = flows[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))
+        x = _chain([self.dc_conv1, self.dc_conv2, self.dc_conv3, self.dc_conv4, self.dc_conv5, self.dc_conv6], x)
+        flow2 = flows[2] + self.dc_conv7(x)
 
         if DECONV_FEWOUT and not self.training:
             return ops.get().upsample_bilinear(flow2, 4, 20.0)   # 20 * self.upsample(flow2), gather backward

@@ -1940,3 +1940,26 @@ def test_conv_workspace_never_frees_a_captured_buffer():
     assert b.data_ptr() != pa and b.numel() * 4 >= 4 * n
     assert any(t.data_ptr() == pa for t in hip_ops._CONV_WS_RETIRED)
     assert hip_ops._conv_workspace(dev, n) is b                # a smaller request keeps the current buffer
+
+
+def test_pwcnet_deferred_leaky_masks_change_no_bit():
+    """PWC-Net closure (PWCNet.py:227-330) with the LeakyReLU backward of single-consumer layers applied in the
+    consumer's data-gradient epilogue (pyramid chains conv_a -> conv_aa -> conv_b, context network dc_conv1..6:
+    nets/pwcnet._chain; dense decoder blocks: hip_ops.DENSE_BLOCK_FUSED_MASKS -- 40 elementwise launches less per
+    closure) against one pcfa_leaky_relu_bwd launch per layer: the same products in the same order, so loss, flow and
+    gradient must be bit-identical."""
+    from pcfa_amd.nets import pwcnet
+    dev = torch.device(DEV)
+
+    def run():
+        r = closure_util.run_closure("PWCNet", 192, 256, "clipping", True, "zero", "aee", seed=5, device=dev)
+        return r["loss"], r["flow"].clone(), r["grads"][0].clone()
+
+    fused = run()
+    pwcnet.DEFER_LEAKY, hip_ops.DENSE_BLOCK_FUSED_MASKS = False, False
+    try:
+        plain = run()
+    finally:
+        pwcnet.DEFER_LEAKY, hip_ops.DENSE_BLOCK_FUSED_MASKS = True, True
+    assert fused[0] == plain[0] and torch.equal(fused[1], plain[1]) and torch.equal(fused[2], plain[2])
+    assert float(fused[2].abs().max()) > 0
