@@ -1391,6 +1391,47 @@ def test_universal_closure_on_gpu_vs_oracle(oracle_ops):
     assert torch.equal(red.flat[:3 * 128 * 160].cpu(), ge[0].flatten())
 
 
+def test_universal_closure_at_baseline_size_two_pairs_vs_cpu_port(oracle_ops):
+    """BASELINE config 5 at size: ONE universal closure, RAFT 436x1024, TWO pairs on one rank (batch-2
+    convolutions take other code paths: conv3x3 policy, conv_s2 batch handling, 110-tile sepconv5 grids), a shared non-zero
+    delta pair, clipping -- eager and replayed from its hipGraph -- against the CPU port: loss 1e-5, gradient 1e-2
+    relative L2 (attack_PCFA.py:427-505)."""
+    import bench
+    from pcfa_amd import attack_PCFA
+    from pcfa_amd.helper_functions import datasets, ownutilities
+    h, w = 436, 1024
+    args = bench.attack_args("RAFT", "clipping", universal=True)
+    pairs = [datasets.synthetic_pair(s, h, w) for s in (100, 101)]
+    im1, im2 = torch.stack([p[0] for p in pairs]), torch.stack([p[1] for p in pairs])
+    _, [p1, p2] = ownutilities.preprocess_img("RAFT", im1[:1], im2[:1])
+    gen = torch.Generator().manual_seed(5)
+    d1, d2 = 0.004 * torch.randn(p1[0].shape, generator=gen), 0.004 * torch.randn(p2[0].shape, generator=gen)
+    torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+
+    def run(dev, use_graph):
+        model = bench.load_model("RAFT", dev, False)
+        ua = attack_PCFA.UniversalAttack(model, p1[0], p2[0], dev, attack_PCFA.default_mu(args), args, use_graph=use_graph)
+        with torch.no_grad():
+            ua.nw_delta1.copy_(d1)
+            ua.nw_delta2.copy_(d2)
+        ua.begin_batch(im1, im2)
+        loss = float(ua.closure())
+        if use_graph:
+            assert ua.st.graphed is not None
+            loss = float(ua.closure())          # a second replay of the same graph
+        return loss, [p.grad.detach().clone().cpu() for p in ua.params]
+
+    with ops.override_for_testing(oracle_ops):
+        lc, gc = run(torch.device("cpu"), False)
+    le, ge = run(torch.device(DEV), False)
+    lg, gg = run(torch.device(DEV), True)
+    assert abs(le - lc) <= 1e-5 * abs(lc), (le, lc)
+    assert abs(lg - le) <= 1e-6 * abs(le), (lg, le)
+    for a, b, c in zip(ge, gg, gc):
+        assert rel_l2(a, c) < 1e-2, rel_l2(a, c)
+        assert rel_l2(b, a) < 1e-5, rel_l2(b, a)
+
+
 def test_schedule_parity_at_baseline_size_vs_cpu_port():
     """The whole schedule at 436x1024 (BASELINE config 2): best-iterate AEE(adv, target), AEE(adv, init) and ||delta|| of
     a PCFA attack on the GPU against the CPU port, inside 3x the port's own spread between two thread counts
