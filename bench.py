@@ -95,13 +95,15 @@ def attack_args(net, boxconstraint="change_of_variables", joint=False, universal
                      weights="random:1234", batch_size=1, epochs=1)
 
 
-def load_model(net, device, cov):
+def load_model(net, device, cov, config=None):
+    """config: a pcfa_amd.config.Config (None: config.DEFAULT) -- the build switches are fixed at construction."""
     from pcfa_amd import attack_PCFA
     from pcfa_amd.helper_functions import ownutilities
     unit = ownutilities.model_takes_unit_input(net)
     kw = {"eps_box": attack_PCFA.EPS_BOX} if cov else {}
     model = ownutilities.import_and_load(net, make_unit_input=not unit, variable_change=cov,
-                                         make_scaled_input_model=True, device=device, weights="random:1234", **kw)
+                                         make_scaled_input_model=True, device=device, weights="random:1234",
+                                         config=config, **kw)
     model.eval()
     for p in model.parameters():
         p.requires_grad = False
@@ -109,7 +111,7 @@ def load_model(net, device, cov):
 
 
 def AttackStepper(net, h, w, device, seed, boxconstraint="change_of_variables", use_graph=False, model=None,
-                  joint=False, target="zero"):
+                  joint=False, target="zero", config=None):
     """`pcfa_amd.attack_PCFA.PairAttack` on one synthetic pair (what pcfa_attack builds per pair), graph off unless
     asked: call `.enable_graph()` -- exactly what pcfa_attack does on the GPU."""
     from pcfa_amd import attack_PCFA
@@ -117,7 +119,7 @@ def AttackStepper(net, h, w, device, seed, boxconstraint="change_of_variables", 
     cov = boxconstraint == "change_of_variables"
     args = attack_args(net, boxconstraint, joint=joint, target=target)
     if model is None:
-        model = load_model(net, device, cov)
+        model = load_model(net, device, cov, config)
     i1, i2, _ = datasets.synthetic_pair(seed, h, w)
     st = attack_PCFA.PairAttack(model, i1[None], i2[None], None, 0, attack_PCFA.EPS_BOX, device, False,
                                 attack_PCFA.default_mu(args), args, use_graph=use_graph)
@@ -801,8 +803,10 @@ def main():
         # extra, eagerly launched step right after the timed region -- with the lookup -> convc1 fusion switched OFF,
         # so that this step also yields the un-fused lookup kernel's own roofline row
         st.graphed = st.repredict = None
-        from pcfa_amd.nets import raft as raft_net
-        raft_net.FUSED_LOOKUP = False
+        import dataclasses
+        from pcfa_amd import config as pcfa_config
+        fused_model = st.model   # same seeded weights, lookup -> convc1 fusion off: a second model (switches are frozen)
+        st.model = load_model(a.net, dev, True, dataclasses.replace(pcfa_config.cfg(fused_model), fused_lookup=False))
         hip_ops.set_dispatch_timer(prof)
         work = {}
         hip_ops.set_work_recorder(work)     # flop / bytes per kernel family of this step (family_rows)
@@ -810,7 +814,7 @@ def main():
         torch.cuda.synchronize()
         hip_ops.set_work_recorder(None)
         hip_ops.set_dispatch_timer(None)
-        raft_net.FUSED_LOOKUP = True
+        st.model = fused_model
 
     # a second pair of the same shape: PairAttack adopts the first pair's static buffers, graphs and optimiser
     second_pair = None

@@ -84,7 +84,7 @@ def corr_lookup(pyramid, coords, radius=4):
 class CorrBlock:
     """models/raft/corr.py:12-50."""
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, bwd_windows=True):   # bwd_windows: a scheduling hint of the product
         self.num_levels = num_levels
         self.radius = radius
         self.corr_pyramid = corr_pyramid(fmap1, fmap2, num_levels)
@@ -517,7 +517,7 @@ def conv_s2_supported(x, weight):
     return kh == kw and ((Cin, kh) == (3, 7) or kh == 3) and x.shape[3] % 4 == 0
 
 
-def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None, grad_premasked=False):
+def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None, grad_premasked=False, own_bwd=True):
     """models/raft/extractor.py:118 (stem) and :23-58 (first convolution of a stride-2 residual block):
     conv2d(x, w, b, stride=2, padding=k//2) followed by the activation the caller fuses."""
     y = F.conv2d(x, weight, bias, stride=2, padding=weight.shape[-1] // 2)
@@ -543,14 +543,14 @@ def conv3x3_cat(convs, tails=(), grad_premasked=False, mask_input_grads=False):
     return torch.cat([F.relu(F.conv2d(x, w, b, stride=1, padding=1)) for x, w, b in convs] + list(tails), dim=1)
 
 
-def dense_block(x, layers, slope=0.1):
+def dense_block(x, layers, slope=0.1, fused_masks=True):   # fused_masks: a scheduling hint of the product
     """models/PWCNet/PWCNet.py:234-323: x = cat((conv_i(x), x), 1) for the five decoder convolutions of a level."""
     for w, b in layers:
         x = torch.cat((F.leaky_relu(F.conv2d(x, w, b, stride=1, padding=1), slope), x), 1)
     return x
 
 
-def pwc_warp(x, flo, mask_threshold=0.0001):
+def pwc_warp(x, flo, mask_threshold=0.0001, deterministic=True):   # deterministic: a scheduling hint of the product
     """models/PWCNet/PWCNet.py:166-206, statement by statement."""
     B, C, H, W = x.size()
     xx = torch.arange(0, W).view(1, -1).repeat(H, 1)

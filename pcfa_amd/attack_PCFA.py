@@ -27,12 +27,11 @@ import time
 import numpy as np
 import torch
 
-from . import ops, sharding
+from . import config, ops, sharding
 from .helper_functions import datasets, logging, losses, ownutilities, parsing_file, targets
 from .helper_functions.config_paths import Conf
 
 EPS_BOX = 1e-7  # attack_PCFA.py:608
-REUSE_PAIR_GRAPHS = True  # pairs of one shape share static buffers + hipGraphs (PairAttack(reuse_graphs=None))
 
 
 def extract_deltas(nw_input1, nw_input2, image1, image2, boxconstraint, eps_box=0.):
@@ -132,8 +131,8 @@ class PairAttack:
     def __init__(self, model, image1, image2, flow, batch, eps_box, device, has_gt, optim_mu, args, use_graph=None,
                  reuse_graphs=None):
         self.model, self.args, self.device, self.batch = model, args, device, batch
-        if reuse_graphs is None:
-            reuse_graphs = REUSE_PAIR_GRAPHS
+        if reuse_graphs is None:   # pairs of one shape share static buffers + hipGraphs unless the model's config says no
+            reuse_graphs = config.cfg(model).reuse_pair_graphs
         self.has_gt, self.optim_mu, self.eps_box = has_gt, optim_mu, eps_box
         curr_step = batch * args.steps
 

@@ -117,16 +117,18 @@ def build_network(net, weights="pretrained", device=torch.device("cpu")):
 
 def import_and_load(net='RAFT', make_unit_input=False, variable_change=False, device=torch.device("cpu"),
                     make_scaled_input_model=False, **kwargs):
-    """Import a model and load weights for it (ownutilities.py:64-169)."""
+    """Import a model and load weights for it (ownutilities.py:64-169).  Extra keyword of this build: `config`, a frozen
+    pcfa_amd.config.Config (default: config.DEFAULT) attached to every sub-module -- the build switches of the network."""
+    from ..config import attach
     if make_unit_input or variable_change or make_scaled_input_model:
         from .own_models import ScaledInputModel
         model = ScaledInputModel(net, make_unit_input=make_unit_input, variable_change=variable_change,
                                  device=device, **kwargs)
         print("--> transforming model to 'make_unit_input'=%s, 'variable_change'=%s\n"
               % (str(make_unit_input), str(variable_change)))
-        return model
+        return attach(model, kwargs.get("config"))
     try:
-        model = build_network(net, weights=kwargs.get("weights", "pretrained"), device=device)
+        model = attach(build_network(net, weights=kwargs.get("weights", "pretrained"), device=device), kwargs.get("config"))
     except FileNotFoundError as e:
         print("\nLoading the model failed, because the checkpoint path was invalid. Are the checkpoints placed in "
               "%s? The full error that caused the loading failure is below:\n\n%s" % (Paths.config("weights"), e))

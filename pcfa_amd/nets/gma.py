@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..config import cfg
 from .raft import (BasicEncoder, BasicMotionEncoder, FlowHead, LookupRef, SepConvGRU, _mask_head, convex_upsample,
                    coords_grid, mask_logits)
 
@@ -58,7 +59,7 @@ class Attention(nn.Module):
                 and not getattr(self.args, "position_and_content", False)):
             # similarity product on the fp32 matrix cores, row softmax with one read + one write of the [N, N] matrix
             # (pcfa_gemm_f32 + pcfa_softmax_rows_*); scale applied to the product instead of to q (gma.py:59)
-            return o.attention_softmax(q.contiguous(), k.contiguous(), self.scale)
+            return o.attention_softmax(q.contiguous(), k.contiguous(), self.scale, gemm=cfg(self).gma_gemm)
         q = self.scale * q
         if getattr(self.args, "position_only", False):
             sim = self.pos_emb(q.reshape(b, heads, h, w, -1)).reshape(b, heads, h * w, h * w)
@@ -189,7 +190,8 @@ class RAFTGMA(nn.Module):
         hdim, cdim = self.hidden_dim, self.context_dim
 
         fmap1, fmap2 = self.fnet(images12, split=image1.shape[0])
-        corr_fn = ops.get().CorrBlock(fmap1.float(), fmap2.float(), num_levels=4, radius=self.args.corr_radius)
+        corr_fn = ops.get().CorrBlock(fmap1.float(), fmap2.float(), num_levels=4, radius=self.args.corr_radius,
+                                      bwd_windows=cfg(self).pyramid_bwd_windows)
 
         net, inp = torch.split(self.cnet(image1), [hdim, cdim], dim=1)
         net, inp = torch.tanh(net), torch.relu(inp)
@@ -206,7 +208,7 @@ class RAFTGMA(nn.Module):
         flow_predictions = []
         flow_up = None
         o = ops.get()   # the gradient of `attention` (used `iters` times) is formed once, by the last node that runs
-        attn_grad = o.AttnGradShare() if hasattr(o, "AttnGradShare") else _SharedAttnGrad()
+        attn_grad = o.AttnGradShare(cfg(self).gma_gemm) if hasattr(o, "AttnGradShare") else _SharedAttnGrad()
         flow_cur = coords1 - coords0
         for itr in range(iters):
             coords1 = coords1.detach()

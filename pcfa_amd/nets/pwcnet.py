@@ -15,12 +15,11 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..config import cfg
 
 
-DILATED_AS_SUBGRIDS = (2, 4, 8, 16)   # dilations run as d*d plain 3x3 convolutions on sub-sampled grids (() = library)
-CONV_S2 = True   # stride-2 pyramid layers on ops.conv_s2 (False: library convolution; tools/dev A/B)
-DECONV_FEWOUT = True   # deconv / upfeat layers and the final x4 upsampling on own kernels (False: library; A/B)
-DEFER_LEAKY = True   # LeakyReLU backward of single-consumer layers in the consumer's data-gradient epilogue (A/B, tests)
+# Build switches (sub-grid form of the dilated layers, own stride-2 / deconv kernels, deferred LeakyReLU masks ...) come
+# from the frozen pcfa_amd.config.Config the model was built with: cfg(module).<switch>.
 
 
 class _ConvLeaky(nn.Sequential):
@@ -45,10 +44,11 @@ class _ConvLeaky(nn.Sequential):
         if c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.out_channels >= 16:
             return "conv3x3"
         d = c.dilation[0]
-        if (DILATED_AS_SUBGRIDS and d in DILATED_AS_SUBGRIDS and c.stride == (1, 1) and c.dilation == (d, d)
+        conf = cfg(self)
+        if (conf.dilated_as_subgrids and d in conf.dilated_as_subgrids and c.stride == (1, 1) and c.dilation == (d, d)
                 and c.padding == (d, d) and c.out_channels >= 16 and x.shape[-2] % d == 0 and x.shape[-1] % d == 0):
             return "subgrid"
-        if (CONV_S2 and c.stride == (2, 2) and c.padding == (1, 1) and c.dilation == (1, 1)
+        if (conf.conv_s2 and c.stride == (2, 2) and c.padding == (1, 1) and c.dilation == (1, 1)
                 and ops.get().conv_s2_supported(x, c.weight)):
             return "s2"
         return None
@@ -65,7 +65,7 @@ class _ConvLeaky(nn.Sequential):
             # the pyramid's stride-2 layers (PWCNet.py:87-104): direct fp32-MFMA kernel, bias + LeakyReLU in the epilogue
             if mask_input_grad:
                 raise RuntimeError("conv_s2 does not apply an input mask")
-            return ops.get().conv_s2(x, c.weight, c.bias, leaky_slope=slope, **kw)
+            return ops.get().conv_s2(x, c.weight, c.bias, leaky_slope=slope, own_bwd=cfg(self).conv_s2_bwd, **kw)
         kw.update(mask_input_grad=mask_input_grad, input_slope=slope if mask_input_grad else 0.)
         if kind == "conv3x3":
             return ops.get().conv3x3(x, c.weight, c.bias, False, slope, **kw)
@@ -84,7 +84,7 @@ def _chain(layers, x, last_premasked=False):
     """x -> layers[0] -> layers[1] -> ...: every intermediate output has exactly one consumer, so its LeakyReLU backward is
     applied by that consumer's data-gradient kernel wherever both layers run on the operator table (and the consumer is
     a stride-1 convolution, whose kernel has the mask epilogue)."""
-    if not DEFER_LEAKY:
+    if not (layers and cfg(layers[0]).defer_leaky):
         for layer in layers:
             x = layer(x)
         return x
@@ -135,7 +135,7 @@ class _Deconv(nn.ConvTranspose2d):
     def forward(self, x):
         if (self.kernel_size == (4, 4) and self.stride == (2, 2) and self.padding == (1, 1)
                 and self.output_padding == (0, 0) and self.dilation == (1, 1) and self.groups == 1
-                and self.out_channels <= 4 and DECONV_FEWOUT
+                and self.out_channels <= 4 and cfg(self).deconv_fewout
                 and not (self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad))):
             return ops.get().deconv4s2_fewout(x, self.weight, self.bias)
         return super().forward(x)
@@ -197,7 +197,7 @@ class PWCDCNet(nn.Module):
     def warp(self, x, flo):
         """Backward-warp x by flo with a validity mask (PWCNet.py:166-206): one fused launch instead of the
         meshgrid / normalise / two grid_sample / compare / multiply sequence."""
-        return ops.get().pwc_warp(x, flo, 0.0001)
+        return ops.get().pwc_warp(x, flo, 0.0001, deterministic=cfg(self).warp_bwd_deterministic)
 
     def _cost_volume(self, f1, f2):
         """leakyRELU(corr(f1, f2)) (PWCNet.py:249,264,278,292,308) in one launch per direction."""
@@ -207,7 +207,8 @@ class PWCDCNet(nn.Module):
         blocks = [getattr(self, "conv%d_%d" % (lvl, i)) for i in range(5)]
         if x.shape[0] == 1 and not any(p.requires_grad for blk in blocks for p in blk.parameters()):
             # one pre-allocated buffer: every convolution reads its channel suffix in place and writes in front of it
-            return ops.get().dense_block(x, [(blk[0].weight, blk[0].bias) for blk in blocks], blocks[0][1].negative_slope)
+            return ops.get().dense_block(x, [(blk[0].weight, blk[0].bias) for blk in blocks], blocks[0][1].negative_slope,
+                                         fused_masks=cfg(self).dense_block_fused_masks)
         for blk in blocks:
             x = torch.cat((blk(x), x), 1)
         return x
@@ -248,7 +249,7 @@ class PWCDCNet(nn.Module):
         x = _chain([self.dc_conv1, self.dc_conv2, self.dc_conv3, self.dc_conv4, self.dc_conv5, self.dc_conv6], x)
         flow2 = flows[2] + self.dc_conv7(x)
 
-        if DECONV_FEWOUT and not self.training:
+        if cfg(self).deconv_fewout and not self.training:
             return ops.get().upsample_bilinear(flow2, 4, 20.0)   # 20 * self.upsample(flow2), gather backward
         flow2 = 20 * self.upsample(flow2)
         if self.training:

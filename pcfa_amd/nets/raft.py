@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..config import cfg
 
 
 def _norm(kind, planes):
@@ -57,17 +58,10 @@ def _fold_batchnorm(conv, bn, cache, tag):
     return hit[1], hit[2]
 
 
-# Opt-in (PCFA_OVERLAP_ENCODERS=1, read once): the context encoder on a second stream beside the feature encoder.
-# Measured 13.10 -> 12.95 ms per captured closure -- and one hard failure: with several closures captured in one process
-# (per-shape graph reuse, tests/test_gpu_parity.py::test_pair_graph_reuse_equals_fresh_capture) a replay of a two-branch
-# graph crashed inside hipGraphLaunch.  Off until that is understood; the single-stream capture is the product path.
-OVERLAP_ENCODERS = os.environ.get("PCFA_OVERLAP_ENCODERS", "0") == "1"
-CONV_S2 = True            # stride-2 layers on ops.conv_s2 (False: library convolution; tools/dev A/B)
-FUSED_DOWNSAMPLE = True   # conv1 + downsample[0] of a stride-2 residual block in one launch (tools/dev A/B: set False)
-_DEFER_RELU = os.environ.get("PCFA_DEFER_RELU", "1") != "0"   # A/B switch: ReLU backward fused into neighbouring kernels
-# Module-level switches, read from the environment ONCE at import (defaults for tools); code that needs another setting
-# assigns the attribute (bench.py, tests) -- nothing reads os.environ at call time.
-FUSED_LOOKUP = os.environ.get("PCFA_FUSED_LOOKUP", "1") == "1"   # lookup -> convc1 -> ReLU in one launch
+# Build switches (fused lookup, stride-2 kernels, deferred ReLU masks, two-stream encoders ...) come from the frozen
+# pcfa_amd.config.Config the model was built with: cfg(module).<switch>.  The two-stream encoders (overlap_encoders) stay
+# opt-in: measured 13.10 -> 12.95 ms per captured closure -- and one hard failure: with several closures captured in one
+# process a replay of a two-branch graph crashed inside hipGraphLaunch.
 
 
 def _conv_norm(conv, norm, x, relu, cache, tag, skip=False, grad_premasked=False, mask_input_grad=False):
@@ -86,8 +80,8 @@ def _conv_norm(conv, norm, x, relu, cache, tag, skip=False, grad_premasked=False
             return ops.get().conv3x3(x, w, b, relu, skip=skip, grad_premasked=grad_premasked,
                                      mask_input_grad=mask_input_grad)
         assert not (skip or grad_premasked or mask_input_grad)
-        if _is_stride2(conv, x):
-            return ops.get().conv_s2(x, w, b, relu)
+        if _is_stride2(conv, x, cfg(conv)):
+            return ops.get().conv_s2(x, w, b, relu, own_bwd=cfg(conv).conv_s2_bwd)
         if relu:
             return ops.get().bias_relu(conv._conv_forward(x, w, None), b)
         return conv._conv_forward(x, w, b)
@@ -97,9 +91,9 @@ def _conv_norm(conv, norm, x, relu, cache, tag, skip=False, grad_premasked=False
             y = ops.get().conv3x3(x, conv.weight, None, False, skip=skip)
             if skip:
                 y, xs = y
-        elif _is_stride2(conv, x):
+        elif _is_stride2(conv, x, cfg(conv)):
             assert not skip
-            y = ops.get().conv_s2(x, conv.weight, None, False)
+            y = ops.get().conv_s2(x, conv.weight, None, False, own_bwd=cfg(conv).conv_s2_bwd)
         else:
             assert not skip
             y = conv._conv_forward(x, conv.weight, None)
@@ -111,10 +105,10 @@ def _conv_norm(conv, norm, x, relu, cache, tag, skip=False, grad_premasked=False
     return F.relu(y, inplace=True) if relu else y
 
 
-def _is_stride2(conv, x):
+def _is_stride2(conv, x, conf):
     """A frozen k x k / stride-2 / padding k//2 convolution ops.conv_s2 covers (the stem, the residual blocks' entry)."""
     k = conv.kernel_size[0]
-    return (CONV_S2 and conv.kernel_size == (k, k) and conv.stride == (2, 2) and conv.padding == (k // 2, k // 2)
+    return (conf.conv_s2 and conv.kernel_size == (k, k) and conv.stride == (2, 2) and conv.padding == (k // 2, k // 2)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
             and ops.get().conv_s2_supported(x, conv.weight))
 
@@ -150,8 +144,8 @@ class ResidualBlock(nn.Module):
         (ops.conv_s2_ds), or None when the fast path does not apply."""
         conv1, convd, n1, nd = self.conv1, self.downsample[0], self.norm1, self.downsample[1]
         o = ops.get()
-        if not (FUSED_DOWNSAMPLE and _all_frozen(self) and conv1.stride == (2, 2) and convd.stride == (2, 2)
-                and convd.kernel_size == (1, 1) and convd.padding == (0, 0) and _is_stride2(conv1, x)
+        if not (cfg(self).fused_downsample and _all_frozen(self) and conv1.stride == (2, 2) and convd.stride == (2, 2)
+                and convd.kernel_size == (1, 1) and convd.padding == (0, 0) and _is_stride2(conv1, x, cfg(self))
                 and o.conv_s2_ds_supported(x, conv1.weight, convd.weight)):
             return None
         if all(isinstance(n, nn.BatchNorm2d) and not n.training and n.track_running_stats for n in (n1, nd)):
@@ -175,13 +169,13 @@ class ResidualBlock(nn.Module):
             # the block input feeds conv1 and the residual sum: conv1's data-gradient kernel adds the residual path's
             # gradient in its epilogue (one autograd `add` over the activation less per block)
             y, x = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1", skip=True,
-                              grad_premasked=_DEFER_RELU and isinstance(self.norm1, nn.BatchNorm2d) and isinstance(self.norm2, nn.BatchNorm2d)
+                              grad_premasked=cfg(self).defer_relu and isinstance(self.norm1, nn.BatchNorm2d) and isinstance(self.norm2, nn.BatchNorm2d)
                               and _can_skip(self.conv2, self.norm2))
         else:
             y = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1")
         # folded-BatchNorm blocks (context encoder) are conv + ReLU chains: conv2's data-gradient kernel applies conv1's
         # ReLU mask, and the block's output ReLU backward masks conv2's gradient in the same pass (2 launches less)
-        chain = (_DEFER_RELU and _all_frozen(self) and isinstance(self.norm2, nn.BatchNorm2d) and _can_skip(self.conv2, self.norm2)
+        chain = (cfg(self).defer_relu and _all_frozen(self) and isinstance(self.norm2, nn.BatchNorm2d) and _can_skip(self.conv2, self.norm2)
                  and _can_skip(self.conv1, self.norm1) and self.downsample is None)
         y = _conv_norm(self.conv2, self.norm2, y, True, self._fold_cache, "2", grad_premasked=chain, mask_input_grad=chain)
         if self.downsample is not None:
@@ -388,7 +382,7 @@ class LookupRef:
 
     def conv_relu(self, conv):
         fused = getattr(self.corr_fn, "lookup_conv_relu", None)
-        if fused is not None and _frozen_conv(conv) and FUSED_LOOKUP:
+        if fused is not None and _frozen_conv(conv) and cfg(conv).fused_lookup:
             out = fused(self.coords, conv.weight, conv.bias, True)
             if out is not None:
                 return out
@@ -464,7 +458,7 @@ class BasicUpdateBlock(nn.Module):
 
     def forward(self, net, inp, corr, flow, want_mask=True, gru_ctx=None):
         # frozen weights: the GRU node is the motion features' only consumer and differentiates their ReLU itself
-        defer = _DEFER_RELU and gru_ctx is not None and self.encoder.can_defer_relu(flow)
+        defer = cfg(self).defer_relu and gru_ctx is not None and self.encoder.can_defer_relu(flow)
         motion_features = self.encoder(flow, corr, defer_relu=defer)
         if gru_ctx is not None:   # frozen weights: context-feature part of the gate convolutions hoisted
             net = self.gru.step(net, gru_ctx, motion_features, self.encoder.RELU_CHANNELS if defer else 0)
@@ -513,7 +507,7 @@ class RAFT(nn.Module):
         hdim, cdim = self.hidden_dim, self.context_dim
 
         side = None
-        if OVERLAP_ENCODERS and image1.is_cuda and hasattr(ops.get(), "side_stream"):
+        if cfg(self).overlap_encoders and image1.is_cuda and hasattr(ops.get(), "side_stream"):
             # the context encoder (one image) runs beside the feature encoder (two images): independent until the GRU,
             # and their small-map layers each leave most of the chip idle.  A second stream forks here and joins below;
             # under capture it becomes a parallel branch of the hipGraph, autograd runs each branch's backward on its
@@ -525,7 +519,7 @@ class RAFT(nn.Module):
                 cnet_out = self.cnet(image1)
         fmap1, fmap2 = self.fnet(images12, split=image1.shape[0])
         corr_fn = ops.get().CorrBlock(fmap1.float(), fmap2.float(), num_levels=self.args["corr_levels"],
-                                      radius=self.args["corr_radius"])
+                                      radius=self.args["corr_radius"], bwd_windows=cfg(self).pyramid_bwd_windows)
         if side is not None:
             main.wait_stream(side)
         else:

@@ -1,0 +1,141 @@
+"""Plumbing shared by every operator module: launches through the C-ABI on torch's current stream (no CPU fallback),
+the optional per-launch timers and the work recorder that bench.py's roofline rows read."""
+import ctypes
+
+import torch
+
+from .. import _hip
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "pcfa_amd HIP operator called with a %s tensor: the MI355X path has no CPU fallback"
+                % t.device)
+        if t.dtype != torch.float32:
+            raise TypeError("pcfa_amd kernels compute in float32, got %s" % t.dtype)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _ptr_off(t, offset_floats):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr() + 4 * offset_floats)
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+_profiler = None
+_dispatch_timer = None
+
+
+def set_launch_profiler(profiler):
+    global _profiler
+    _profiler = profiler
+
+
+def set_dispatch_timer(timer):
+    global _dispatch_timer
+    _dispatch_timer = timer
+
+
+# ---- work accounting for the roofline rows of bench.py (off unless a recorder is set) -----------------------------------
+# family -> [direct-form flop (or algorithmic bytes), flop the matrix cores actually issue, calls]; the arithmetic of a
+# Winograd kernel is its direct-form flop divided by the transform's saving: F(2x2,3x3) 36 / 16, F(4x4,3x3) 144 / 36,
+# F(2,5) 10 / 6.
+_work = None
+
+
+def set_work_recorder(rec):
+    """rec: a dict that _call fills per kernel family while set (None: off)."""
+    global _work
+    _work = rec
+
+
+def _note_work(family, direct, issued):
+    e = _work.setdefault(family, [0.0, 0.0, 0])
+    e[0] += direct
+    e[1] += issued
+    e[2] += 1
+
+
+def _conv3x3_work(B, K, N, H, W):
+    direct = 2.0 * 9 * K * N * B * H * W
+    if _hip.load().pcfa_conv3x3_algo(B, K, N, H, W) == 43:
+        _note_work("conv3x3_f43", direct, direct / 4.0)
+    else:
+        _note_work("conv3x3_winograd", direct, direct / 2.25)
+
+
+def _sepconv5_work(B, Ca, Cb, Cout, H, W, vertical):
+    direct = 2.0 * 5 * (Ca + Cb) * Cout * B * H * W
+    if _hip.load().pcfa_sepconv5_uses_winograd(B, Ca, Cb, Cout, H, W, int(vertical)):
+        _note_work("sepconv5_winograd", direct, direct * 0.6)
+    else:
+        _note_work("sepconv5_direct", direct, direct)
+
+
+_WORK_TABLE = {   # entry point -> accounting of its positional arguments (the order of include/pcfa_hip.h)
+    "pcfa_conv3x3_run": lambda a: _conv3x3_work(a[6], a[7], a[8], a[9], a[10]),
+    "pcfa_conv3x3_act_fwd_pair": lambda a: (_conv3x3_work(1, a[4], a[5], a[12], a[13]),
+                                            _conv3x3_work(1, a[10], a[11], a[12], a[13])),
+    "pcfa_sepconv5_fwd": lambda a: _sepconv5_work(a[6], a[1], a[3], a[7], a[8], a[9], a[10]),
+    "pcfa_sepconv5_fwd_split": lambda a: _sepconv5_work(a[10], a[1], a[3], a[11], a[12], a[13], a[14]),
+    "pcfa_sepconv5_fwd_split_masked": lambda a: _sepconv5_work(a[12], a[1], a[3], a[13], a[14], a[15], a[16]),
+    "pcfa_sepconv5_gru_gates_fwd": lambda a: _sepconv5_work(a[9], a[1], a[3], 2 * a[1], a[10], a[11], a[12]),
+    "pcfa_sepconv5_gru_update_fwd": lambda a: _sepconv5_work(a[10], a[1], a[3], a[1], a[11], a[12], a[13]),
+    "pcfa_sepconv5_gru_gates_bwd": lambda a: _sepconv5_work(a[13], a[1], 0, a[1] + a[2], a[14], a[15], a[16]),
+    "pcfa_sepconv5_gru_update_bwd": lambda a: _sepconv5_work(a[12], 2 * a[1], 0, a[1] + a[2], a[13], a[14], a[15]),
+    # instance norm: algorithmic traffic = x in + y out (forward), x + grad_out in + grad_x out (backward)
+    "pcfa_instnorm_fwd": lambda a: _note_work("instnorm_fwd", 2.0 * a[4] * a[5] * 4, 0.0),
+    "pcfa_instnorm_bwd": lambda a: _note_work("instnorm_bwd", 3.0 * a[5] * a[6] * 4, 0.0),
+    # streams: input once + the small output (flow-prediction convolutions), elementwise passes
+    "pcfa_conv3x3_fewout_fwd": lambda a: _note_work("conv3x3_fewout_fwd", 4.0 * a[5] * (a[6] + a[7]) * a[8] * a[9], 0.0),
+    "pcfa_conv3x3_fewout_bwd": lambda a: _note_work("conv3x3_fewout_bwd", 4.0 * a[3] * (a[4] + a[5]) * a[6] * a[7], 0.0),
+    "pcfa_relu_bwd": lambda a: _note_work("relu_bwd", 12.0 * a[3], 0.0),
+    "pcfa_relu_bwd2": lambda a: _note_work("relu_bwd2", 20.0 * a[5], 0.0),
+    "pcfa_add_relu_fwd": lambda a: _note_work("add_relu_fwd", 12.0 * a[3], 0.0),
+    "pcfa_conv_fewin_packed_fwd": lambda a: _note_work("conv_fewin_fwd", *(2 * [2.0 * a[5] * a[9] * a[9] * a[6] * a[4] * a[7] * a[8]])),
+}
+
+
+def _call(name, *args):
+    """Invoke C-ABI entry point `name` on torch's current stream and raise on a non-zero status."""
+    fn = getattr(_hip.load(), name)
+    if _work is not None and name in _WORK_TABLE:
+        _WORK_TABLE[name](args)
+    prof = _profiler
+    timer = _dispatch_timer
+    if timer is not None and name in timer.plan:
+        lib = _hip.load()
+        for label, nth in timer.plan[name]:
+            e0, e1 = timer.new_pair(label)
+            _hip.check(lib.pcfa_timing_arm(e0, e1, nth), "pcfa_timing_arm")
+        try:
+            status = fn(*args, _stream())
+        finally:
+            lib.pcfa_timing_arm(None, None, -1)  # drop pairs the entry point did not reach
+    elif prof is not None and prof.wants(name):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        status = fn(*args, _stream())
+        e.record()
+        prof.events.setdefault(name, []).append((s, e))
+    else:
+        status = fn(*args, _stream())
+    _hip.check(status, name)
+
+
+def work_recorder():
+    """The dict set_work_recorder() installed, or None."""
+    return _work

@@ -15,14 +15,14 @@ def test_images(seed, h, w):
     return i1.round().clamp(0, 255)[None], i2.round().clamp(0, 255)[None]
 
 
-def load_model(net, variable_change, device, eps_box=1e-7):
-    key = (net, variable_change, str(device))
+def load_model(net, variable_change, device, eps_box=1e-7, config=None):
+    key = (net, variable_change, str(device), config)
     if key not in _MODELS:
         unit = ownutilities.model_takes_unit_input(net)
         kw = {"eps_box": eps_box} if variable_change else {}
         m = ownutilities.import_and_load(net, make_unit_input=not unit, variable_change=variable_change,
                                          make_scaled_input_model=True, device=device,
-                                         weights="random:%d" % WEIGHT_SEED, **kw)
+                                         weights="random:%d" % WEIGHT_SEED, config=config, **kw)
         m.eval()
         for p in m.parameters():
             p.requires_grad = False
@@ -30,10 +30,11 @@ def load_model(net, variable_change, device, eps_box=1e-7):
     return _MODELS[key]
 
 
-def run_closure(net, h, w, boxconstraint, joint, target_name, loss_name, seed, device, images=None, leaves=None):
+def run_closure(net, h, w, boxconstraint, joint, target_name, loss_name, seed, device, images=None, leaves=None,
+                config=None):
     cov = boxconstraint == "change_of_variables"
     eps = 1e-7
-    model = load_model(net, cov, device, eps)
+    model = load_model(net, cov, device, eps, config)
     im1, im2 = images if images is not None else test_images(seed, h, w)
     a, b = im1.clone().float().to(device), im2.clone().float().to(device)
     if not ownutilities.model_takes_unit_input(net):

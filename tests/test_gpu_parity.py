@@ -121,19 +121,15 @@ def test_pyramid_backward_windows_matches_dense(case):
     gos = [torch.randn(B, 324, H, W, generator=gen).to(DEV) for _ in range(n)]
 
     def run(windows):
-        hip_ops.PYRAMID_BWD_WINDOWS = windows
-        try:
-            a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
-            blk = hip_ops.CorrBlock(a, b)
-            loss = 0.
-            for i, (c, g) in enumerate(zip(coords, gos)):
-                out = blk(c)
-                if not (case == "wild" and i == 2):      # this lookup's backward never runs
-                    loss = loss + (out * g).sum()
-            loss.backward()
-            return a.grad, b.grad
-        finally:
-            hip_ops.PYRAMID_BWD_WINDOWS = True
+        a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+        blk = hip_ops.CorrBlock(a, b, bwd_windows=windows)   # Config.pyramid_bwd_windows, as the networks pass it
+        loss = 0.
+        for i, (c, g) in enumerate(zip(coords, gos)):
+            out = blk(c)
+            if not (case == "wild" and i == 2):      # this lookup's backward never runs
+                loss = loss + (out * g).sum()
+        loss.backward()
+        return a.grad, b.grad
 
     (a1, b1), (a0, b0) = run(True), run(False)
     assert float(a0.abs().max()) > 0 and float(b0.abs().max()) > 0
@@ -291,11 +287,11 @@ def test_lookup_convc1_fused_vs_unfused_and_oracle(oracle_ops, shape):
 
 
 @pytest.mark.parametrize("gemm", ["lib", "hip"])
-def test_gma_attention_ops_vs_torch(gemm, monkeypatch):
+def test_gma_attention_ops_vs_torch(gemm):
     """SURVEY 8f row f1 (models/gma/gma.py:34-77 Attention, :79-115 Aggregate): similarity product + row softmax and
     the attention-times-value products on the hand-written fp32 MFMA GEMM, against torch in float64.
     N = 1000 (not a multiple of 128: ragged tiles, rows held in registers) and 2 heads."""
-    monkeypatch.setattr(hip_ops, "GMA_GEMM", gemm)   # plain products on rocBLAS (default) or on pcfa_gemm_f32
+    # gemm (Config.gma_gemm): plain products on rocBLAS (default) or on pcfa_gemm_f32
     gen = torch.Generator().manual_seed(3)
     h, n, d = 2, 1000, 128
     q = torch.randn(1, h, n, d, generator=gen).to(DEV).requires_grad_(True)
@@ -303,8 +299,8 @@ def test_gma_attention_ops_vs_torch(gemm, monkeypatch):
     vs = [torch.randn(1, h, n, d, generator=gen).to(DEV).requires_grad_(True) for _ in range(3)]
     gos = [torch.randn(1, h, n, d, generator=gen).to(DEV) for _ in range(3)]
     scale = d ** -0.5
-    attn = hip_ops.attention_softmax(q, k, scale)
-    share = hip_ops.AttnGradShare()
+    attn = hip_ops.attention_softmax(q, k, scale, gemm=gemm)
+    share = hip_ops.AttnGradShare(gemm)
     outs = [hip_ops.attn_times_value(attn, v, share) for v in vs]
     sum((o * g).sum() for o, g in zip(outs, gos)).backward()
     qd, kd = q.detach().double().requires_grad_(True), k.detach().double().requires_grad_(True)
@@ -547,10 +543,12 @@ def test_conv3x3_skip_gradient_sums_in_the_epilogue(shape):
         assert torch.equal(ya, yb) and torch.equal(ga, gb)
 
 
-def test_context_encoder_block_deferred_masks_change_no_bit(monkeypatch):
+def test_context_encoder_block_deferred_masks_change_no_bit():
     """A folded-BatchNorm ResidualBlock (context encoder, extractor.py:23-58) with its three ReLU backward passes riding in
     neighbouring kernels (pcfa_conv3x3_fused_bwd mask + addend, pcfa_relu_bwd2) against one launch per ReLU and autograd's
     own residual add: masks multiply by exactly 0 or 1 and the residual sum is one fp32 add either way: bit-identical."""
+    import dataclasses
+    from pcfa_amd import config
     from pcfa_amd.nets import raft as raft_mod
     torch.manual_seed(5)
     blk = raft_mod.ResidualBlock(64, 64, norm_fn="batch", stride=1).to(DEV).eval()
@@ -563,7 +561,7 @@ def test_context_encoder_block_deferred_masks_change_no_bit(monkeypatch):
     go = torch.randn(1, 64, 40, 48, device=DEV)
 
     def run(defer):
-        monkeypatch.setattr(raft_mod, "_DEFER_RELU", defer)
+        config.attach(blk, dataclasses.replace(config.DEFAULT, defer_relu=defer))   # as import_and_load(config=...) does
         x = x0.clone().requires_grad_(True)
         out = blk(x)   # the package's operator table is hip_ops
         (gx,) = torch.autograd.grad((out * go).sum(), x)
@@ -682,13 +680,9 @@ def test_pwc_warp_vs_oracle(oracle_ops, shape, scale):
         xg.grad = fg.grad = None
         hip_ops.pwc_warp(xg, fg).backward(go.to(DEV))
         assert torch.equal(xg.grad, g1x) and torch.equal(fg.grad, g1f)
-    hip_ops.WARP_BWD_DETERMINISTIC = False
-    try:
-        xg.grad = fg.grad = None
-        hip_ops.pwc_warp(xg, fg).backward(go.to(DEV))
-        assert rel_l2(xg.grad, g1x) < 1e-6 and rel_l2(fg.grad, g1f) < 1e-6
-    finally:
-        hip_ops.WARP_BWD_DETERMINISTIC = True
+    xg.grad = fg.grad = None
+    hip_ops.pwc_warp(xg, fg, deterministic=False).backward(go.to(DEV))   # Config.warp_bwd_deterministic = False
+    assert rel_l2(xg.grad, g1x) < 1e-6 and rel_l2(fg.grad, g1f) < 1e-6
     # the fixed point is scaled per call, so gradients of any absolute size keep fp32's resolution -- the
     # AEE / npix-scaled gradients of the deep PWC levels (1e-9) and huge ones alike (an absolute 2^-40 unit flushed
     # addends below 4.5e-13 and overflowed above 8.4e6)
@@ -1986,21 +1980,20 @@ def test_conv_workspace_never_frees_a_captured_buffer():
 def test_pwcnet_deferred_leaky_masks_change_no_bit():
     """PWC-Net closure (PWCNet.py:227-330) with the LeakyReLU backward of single-consumer layers applied in the
     consumer's data-gradient epilogue (pyramid chains conv_a -> conv_aa -> conv_b, context network dc_conv1..6:
-    nets/pwcnet._chain; dense decoder blocks: hip_ops.DENSE_BLOCK_FUSED_MASKS -- 40 elementwise launches less per
+    nets/pwcnet._chain; dense decoder blocks: Config.dense_block_fused_masks -- 40 elementwise launches less per
     closure) against one pcfa_leaky_relu_bwd launch per layer: the same products in the same order, so loss, flow and
     gradient must be bit-identical."""
-    from pcfa_amd.nets import pwcnet
+    import dataclasses
+    from pcfa_amd import config
     dev = torch.device(DEV)
 
-    def run():
-        r = closure_util.run_closure("PWCNet", 192, 256, "clipping", True, "zero", "aee", seed=5, device=dev)
+    def run(conf):
+        closure_util._MODELS.clear()
+        r = closure_util.run_closure("PWCNet", 192, 256, "clipping", True, "zero", "aee", seed=5, device=dev, config=conf)
+        closure_util._MODELS.clear()
         return r["loss"], r["flow"].clone(), r["grads"][0].clone()
 
-    fused = run()
-    pwcnet.DEFER_LEAKY, hip_ops.DENSE_BLOCK_FUSED_MASKS = False, False
-    try:
-        plain = run()
-    finally:
-        pwcnet.DEFER_LEAKY, hip_ops.DENSE_BLOCK_FUSED_MASKS = True, True
+    fused = run(config.DEFAULT)
+    plain = run(dataclasses.replace(config.DEFAULT, defer_leaky=False, dense_block_fused_masks=False))
     assert fused[0] == plain[0] and torch.equal(fused[1], plain[1]) and torch.equal(fused[2], plain[2])
     assert float(fused[2].abs().max()) > 0

@@ -19,9 +19,8 @@ for shape, scale in (((1, 32, 96, 320), 6.0), ((1, 64, 48, 160), 3.0), ((1, 96, 
     for kind in ("smooth", "noisy"):
         f = scale * torch.randn(B, 2, 1, 1, generator=g).expand(B, 2, H, W) if kind == "smooth" else scale * torch.randn(B, 2, H, W, generator=g)
         flo = f.contiguous().to(dev).requires_grad_(True)
-        out = hip_ops.pwc_warp(x, flo)
         for det in (False, True):
-            hip_ops.WARP_BWD_DETERMINISTIC = det
+            out = hip_ops.pwc_warp(x, flo, deterministic=det)
             t, parts = device_us(lambda: torch.autograd.grad(out, (x, flo), go, retain_graph=True))
             print("%-18s %-6s %s  %7.1f us   %s" % (shape, kind, "fixed-point" if det else "fp32 atomics", t,
                                                    "  ".join("%s %.1f" % (k.split("(")[0][-28:], v) for k, v in parts.items())))

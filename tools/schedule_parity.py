@@ -27,7 +27,7 @@ FLOORS = {"aee_adv_tgt_min": 1e-3, "aee_adv_init_at_min": 1e-3, "l2_delta_min": 
 
 
 def run(net, h, w, steps, device, threads=None, progress=None, box="change_of_variables", joint=False, target="zero",
-        seed=0):
+        seed=0, config=None):
     from pcfa_amd import ops
     t0 = time.perf_counter()
     if device.type == "cpu":
@@ -44,7 +44,7 @@ def run(net, h, w, steps, device, threads=None, progress=None, box="change_of_va
             res = st.result()
     else:
         st = bench.AttackStepper(net, h, w, device, seed=seed, use_graph=True, boxconstraint=box, joint=joint,
-                                 target=target)
+                                 target=target, config=config)
         hist = [st.step() for _ in range(steps)]
         res = st.result()
     return {"per_step": [dict(zip(("aee_adv_tgt", "aee_adv_init", "l2_delta"), s)) for s in hist],
