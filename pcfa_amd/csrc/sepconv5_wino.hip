@@ -23,6 +23,13 @@
 #include <cstdlib>
 #include "sepconv5.hpp"
 
+// Timing-only ablation builds (tools/dev/sc5w_ablate.sh; results are WRONG with any bit set): PCFA_SC5W_DBG bit 1 = no
+// barrier in the K loop, 2 = no input transform (V = d), 4 = no LDS operand reads, 8 = no weight loads after the first
+// chunk, 16 = no patch loads / LDS stores after the first chunk.
+#ifndef PCFA_SC5W_DBG
+#define PCFA_SC5W_DBG 0
+#endif
+
 namespace {
 using namespace pcfa_sc5;
 
@@ -206,14 +213,17 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
   auto item = [&](int chunk, const float (&wcur)[STEPS], float (&wnext)[STEPS], f32x4 (&rload)[NLOAD],
                   const f32x4 (&rstore)[NLOAD]) {
     const float* sp = smem + (chunk & 1) * PATCH + bl;
-    load_patch(min(chunk + 2, nchunk - 1), rload);
+    if (!(PCFA_SC5W_DBG & 16)) load_patch(min(chunk + 2, nchunk - 1), rload);
     const float* qn = pw + (long long)(KS * min(chunk + 1, nchunk - 1) + grp) * STEPS * 64;
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) wnext[s] = qn[s * 64 + lane];
+    for (int s = 0; s < STEPS; ++s) wnext[s] = (PCFA_SC5W_DBG & 8) ? wcur[s] : qn[s * 64 + lane];
     __builtin_amdgcn_sched_barrier(0);
     float d[2][6];
     auto rd = [&](int p, float (&dd)[6]) {
-      if (VERT) {
+      if (PCFA_SC5W_DBG & 4) {
+#pragma unroll
+        for (int h = 0; h < 6; ++h) dd[h] = wcur[6 * p + h] + (float)h;
+      } else if (VERT) {
 #pragma unroll
         for (int h = 0; h < 6; ++h) dd[h] = sp[2 * p * CHS + 64 * h];
       } else {
@@ -230,12 +240,13 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
     for (int p = 0; p < CK / 2; ++p) {
       if (p + 1 < CK / 2) rd(p + 1, d[(p + 1) & 1]);
       const float d0 = d[p & 1][0], d1 = d[p & 1][1], d2 = d[p & 1][2], d3 = d[p & 1][3], d4 = d[p & 1][4], d5 = d[p & 1][5];
-      const float v0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+      float v0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
       const float a1 = fmaf(-4.f, d2, d4), b1 = fmaf(-4.f, d1, d3);
-      const float v1 = a1 + b1, v2 = a1 - b1;
+      float v1 = a1 + b1, v2 = a1 - b1;
       const float a2 = d4 - d2, b2 = 2.f * (d3 - d1);
-      const float v3 = a2 + b2, v4 = a2 - b2;
-      const float v5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+      float v3 = a2 + b2, v4 = a2 - b2;
+      float v5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+      if (PCFA_SC5W_DBG & 2) { v0 = d0; v1 = d1; v2 = d2; v3 = d3; v4 = d4; v5 = d5; }
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 0], v0, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 1], v1, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 2], v2, acc[2], 0, 0, 0);
@@ -244,8 +255,8 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
       acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 5], v5, acc[5], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    store_patch((chunk + 1) & 1, rstore);
-    __syncthreads();
+    if (!(PCFA_SC5W_DBG & 16)) store_patch((chunk + 1) & 1, rstore);
+    if (!(PCFA_SC5W_DBG & 1)) __syncthreads();
   };
   for (int chunk = 0; chunk < nchunk; chunk += 2) {   // host: nchunk even
     item(chunk, wa, wb, ra, rb);
