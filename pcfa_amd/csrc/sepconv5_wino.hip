@@ -49,7 +49,10 @@ __device__ __forceinline__ const float* wino_plane(const Operand& in, int ci, lo
   return ci < in.Ca ? in.a + ci * plane : in.b + (ci - in.Ca) * plane;
 }
 
-// U[nb][chunk][s = 6 p + i][lane] = (G w)_i [n = 32 nb + (lane & 31)] [c = 8 chunk + 2 p + (lane >> 5)]
+// U[nb][chunk][s / 4][lane][s % 4] = (G w)_i [n = 32 nb + (lane & 31)] [c = 8 chunk + 2 p + (lane >> 5)],  s = 6 p + i:
+// a wave fetches the 24 operands of a chunk with six fully coalesced 16-B-per-lane loads (24 dword loads kept the
+// texture-address path as busy as the matrix pipe: a wave-wide load costs ~16 cycles of address processing whatever its
+// width -- 8 waves x 24 x 16 = 3072 cycles per chunk against 3072 cycles of MFMA).
 //   transpose = 0: w'[n][c][t] = w[n][c][t]         (forward: N = Cout, C = Cin of the Conv2d weight [N][C][5])
 //   transpose = 1: w'[n][c][t] = w[c][n][4 - t]     (data gradient: N = Cin, C = Cout of the weight [C][N][5])
 __global__ void sc5_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ P, int N, int C, int transpose,
@@ -62,7 +65,7 @@ __global__ void sc5_wino_pack_kernel(const float* __restrict__ w, float* __restr
                           {0., 0., 0., 0., 1.}};
   const int nchunk = C / CK;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int lane = (int)(e & 63), s = (int)((e >> 6) % STEPS);
+    const int lane = (int)((e >> 2) & 63), s = 4 * (int)((e >> 8) % (STEPS / 4)) + (int)(e & 3);
     const long long blk = (e >> 6) / STEPS;
     const int chunk = (int)(blk % nchunk), nb = (int)(blk / nchunk);
     const int n = 32 * nb + (lane & 31), c = chunk * CK + 2 * (s / 6) + (lane >> 5), i = s % 6;
@@ -141,8 +144,18 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
   f32x4 ra[NLOAD], rb[NLOAD];
   float wa[STEPS], wb[STEPS];
   load_patch(0, ra);
+  auto load_w = [&](int chunk_global, float (&w)[STEPS]) {
+    const f32x4* q4 = reinterpret_cast<const f32x4*>(pw + (long long)chunk_global * STEPS * 64);
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) wa[s] = pw[((long long)grp * STEPS + s) * 64 + lane];
+    for (int sq = 0; sq < STEPS / 4; ++sq) {
+      const f32x4 t = q4[sq * 64 + lane];
+      w[4 * sq] = t.x;
+      w[4 * sq + 1] = t.y;
+      w[4 * sq + 2] = t.z;
+      w[4 * sq + 3] = t.w;
+    }
+  };
+  load_w(grp, wa);
 
   // ---- this lane's two output pixels and the rows of the accumulator tile its group finalises ----------------------
   const int mw = 32 * nb;                       // first output channel of the wave
@@ -214,9 +227,12 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
                   const f32x4 (&rstore)[NLOAD]) {
     const float* sp = smem + (chunk & 1) * PATCH + bl;
     if (!(PCFA_SC5W_DBG & 16)) load_patch(min(chunk + 2, nchunk - 1), rload);
-    const float* qn = pw + (long long)(KS * min(chunk + 1, nchunk - 1) + grp) * STEPS * 64;
+    if (PCFA_SC5W_DBG & 8) {
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) wnext[s] = (PCFA_SC5W_DBG & 8) ? wcur[s] : qn[s * 64 + lane];
+      for (int s = 0; s < STEPS; ++s) wnext[s] = wcur[s];
+    } else {
+      load_w(KS * min(chunk + 1, nchunk - 1) + grp, wnext);
+    }
     __builtin_amdgcn_sched_barrier(0);
     float d[2][6];
     auto rd = [&](int p, float (&dd)[6]) {
