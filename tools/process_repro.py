@@ -75,7 +75,12 @@ def child(a):
     recording = [False]
     result = {"pairs": []}
     with ops.override_for_testing(Recorder()):
-        model = bench.load_model(a.net, dev, a.box == "change_of_variables")
+        conf = None
+        if a.library_deconv:   # the r03 state: PWC-Net's transposed convolutions and x4 up-sampling in the library
+            import dataclasses
+            from pcfa_amd import config
+            conf = dataclasses.replace(config.DEFAULT, deconv_fewout=False)
+        model = bench.load_model(a.net, dev, a.box == "change_of_variables", conf)
         hooks = []
         for name, mod in model.named_modules():
             if not list(mod.children()):
@@ -164,6 +169,9 @@ def main():
     ap.add_argument("--procs", type=int, default=2)
     ap.add_argument("--seeds", default="0")
     ap.add_argument("--out", default="")
+    ap.add_argument("--library-deconv", action="store_true",
+                    help="Config(deconv_fewout=False): PWC-Net's deconv / upfeat layers and the x4 up-sampling in the library "
+                         "(what r03 shipped) -- shows what the probe reports for a process-unstable path")
     ap.add_argument("--child", action="store_true")
     a = ap.parse_args()
     a.seeds = [int(v) for v in str(a.seeds).split(",")]
@@ -173,7 +181,8 @@ def main():
     runs = []
     for k in range(a.procs):
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--net", a.net, "--size", a.size, "--box", a.box,
-               "--steps", str(a.steps), "--seeds", ",".join(str(s) for s in a.seeds)] + (["--joint"] if a.joint else [])
+               "--steps", str(a.steps), "--seeds", ",".join(str(s) for s in a.seeds)] + (["--joint"] if a.joint else []) + \
+              (["--library-deconv"] if a.library_deconv else [])
         p = subprocess.run(cmd, capture_output=True, text=True)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("PROCESS_REPRO ")]
         if p.returncode != 0 or not line:
