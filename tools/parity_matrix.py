@@ -9,7 +9,7 @@ then holds
     delta           = GPU - port@16 for AEE(adv, target) / AEE(adv, init) at the best iterate and ||delta|| there,
     port_spread     = |port@16 - port@8|  (the reference's own noise floor),
     inside          = |delta| <= max(floor, 3 x port_spread)   (floor 1e-3 AEE, 1e-5 for ||delta||),
-    first_step_divergence = the first step whose AEE(adv, target) differs by more than 0.1 between GPU and port@16 -- where
+    first_step_divergence = the first step whose AEE(adv, target) differs by more than max(0.1, 2 %) between GPU and port@16 -- where
                       the two trajectories leave each other (a shifted overshoot cycle shows as > 1; legs on one branch stay
                       within 0.04 even on overshoot steps).  Also recorded: the first closure evaluation whose loss differs by
                       more than 1e-3 relative (early, at the first overshoot point, for every pair of legs),
@@ -183,7 +183,7 @@ def first_step_divergence(sa, sb, thr=STEP_DIVERGENCE_AEE):
     included) sit 0.01-0.04 apart while sharing a branch, and a branch change (the overshoot cycle shifted by one step)
     shows as > 1 -- any threshold between 0.05 and 1 separates the two."""
     for k, (x, y) in enumerate(zip(sa, sb)):
-        if abs(x[0] - y[0]) > thr:
+        if abs(x[0] - y[0]) > max(thr, 0.02 * abs(y[0])):   # PWC-Net's AEE is 30-50: legs on one branch sit 0.05-0.3 apart
             return {"step": k, "aee_adv_tgt_a": x[0], "aee_adv_tgt_b": y[0]}
     return None
 
