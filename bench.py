@@ -779,6 +779,7 @@ def main():
     if use_graph:
         st.enable_graph()   # what pcfa_attack does per pair: 2 warm-up closures + capture, 1 warm-up + capture forward
         torch.cuda.synchronize()
+    graph_active = st.graphed is not None   # False after a failed capture: PairAttack logs it and launches eagerly
     setup_graph = time.perf_counter() - t0
     for _ in range(a.warmup):
         st.step()
@@ -857,7 +858,8 @@ def main():
                                    "change_of_variables, delta_bound=0.005, zero target, L-BFGS max_iter=10"
                                    % (a.net, h, w, hp, wp), "weights": "random:1234",
                        "closure_evals_per_step": closures / a.steps, "parallelism": "pairs sharded 1/GPU",
-                       "closure_launch": "hipGraph replay" if use_graph else "eager",
+                       "closure_launch": "hipGraph replay" if graph_active else
+                                         ("eager (hipGraph capture FAILED: see the log)" if use_graph else "eager"),
                        "timed_object": "pcfa_amd.attack_PCFA.PairAttack.step (the body of pcfa_attack's loop)"},
             "closure_evals_per_sec": world * closures / elapsed,
             "per_pair_setup_s": {"upload_init_forward_target": setup_eager, "graph_warmup_and_capture": setup_graph,
