@@ -29,6 +29,9 @@
 #ifndef PCFA_SC5W_DBG
 #define PCFA_SC5W_DBG 0
 #endif
+#ifndef PCFA_SC5W_STORE_AT
+#define PCFA_SC5W_STORE_AT 1   // channel pair after whose MFMAs the next patch is written to LDS (4 = after the last: r04a)
+#endif
 
 namespace {
 using namespace pcfa_sc5;
@@ -269,9 +272,13 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
       acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 3], v3, acc[3], 0, 0, 0);
       acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 4], v4, acc[4], 0, 0, 0);
       acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 5], v5, acc[5], 0, 0, 0);
+      // the next chunk's patch goes to the other LDS buffer in the shadow of this chunk's MFMAs (nobody reads that buffer
+      // since the previous barrier) instead of between the last MFMA and the barrier, where the slowest wave's wait for
+      // its load stalled all eight
+      if (p == PCFA_SC5W_STORE_AT && !(PCFA_SC5W_DBG & 16)) store_patch((chunk + 1) & 1, rstore);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(PCFA_SC5W_DBG & 16)) store_patch((chunk + 1) & 1, rstore);
+    if (PCFA_SC5W_STORE_AT >= CK / 2 && !(PCFA_SC5W_DBG & 16)) store_patch((chunk + 1) & 1, rstore);
     if (!(PCFA_SC5W_DBG & 1)) __syncthreads();
   };
   for (int chunk = 0; chunk < nchunk; chunk += 2) {   // host: nchunk even
