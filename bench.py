@@ -808,12 +808,18 @@ def main():
         from pcfa_amd import config as pcfa_config
         fused_model = st.model   # same seeded weights, lookup -> convc1 fusion off: a second model (switches are frozen)
         st.model = load_model(a.net, dev, True, dataclasses.replace(pcfa_config.cfg(fused_model), fused_lookup=False))
-        hip_ops.set_dispatch_timer(prof)
+        # two eagerly launched steps: the first packs the second model's weights and records the work per kernel family
+        # (family_rows; host-side bookkeeping in every operator call), the second carries the dispatch-attached events --
+        # without the bookkeeping, whose host gaps let the GPU idle between launches and lengthen a 7 us latency chain
+        # like the lookup by ~1 us
         work = {}
-        hip_ops.set_work_recorder(work)     # flop / bytes per kernel family of this step (family_rows)
+        hip_ops.set_work_recorder(work)
+        st.step()
+        hip_ops.set_work_recorder(None)
+        torch.cuda.synchronize()
+        hip_ops.set_dispatch_timer(prof)
         st.step()
         torch.cuda.synchronize()
-        hip_ops.set_work_recorder(None)
         hip_ops.set_dispatch_timer(None)
         st.model = fused_model
 
