@@ -242,8 +242,9 @@ def cmd_assemble(a):
             if pa:
                 row["per_step_aee_adv_tgt_port16"] = [round(s[0], 4) for s in pa["per_step"]]
             rows.append(row)
-        full = [r for r in rows if "inside_all" in r]
+        full = [r for r in rows if "inside_all" in r and len(r["legs_present"]) == 3]   # the rule needs all three legs
         cfg = {"net": net, "steps": steps, "config": CONFIGS[net], "pairs": rows, "pairs_total": len(full),
+               "pairs_with_two_legs_only": [r["pair"] for r in rows if "inside_all" in r and len(r["legs_present"]) < 3],
                "pairs_ok": sum(r["inside_all"] for r in full),
                "pairs_ok_per_metric": {k: sum(r[k]["inside"] for r in full) for k in FLOORS},
                "pairs_on_the_ports_branch": sum(r["first_step_divergence_gpu_vs_port16"] is None for r in full),
