@@ -24,6 +24,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef PCFA_GEMM_BK
 #define PCFA_GEMM_BK 16
 #endif
+#ifndef PCFA_GEMM_STORE_MID
+#define PCFA_GEMM_STORE_MID 0          // tools/dev A/B: write the next stage to LDS after MFMA pair PCFA_GEMM_STORE_MID_AT
+#endif
+#ifndef PCFA_GEMM_STORE_MID_AT
+#define PCFA_GEMM_STORE_MID_AT 4
+#endif
 constexpr int BM = 128, BN = 128, BK = PCFA_GEMM_BK;
 constexpr int NLD = BK / 8;   // float4 per thread and operand tile (128 x BK floats over 256 threads)
 constexpr int KV = BK / 4;    // float4 per row of a k-contiguous operand tile
@@ -190,7 +196,7 @@ __device__ __forceinline__ float4 unpool_piece(const float* __restrict__ row, fl
 template <bool KMAJ>
 __device__ __forceinline__ void tile_load_unpool(const float* __restrict__ X, long long ld, int dim, int d0, int k0,
                                                  int kend, const UnpoolArgs& u, float4 (&r)[NLD]) {
-  static_assert(BK == 16, "one 4x4 tile per stage and query");
+  static_assert(BK % 16 == 0, "whole 4x4 tiles per stage and query");
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -343,13 +349,25 @@ __device__ __forceinline__ void gemm_f32_mfma_body(
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#if PCFA_GEMM_STORE_MID
+      if (FAST && kk == PCFA_GEMM_STORE_MID_AT) {   // the next stage's LDS write in the shadow of this stage's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        tile_mask<A_KM>(M, m0, k0, kend, ra);
+        tile_mask<B_KN>(N, n0, k0, kend, rb);
+        tile_store<A_KM>(sA[cur ^ 1], ra);
+        tile_store<B_KN>(sB[cur ^ 1], rb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
     }
     if (FAST) {  // unconditional (also after the last stage, into the idle buffer): a store under `if (more)`
                  // lets hipcc sink the loads into that branch, i.e. below the MFMAs
+#if !PCFA_GEMM_STORE_MID
       tile_mask<A_KM>(M, m0, k0, kend, ra);
       tile_mask<B_KN>(N, n0, k0, kend, rb);
       tile_store<A_KM>(sA[cur ^ 1], ra);
       tile_store<B_KN>(sB[cur ^ 1], rb);
+#endif
     } else if (more) {
       tile_store<A_KM>(sA[cur ^ 1], ra);
       tile_store<B_KN>(sB[cur ^ 1], rb);
