@@ -193,7 +193,10 @@ def fanout(x, n):
 
 def pwc_cost_volume(input1, input2, slope=0.1):
     """leakyRELU(correlate(input1, input2)): models/PWCNet/PWCNet.py:45-58 followed by :249,264,278,292,308."""
-    out = spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=9, stride=1)
+    if input1.dtype == torch.float64:   # the fp64 arbiter of tools/trajectory_closure_parity.py (the C kernel is fp32)
+        out = spatial_correlation_shift_sum(input1, input2, 9)
+    else:
+        out = spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=9, stride=1)
     b, ph, pw, h, w = out.size()
     return F.leaky_relu(out.view(b, ph * pw, h, w) / input1.size(1), slope)
 
@@ -557,14 +560,14 @@ def pwc_warp(x, flo, mask_threshold=0.0001, deterministic=True):   # determinist
     yy = torch.arange(0, H).view(-1, 1).repeat(1, W)
     xx = xx.view(1, 1, H, W).repeat(B, 1, 1, 1)
     yy = yy.view(1, 1, H, W).repeat(B, 1, 1, 1)
-    grid = torch.cat((xx, yy), 1).float()
+    grid = torch.cat((xx, yy), 1).to(x.dtype)   # (.float() in the reference; fp64 only for the arbiter run)
     vgrid = grid + flo
     vx = 2.0 * vgrid[:, 0, :, :] / max(W - 1, 1) - 1.0
     vy = 2.0 * vgrid[:, 1, :, :] / max(H - 1, 1) - 1.0
     vgrid = torch.stack((vx, vy), dim=3)
     output = F.grid_sample(x, vgrid, align_corners=False)
-    mask = F.grid_sample(torch.ones(x.size()), vgrid, align_corners=False)
-    mask = (mask >= mask_threshold).float()
+    mask = F.grid_sample(torch.ones(x.size(), dtype=x.dtype), vgrid, align_corners=False)
+    mask = (mask >= mask_threshold).to(x.dtype)
     return output * mask
 
 

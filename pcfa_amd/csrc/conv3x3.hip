@@ -109,7 +109,10 @@ struct Second {
   float* out;
   int K, N, nb0;
   int mask_n;   // epilogue mask mode of the FIRST problem: 0 = every channel, before the addend; > 0 = channels < mask_n only,
-};              // AFTER the addend (the dense-block backward: the producer's LeakyReLU backward once its gradient is complete)
+                // AFTER the addend (the dense-block backward: the producer's LeakyReLU backward once its gradient is complete)
+  int ksl;      // K slices over workgroups (blockIdx.z = image * ksl + slice): slice s convolves chunks [s cper, (s+1) cper)
+  int cper;     // and writes its raw sums to out[(s * images + image)] -- a partial output for f43_finish_kernel (small
+};              // maps: a handful of workgroups walking the whole K is a latency chain of ~1 us per chunk)
 
 // KS = 2: in-workgroup split-K for launches of at most one workgroup per CU (e.g. conv 256 -> 126 at 55x128: 224
 // workgroups, one wave per SIMD, 37 us for 17 us of MFMA work).  Two groups of four waves run the same pipeline on
@@ -162,10 +165,11 @@ __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(K
   const int n0 = nby * CBT;
   if (n0 >= N) return;  // (the packing pads N to 64: a 32-channel block may lie entirely in the padding)
   const long long plane = (long long)H * W;
-  x += (long long)blockIdx.z * K * plane;
-  out += (long long)blockIdx.z * N * plane;
-  if (mask != nullptr) mask += (long long)blockIdx.z * N * plane;   // same shape as `out`
-  if (addend != nullptr) addend += (long long)blockIdx.z * N * plane;
+  const int ksl = second.ksl, img = blockIdx.z / ksl, slice = blockIdx.z - img * ksl;   // ksl = 1: img = blockIdx.z
+  x += (long long)img * K * plane;
+  out += ((long long)slice * (gridDim.z / ksl) + img) * N * plane;
+  if (mask != nullptr) mask += (long long)img * N * plane;   // same shape as `out`
+  if (addend != nullptr) addend += (long long)img * N * plane;
 
   // ---- per-thread constants of the staging loads (chunk-invariant) ----
   unsigned praw[RAW_LOADS];      // chunk 0 source of the patch element (clamped into the image), floats from x
@@ -280,8 +284,9 @@ __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(K
   // Ring slot c % NRING holds chunk c: its patch is written to LDS one iteration before its MFMAs, its U operands
   // stay in registers until the MFMAs have consumed them; the slot is reloaded (chunk c + NRING) right after.
   // local chunk cl of this wave group = global chunk cl * KS + kgrp
-  const int nchunk_g = nchunk / KS;
-  auto gc0 = [&](int cl) { return (cl * KS + kgrp) * KC; };
+  const int cbeg = ksl > 1 ? slice * second.cper : 0, cend = ksl > 1 ? min(nchunk, cbeg + second.cper) : nchunk;
+  const int nchunk_g = (cend - cbeg) / KS;
+  auto gc0 = [&](int cl) { return (cbeg + cl * KS + kgrp) * KC; };
   const int lastc = gc0(nchunk_g - 1);
 #ifdef PCFA_C3_STAMPS
   unsigned long long stamp_prev = 0, stamp_acc[5] = {0, 0, 0, 0, 0};
@@ -502,7 +507,7 @@ extern "C" int pcfa_leaky_relu_bwd(const float* out, const float* grad_out, floa
 static int conv3x3_launch(const float* x, const float* packed, const float* bias, const float* mask, float* out, int B,
                           int K, int N, int H, int W, int act, float slope, void* stream, const float* x2 = nullptr,
                           const float* packed2 = nullptr, const float* bias2 = nullptr, float* out2 = nullptr,
-                          int K2 = 0, int N2 = 0, const float* addend = nullptr, int mask_n = 0);
+                          int K2 = 0, int N2 = 0, const float* addend = nullptr, int mask_n = 0, int ksl = 1);
 
 extern "C" int pcfa_conv3x3_fwd(const float* x, const float* packed, const float* bias, float* out, int B, int K,
                                 int N, int H, int W, int relu, void* stream) {
@@ -536,6 +541,23 @@ extern "C" int pcfa_conv3x3_fused_bwd(const float* g, const float* packed_bwd, c
                         nullptr, 0, 0, addend);
 }
 
+// K slices of the F(2x2,3x3) kernel over workgroups (Second::ksl), 1 = none.  Small single-image maps (PWC-Net's levels 6-4:
+// 6x20 .. 24x80) are 3..48 workgroups that walk 16-79 chunks one after the other -- a ~1 us per chunk latency chain on an
+// empty chip; `ksl` slices turn it into ksl x the workgroups with a ksl x shorter chain, and f43_finish_kernel adds the
+// partial outputs in index order (deterministic).  PCFA_CONV3X3_KSL=0 switches it off, =n forces n (dev A/B).
+static int f23_kslices(int B, int K, int N, int H, int W) {
+  static const int env = getenv("PCFA_CONV3X3_KSL") ? atoi(getenv("PCFA_CONV3X3_KSL")) : -1;
+  if (env == 0 || ((long long)H * W) % 4 != 0) return 1;
+  const int nchunk = (K + KC - 1) / KC;
+  const long long nwg = (long long)pcfa_cdiv(W, 2 * TC) * pcfa_cdiv(H, 8) * ((N + 31) / 32) * B;
+  long long want = env > 0 ? env : min(256 / max(nwg, 1LL), (long long)nchunk / 2);
+  if (env < 0 && (B != 1 || (long long)H * W > 2048 || nwg > 64)) want = 1;
+  if (want < 2 || nchunk < 2) return 1;
+  want = min(want, (long long)nchunk);
+  const int cper = (int)((nchunk + want - 1) / want);
+  return (nchunk + cper - 1) / cper;   // every slice holds at least one chunk
+}
+
 // Which transform serves a shape.  F(4x4,3x3) needs 1.78x fewer matrix instructions, but three waves per SIMD leave
 // its loop 168 registers (96 of them accumulators): the U operand stream can only run one channel pair ahead and the
 // channel-split path pays for its partial outputs, so it wins where the matrix work dominates -- measured on MI355X
@@ -556,6 +578,9 @@ static bool use_f43(int B, int K, int N, int H, int W) {
   // tools/dev/conv3x3_shapes_ab.py (every conv3x3 shape of a PWC-Net closure, both algorithms): -1.0 ms per closure.
   if (B == 1) {
     const long long px = (long long)H * W;
+    // levels 6-4 (6x20 .. 24x80): the F(2x2,3x3) kernel with K sliced over workgroups (f23_kslices; r04) beats the
+    // channel-split F(4x4,3x3) path on every such shape but one (tools/dev/conv_ksl_ab.sh: 21-30 us -> 16-23 us)
+    if (px <= 2048 && f23_kslices(B, K, N, H, W) > 1) return false;
     if (px <= 4096 && K >= 176) return true;
     if (px > 4096 && px <= 16384 && K >= 384) return true;
     if (px >= 16384 && px < 100000 && (long long)K * N >= 15000) return true;
@@ -577,7 +602,10 @@ extern "C" int pcfa_conv3x3_algo(int B, int K, int N, int H, int W) {
 
 extern "C" size_t pcfa_conv3x3_workspace_bytes(int B, int K, int N, int H, int W) {
   if (B < 1 || K < 1 || N < 1 || H < 1 || W < 1) return 0;
-  return use_f43(B, K, N, H, W) ? pcfa_f43_workspace_bytes(B, K, N, H, W) : 0;
+  // (an upper bound over both paths: a misaligned view falls from F(4x4,3x3) through to the sliced F(2x2,3x3) kernel)
+  const int ksl = f23_kslices(B, K, N, H, W);
+  const size_t sliced = ksl > 1 ? (size_t)ksl * B * N * H * W * sizeof(float) : 0;
+  return max(use_f43(B, K, N, H, W) ? pcfa_f43_workspace_bytes(B, K, N, H, W) : (size_t)0, sliced);
 }
 
 extern "C" int pcfa_conv3x3_run(const float* x, const float* packed, const float* bias, const float* mask,
@@ -591,6 +619,15 @@ extern "C" int pcfa_conv3x3_run(const float* x, const float* packed, const float
                                 slope, mask_channels, workspace, workspace_bytes, (hipStream_t)stream);
     if (rc != PCFA_ERR_UNSUPPORTED) return rc;   // (misaligned views fall through to the F(2x2,3x3) kernel)
   }
+  const int ksl = f23_kslices(B, K, N, H, W);
+  if (ksl > 1 && workspace && aligned16(workspace) && aligned16(out) && (!mask || aligned16(mask)) &&
+      (!addend || aligned16(addend)) && workspace_bytes >= (size_t)ksl * B * N * H * W * sizeof(float)) {
+    float* part = (float*)workspace;
+    const int rc = conv3x3_launch(x, packed, nullptr, nullptr, part, B, K, N, H, W, 0, 0.f, stream, nullptr, nullptr,
+                                  nullptr, nullptr, 0, 0, nullptr, 0, ksl);
+    if (rc != PCFA_OK) return rc;
+    return pcfa_f43_finish(part, bias, mask, addend, out, ksl, B, N, H, W, act, slope, mask_channels, (hipStream_t)stream);
+  }
   return conv3x3_launch(x, packed, bias, mask, out, B, K, N, H, W, act, slope, stream, nullptr, nullptr, nullptr,
                         nullptr, 0, 0, addend, mask_channels);
 }
@@ -598,7 +635,7 @@ extern "C" int pcfa_conv3x3_run(const float* x, const float* packed, const float
 static int conv3x3_launch(const float* x, const float* packed, const float* bias, const float* mask, float* out, int B,
                           int K, int N, int H, int W, int act, float slope, void* stream, const float* x2,
                           const float* packed2, const float* bias2, float* out2, int K2, int N2, const float* addend,
-                          int mask_n) {
+                          int mask_n, int ksl) {
   if (act < 0 || act > 2 || mask_n < 0 || (mask_n > 0 && (act != 0 || !mask))) return PCFA_ERR_INVALID_ARG;
   if (!x || !packed || !out || B < 1 || K < 1 || N < 1 || H < 1 || W < 1 || !aligned16(packed))
     return PCFA_ERR_INVALID_ARG;
@@ -621,7 +658,13 @@ static int conv3x3_launch(const float* x, const float* packed, const float* bias
     block.x = 512;
   }
   grid.y = Npad / 32;
-  Second second{x2, packed2, bias2, out2, K2, N2, (int)grid.y, mask_n};
+  const int nchunk_all = (K + KC - 1) / KC, cper = (nchunk_all + ksl - 1) / ksl;
+  if (ksl > 1) {   // K slices over workgroups: raw partial sums (the caller runs the finish pass)
+    if (x2 != nullptr || mt != 1 || bias || mask || addend || act != 0 || (cper * (ksl - 1)) >= nchunk_all) return PCFA_ERR_INVALID_ARG;
+    grid.z = (unsigned)(B * ksl);
+    if (grid.z > 65535) return PCFA_ERR_UNSUPPORTED;
+  }
+  Second second{x2, packed2, bias2, out2, K2, N2, (int)grid.y, mask_n, ksl, cper};
   if (x2 != nullptr) {
     if (mt == 2) return PCFA_ERR_UNSUPPORTED;
     grid.y += (unsigned)((N2 + CB - 1) / CB * CB / 32);
@@ -638,7 +681,7 @@ static int conv3x3_launch(const float* x, const float* packed, const float* bias
   // at most one workgroup per CU: split K inside the workgroup (8 waves, two per SIMD)
   static const int ks_env = getenv("PCFA_CONV3X3_KS") ? atoi(getenv("PCFA_CONV3X3_KS")) : 0;   // tuning override (1 / 2)
   const long long nwg = (long long)grid.x * grid.y * grid.z;
-  if (mt == 1 && x2 == nullptr && K % (2 * KC) == 0 && (ks_env ? ks_env == 2 : nwg <= 256)) {
+  if (ksl == 1 && mt == 1 && x2 == nullptr && K % (2 * KC) == 0 && (ks_env ? ks_env == 2 : nwg <= 256)) {
     block.x = 512;
     if (act == 1) pcfa_launch(conv3x3_winograd_kernel<1, 32, 1, true, 2, 2>, PCFA_C3_ARGS);
     else if (act == 2) pcfa_launch(conv3x3_winograd_kernel<2, 32, 1, true, 2, 2>, PCFA_C3_ARGS);

@@ -511,10 +511,20 @@ int pcfa_f43_run(const float* x, const float* packed, const float* bias, const f
     pcfa_launch(conv3x3_f43_kernel<0, true>, grid, block, 0, s, x, packed, (const float*)nullptr, (const float*)nullptr,
                 (const float*)nullptr, part, K, N, H, W, blocks_x, ksplit, B, 0.f, 0);
   PCFA_LAUNCH_CHECK();
+  return pcfa_f43_finish(part, bias, mask, addend, out, ksplit, B, N, H, W, act, slope, mask_n, s);
+}
+
+// The finish pass alone: out = epilogue(sum of `ksplit` partial outputs [ksplit][B][N][H][W], in index order).  Also
+// serves conv3x3.hip's F(2x2,3x3) kernel when it slices K over workgroups.  H * W % 4 == 0.
+int pcfa_f43_finish(const float* part, const float* bias, const float* mask, const float* addend, float* out, int ksplit,
+                    int B, int N, int H, int W, int act, float slope, int mask_n, hipStream_t s) {
+  if (((long long)H * W) % 4 != 0 || !aligned16(part) || !aligned16(out) || (mask && !aligned16(mask)) ||
+      (addend && !aligned16(addend)))
+    return PCFA_ERR_UNSUPPORTED;
   const long long total4 = (long long)B * N * H * W / 4, plane4 = (long long)H * W / 4;
   const dim3 fg((unsigned)min((total4 + 255) / 256, 2048LL)), fb(256);
 #define PCFA_F43_FINISH(A_) \
-  pcfa_launch(f43_finish_kernel<A_>, fg, fb, 0, s, (const float*)part, bias, mask, addend, out, ksplit, total4, plane4, N, slope, mask_n)
+  pcfa_launch(f43_finish_kernel<A_>, fg, fb, 0, s, part, bias, mask, addend, out, ksplit, total4, plane4, N, slope, mask_n)
   if (act == 1) PCFA_F43_FINISH(1); else if (act == 2) PCFA_F43_FINISH(2); else PCFA_F43_FINISH(0);
 #undef PCFA_F43_FINISH
   PCFA_LAUNCH_CHECK();

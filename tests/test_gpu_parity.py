@@ -969,8 +969,10 @@ def test_conv3x3_winograd_vs_oracle(oracle_ops, shape, relu):
     if os.environ.get("PCFA_CONV3X3_ALGO") == "f43":
         assert f43 == (W % 4 == 0 and W >= 8)
     elif "PCFA_CONV3X3_ALGO" not in os.environ:
-        assert f43 == (shape in ((1, 192, 256, 55, 128), (2, 64, 64, 220, 512), (1, 565, 128, 24, 80),
-                                 (1, 245, 128, 96, 320), (1, 501, 64, 48, 160), (1, 196, 196, 6, 20)))
+        # ((1, 565, 128, 24, 80) and (1, 196, 196, 6, 20) went from the channel-split F(4x4,3x3) path to F(2x2,3x3) with K
+        # sliced over workgroups in r04; PCFA_CONV3X3_ALGO=f43 still runs them through F(4x4,3x3))
+        assert f43 == (shape in ((1, 192, 256, 55, 128), (2, 64, 64, 220, 512), (1, 245, 128, 96, 320),
+                                 (1, 501, 64, 48, 160)))
     tol = 1.5e-5 if f43 else 5e-6
     gen = torch.Generator().manual_seed(3 + Cin + W)
     x = torch.randn(B, Cin, H, W, generator=gen)
@@ -1006,7 +1008,22 @@ def test_conv3x3_f43_forced():
     import sys
     env = dict(os.environ, PCFA_CONV3X3_ALGO="f43")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
-                        "conv3x3 and not f43_forced and not fewout"], env=env, capture_output=True, text=True,
+                        "conv3x3 and not forced and not fewout"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout
+
+
+def test_conv3x3_k_slices_forced():
+    """Every conv3x3 test once more with the F(2x2,3x3) kernel's input channels sliced over three workgroups wherever the
+    shape allows (H W % 4 == 0, >= 2 chunks; the policy only slices small single-image maps): partial outputs + the
+    finish pass with every epilogue (bias, activations, masks, channel-prefix masks, addends), ragged K."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PCFA_CONV3X3_ALGO="f23", PCFA_CONV3X3_KSL="3")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "conv3x3 and not forced and not fewout"], env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout
@@ -1463,7 +1480,10 @@ def test_trajectory_closure_parity_vs_cpu_port(cfg):
     evaluations, the fixed-step optimiser's overshoot points included) and the GPU closure is evaluated at exactly
     those iterates: loss 1e-5 relative, gradient 1e-2 relative L2 at every point (tools/trajectory_closure_parity.py).
     Unlike end-of-attack metrics this cannot land on another branch of torch.optim.LBFGS's hard thresholds (DESIGN.md
-    section 4); 3-step records under profiles/r03_trajectory_closure_parity_*.json."""
+    section 4); 3-step records under profiles/r0*_trajectory_closure_parity_*.json.  A point whose gradient misses 1e-2
+    against the fp32 port is judged by the port in FP64 (a single LeakyReLU unit of PWC-Net's 6x20 level within rounding
+    of zero moves the image gradient by 1.6e-2; r04 found the fp32 PORT on the wrong side of one at point 8):
+    |gpu - fp64| <= max(1e-2, 3 |port_fp32 - fp64|)."""
     import json
     import os
     import subprocess

@@ -9,7 +9,15 @@ cannot.
 
     python tools/trajectory_closure_parity.py [--net RAFT] [--size 436x1024] [--steps 3] [--threads 16] [--seed 0]
                                               [--box change_of_variables] [--joint] [--out FILE.json]
-Exit code 0 iff every point is inside --loss-tol / --grad-tol."""
+Exit code 0 iff every point is inside --loss-tol / --grad-tol -- or, for the gradient, is closer to the port evaluated in
+FP64 than the fp32 port itself allows.  The closure is piecewise smooth: a (Leaky)ReLU pre-activation or a warp
+validity mask within rounding of its threshold lands on either side depending on the summation order, and ONE such unit
+on PWC-Net's 6x20 level moves the image gradient by 1.6e-2 relative L2 (r04: point 8 of pair 0, where the fp32 port is
+1.65e-2 away from its own fp64 evaluation and the GPU 8.9e-4).  A point that misses --grad-tol against the fp32 port is
+therefore re-evaluated by the port in fp64 (the arbiter) and passes when
+    |gpu - fp64| <= max(grad_tol, 3 x |port_fp32 - fp64|)   (relative L2).
+Networks whose oracle operators are fp32-only C code (RAFT's lookup) fall back to the port's own spread between two host
+thread counts as the floor (the rule of tools/schedule_parity.py)."""
 import argparse
 import json
 import os
@@ -33,6 +41,16 @@ def main():
     ap.add_argument("--joint", action="store_true")
     ap.add_argument("--loss-tol", type=float, default=1e-5)
     ap.add_argument("--grad-tol", type=float, default=1e-2, help="relative L2, as test_closure_at_baseline_size_vs_cpu_port")
+    ap.add_argument("--floor-threads", type=int, default=8,
+                    help="a point whose gradient misses --grad-tol is re-evaluated by the PORT at this thread count: the "
+                         "port's own relative L2 between its two thread counts is that point's noise floor, and the point "
+                         "passes when gpu-vs-port <= 3 x floor (the rule of tools/schedule_parity.py, SURVEY D10); 0 = off")
+    ap.add_argument("--arbiter", default="fp64", choices=["fp64", "threads"],
+                    help="what judges a point that misses --grad-tol: the port in fp64 (falls back to 'threads' when the "
+                         "network's oracle operators are fp32-only), or only the port's thread-count spread")
+    ap.add_argument("--floor-all", action="store_true", help="arbiter / floor at every point (a record, not a gate)")
+    ap.add_argument("--dump-point", default="", metavar="N:FILE.pt",
+                    help="save the variables and both gradients of point N (torch.save) for a post-mortem")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     from oracle import ops as oracle_ops
@@ -56,6 +74,67 @@ def main():
             cst.step()
             print("port step %d/%d: %d points (%.0f s)" % (k + 1, a.steps, len(points), time.perf_counter() - t0),
                   file=sys.stderr, flush=True)
+
+    def to_double(obj, seen, depth=0):
+        """the port's state in fp64: module parameters / buffers and every fp32 tensor attribute of the stepper."""
+        if id(obj) in seen or depth > 3:
+            return
+        seen.add(id(obj))
+        if isinstance(obj, torch.nn.Module):
+            obj.double()
+        for k, t in list(getattr(obj, "__dict__", {}).items()):
+            if isinstance(t, torch.nn.Parameter):
+                continue
+            if torch.is_tensor(t):
+                if t.dtype == torch.float32:
+                    t.data = t.data.double()   # in place: the variables are referenced from several attributes
+            elif hasattr(t, "__dict__") and not isinstance(t, (type, torch.optim.Optimizer)):
+                to_double(t, seen, depth + 1)
+
+    arbiter = []   # [stepper in fp64] once built; [None] when the network's oracle operators are fp32-only
+
+    def port_fp64(x):
+        """the port's gradient at `x` evaluated in fp64, or None when this network's port cannot run in fp64."""
+        if not arbiter:
+            try:
+                with ops.override_for_testing(oracle_ops):
+                    dst = bench.AttackStepper(a.net, h, w, torch.device("cpu"), seed=a.seed, **kw)
+                    to_double(dst, set())
+                    for p in dst.params:
+                        if p.dtype != torch.float64:
+                            p.data = p.data.double()
+                    dst.optimizer.zero_grad()
+                    dst._closure_body()
+                arbiter.append(dst)
+            except (RuntimeError, TypeError) as e:
+                print("fp64 arbiter unavailable for %s: %s" % (a.net, str(e).splitlines()[0]), file=sys.stderr)
+                arbiter.append(None)
+        dst = arbiter[0]
+        if dst is None:
+            return None
+        with ops.override_for_testing(oracle_ops):
+            with torch.no_grad():
+                for p, v in zip(dst.params, x):
+                    p.copy_(v.double())
+            dst.optimizer.zero_grad()
+            dst._closure_body()
+            return torch.cat([p.grad.detach().flatten() for p in dst.params]).clone()
+
+    def port_floor(x, grad_c):
+        """relative L2 between the port's gradient at `x` with --threads and with --floor-threads host threads."""
+        torch.set_num_threads(a.floor_threads)
+        try:
+            with ops.override_for_testing(oracle_ops):
+                with torch.no_grad():
+                    for p, v in zip(cst.params, x):
+                        p.copy_(v)
+                cst.optimizer.zero_grad()
+                inner()
+                g = torch.cat([p.grad.detach().flatten() for p in cst.params])
+        finally:
+            torch.set_num_threads(a.threads)
+        return float((g - grad_c).norm() / grad_c.norm())
+
     gst = bench.AttackStepper(a.net, h, w, torch.device("cuda", 0), seed=a.seed, **kw)
     rows, ok = [], True
     for i, (x, loss_c, grad_c) in enumerate(points):
@@ -67,12 +146,32 @@ def main():
         grad_g = torch.cat([p.grad.detach().flatten() for p in gst.params]).cpu()
         lr = abs(loss_g - loss_c) / abs(loss_c)
         gr = float((grad_g - grad_c).norm() / grad_c.norm())
-        rows.append({"point": i, "loss_port": loss_c, "loss_gpu": loss_g, "loss_rel": lr, "grad_rel_l2": gr})
-        ok = ok and lr <= a.loss_tol and gr <= a.grad_tol
+        if a.dump_point and int(a.dump_point.split(":")[0]) == i:
+            torch.save({"x": x, "grad_port": grad_c, "grad_gpu": grad_g, "loss_port": loss_c, "loss_gpu": loss_g,
+                        "args": vars(a)}, a.dump_point.split(":", 1)[1])
+        row = {"point": i, "loss_port": loss_c, "loss_gpu": loss_g, "loss_rel": lr, "grad_rel_l2": gr}
+        tol, gerr = a.grad_tol, gr
+        if gr > a.grad_tol or a.floor_all:
+            g64 = port_fp64(x) if a.arbiter == "fp64" else None
+            if g64 is not None:
+                n64 = g64.norm()
+                row["port_fp32_vs_fp64"] = float((grad_c.double() - g64).norm() / n64)
+                row["gpu_vs_fp64"] = gerr = float((grad_g.double() - g64).norm() / n64)
+                tol = max(tol, 3 * row["port_fp32_vs_fp64"])
+            elif a.floor_threads:
+                row["port_floor_grad_rel_l2"] = port_floor(x, grad_c)
+                tol = max(tol, 3 * row["port_floor_grad_rel_l2"])
+        row["grad_tol"] = tol
+        rows.append(row)
+        ok = ok and lr <= a.loss_tol and gerr <= tol
     out = {"what": "loss and gradient of the GPU closure at every iterate of a %d-step CPU-port attack (%d points), %s %dx%d, "
                    "%s%s, synthetic pair %d" % (a.steps, len(points), a.net, h, w, a.box, ", joint" if a.joint else "", a.seed),
            "ok": ok, "loss_tol": a.loss_tol, "grad_tol": a.grad_tol,
            "max_loss_rel": max(r["loss_rel"] for r in rows), "max_grad_rel_l2": max(r["grad_rel_l2"] for r in rows),
+           "rule": "loss_rel <= loss_tol and (grad_rel_l2 <= grad_tol or gpu_vs_fp64 <= max(grad_tol, 3 x port_fp32_vs_fp64); "
+                   "without an fp64 port: grad_rel_l2 <= max(grad_tol, 3 x the port's %d-vs-%d-thread difference))"
+                   % (a.threads, a.floor_threads),
+           "points_over_grad_tol": [r["point"] for r in rows if r["grad_rel_l2"] > a.grad_tol],
            "loss_range": [min(r["loss_port"] for r in rows), max(r["loss_port"] for r in rows)], "points": rows}
     txt = json.dumps(out)
     if a.out:
