@@ -558,11 +558,14 @@ PCFA_API int pcfa_conv_s2_ds_bwd(const float* grad_out, const float* grad_out_d,
  * bilinear, zero padding, align_corners = False, the reference's fp32 coordinate arithmetic (normalise by W-1, then
  * grid_sample's un-normalisation by W).  x, out, grad_*: [B][C][H][W]; flo, grad_flo: [B][2][H][W].
  * pcfa_pwc_warp_bwd = {clear grad_x and grad_flo, scatter (hardware fp32 atomics, like grid_sampler_2d_backward) +
- * flow gradient}. */
+ * flow gradient}.  flow_scale: the warp is taken along flow_scale * flo (PWCNet.py:262,276,290,306 pass `up_flow * 0.625`
+ * ... `* 5.0`): the product is rounded to fp32 before use and grad_flo = flow_scale * (gradient of the scaled flow), i.e.
+ * bit for bit what the two element-wise launches of `warp(x, up_flow * s)` and its backward give; 1.0f = plain flo. */
 PCFA_API int pcfa_pwc_warp_fwd(const float* x, const float* flo, float* out, int B, int C, int H, int W,
-                               float mask_threshold, void* stream);
+                               float mask_threshold, float flow_scale, void* stream);
 PCFA_API int pcfa_pwc_warp_bwd(const float* x, const float* flo, const float* grad_out, float* grad_x,
-                               float* grad_flo, int B, int C, int H, int W, float mask_threshold, void* stream);
+                               float* grad_flo, int B, int C, int H, int W, float mask_threshold, float flow_scale,
+                               void* stream);
 /* The same backward, bit-reproducible: the scatter adds fixed-point int64 values (integer adds commute, so the
  * order in which the atomics land does not matter) and the flow gradient's channel groups are summed in index order;
  * grid_sampler_2d_backward (and pcfa_pwc_warp_bwd) add fp32 values in whatever order the hardware serves them, which
@@ -572,7 +575,7 @@ PCFA_API int pcfa_pwc_warp_bwd(const float* x, const float* flo, const float* gr
 PCFA_API size_t pcfa_pwc_warp_bwd_det_workspace_bytes(int B, int C, int H, int W);
 PCFA_API int pcfa_pwc_warp_bwd_det(const float* x, const float* flo, const float* grad_out, float* grad_x,
                           float* grad_flo, void* workspace, size_t workspace_bytes, int B, int C, int H, int W,
-                          float mask_threshold, void* stream);
+                          float mask_threshold, float flow_scale, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution with N <= 4 output channels and its data gradient (frozen weights): the
  * flow-prediction layers -- FlowHead.conv2 of RAFT / GMA (models/raft/update.py:6-14), predict_flow of PWC-Net

@@ -548,13 +548,17 @@ def conv3x3_cat(convs, tails=(), grad_premasked=False, mask_input_grads=False):
 
 def dense_block(x, layers, slope=0.1, fused_masks=True):   # fused_masks: a scheduling hint of the product
     """models/PWCNet/PWCNet.py:234-323: x = cat((conv_i(x), x), 1) for the five decoder convolutions of a level."""
+    if isinstance(x, (tuple, list)):   # the product takes the parts of PWCNet.py:265's concatenation separately
+        x = torch.cat(tuple(x), 1)
     for w, b in layers:
         x = torch.cat((F.leaky_relu(F.conv2d(x, w, b, stride=1, padding=1), slope), x), 1)
     return x
 
 
-def pwc_warp(x, flo, mask_threshold=0.0001, deterministic=True):   # deterministic: a scheduling hint of the product
-    """models/PWCNet/PWCNet.py:166-206, statement by statement."""
+def pwc_warp(x, flo, mask_threshold=0.0001, deterministic=True, flow_scale=1.0):   # deterministic: a scheduling hint
+    """models/PWCNet/PWCNet.py:166-206, statement by statement; flow_scale: the caller's `up_flow * 0.625` (:262)."""
+    if flow_scale != 1.0:
+        flo = flo * flow_scale
     B, C, H, W = x.size()
     xx = torch.arange(0, W).view(1, -1).repeat(H, 1)
     yy = torch.arange(0, H).view(-1, 1).repeat(1, W)

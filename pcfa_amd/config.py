@@ -34,6 +34,8 @@ class Config:
     defer_leaky: bool = True             # LeakyReLU backward of single-consumer layers in the consumer's epilogue
     dense_block_fused_masks: bool = True   # the same inside the dense decoder blocks
     warp_bwd_deterministic: bool = True  # fixed-point scatter in the warp backward (False: hardware fp32 atomics)
+    pwc_fold_glue: bool = True           # RGB->BGR in conv1a's weights, `up_flow * s` inside the warp, decoder inputs written
+                                         # straight into the dense-block buffer, one re-gridding copy between dilated layers
     # ---- attack loop (attack_PCFA.py) ----
     reuse_pair_graphs: bool = True       # pairs of one shape share static buffers + hipGraphs
 

@@ -16,6 +16,13 @@
 
 namespace {
 
+// a * b rounded to fp32 on its own: never contracted into a following add (the scaled flow meets the meshgrid as the
+// reference's `up_flow * s` tensor does -- a rounded product).  (__fmul_rn is a plain `*` in this toolchain.)
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
 struct WarpTaps {
   int x0, y0;          // north-west tap
   float wx1, wy1;      // weight of the east / south neighbour (ix - x0, iy - y0)
@@ -46,14 +53,14 @@ __device__ __forceinline__ WarpTaps warp_taps(float ix, float iy, int H, int W) 
 // grid = (pixel blocks, channel groups, B); thread = one pixel, channels c = group, group + G, ...
 __global__ __launch_bounds__(256) void pwc_warp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ flo,
                                                           float* __restrict__ out, int C, int H, int W,
-                                                          float mask_thresh) {
+                                                          float mask_thresh, float fs) {
   const long long plane = (long long)H * W;
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= plane) return;
   const int b = blockIdx.z, G = gridDim.y;
   const int py = (int)(p / W), px = (int)(p % W);
   const float* fb = flo + (size_t)b * 2 * plane;
-  const float ix = warp_coord((float)px, fb[p], W), iy = warp_coord((float)py, fb[plane + p], H);
+  const float ix = warp_coord((float)px, mul_rounded(fb[p], fs), W), iy = warp_coord((float)py, mul_rounded(fb[plane + p], fs), H);
   const WarpTaps t = warp_taps(ix, iy, H, W);
   // weights as grid_sampler_2d forms them: nw = (ix_se - ix) * (iy_se - iy), ...
   const float ex = (float)(t.x0 + 1) - ix, ey = (float)(t.y0 + 1) - iy;  // ix_se - ix, iy_se - iy
@@ -85,14 +92,14 @@ __global__ __launch_bounds__(256) void pwc_warp_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void pwc_warp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ flo,
                                                           const float* __restrict__ gout, float* __restrict__ gx,
                                                           float* __restrict__ gflo, int C, int H, int W,
-                                                          float mask_thresh) {
+                                                          float mask_thresh, float fs) {
   const long long plane = (long long)H * W;
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= plane) return;
   const int b = blockIdx.z, G = gridDim.y;
   const int py = (int)(p / W), px = (int)(p % W);
   const float* fb = flo + (size_t)b * 2 * plane;
-  const float ix = warp_coord((float)px, fb[p], W), iy = warp_coord((float)py, fb[plane + p], H);
+  const float ix = warp_coord((float)px, mul_rounded(fb[p], fs), W), iy = warp_coord((float)py, mul_rounded(fb[plane + p], fs), H);
   const WarpTaps t = warp_taps(ix, iy, H, W);
   const float ex = (float)(t.x0 + 1) - ix, ey = (float)(t.y0 + 1) - iy;
   const float nw = ex * ey, ne = t.wx1 * ey, sw = ex * t.wy1, se = t.wx1 * t.wy1;
@@ -138,8 +145,8 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_kernel(const float* __restri
     }
   }
   // d ix / d grid = W / 2 (unnormalize), d grid / d flo = 2 / max(W - 1, 1) (the reference divides, then doubles)
-  const float dfx = 2.0f * ((0.5f * (float)W * gix) / (float)max(W - 1, 1));
-  const float dfy = 2.0f * ((0.5f * (float)H * giy) / (float)max(H - 1, 1));
+  const float dfx = mul_rounded(2.0f * ((0.5f * (float)W * gix) / (float)max(W - 1, 1)), fs);   // d (fs flo) / d flo
+  const float dfy = mul_rounded(2.0f * ((0.5f * (float)H * giy) / (float)max(H - 1, 1)), fs);
   float* gf = gflo + (size_t)b * 2 * plane;
   if (G == 1) {
     gf[p] = dfx;
@@ -186,7 +193,8 @@ __device__ __forceinline__ void fix_add(long long* p, float v, double scale) {
 __global__ __launch_bounds__(256) void pwc_warp_bwd_det_kernel(const float* __restrict__ x, const float* __restrict__ flo,
                                                               const float* __restrict__ gout, long long* __restrict__ gxi,
                                                               float* __restrict__ gfpart, const float* __restrict__ bmax,
-                                                              int nblk, int C, int H, int W, float mask_thresh) {
+                                                              int nblk, int C, int H, int W, float mask_thresh,
+                                                              float fs) {
   __shared__ float red[4];
   const double scale = ldexp(1.0, warp_fix_shift(bmax, nblk, red));
   const long long plane = (long long)H * W;
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_det_kernel(const float* __re
   const int py = (int)(p / W), px = (int)(p % W);
   const float* fb = flo + (size_t)b * 2 * plane;
   float* gf = gfpart + ((size_t)blockIdx.y * B + b) * 2 * plane;   // this channel group's partial flow gradient
-  const float ix = warp_coord((float)px, fb[p], W), iy = warp_coord((float)py, fb[plane + p], H);
+  const float ix = warp_coord((float)px, mul_rounded(fb[p], fs), W), iy = warp_coord((float)py, mul_rounded(fb[plane + p], fs), H);
   const WarpTaps t = warp_taps(ix, iy, H, W);
   const float ex = (float)(t.x0 + 1) - ix, ey = (float)(t.y0 + 1) - iy;
   const float nw = ex * ey, ne = t.wx1 * ey, sw = ex * t.wy1, se = t.wx1 * t.wy1;
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256) void pwc_warp_finish_kernel(const long long* _
                                                               const float* __restrict__ gfpart,
                                                               const float* __restrict__ bmax, int nblk,
                                                               float* __restrict__ gx, float* __restrict__ gflo,
-                                                              long long nx, long long nf, int G) {
+                                                              long long nx, long long nf, int G, float fs) {
   __shared__ float red[4];
   const double inv = ldexp(1.0, -warp_fix_shift(bmax, nblk, red));
   const long long step = (long long)gridDim.x * blockDim.x;
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(256) void pwc_warp_finish_kernel(const long long* _
       const long long j = i - nx;
       float s = gfpart[j];
       for (int g = 1; g < G; ++g) s += gfpart[j + (long long)g * nf];   // channel groups in index order
-      gflo[j] = s;
+      gflo[j] = mul_rounded(s, fs);   // gradient of the scaled flow times the scale, as autograd's mul backward
     }
   }
 }
@@ -298,11 +306,11 @@ int channel_groups(long long plane, int C) {
 }  // namespace
 
 extern "C" int pcfa_pwc_warp_fwd(const float* x, const float* flo, float* out, int B, int C, int H, int W,
-                                 float mask_threshold, void* stream) {
+                                 float mask_threshold, float flow_scale, void* stream) {
   if (!x || !flo || !out || B < 1 || C < 1 || H < 1 || W < 1) return PCFA_ERR_INVALID_ARG;
   const long long plane = (long long)H * W;
   dim3 grid(pcfa_cdiv(plane, 256), channel_groups(plane, C), B);
-  pcfa_launch(pwc_warp_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, flo, out, C, H, W, mask_threshold);
+  pcfa_launch(pwc_warp_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, flo, out, C, H, W, mask_threshold, flow_scale);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
@@ -316,7 +324,7 @@ extern "C" size_t pcfa_pwc_warp_bwd_det_workspace_bytes(int B, int C, int H, int
 
 extern "C" int pcfa_pwc_warp_bwd_det(const float* x, const float* flo, const float* grad_out, float* grad_x,
                                      float* grad_flo, void* workspace, size_t workspace_bytes, int B, int C, int H,
-                                     int W, float mask_threshold, void* stream) {
+                                     int W, float mask_threshold, float flow_scale, void* stream) {
   if (!x || !flo || !grad_out || !grad_x || !grad_flo || !workspace || B < 1 || C < 1 || H < 1 || W < 1)
     return PCFA_ERR_INVALID_ARG;
   if (workspace_bytes < pcfa_pwc_warp_bwd_det_workspace_bytes(B, C, H, W)) return PCFA_ERR_WORKSPACE;
@@ -333,16 +341,17 @@ extern "C" int pcfa_pwc_warp_bwd_det(const float* x, const float* flo, const flo
   PCFA_LAUNCH_CHECK();
   dim3 grid(pcfa_cdiv(plane, 256), G, B);
   pcfa_launch(pwc_warp_bwd_det_kernel, grid, dim3(256), 0, s, x, flo, grad_out, gxi, gfpart, (const float*)bmax, nblk, C,
-              H, W, mask_threshold);
+              H, W, mask_threshold, flow_scale);
   PCFA_LAUNCH_CHECK();
   pcfa_launch(pwc_warp_finish_kernel, dim3((int)min((nx + nf + 255) / 256, 4096LL)), dim3(256), 0, s,
-              (const long long*)gxi, (const float*)gfpart, (const float*)bmax, nblk, grad_x, grad_flo, nx, nf, G);
+              (const long long*)gxi, (const float*)gfpart, (const float*)bmax, nblk, grad_x, grad_flo, nx, nf, G, flow_scale);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }
 
 extern "C" int pcfa_pwc_warp_bwd(const float* x, const float* flo, const float* grad_out, float* grad_x,
-                                 float* grad_flo, int B, int C, int H, int W, float mask_threshold, void* stream) {
+                                 float* grad_flo, int B, int C, int H, int W, float mask_threshold, float flow_scale,
+                                 void* stream) {
   if (!x || !flo || !grad_out || !grad_x || !grad_flo || B < 1 || C < 1 || H < 1 || W < 1)
     return PCFA_ERR_INVALID_ARG;
   const long long plane = (long long)H * W;
@@ -354,7 +363,7 @@ extern "C" int pcfa_pwc_warp_bwd(const float* x, const float* flo, const float* 
   PCFA_LAUNCH_CHECK();
   dim3 grid(pcfa_cdiv(plane, 256), channel_groups(plane, C), B);
   pcfa_launch(pwc_warp_bwd_kernel, grid, dim3(256), 0, s, x, flo, grad_out, grad_x, grad_flo, C, H, W,
-              mask_threshold);
+              mask_threshold, flow_scale);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }

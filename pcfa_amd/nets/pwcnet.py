@@ -22,6 +22,24 @@ from ..config import cfg
 # from the frozen pcfa_amd.config.Config the model was built with: cfg(module).<switch>.
 
 
+def _regrid(x, d_from, d_to, batch):
+    """x in sub-grid layout d_from -- [batch * d_from^2, C, H / d_from, W / d_from], image (gy, gx) = the pixels with
+    (y mod d_from, x mod d_from) = (gy, gx); d = 1 is the plain tensor -- to layout d_to, as ONE strided copy where d_to is
+    a multiple of d_from or 1 (consecutive dilated layers: 1 -> 2 -> 4 -> 8 -> 16 -> 1 in the context network)."""
+    if d_from == d_to:
+        return x
+    _, C, h, w = x.shape
+    # the full-resolution tensor as a view: [B, C, H/d_from, d_from, W/d_from, d_from], y = sy * d_from + gy
+    full = x.reshape(batch, d_from, d_from, C, h, w).permute(0, 3, 4, 1, 5, 2)
+    if d_to == 1:
+        return full.reshape(batch, C, h * d_from, w * d_from)
+    if d_to % d_from:
+        return _regrid(full.reshape(batch, C, h * d_from, w * d_from), 1, d_to, batch)
+    r = d_to // d_from   # y mod d_to = (sy mod r) * d_from + gy,  y div d_to = sy div r
+    v = full.reshape(batch, C, h // r, r, d_from, w // r, r, d_from).permute(0, 3, 4, 6, 7, 1, 2, 5)
+    return v.reshape(batch * d_to * d_to, C, h // r, w // r)
+
+
 class _ConvLeaky(nn.Sequential):
     """conv() of the reference (PWCNet.py:29-35): Conv2d + LeakyReLU(0.1); same parameter names ("0.weight", "0.bias").
     Frozen 3x3 / stride 1 / pad 1 instances run as ops.conv3x3 (Winograd on the fp32 matrix cores, bias and
@@ -36,8 +54,24 @@ class _ConvLeaky(nn.Sequential):
         c = self[0]
         return not (c.weight.requires_grad or (c.bias is not None and c.bias.requires_grad))
 
+    def grid(self, x):
+        """The sub-grid layout this layer computes in: its dilation on the "subgrid" path, else 1."""
+        return self[0].dilation[0] if self.kind(x) == "subgrid" else 1
+
+    def _bgr_weight(self):
+        """The weight with its three input channels reversed: conv(x[:, [2, 1, 0]], w) = conv(x, w[:, [2, 1, 0]]) -- the
+        RGB -> BGR stack of PWCNet.py:231-232 (two concatenations forward, six fills / copies / adds backward at full
+        image size) costs nothing this way.  Cached per weight version (the frozen path)."""
+        w = self[0].weight
+        hit = getattr(self, "_bgr_cache", None)
+        if hit is None or hit[0] != w._version or hit[1].device != w.device:
+            hit = (w._version, w.detach().flip(1).contiguous())
+            object.__setattr__(self, "_bgr_cache", hit)
+        return hit[1]
+
     def kind(self, x):
-        """Which path forward(x) takes: "conv3x3" | "subgrid" | "s2" | None (the library modules)."""
+        """Which path forward(x) takes: "conv3x3" | "subgrid" | "s2" | None (the library modules).  x: the input at full
+        resolution (or a meta tensor of that shape)."""
         c = self[0]
         if not self._frozen() or c.kernel_size != (3, 3) or c.groups != 1:
             return None
@@ -53,55 +87,71 @@ class _ConvLeaky(nn.Sequential):
             return "s2"
         return None
 
-    def forward(self, x, grad_premasked=False, mask_input_grad=False):
+    def forward(self, x, grad_premasked=False, mask_input_grad=False, grid_in=1, grid_out=1, bgr_input=False):
+        """grid_in / grid_out: the sub-grid layout (_regrid) x arrives in / the result is wanted in -- _chain passes the
+        next dilated layer's dilation so that two such layers exchange ONE copy; bgr_input: x is the RGB image and the
+        layer is to see it as BGR (PWCNet.py:231-232)."""
         c, slope = self[0], self[1].negative_slope
-        kind = self.kind(x)
+        batch = x.shape[0] // (grid_in * grid_in)
+        probe = x if grid_in == 1 else torch.empty((batch, x.shape[1], x.shape[2] * grid_in, x.shape[3] * grid_in),
+                                                   device="meta")
+        kind = self.kind(probe)
         if kind is None:
             if grad_premasked or mask_input_grad:
                 raise RuntimeError("deferred LeakyReLU masks need the operator-table path on both sides (kind() is None)")
-            return super().forward(x)
+            x = _regrid(x, grid_in, 1, batch)
+            return _regrid(super().forward(x.flip(1) if bgr_input else x), 1, grid_out, batch)
         kw = dict(grad_premasked=grad_premasked)
+        weight = self._bgr_weight() if bgr_input else c.weight
         if kind == "s2":
             # the pyramid's stride-2 layers (PWCNet.py:87-104): direct fp32-MFMA kernel, bias + LeakyReLU in the epilogue
             if mask_input_grad:
                 raise RuntimeError("conv_s2 does not apply an input mask")
-            return ops.get().conv_s2(x, c.weight, c.bias, leaky_slope=slope, own_bwd=cfg(self).conv_s2_bwd, **kw)
+            y = ops.get().conv_s2(_regrid(x, grid_in, 1, batch), weight, c.bias, leaky_slope=slope,
+                                  own_bwd=cfg(self).conv_s2_bwd, **kw)
+            return _regrid(y, 1, grid_out, batch)
         kw.update(mask_input_grad=mask_input_grad, input_slope=slope if mask_input_grad else 0.)
-        if kind == "conv3x3":
-            return ops.get().conv3x3(x, c.weight, c.bias, False, slope, **kw)
         # A 3x3 convolution with dilation d (the context network, PWCNet.py:160-166) never mixes pixels of different
         # (y mod d, x mod d): it is d*d independent plain 3x3 convolutions on the sub-sampled grids, zero padding
         # included (H, W multiples of d).  Sub-grids go to the batch axis and run on the Winograd kernel.
-        d = c.dilation[0]
-        B, C, H, W = x.shape
-        xs = x.reshape(B, C, H // d, d, W // d, d).permute(0, 3, 5, 1, 2, 4).reshape(B * d * d, C, H // d, W // d)
-        ys = ops.get().conv3x3(xs.contiguous(), c.weight, c.bias, False, slope, **kw)
-        N = ys.shape[1]
-        return ys.reshape(B, d, d, N, H // d, W // d).permute(0, 3, 4, 1, 5, 2).reshape(B, N, H, W)
+        d = c.dilation[0] if kind == "subgrid" else 1
+        ys = ops.get().conv3x3(_regrid(x, grid_in, d, batch).contiguous(), weight, c.bias, False, slope, **kw)
+        return _regrid(ys, d, grid_out, batch)
 
 
-def _chain(layers, x, last_premasked=False):
+def _chain(layers, x, last_premasked=False, bgr_input=False):
     """x -> layers[0] -> layers[1] -> ...: every intermediate output has exactly one consumer, so its LeakyReLU backward is
     applied by that consumer's data-gradient kernel wherever both layers run on the operator table (and the consumer is
     a stride-1 convolution, whose kernel has the mask epilogue)."""
     if not (layers and cfg(layers[0]).defer_leaky):
-        for layer in layers:
-            x = layer(x)
+        for i, layer in enumerate(layers):
+            x = layer(x, bgr_input=bgr_input and i == 0)
         return x
     masked_in = False
+    regrid = cfg(layers[0]).pwc_fold_glue
+    grid = 1           # the sub-grid layout x is in
+    hw = x.shape[-2:]  # its full-resolution size
+    batch = x.shape[0]
     for i, layer in enumerate(layers):
-        k = layer.kind(x)
+        probe_in = torch.empty((batch, x.shape[1]) + tuple(hw), device="meta")
+        k = layer.kind(probe_in)
         nxt = layers[i + 1] if i + 1 < len(layers) else None
         # the next layer's path depends on its input only through the spatial size (sub-grid divisibility), which a
         # stride-1 / stride-2 3x3 layer fixes: decide on a shape probe
         premask = False
+        c = layer[0]
+        hw = tuple((n + 2 * c.padding[j] - c.dilation[j] * (c.kernel_size[j] - 1) - 1) // c.stride[j] + 1
+                   for j, n in enumerate(hw))   # this layer's output size
+        nxt_grid = 1
         if k is not None and nxt is not None:
-            c = layer[0]
-            ho = (x.shape[-2] - 1) // c.stride[0] + 1 if c.stride[0] == 2 else x.shape[-2]
-            wo = (x.shape[-1] - 1) // c.stride[1] + 1 if c.stride[1] == 2 else x.shape[-1]
-            probe = torch.empty((x.shape[0], c.out_channels, ho, wo), device="meta")
+            probe = torch.empty((batch, c.out_channels) + hw, device="meta")
             premask = nxt.kind(probe) in ("conv3x3", "subgrid")
-        x = layer(x, grad_premasked=premask, mask_input_grad=masked_in)
+            # hand the result over in the layout the next layer computes in (one copy instead of two); a deferred mask
+            # is element-wise, so producer and consumer only have to agree on the layout -- they do, it is this tensor
+            nxt_grid = nxt.grid(probe) if regrid else 1
+        x = layer(x, grad_premasked=premask, mask_input_grad=masked_in, grid_in=grid, grid_out=nxt_grid,
+                  bgr_input=bgr_input and i == 0)
+        grid = nxt_grid
         masked_in = premask
     return x
 
@@ -194,36 +244,44 @@ class PWCDCNet(nn.Module):
                 if m.bias is not None:
                     m.bias.data.zero_()
 
-    def warp(self, x, flo):
-        """Backward-warp x by flo with a validity mask (PWCNet.py:166-206): one fused launch instead of the
+    def warp(self, x, flo, scale=1.0):
+        """Backward-warp x by scale * flo with a validity mask (PWCNet.py:166-206): one fused launch instead of the
         meshgrid / normalise / two grid_sample / compare / multiply sequence."""
-        return ops.get().pwc_warp(x, flo, 0.0001, deterministic=cfg(self).warp_bwd_deterministic)
+        if scale != 1.0 and not cfg(self).pwc_fold_glue:
+            flo, scale = flo * scale, 1.0
+        return ops.get().pwc_warp(x, flo, 0.0001, deterministic=cfg(self).warp_bwd_deterministic, flow_scale=scale)
 
     def _cost_volume(self, f1, f2):
         """leakyRELU(corr(f1, f2)) (PWCNet.py:249,264,278,292,308) in one launch per direction."""
         return ops.get().pwc_cost_volume(f1, f2, self.leakyRELU.negative_slope)
 
-    def _decode(self, lvl, x):
+    def _decode(self, lvl, *parts):
+        """The level's DenseNet block on cat(parts, 1) (PWCNet.py:250-255,265-270, ...)."""
         blocks = [getattr(self, "conv%d_%d" % (lvl, i)) for i in range(5)]
-        if x.shape[0] == 1 and not any(p.requires_grad for blk in blocks for p in blk.parameters()):
-            # one pre-allocated buffer: every convolution reads its channel suffix in place and writes in front of it
+        if parts[0].shape[0] == 1 and not any(p.requires_grad for blk in blocks for p in blk.parameters()):
+            # one pre-allocated buffer: the parts are written behind each other at its end, every convolution reads its
+            # channel suffix in place and writes in front of it
+            x = parts if len(parts) > 1 and cfg(self).pwc_fold_glue else (parts[0] if len(parts) == 1 else torch.cat(parts, 1))
             return ops.get().dense_block(x, [(blk[0].weight, blk[0].bias) for blk in blocks], blocks[0][1].negative_slope,
                                          fused_masks=cfg(self).dense_block_fused_masks)
+        x = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
         for blk in blocks:
             x = torch.cat((blk(x), x), 1)
         return x
 
     def forward(self, im1, im2):
-        # RGB -> BGR
-        im1 = torch.stack((im1[:, 2, :, :], im1[:, 1, :, :], im1[:, 0, :, :]), 1)
-        im2 = torch.stack((im2[:, 2, :, :], im2[:, 1, :, :], im2[:, 0, :, :]), 1)
+        # RGB -> BGR (PWCNet.py:231-232): in conv1a's weights where that layer runs on the operator table
+        fold_bgr = cfg(self).pwc_fold_glue and self.conv1a.kind(im1) is not None
+        if not fold_bgr:
+            im1 = torch.stack((im1[:, 2, :, :], im1[:, 1, :, :], im1[:, 0, :, :]), 1)
+            im2 = torch.stack((im2[:, 2, :, :], im2[:, 1, :, :], im2[:, 0, :, :]), 1)
 
         def pyramid(im):
             feats, x = [], im
             for lvl in range(1, 7):
                 first, second = ("aa", "a") if lvl == 6 else ("a", "aa")
                 x = _chain([getattr(self, "conv%d%s" % (lvl, first)), getattr(self, "conv%d%s" % (lvl, second)),
-                            getattr(self, "conv%db" % lvl)], x)
+                            getattr(self, "conv%db" % lvl)], x, bgr_input=fold_bgr and lvl == 1)
                 feats.append(x)
             return feats
 
@@ -237,9 +295,9 @@ class PWCDCNet(nn.Module):
 
         for lvl, scale in ((5, 0.625), (4, 1.25), (3, 2.5), (2, 5.0)):
             f1, f2 = c1[lvl - 1], c2[lvl - 1]
-            warped = self.warp(f2, up_flow * scale)
+            warped = self.warp(f2, up_flow, scale)
             corr = self._cost_volume(f1, warped)
-            x = self._decode(lvl, torch.cat((corr, f1, up_flow, up_feat), 1))
+            x = self._decode(lvl, corr, f1, up_flow, up_feat)
             flow = getattr(self, "predict_flow%d" % lvl)(x)
             flows[lvl] = flow
             if lvl > 2:

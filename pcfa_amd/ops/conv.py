@@ -614,20 +614,28 @@ class _DenseBlock(torch.autograd.Function):
     Batch size 1 only (a channel suffix of an NCHW tensor is contiguous only then)."""
 
     @staticmethod
-    def forward(ctx, x0, slope, fused_masks, *wb):
+    def forward(ctx, slope, fused_masks, nparts, *rest):
+        parts, wb = rest[:nparts], rest[nparts:]
         weights, biases = wb[0::2], wb[1::2]
         ctx.fused_masks = bool(fused_masks)
-        _dev(x0, *weights)
-        x0 = x0.contiguous()
-        B, K0, H, W = x0.shape
+        _dev(*parts, *weights)
+        x0 = parts[0]
+        B, _, H, W = x0.shape
         if B != 1:
             raise ValueError("dense_block: batch size 1 only")
+        if any(p.shape[0] != 1 or tuple(p.shape[2:]) != (H, W) or p.dtype != torch.float32 for p in parts):
+            raise ValueError("dense_block: input parts %s do not share batch 1 / size / fp32" % ([tuple(p.shape) for p in parts],))
+        ctx.part_widths = [p.shape[1] for p in parts]
+        K0 = sum(ctx.part_widths)
         widths = [w.shape[0] for w in weights]
         total = K0 + sum(widths)
         buf = torch.empty((1, total, H, W), device=x0.device, dtype=torch.float32)
         plane = H * W
         start = total - K0
-        buf[:, start:].copy_(x0)
+        if nparts == 1:
+            buf[:, start:].copy_(x0)
+        else:   # the caller's torch.cat((corr, f1, up_flow, up_feat), 1) lands in the block buffer directly
+            torch.cat(parts, 1, out=buf[:, start:])
         packs = []
         k = K0
         for w, b, n in zip(weights, biases, widths):
@@ -645,20 +653,24 @@ class _DenseBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        if any(ctx.needs_input_grad[3:]):
+        if any(ctx.needs_input_grad[3 + len(ctx.part_widths):]):
             raise RuntimeError("dense_block is the frozen-weight path: no weight / bias gradient")
         (buf,) = ctx.saved_tensors
         total, K0, H, W = ctx.dims
         plane = H * W
-        gb = g.contiguous().clone()  # running gradient of the buffer: every layer adds its input gradient to a suffix
+        # running gradient of the buffer: every layer adds its input gradient to a suffix.  `g` itself must not be written
+        # (autograd may share it): the TOP layer reads its addend from g and writes the sum into gb -- its suffix is
+        # everything any later step reads, so g is never copied (r03 cloned it: up to 69 MB per level)
+        g = g.contiguous()
+        gb = torch.empty_like(g)
         npk = len(ctx.packs)
         for i in range(npk - 1, -1, -1):
             bwd, k, n, start = ctx.packs[i]
             if i == npk - 1 or not ctx.fused_masks:
                 # LeakyReLU backward of this layer's output (the top layer's gradient arrives from outside only)
                 gm = torch.empty((1, n, H, W), device=g.device, dtype=torch.float32)
-                _call("pcfa_leaky_relu_bwd", _ptr_off(buf, (start - n) * plane), _ptr_off(gb, (start - n) * plane),
-                      _ptr(gm), ctx.slope, n * plane)
+                _call("pcfa_leaky_relu_bwd", _ptr_off(buf, (start - n) * plane),
+                      _ptr_off(g if i == npk - 1 else gb, (start - n) * plane), _ptr(gm), ctx.slope, n * plane)
                 gm_ptr = _ptr(gm)
             else:   # already multiplied by the layer above (below): its slot of the running gradient IS the masked gradient
                 gm_ptr = _ptr_off(gb, (start - n) * plane)
@@ -668,22 +680,30 @@ class _DenseBlock(torch.autograd.Function):
             # LeakyReLU backward rides in the same epilogue (mask = that layer's output in the block buffer, applied
             # after the addend) -- 4 elementwise launches less per block.
             dst = _ptr_off(gb, start * plane)
+            src = _ptr_off(g, start * plane) if i == npk - 1 else dst
             if i > 0 and ctx.fused_masks:
-                _conv3x3_run(g.device, gm_ptr, bwd, None, _ptr_off(buf, start * plane), dst, dst, 1, n, k, H, W,
+                _conv3x3_run(g.device, gm_ptr, bwd, None, _ptr_off(buf, start * plane), src, dst, 1, n, k, H, W,
                              slope=ctx.slope, mask_channels=ctx.packs[i - 1][2])
             else:
-                _conv3x3_run(g.device, gm_ptr, bwd, None, None, dst, dst, 1, n, k, H, W)
-        return (gb[:, total - K0:], None, None) + (None,) * (2 * len(ctx.packs))
+                _conv3x3_run(g.device, gm_ptr, bwd, None, None, src, dst, 1, n, k, H, W)
+        grads, c0 = [], total - K0
+        for wdt, need in zip(ctx.part_widths, ctx.needs_input_grad[3:]):   # channel ranges of one image: contiguous views
+            grads.append(gb[:, c0:c0 + wdt] if need else None)
+            c0 += wdt
+        return (None, None, None) + tuple(grads) + (None,) * (2 * len(ctx.packs))
 
 
 def dense_block(x, layers, slope=0.1, fused_masks=True):
     """layers = [(weight, bias), ...] of frozen 3x3 convolutions; returns cat(y_n-1, ..., y_0, x) along channels.
+    x: one tensor, or a tuple of tensors standing for their channel concatenation (PWCNet.py:265: cat((corr, c1, up_flow,
+    up_feat), 1)) -- the parts are written into the block's buffer directly and get their gradients as views of it.
     fused_masks (Config.dense_block_fused_masks): the LeakyReLU backward of layers 0..n-2 rides in the data-gradient
     epilogue of the layer above; False = one pcfa_leaky_relu_bwd launch per layer."""
     flat = []
     for w, b in layers:
         flat += [w, b]
-    return _DenseBlock.apply(x, slope, fused_masks, *flat)
+    parts = tuple(x) if isinstance(x, (tuple, list)) else (x,)
+    return _DenseBlock.apply(slope, fused_masks, len(parts), *[p.contiguous() for p in parts], *flat)
 
 
 def conv3x3(x, weight, bias=None, relu=False, leaky_slope=None, skip=False, grad_premasked=False, mask_input_grad=False,

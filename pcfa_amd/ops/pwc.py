@@ -100,7 +100,7 @@ class _PwcWarp(torch.autograd.Function):
     """PWCDCNet.warp (models/PWCNet/PWCNet.py:166-206) on pcfa_pwc_warp_fwd/bwd."""
 
     @staticmethod
-    def forward(ctx, x, flo, mask_threshold, deterministic=True):
+    def forward(ctx, x, flo, mask_threshold, deterministic=True, flow_scale=1.0):
         _dev(x, flo)
         ctx.deterministic = bool(deterministic)
         x, flo = x.contiguous(), flo.contiguous()
@@ -108,7 +108,7 @@ class _PwcWarp(torch.autograd.Function):
         if tuple(flo.shape) != (B, 2, H, W):
             raise ValueError("pwc_warp: flow %s does not match features %s" % (tuple(flo.shape), tuple(x.shape)))
         out = torch.empty_like(x)
-        ctx.params = (B, C, H, W, float(mask_threshold))
+        ctx.params = (B, C, H, W, float(mask_threshold), float(flow_scale))
         _call("pcfa_pwc_warp_fwd", _ptr(x), _ptr(flo), _ptr(out), *ctx.params)
         ctx.save_for_backward(x, flo)
         return out
@@ -120,20 +120,22 @@ class _PwcWarp(torch.autograd.Function):
         g = g.contiguous()
         gx, gf = torch.empty_like(x), torch.empty_like(flo)
         if ctx.deterministic:   # fixed-point scatter (bit-reproducible); else hardware fp32 atomics
-            B, C, H, W, thr = ctx.params
+            B, C, H, W, thr, fs = ctx.params
             nws = int(_hip.load().pcfa_pwc_warp_bwd_det_workspace_bytes(B, C, H, W))
             ws = torch.empty((nws + 7) // 8, device=x.device, dtype=torch.int64)
             _call("pcfa_pwc_warp_bwd_det", _ptr(x), _ptr(flo), _ptr(g), _ptr(gx), _ptr(gf), _ptr(ws), nws, B, C, H, W,
-                  thr)
+                  thr, fs)
         else:
             _call("pcfa_pwc_warp_bwd", _ptr(x), _ptr(flo), _ptr(g), _ptr(gx), _ptr(gf), *ctx.params)
-        return gx, gf, None, None
+        return gx, gf, None, None, None
 
 
-def pwc_warp(x, flo, mask_threshold=0.0001, deterministic=True):
-    """Backward-warp x by flo with PWC-Net's validity mask: one launch forward, three backward.  deterministic
-    (Config.warp_bwd_deterministic): the backward scatters fixed-point values (bit-reproducible); False: fp32 atomics."""
-    return _PwcWarp.apply(x, flo, mask_threshold, deterministic)
+def pwc_warp(x, flo, mask_threshold=0.0001, deterministic=True, flow_scale=1.0):
+    """Backward-warp x by flow_scale * flo with PWC-Net's validity mask: one launch forward, three backward.  deterministic
+    (Config.warp_bwd_deterministic): the backward scatters fixed-point values (bit-reproducible); False: fp32 atomics.
+    flow_scale: `self.warp(c2, up_flow * 0.625)` (PWCNet.py:262,276,290,306) without the two element-wise launches; the
+    same bits (the product is rounded before use, the flow gradient is multiplied after the sum)."""
+    return _PwcWarp.apply(x, flo, mask_threshold, deterministic, flow_scale)
 
 
 class _Deconv4s2FewOut(torch.autograd.Function):

@@ -652,6 +652,19 @@ def test_dense_block_vs_oracle(oracle_ops, shape):
     assert rel_l2(xg.grad, x.grad) < 1e-4
     with pytest.raises(ValueError):
         hip_ops.dense_block(torch.cat([xg.detach(), xg.detach()]), [(w.to(DEV), b.to(DEV)) for w, b in layers], 0.1)
+    # the input as the parts of the caller's concatenation (PWCNet.py:265: cat((corr, c1, up_flow, up_feat), 1)): written
+    # into the block buffer directly, gradients handed back as views of the running gradient -- the same bits
+    if K > 4:
+        cuts = [0, K - 4, K - 2, K]
+        parts = [x.detach()[:, a:b].clone().to(DEV).requires_grad_(True) for a, b in zip(cuts[:-1], cuts[1:])]
+        got2 = hip_ops.dense_block(tuple(parts), [(w.to(DEV), b.to(DEV)) for w, b in layers], 0.1)
+        assert torch.equal(got2, got)
+        got2.backward(go.to(DEV))
+        assert torch.equal(torch.cat([p.grad for p in parts], 1), xg.grad)
+        grad_seen = go.to(DEV).clone()
+        got3 = hip_ops.dense_block(xg.detach().requires_grad_(True), [(w.to(DEV), b.to(DEV)) for w, b in layers], 0.1)
+        got3.backward(grad_seen)
+        assert torch.equal(grad_seen, go.to(DEV))     # the incoming gradient is read, never written
 
 
 # --------------------------------------------------------------------------- PWC-Net warp
@@ -694,6 +707,22 @@ def test_pwc_warp_vs_oracle(oracle_ops, shape, scale):
     # zero flow: the align_corners mismatch of the original code samples at x * W / (W - 1) - 0.5, not at x
     ident = hip_ops.pwc_warp(xg.detach(), torch.zeros_like(fg))
     assert max_abs(ident, oracle_ops.pwc_warp(x.detach(), torch.zeros_like(flo))) <= 2e-6 * float(x.detach().abs().max())
+    # flow_scale: `self.warp(c2, up_flow * 0.625)` (PWCNet.py:262) in the kernel = the two element-wise launches, bit for bit
+    for det in (True, False):
+        for fs in (0.625, 5.0):
+            xa, fa = x.detach().to(DEV).requires_grad_(True), flo.detach().to(DEV).requires_grad_(True)
+            xb, fb = x.detach().to(DEV).requires_grad_(True), flo.detach().to(DEV).requires_grad_(True)
+            ya = hip_ops.pwc_warp(xa, fa, deterministic=det, flow_scale=fs)
+            yb = hip_ops.pwc_warp(xb, fb * fs, deterministic=det)
+            assert torch.equal(ya, yb)
+            ya.backward(go.to(DEV))
+            yb.backward(go.to(DEV))
+            if det:
+                assert torch.equal(xa.grad, xb.grad) and torch.equal(fa.grad, fb.grad)
+            else:   # hardware atomics: order-dependent roundings
+                assert rel_l2(xa.grad, xb.grad) < 1e-6 and rel_l2(fa.grad, fb.grad) < 1e-6
+    ws = oracle_ops.pwc_warp(x.detach(), flo.detach(), flow_scale=0.625)
+    assert max_abs(hip_ops.pwc_warp(xg.detach(), fg.detach(), flow_scale=0.625), ws) <= 2e-6 * float(x.detach().abs().max())
 
 
 # --------------------------------------------------------------------------- flow-prediction convolutions
@@ -2021,3 +2050,11 @@ def test_pwcnet_deferred_leaky_masks_change_no_bit():
     plain = run(dataclasses.replace(config.DEFAULT, defer_leaky=False, dense_block_fused_masks=False))
     assert fused[0] == plain[0] and torch.equal(fused[1], plain[1]) and torch.equal(fused[2], plain[2])
     assert float(fused[2].abs().max()) > 0
+    # Config.pwc_fold_glue (r04): `up_flow * s` inside the warp, decoder inputs handed to the dense block as parts, ONE
+    # re-gridding copy between dilated layers move no bit either; RGB -> BGR folded into conv1a's weights sums that
+    # layer's three input channels in another order (the stride-2 kernel's K axis), so against the reference's explicit
+    # stack the closure agrees to rounding only
+    unfolded = run(dataclasses.replace(config.DEFAULT, pwc_fold_glue=False))
+    assert abs(fused[0] - unfolded[0]) <= 1e-6 * abs(unfolded[0])
+    assert max_abs(fused[1], unfolded[1]) <= 2e-5 * float(unfolded[1].abs().max())
+    assert rel_l2(fused[2], unfolded[2]) < 2e-3

@@ -51,6 +51,28 @@ def test_closure_matches_reference(name):
         assert rel_l2(gr, t(g["grad%d" % i])) < 1e-3
 
 
+def test_pwcnet_folded_glue_is_the_same_network():
+    """Config.pwc_fold_glue (RGB -> BGR in conv1a's weights, `up_flow * s` inside the warp, decoder inputs handed to the
+    dense block as parts, one re-gridding copy between the dilated context layers) against the reference's statement
+    order (PWCNet.py:227-330) on the CPU port: the same network -- only conv1a's three input channels are summed in
+    another order."""
+    import dataclasses
+    from pcfa_amd import config
+
+    def run(conf):
+        closure_util._MODELS.clear()
+        r = closure_util.run_closure("PWCNet", 128, 192, "clipping", True, "zero", "aee", 5, torch.device("cpu"),
+                                     config=conf)
+        closure_util._MODELS.clear()
+        return r
+    a = run(config.DEFAULT)
+    b = run(dataclasses.replace(config.DEFAULT, pwc_fold_glue=False))
+    assert config.DEFAULT.pwc_fold_glue
+    assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(b["loss"])
+    assert max_abs(a["flow"], b["flow"]) <= 1e-5 * float(b["flow"].abs().max())
+    assert rel_l2(a["grads"][0], b["grads"][0]) < 1e-4
+
+
 def test_seeded_inputs_are_reproducible():
     """The generated leaves equal the stored ones (so GPU tests can regenerate instead of loading)."""
     g = load_golden("closure_raft")
