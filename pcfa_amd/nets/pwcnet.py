@@ -133,8 +133,8 @@ def _chain(layers, x, last_premasked=False, bgr_input=False):
     hw = x.shape[-2:]  # its full-resolution size
     batch = x.shape[0]
     for i, layer in enumerate(layers):
-        probe_in = torch.empty((batch, x.shape[1]) + tuple(hw), device="meta")
-        k = layer.kind(probe_in)
+        # (the real tensor where it is at full resolution: conv_s2_supported looks at more than the shape)
+        k = layer.kind(x if grid == 1 else torch.empty((batch, x.shape[1]) + tuple(hw), device="meta"))
         nxt = layers[i + 1] if i + 1 < len(layers) else None
         # the next layer's path depends on its input only through the spatial size (sub-grid divisibility), which a
         # stride-1 / stride-2 3x3 layer fixes: decide on a shape probe
