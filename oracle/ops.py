@@ -580,6 +580,11 @@ def conv3x3_fewout(x, weight, bias=None):
     return F.conv2d(x, weight, bias, stride=1, padding=1)
 
 
+def split_batch(x, b):
+    """The product computes PWC-Net's two feature pyramids (PWCNet.py:233-244) in one batch; this hands the halves back."""
+    return x[:b], x[b:]
+
+
 def deconv4s2_fewout(x, weight, bias=None):
     """deconv() of PWC-Net (models/PWCNet/PWCNet.py:42-43): nn.ConvTranspose2d(in, out, 4, 2, 1)."""
     return F.conv_transpose2d(x, weight, bias, stride=2, padding=1)

@@ -551,7 +551,7 @@ static int f23_kslices(int B, int K, int N, int H, int W) {
   const int nchunk = (K + KC - 1) / KC;
   const long long nwg = (long long)pcfa_cdiv(W, 2 * TC) * pcfa_cdiv(H, 8) * ((N + 31) / 32) * B;
   long long want = env > 0 ? env : min(256 / max(nwg, 1LL), (long long)nchunk / 2);
-  if (env < 0 && (B != 1 || (long long)H * W > 2048 || nwg > 64)) want = 1;
+  if (env < 0 && (B > 2 || (long long)H * W > 2048 || nwg > 128)) want = 1;   // (B = 2: PWC-Net's two pyramids in one batch)
   if (want < 2 || nchunk < 2) return 1;
   want = min(want, (long long)nchunk);
   const int cper = (int)((nchunk + want - 1) / want);

@@ -87,15 +87,22 @@ class _ConvLeaky(nn.Sequential):
             return "s2"
         return None
 
-    def forward(self, x, grad_premasked=False, mask_input_grad=False, grid_in=1, grid_out=1, bgr_input=False):
+    def forward(self, x, grad_premasked=False, mask_input_grad=False, grid_in=1, grid_out=1, bgr_input=False, skip=False):
         """grid_in / grid_out: the sub-grid layout (_regrid) x arrives in / the result is wanted in -- _chain passes the
         next dilated layer's dilation so that two such layers exchange ONE copy; bgr_input: x is the RGB image and the
-        layer is to see it as BGR (PWCNet.py:231-232)."""
+        layer is to see it as BGR (PWCNet.py:231-232); skip: also return an alias of x for its other consumer (ops.conv3x3:
+        the gradient arriving there is added in this layer's data-gradient epilogue) -- plain conv3x3 layers only."""
         c, slope = self[0], self[1].negative_slope
         batch = x.shape[0] // (grid_in * grid_in)
         probe = x if grid_in == 1 else torch.empty((batch, x.shape[1], x.shape[2] * grid_in, x.shape[3] * grid_in),
                                                    device="meta")
         kind = self.kind(probe)
+        if skip:
+            if kind != "conv3x3" or grid_in != 1:
+                raise RuntimeError("skip needs a plain 3x3 layer on the operator table")
+            y, alias = ops.get().conv3x3(x, c.weight, c.bias, False, slope, skip=True, grad_premasked=grad_premasked,
+                                         mask_input_grad=mask_input_grad, input_slope=slope if mask_input_grad else 0.)
+            return _regrid(y, 1, grid_out, batch), alias
         if kind is None:
             if grad_premasked or mask_input_grad:
                 raise RuntimeError("deferred LeakyReLU masks need the operator-table path on both sides (kind() is None)")
@@ -119,7 +126,7 @@ class _ConvLeaky(nn.Sequential):
         return _regrid(ys, d, grid_out, batch)
 
 
-def _chain(layers, x, last_premasked=False, bgr_input=False):
+def _chain(layers, x, last_premasked=False, bgr_input=False, skip_first=False):
     """x -> layers[0] -> layers[1] -> ...: every intermediate output has exactly one consumer, so its LeakyReLU backward is
     applied by that consumer's data-gradient kernel wherever both layers run on the operator table (and the consumer is
     a stride-1 convolution, whose kernel has the mask epilogue)."""
@@ -150,10 +157,12 @@ def _chain(layers, x, last_premasked=False, bgr_input=False):
             # is element-wise, so producer and consumer only have to agree on the layout -- they do, it is this tensor
             nxt_grid = nxt.grid(probe) if regrid else 1
         x = layer(x, grad_premasked=premask, mask_input_grad=masked_in, grid_in=grid, grid_out=nxt_grid,
-                  bgr_input=bgr_input and i == 0)
+                  bgr_input=bgr_input and i == 0, skip=skip_first and i == 0)
+        if skip_first and i == 0:
+            x, alias = x
         grid = nxt_grid
         masked_in = premask
-    return x
+    return (x, alias) if skip_first else x
 
 
 def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
@@ -285,7 +294,13 @@ class PWCDCNet(nn.Module):
                 feats.append(x)
             return feats
 
-        c1, c2 = pyramid(im1), pyramid(im2)  # index 0 = level 1 ... index 5 = level 6
+        if cfg(self).pwc_fold_glue and fold_bgr and im1.shape == im2.shape:
+            # both pyramids in one batch (the layers are per-sample, so nothing is shared but the launches: half as
+            # many, each with twice the workgroups -- the coarse levels are a handful of workgroups per image)
+            b = im1.shape[0]
+            c1, c2 = zip(*[ops.get().split_batch(f, b) for f in pyramid(torch.cat((im1, im2), 0))])
+        else:
+            c1, c2 = pyramid(im1), pyramid(im2)  # index 0 = level 1 ... index 5 = level 6
 
         corr6 = self._cost_volume(c1[5], c2[5])
         x = self._decode(6, corr6)
@@ -298,14 +313,23 @@ class PWCDCNet(nn.Module):
             warped = self.warp(f2, up_flow, scale)
             corr = self._cost_volume(f1, warped)
             x = self._decode(lvl, corr, f1, up_flow, up_feat)
-            flow = getattr(self, "predict_flow%d" % lvl)(x)
-            flows[lvl] = flow
             if lvl > 2:
+                flow = getattr(self, "predict_flow%d" % lvl)(x)
+                flows[lvl] = flow
                 up_flow = getattr(self, "deconv%d" % lvl)(flow)
                 up_feat = getattr(self, "upfeat%d" % lvl)(x)
 
-        x = _chain([self.dc_conv1, self.dc_conv2, self.dc_conv3, self.dc_conv4, self.dc_conv5, self.dc_conv6], x)
-        flow2 = flows[2] + self.dc_conv7(x)
+        # level 2's decoder output feeds predict_flow2 and the context network (PWCNet.py:311-316).  On the operator table
+        # dc_conv1 hands back an alias of its input for the other consumer: that one's gradient is then added in
+        # dc_conv1's data-gradient epilogue instead of by an autograd add over [565, H/4, W/4]
+        dc = [self.dc_conv1, self.dc_conv2, self.dc_conv3, self.dc_conv4, self.dc_conv5, self.dc_conv6]
+        if cfg(self).pwc_fold_glue and cfg(self).defer_leaky and self.dc_conv1.kind(x) == "conv3x3":
+            ctx_feat, x = _chain(dc, x, skip_first=True)
+            flows[2] = self.predict_flow2(x)
+        else:
+            flows[2] = self.predict_flow2(x)
+            ctx_feat = _chain(dc, x)
+        flow2 = flows[2] + self.dc_conv7(ctx_feat)
 
         if cfg(self).deconv_fewout and not self.training:
             return ops.get().upsample_bilinear(flow2, 4, 20.0)   # 20 * self.upsample(flow2), gather backward

@@ -138,6 +138,35 @@ def pwc_warp(x, flo, mask_threshold=0.0001, deterministic=True, flow_scale=1.0):
     return _PwcWarp.apply(x, flo, mask_threshold, deterministic, flow_scale)
 
 
+class _SplitBatch(torch.autograd.Function):
+    """(x[:b], x[b:]) as views; the backward writes both gradients into one tensor with ONE concatenation (autograd's own
+    slice backward is a fill + copy per half and an add)."""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        ctx.dims = (b, tuple(x.shape))
+        ctx.set_materialize_grads(False)
+        return x[:b], x[b:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        b, shape = ctx.dims
+        if g0 is None and g1 is None:
+            return None, None
+        ref = g0 if g0 is not None else g1
+        if g0 is None:
+            g0 = ref.new_zeros((b,) + shape[1:])
+        if g1 is None:
+            g1 = ref.new_zeros((shape[0] - b,) + shape[1:])
+        return torch.cat((g0, g1), 0), None
+
+
+def split_batch(x, b):
+    """x[:b], x[b:] -- the two images' halves of a feature tensor computed for both at once (nets/pwcnet.py runs the
+    feature pyramid of PWCNet.py:233-244 on cat((im1, im2), 0): half the launches, twice the workgroups per launch)."""
+    return _SplitBatch.apply(x, b)
+
+
 class _Deconv4s2FewOut(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
