@@ -64,7 +64,7 @@ class _ConvLeaky(nn.Sequential):
         image size) costs nothing this way.  Cached per weight version (the frozen path)."""
         w = self[0].weight
         hit = getattr(self, "_bgr_cache", None)
-        if hit is None or hit[0] != w._version or hit[1].device != w.device:
+        if hit is None or hit[0] != w._version or hit[1].device != w.device or hit[1].dtype != w.dtype:
             hit = (w._version, w.detach().flip(1).contiguous())
             object.__setattr__(self, "_bgr_cache", hit)
         return hit[1]
