@@ -587,8 +587,10 @@ PCFA_API int pcfa_pwc_warp_bwd_det(const float* x, const float* flo, const float
 PCFA_API size_t pcfa_conv3x3_fewout_workspace_bytes(int B, int K, int N, int H, int W);
 PCFA_API int pcfa_conv3x3_fewout_fwd(const float* x, const float* w, const float* bias, float* out, void* workspace,
                                      int B, int K, int N, int H, int W, void* stream);
-PCFA_API int pcfa_conv3x3_fewout_bwd(const float* grad_out, const float* w, float* grad_x, int B, int K, int N, int H,
-                                     int W, void* stream);
+/* addend ([B][K][H][W] or NULL): grad_x = data gradient + addend -- the gradient another consumer of x produced (PWC-Net:
+ * upfeat reads the same decoder output as predict_flow, PWCNet.py:256-257), summed here instead of by a separate pass. */
+PCFA_API int pcfa_conv3x3_fewout_bwd(const float* grad_out, const float* w, const float* addend, float* grad_x, int B,
+                                     int K, int N, int H, int W, void* stream);
 
 /* ConvTranspose2d(K, N, kernel_size=4, stride=2, padding=1) with N <= 4 output channels and its data gradient (frozen
  * weights): PWC-Net's `deconv` layers -- deconv6..2 (2 -> 2 channels) and upfeat6..3 (529..661 -> 2 channels)

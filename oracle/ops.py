@@ -575,9 +575,11 @@ def pwc_warp(x, flo, mask_threshold=0.0001, deterministic=True, flow_scale=1.0):
     return output * mask
 
 
-def conv3x3_fewout(x, weight, bias=None):
-    """The flow-prediction convolutions (models/raft/update.py:6-14, PWCNet.py:37-38, FlowNet/submodules.py:33-34)."""
-    return F.conv2d(x, weight, bias, stride=1, padding=1)
+def conv3x3_fewout(x, weight, bias=None, skip=False):
+    """The flow-prediction convolutions (models/raft/update.py:6-14, PWCNet.py:37-38, FlowNet/submodules.py:33-34).
+    skip: also return x (the product sums the other consumer's gradient of x in its data-gradient kernel)."""
+    y = F.conv2d(x, weight, bias, stride=1, padding=1)
+    return (y, x) if skip else y
 
 
 def split_batch(x, b):

@@ -148,7 +148,7 @@ SIGNATURES = {
     "pcfa_pwc_warp_bwd_det": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "pcfa_conv3x3_fewout_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "pcfa_conv3x3_fewout_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "pcfa_conv3x3_fewout_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pcfa_conv3x3_fewout_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_deconv4s2_fewout_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "pcfa_deconv4s2_fewout_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "pcfa_deconv4s2_fewout_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -209,8 +209,8 @@ __global__ void fewout_reduce_kernel(const float* __restrict__ part, const float
 
 template <int N>
 __global__ __launch_bounds__(FO_PX* FO_WAVES) void conv3x3_fewout_bwd_kernel(
-    const float* __restrict__ gout, const float* __restrict__ w, float* __restrict__ gx, int K, int H, int W,
-    int csplit) {
+    const float* __restrict__ gout, const float* __restrict__ w, const float* __restrict__ addend, float* __restrict__ gx,
+    int K, int H, int W, int csplit) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y / csplit, part = blockIdx.y % csplit;
@@ -235,10 +235,16 @@ __global__ __launch_bounds__(FO_PX* FO_WAVES) void conv3x3_fewout_bwd_kernel(
       }
     }
   float* xb = gx + (size_t)b * K * plane;
+  const float* ab = addend != nullptr ? addend + (size_t)b * K * plane : nullptr;   // another consumer's gradient of x
   constexpr int U = 4;
   const int cstep = FO_WAVES * csplit;
   for (int c0 = part * FO_WAVES + wave; c0 < K; c0 += U * cstep) {
-    float s[U];
+    float s[U], a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * cstep;  // wave-uniform
+      a[u] = (ab != nullptr && c < K && live) ? ab[(size_t)c * plane + p] : 0.f;   // requested ahead of the products
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int c = c0 + u * cstep;  // wave-uniform
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(FO_PX* FO_WAVES) void conv3x3_fewout_bwd_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int c = c0 + u * cstep;
-      if (c < K && live) xb[(size_t)c * plane + p] = s[u];
+      if (c < K && live) xb[(size_t)c * plane + p] = s[u] + a[u];
     }
   }
 }
@@ -474,8 +480,8 @@ extern "C" int pcfa_conv3x3_fewout_fwd(const float* x, const float* w, const flo
   return PCFA_OK;
 }
 
-extern "C" int pcfa_conv3x3_fewout_bwd(const float* grad_out, const float* w, float* grad_x, int B, int K, int N,
-                                       int H, int W, void* stream) {
+extern "C" int pcfa_conv3x3_fewout_bwd(const float* grad_out, const float* w, const float* addend, float* grad_x, int B,
+                                       int K, int N, int H, int W, void* stream) {
   if (!grad_out || !w || !grad_x || B < 1 || K < 1 || H < 1 || W < 1) return PCFA_ERR_INVALID_ARG;
   if (N < 1 || N > 4) return PCFA_ERR_UNSUPPORTED;
   const long long plane = (long long)H * W;
@@ -486,10 +492,10 @@ extern "C" int pcfa_conv3x3_fewout_bwd(const float* grad_out, const float* w, fl
   dim3 grid(pcfa_cdiv(plane, FO_PX), B * csplit), block(FO_PX * FO_WAVES);
   hipStream_t s = (hipStream_t)stream;
   switch (N) {
-    case 1: pcfa_launch(conv3x3_fewout_bwd_kernel<1>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
-    case 2: pcfa_launch(conv3x3_fewout_bwd_kernel<2>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
-    case 3: pcfa_launch(conv3x3_fewout_bwd_kernel<3>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
-    default: pcfa_launch(conv3x3_fewout_bwd_kernel<4>, grid, block, 0, s, grad_out, w, grad_x, K, H, W, csplit); break;
+    case 1: pcfa_launch(conv3x3_fewout_bwd_kernel<1>, grid, block, 0, s, grad_out, w, addend, grad_x, K, H, W, csplit); break;
+    case 2: pcfa_launch(conv3x3_fewout_bwd_kernel<2>, grid, block, 0, s, grad_out, w, addend, grad_x, K, H, W, csplit); break;
+    case 3: pcfa_launch(conv3x3_fewout_bwd_kernel<3>, grid, block, 0, s, grad_out, w, addend, grad_x, K, H, W, csplit); break;
+    default: pcfa_launch(conv3x3_fewout_bwd_kernel<4>, grid, block, 0, s, grad_out, w, addend, grad_x, K, H, W, csplit); break;
   }
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;

@@ -176,10 +176,12 @@ class _PredictFlow(nn.Conv2d):
     """A 3x3 flow-prediction layer (2 output channels).  Frozen weights stream through ops.conv3x3_fewout (an
     HBM-bound kernel) instead of a library convolution padded to a matrix-core tile; parameter names unchanged."""
 
-    def forward(self, x):
+    def forward(self, x, skip=False):
+        """skip: also return an alias of x for its other consumer (ops.conv3x3_fewout)."""
         if not (self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad)):
-            return ops.get().conv3x3_fewout(x, self.weight, self.bias)
-        return super().forward(x)
+            return ops.get().conv3x3_fewout(x, self.weight, self.bias, skip=skip)
+        y = super().forward(x)
+        return (y, x) if skip else y
 
 
 def predict_flow(in_planes):
@@ -264,6 +266,14 @@ class PWCDCNet(nn.Module):
         """leakyRELU(corr(f1, f2)) (PWCNet.py:249,264,278,292,308) in one launch per direction."""
         return ops.get().pwc_cost_volume(f1, f2, self.leakyRELU.negative_slope)
 
+    def _flow_head(self, lvl, x):
+        """(predict_flow(x), x for upfeat): with Config.pwc_fold_glue the second is predict_flow's alias of x, so that
+        upfeat's gradient is added inside predict_flow's data-gradient kernel instead of by an autograd add."""
+        head = getattr(self, "predict_flow%d" % lvl)
+        if cfg(self).pwc_fold_glue:
+            return head(x, skip=True)
+        return head(x), x
+
     def _decode(self, lvl, *parts):
         """The level's DenseNet block on cat(parts, 1) (PWCNet.py:250-255,265-270, ...)."""
         blocks = [getattr(self, "conv%d_%d" % (lvl, i)) for i in range(5)]
@@ -304,7 +314,7 @@ class PWCDCNet(nn.Module):
 
         corr6 = self._cost_volume(c1[5], c2[5])
         x = self._decode(6, corr6)
-        flow = self.predict_flow6(x)
+        flow, x = self._flow_head(6, x)
         flows = {6: flow}
         up_flow, up_feat = self.deconv6(flow), self.upfeat6(x)
 
@@ -314,7 +324,8 @@ class PWCDCNet(nn.Module):
             corr = self._cost_volume(f1, warped)
             x = self._decode(lvl, corr, f1, up_flow, up_feat)
             if lvl > 2:
-                flow = getattr(self, "predict_flow%d" % lvl)(x)
+                # (predict_flow hands upfeat an alias of x: upfeat's gradient is added in predict_flow's data-gradient kernel)
+                flow, x = self._flow_head(lvl, x)
                 flows[lvl] = flow
                 up_flow = getattr(self, "deconv%d" % lvl)(flow)
                 up_feat = getattr(self, "upfeat%d" % lvl)(x)

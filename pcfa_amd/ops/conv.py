@@ -231,8 +231,9 @@ def conv_s2(x, weight, bias=None, relu=False, leaky_slope=None, grad_premasked=F
 
 class _Conv3x3FewOut(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, skip=False):
         _dev(x, weight, bias)
+        ctx.set_materialize_grads(False)
         if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or not 1 <= weight.shape[0] <= 4:
             raise ValueError("conv3x3_fewout expects a [N<=4, K, 3, 3] weight, got %s" % (tuple(weight.shape),))
         x = x.contiguous()
@@ -247,25 +248,32 @@ class _Conv3x3FewOut(torch.autograd.Function):
         _call("pcfa_conv3x3_fewout_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(ws), B, K, N, H, W)
         ctx.save_for_backward(w)
         ctx.dims = (B, K, N, H, W)
+        if skip:
+            return out, x.view_as(x)   # the alias feeds x's other consumer: its gradient is summed in the kernel below
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, g_skip=None):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise RuntimeError("conv3x3_fewout is the frozen-weight path: no weight / bias gradient")
+        if g is None:
+            return g_skip, None, None, None
         (w,) = ctx.saved_tensors
         B, K, N, H, W = ctx.dims
         g = g.contiguous()
         gx = torch.empty((B, K, H, W), device=g.device, dtype=torch.float32)
-        _call("pcfa_conv3x3_fewout_bwd", _ptr(g), _ptr(w), _ptr(gx), B, K, N, H, W)
-        return gx, None, None
+        _call("pcfa_conv3x3_fewout_bwd", _ptr(g), _ptr(w), _ptr(None if g_skip is None else g_skip.contiguous()), _ptr(gx),
+              B, K, N, H, W)
+        return gx, None, None, None
 
 
-def conv3x3_fewout(x, weight, bias=None):
+def conv3x3_fewout(x, weight, bias=None, skip=False):
     """conv2d(x, weight, bias, stride=1, padding=1) for a frozen 3x3 weight with at most 4 output channels (the
-    flow-prediction layers): a streaming kernel instead of a padded matrix-core tile."""
-    return _Conv3x3FewOut.apply(x, weight, bias)
+    flow-prediction layers): a streaming kernel instead of a padded matrix-core tile.  skip=True returns (result, x_alias):
+    hand x_alias to x's OTHER consumer (PWC-Net: upfeat beside predict_flow) and its gradient is added inside this layer's
+    data-gradient kernel instead of by an autograd add over the whole tensor (as ops.conv3x3(skip=True))."""
+    return _Conv3x3FewOut.apply(x, weight, bias, skip)
 
 
 class _InstNormRelu(torch.autograd.Function):

@@ -101,7 +101,7 @@ _WORK_TABLE = {   # entry point -> accounting of its positional arguments (the o
     "pcfa_instnorm_bwd": lambda a: _note_work("instnorm_bwd", 3.0 * a[5] * a[6] * 4, 0.0),
     # streams: input once + the small output (flow-prediction convolutions), elementwise passes
     "pcfa_conv3x3_fewout_fwd": lambda a: _note_work("conv3x3_fewout_fwd", 4.0 * a[5] * (a[6] + a[7]) * a[8] * a[9], 0.0),
-    "pcfa_conv3x3_fewout_bwd": lambda a: _note_work("conv3x3_fewout_bwd", 4.0 * a[3] * (a[4] + a[5]) * a[6] * a[7], 0.0),
+    "pcfa_conv3x3_fewout_bwd": lambda a: _note_work("conv3x3_fewout_bwd", 4.0 * a[4] * (a[5] + a[6]) * a[7] * a[8], 0.0),
     "pcfa_relu_bwd": lambda a: _note_work("relu_bwd", 12.0 * a[3], 0.0),
     "pcfa_relu_bwd2": lambda a: _note_work("relu_bwd2", 20.0 * a[5], 0.0),
     "pcfa_add_relu_fwd": lambda a: _note_work("add_relu_fwd", 12.0 * a[3], 0.0),

@@ -752,6 +752,16 @@ def test_conv3x3_fewout_vs_oracle(oracle_ops, shape, n):
     assert torch.equal(got2, got) and torch.equal(xg2.grad, xg.grad)
     with pytest.raises(ValueError):
         hip_ops.conv3x3_fewout(xg.detach(), torch.zeros(5, K, 3, 3, device=DEV))
+    # skip=True: x's other consumer reads the alias, and its gradient is added inside the data-gradient kernel
+    xg3 = x.detach().to(DEV).requires_grad_(True)
+    got3, alias = hip_ops.conv3x3_fewout(xg3, w.to(DEV), None if bias is None else bias.to(DEV), skip=True)
+    other = torch.randn(shape, generator=gen).to(DEV)
+    (got3 * go.to(DEV)).sum().add((alias * other).sum()).backward()
+    assert torch.equal(got3, got) and torch.equal(xg3.grad, xg.grad + other)
+    xg4 = x.detach().to(DEV).requires_grad_(True)
+    _, alias = hip_ops.conv3x3_fewout(xg4, w.to(DEV), None, skip=True)
+    (alias * other).sum().backward()                 # only the alias is used: its gradient passes through
+    assert torch.equal(xg4.grad, other)
 
 
 @pytest.mark.parametrize("shape,n", [((1, 597, 48, 160), 2), ((1, 2, 48, 160), 2), ((1, 529, 6, 20), 2),
