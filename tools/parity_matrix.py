@@ -249,6 +249,28 @@ def cmd_assemble(a):
                "pairs_ok_per_metric": {k: sum(r[k]["inside"] for r in full) for k in FLOORS},
                "pairs_on_the_ports_branch": sum(r["first_step_divergence_gpu_vs_port16"] is None for r in full),
                "fraction_inside": (sum(r["inside_all"] for r in full) / len(full)) if full else None}
+        # the same records read as DISTRIBUTIONS over the pairs (an un-damped L-BFGS attack is chaotic per pair -- the legs
+        # take different branches at the same few steps -- so the per-pair rule mostly measures branch luck; what a user of
+        # the attack sees is the distribution of its results): per leg mean / std / range of the best-iterate metrics, and
+        # the per-pair |difference| of GPU vs port16 beside the port's own port16 vs port8
+        def stats(v):
+            v = sorted(v)
+            m = sum(v) / len(v)
+            return {"mean": m, "std": (sum((x - m) ** 2 for x in v) / len(v)) ** .5, "min": v[0], "max": v[-1],
+                    "median": v[len(v) // 2] if len(v) % 2 else .5 * (v[len(v) // 2 - 1] + v[len(v) // 2])}
+        if full:
+            cfg["distribution"] = {key: {leg: stats([r[key][leg] for r in full]) for leg in ("gpu", "port16", "port8")}
+                                   for key in FLOORS}
+            cfg["abs_difference_over_pairs"] = {key: {"gpu_vs_port16": stats([abs(r[key]["gpu"] - r[key]["port16"]) for r in full]),
+                                                      "gpu_vs_port8": stats([abs(r[key]["gpu"] - r[key]["port8"]) for r in full]),
+                                                      "port16_vs_port8": stats([abs(r[key]["port16"] - r[key]["port8"]) for r in full])}
+                                                for key in FLOORS}
+            cfg["first_split_step"] = {"gpu_vs_port16": [(r["first_step_divergence_gpu_vs_port16"] or {}).get("step") for r in full],
+                                       "port16_vs_port8": [(r.get("first_step_divergence_port16_vs_port8") or {}).get("step") for r in full]}
+            cl = [r["closure_delta_at_port_iterate"] for r in full if "closure_delta_at_port_iterate" in r]
+            if cl:
+                cfg["closure_at_the_split_gpu_vs_port16"] = {"max_loss_rel": max(c["loss_rel"] for c in cl),
+                                                             "max_grad_rel_l2": max(c["grad_rel_l2"] for c in cl)}
         out["configs"].append(cfg)
     txt = json.dumps(out, indent=1)
     with open(a.out, "w") as f:
@@ -257,6 +279,12 @@ def cmd_assemble(a):
         print("%s %d steps: %d/%d pairs inside (per metric %s), %d on the port's branch throughout" % (
             cfg["net"], cfg["steps"], cfg["pairs_ok"], cfg["pairs_total"], cfg["pairs_ok_per_metric"],
             cfg["pairs_on_the_ports_branch"]))
+        if "distribution" in cfg:
+            d, ad = cfg["distribution"]["aee_adv_tgt_min"], cfg["abs_difference_over_pairs"]["aee_adv_tgt_min"]
+            print("    AEE(adv,tgt) at the best iterate, mean +- std over pairs: " + ", ".join(
+                "%s %.3f +- %.3f" % (leg, d[leg]["mean"], d[leg]["std"]) for leg in ("gpu", "port16", "port8")))
+            print("    per-pair |difference|, median / max: " + ", ".join(
+                "%s %.3f / %.3f" % (k, v["median"], v["max"]) for k, v in ad.items()))
 
 
 def main():
