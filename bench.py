@@ -527,6 +527,12 @@ def schedule_parity_record():
         rec[key] = {"pairs_ok": cfg["pairs_ok"], "pairs_total": cfg["pairs_total"],
                     "pairs_ok_per_metric": cfg.get("pairs_ok_per_metric"),
                     "bench_pair_0_inside": next((r.get("inside_all") for r in cfg["pairs"] if r["pair"] == 0), None)}
+        dist = (cfg.get("distribution") or {}).get("aee_adv_tgt_min")
+        if dist:   # the same legs as distributions over the pairs: [mean, std] of AEE(adv, target) at the best iterate
+            rec[key]["aee_adv_tgt_min_mean_std"] = {leg: [round(v["mean"], 4), round(v["std"], 4)] for leg, v in dist.items()}
+            ad = cfg["abs_difference_over_pairs"]["aee_adv_tgt_min"]
+            rec[key]["abs_difference_median_max"] = {k: [round(v["median"], 4), round(v["max"], 4)] for k, v in ad.items()}
+            rec[key]["closure_at_the_split_gpu_vs_port16"] = cfg.get("closure_at_the_split_gpu_vs_port16")
         if cfg["net"] == "RAFT" and cfg["steps"] == 20:
             rec["pairs_ok"], rec["pairs_total"] = cfg["pairs_ok"], cfg["pairs_total"]
     return rec
