@@ -131,9 +131,12 @@ def _chain(layers, x, last_premasked=False, bgr_input=False, skip_first=False):
     applied by that consumer's data-gradient kernel wherever both layers run on the operator table (and the consumer is
     a stride-1 convolution, whose kernel has the mask epilogue)."""
     if not (layers and cfg(layers[0]).defer_leaky):
+        alias = None
         for i, layer in enumerate(layers):
-            x = layer(x, bgr_input=bgr_input and i == 0)
-        return x
+            x = layer(x, bgr_input=bgr_input and i == 0, skip=skip_first and i == 0)
+            if skip_first and i == 0:
+                x, alias = x
+        return (x, alias) if skip_first else x
     masked_in = False
     regrid = cfg(layers[0]).pwc_fold_glue
     grid = 1           # the sub-grid layout x is in
