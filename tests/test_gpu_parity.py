@@ -667,6 +667,21 @@ def test_dense_block_vs_oracle(oracle_ops, shape):
         assert torch.equal(grad_seen, go.to(DEV))     # the incoming gradient is read, never written
 
 
+def test_split_batch_views_and_one_concatenation():
+    """ops.split_batch: the halves of a feature tensor computed for both images at once (nets/pwcnet.py) are views; the
+    backward assembles their gradients with one concatenation, also when only one half is used."""
+    x = torch.randn(4, 3, 5, 7, device=DEV, requires_grad=True)
+    a, b = hip_ops.split_batch(x, 1)
+    assert a.shape[0] == 1 and b.shape[0] == 3 and a.data_ptr() == x.data_ptr()
+    ga, gb = torch.randn_like(a), torch.randn_like(b)
+    ((a * ga).sum() + (b * gb).sum()).backward()
+    assert torch.equal(x.grad, torch.cat((ga, gb), 0))
+    x.grad = None
+    a, b = hip_ops.split_batch(x, 2)
+    (b * 2.0).sum().backward()
+    assert torch.equal(x.grad[:2], torch.zeros_like(x.grad[:2])) and torch.equal(x.grad[2:], torch.full_like(x.grad[2:], 2.0))
+
+
 # --------------------------------------------------------------------------- PWC-Net warp
 @pytest.mark.parametrize("shape,scale", [((1, 128, 12, 40), 1.5), ((1, 96, 24, 80), 3.0), ((2, 64, 48, 160), 6.0),
                                          ((1, 32, 96, 320), 12.0), ((1, 5, 7, 9), 4.0)])

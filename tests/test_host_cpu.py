@@ -73,6 +73,53 @@ def test_pwcnet_folded_glue_is_the_same_network():
     assert rel_l2(a["grads"][0], b["grads"][0]) < 1e-4
 
 
+def test_pwcnet_regrid_between_subgrid_layouts():
+    """nets/pwcnet._regrid: from the d_from*d_from sub-grid layout of a dilated convolution straight to the d_to layout of
+    the next one equals batch-to-space followed by space-to-batch, for every pair of layouts the context network chains
+    (1 -> 2 -> 4 -> 8 -> 16 -> 1) and for layouts that do not divide each other."""
+    from pcfa_amd.nets.pwcnet import _regrid
+
+    def to_grid(x, d):
+        B, C, H, W = x.shape
+        return x.reshape(B, C, H // d, d, W // d, d).permute(0, 3, 5, 1, 2, 4).reshape(B * d * d, C, H // d, W // d)
+    for B in (1, 2):
+        x = torch.randn(B, 3, 48, 96)
+        for df in (1, 2, 4, 8, 16, 3):
+            for dt in (1, 2, 4, 8, 16, 3, 6):
+                if 48 % df or 96 % df or 48 % dt or 96 % dt:
+                    continue
+                assert torch.equal(_regrid(to_grid(x, df), df, dt, B), to_grid(x, dt)), (df, dt)
+    xs = to_grid(torch.randn(1, 2, 16, 32), 2).requires_grad_(True)
+    _regrid(xs, 2, 8, 1).square().sum().backward()     # one strided copy forward, one backward
+    assert torch.equal(xs.grad, 2 * xs.detach())
+
+
+def test_fp64_port_is_the_arbiter_it_claims_to_be():
+    """tools/trajectory_closure_parity.py judges a point where GPU and fp32 port disagree by the port in fp64: the same host
+    code with every parameter, buffer, cached weight and stepper tensor in float64 (oracle operators are dtype-generic for
+    PWC-Net).  The fp64 closure must actually run in fp64 and agree with the fp32 one to fp32 rounding."""
+    import bench
+    from tools.trajectory_closure_parity import to_double
+    kw = dict(seed=0, boxconstraint="clipping", joint=True)
+    a = bench.AttackStepper("PWCNet", 128, 192, torch.device("cpu"), **kw)
+    b = bench.AttackStepper("PWCNet", 128, 192, torch.device("cpu"), **kw)
+    to_double(b)
+    g = torch.Generator().manual_seed(3)
+    pert = [0.01 * torch.randn(p.shape, generator=g) for p in a.params]
+    grads = []
+    for st in (a, b):
+        with torch.no_grad():
+            for p, d in zip(st.params, pert):
+                p.add_(d.to(p.dtype))
+        st.optimizer.zero_grad()
+        loss = st._closure_body()
+        grads.append((loss, torch.cat([p.grad.flatten() for p in st.params])))
+    assert grads[1][0].dtype == torch.float64 and grads[1][1].dtype == torch.float64
+    assert all(p.dtype == torch.float64 for p in b.model.parameters())
+    assert abs(float(grads[0][0]) - float(grads[1][0])) <= 1e-5 * abs(float(grads[1][0]))
+    assert rel_l2(grads[0][1].double(), grads[1][1]) < 1e-3
+
+
 def test_seeded_inputs_are_reproducible():
     """The generated leaves equal the stored ones (so GPU tests can regenerate instead of loading)."""
     g = load_golden("closure_raft")

@@ -30,6 +30,24 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 
+def to_double(obj, seen=None, depth=0):
+    """the port's state in fp64: module parameters / buffers and every fp32 tensor attribute of the stepper."""
+    seen = set() if seen is None else seen
+    if id(obj) in seen or depth > 3:
+        return
+    seen.add(id(obj))
+    if isinstance(obj, torch.nn.Module):
+        obj.double()
+    for k, t in list(getattr(obj, "__dict__", {}).items()):
+        if isinstance(t, torch.nn.Parameter):
+            continue
+        if torch.is_tensor(t):
+            if t.dtype == torch.float32:
+                t.data = t.data.double()   # in place: the variables are referenced from several attributes
+        elif hasattr(t, "__dict__") and not isinstance(t, (type, torch.optim.Optimizer)):
+            to_double(t, seen, depth + 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--net", default="RAFT")
@@ -75,22 +93,6 @@ def main():
             print("port step %d/%d: %d points (%.0f s)" % (k + 1, a.steps, len(points), time.perf_counter() - t0),
                   file=sys.stderr, flush=True)
 
-    def to_double(obj, seen, depth=0):
-        """the port's state in fp64: module parameters / buffers and every fp32 tensor attribute of the stepper."""
-        if id(obj) in seen or depth > 3:
-            return
-        seen.add(id(obj))
-        if isinstance(obj, torch.nn.Module):
-            obj.double()
-        for k, t in list(getattr(obj, "__dict__", {}).items()):
-            if isinstance(t, torch.nn.Parameter):
-                continue
-            if torch.is_tensor(t):
-                if t.dtype == torch.float32:
-                    t.data = t.data.double()   # in place: the variables are referenced from several attributes
-            elif hasattr(t, "__dict__") and not isinstance(t, (type, torch.optim.Optimizer)):
-                to_double(t, seen, depth + 1)
-
     arbiter = []   # [stepper in fp64] once built; [None] when the network's oracle operators are fp32-only
 
     def port_fp64(x):
@@ -99,7 +101,7 @@ def main():
             try:
                 with ops.override_for_testing(oracle_ops):
                     dst = bench.AttackStepper(a.net, h, w, torch.device("cpu"), seed=a.seed, **kw)
-                    to_double(dst, set())
+                    to_double(dst)
                     for p in dst.params:
                         if p.dtype != torch.float64:
                             p.data = p.data.double()
