@@ -667,6 +667,30 @@ def test_dense_block_vs_oracle(oracle_ops, shape):
         assert torch.equal(grad_seen, go.to(DEV))     # the incoming gradient is read, never written
 
 
+def test_pwcnet_batch_of_pairs_matches_single_pairs():
+    """PWC-Net on a batch of two pairs (the universal attack's local batch, attack_PCFA.py:344-350) against the same pairs
+    one at a time: the batched pyramid (4 images per layer), the decoder's generic path (the dense-block buffer is a
+    batch-1 layout) and the folded glue must give the per-pair flows and input gradients -- to rounding, the batch sizes
+    pick other convolution algorithms."""
+    from pcfa_amd.nets.pwcnet import PWCDCNet
+    torch.manual_seed(11)
+    net = PWCDCNet().to(DEV).eval()
+    for p in net.parameters():
+        p.requires_grad = False
+    a = torch.rand(2, 3, 128, 192, device=DEV, requires_grad=True)
+    b = torch.rand(2, 3, 128, 192, device=DEV, requires_grad=True)
+    go = torch.randn(2, 2, 128, 192, device=DEV)
+    flow = net(a, b)
+    (flow * go).sum().backward()
+    for i in range(2):
+        ai = a.detach()[i:i + 1].clone().requires_grad_(True)
+        bi = b.detach()[i:i + 1].clone().requires_grad_(True)
+        fi = net(ai, bi)
+        (fi * go[i:i + 1]).sum().backward()
+        assert max_abs(flow.detach()[i:i + 1], fi.detach()) <= 1e-4 * float(fi.detach().abs().max())
+        assert rel_l2(a.grad[i:i + 1], ai.grad) < 2e-3 and rel_l2(b.grad[i:i + 1], bi.grad) < 2e-3
+
+
 def test_split_batch_views_and_one_concatenation():
     """ops.split_batch: the halves of a feature tensor computed for both images at once (nets/pwcnet.py) are views; the
     backward assembles their gradients with one concatenation, also when only one half is used."""
