@@ -12,6 +12,7 @@
 // The coordinate arithmetic repeats the reference's fp32 operation sequence: normalise (x2, /(W-1), -1), then
 // grid_sample's un-normalisation ((g + 1) * W - 1) / 2 -- the two do NOT cancel (align_corners mismatch of the
 // original PWC-Net code), the sample position is x * W / (W - 1) - 0.5.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -255,6 +256,117 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_det_kernel(const float* __re
   gf[plane + p] = 2.0f * ((0.5f * (float)H * giy) / (float)max(H - 1, 1));
 }
 
+// The same scatter through an LDS window.  The cost of the kernel above is its global atomics, and an atomic instruction
+// costs by the cache lines it touches, not by its lanes (profiles/r04_warp_bwd_scatter_ablation.txt: a constant flow runs
+// 6-8x faster than a textured one).  Here a workgroup owns a 16 x 16 pixel tile; its taps land in a 32 x 32 texel window
+// around the tile centre's target, kept in LDS for WCH channels at a time (ds_add_u64: integers, so any order gives the
+// same bits as the kernel above); the window is then flushed with one global atomic per NON-ZERO texel, consecutive lanes
+// on consecutive texels of a row (2 cache lines per 32 lanes).  Taps outside the window (a flow that tears the tile
+// apart) go to global memory directly, as above.
+constexpr int WT = 16, WWIN = 32, WCH = 4;
+__global__ __launch_bounds__(256) void pwc_warp_bwd_det_lds_kernel(
+    const float* __restrict__ x, const float* __restrict__ flo, const float* __restrict__ gout, long long* __restrict__ gxi,
+    float* __restrict__ gfpart, const float* __restrict__ bmax, int nblk, int C, int H, int W, float mask_thresh, float fs,
+    int tiles_x) {
+  __shared__ float red[4];
+  __shared__ unsigned long long win[WCH][WWIN * WWIN];
+  __shared__ int s_org[2];
+  const double scale = ldexp(1.0, warp_fix_shift(bmax, nblk, red));
+  const long long plane = (long long)H * W;
+  const int tid = threadIdx.x;
+  const int tby = blockIdx.x / tiles_x, tbx = blockIdx.x - tby * tiles_x;
+  const int py0 = tby * WT + (tid >> 4), px0 = tbx * WT + (tid & 15);
+  const bool inside = py0 < H && px0 < W;
+  const int py = min(py0, H - 1), px = min(px0, W - 1);
+  const long long p = (long long)py * W + px;
+  const int b = blockIdx.z, G = gridDim.y, B = gridDim.z;
+  const float* fb = flo + (size_t)b * 2 * plane;
+  float* gf = gfpart + ((size_t)blockIdx.y * B + b) * 2 * plane;
+  const float ix = warp_coord((float)px, mul_rounded(fb[p], fs), W), iy = warp_coord((float)py, mul_rounded(fb[plane + p], fs), H);
+  const WarpTaps t = warp_taps(ix, iy, H, W);
+  const float ex = (float)(t.x0 + 1) - ix, ey = (float)(t.y0 + 1) - iy;
+  const float nw = ex * ey, ne = t.wx1 * ey, sw = ex * t.wy1, se = t.wx1 * t.wy1;
+  const bool bnw = t.vx0 && t.vy0, bne = t.vx1 && t.vy0, bsw = t.vx0 && t.vy1, bse = t.vx1 && t.vy1;
+  float msum = 0.f;
+  if (bnw) msum += nw;
+  if (bne) msum += ne;
+  if (bsw) msum += sw;
+  if (bse) msum += se;
+  const bool act = inside && msum >= mask_thresh;   // else output * 0: no gradient to either input
+  if (tid == (WT / 2) * WT + WT / 2) {   // window origin: the centre pixel's target, centred (clamped so that the window
+    s_org[0] = min(max(t.y0 - (WWIN - WT) / 2 - WT / 2 + 1, -1), max(H - WWIN + 1, -1));   // overlaps the image where it can)
+    s_org[1] = min(max(t.x0 - (WWIN - WT) / 2 - WT / 2 + 1, -1), max(W - WWIN + 1, -1));
+  }
+  for (int e = tid; e < WCH * WWIN * WWIN; e += 256) (&win[0][0])[e] = 0ull;
+  __syncthreads();
+  const int wy0 = s_org[0], wx0 = s_org[1];
+  // taps as window cells (or -1: outside the window -> global atomic)
+  const int ly = t.y0 - wy0, lx = t.x0 - wx0;
+  const bool iny0 = ly >= 0 && ly < WWIN, iny1 = ly + 1 >= 0 && ly + 1 < WWIN;
+  const bool inx0 = lx >= 0 && lx < WWIN, inx1 = lx + 1 >= 0 && lx + 1 < WWIN;
+  const int cnw = (iny0 && inx0) ? ly * WWIN + lx : -1, cne = (iny0 && inx1) ? ly * WWIN + lx + 1 : -1;
+  const int csw = (iny1 && inx0) ? (ly + 1) * WWIN + lx : -1, cse = (iny1 && inx1) ? (ly + 1) * WWIN + lx + 1 : -1;
+  const int onw = bnw ? t.y0 * W + t.x0 : 0, one = bne ? t.y0 * W + t.x0 + 1 : 0;
+  const int osw = bsw ? (t.y0 + 1) * W + t.x0 : 0, ose = bse ? (t.y0 + 1) * W + t.x0 + 1 : 0;
+  const float* xb = x + (size_t)b * C * plane;
+  long long* gb = gxi + (size_t)b * C * plane;
+  const float* go = gout + (size_t)b * C * plane + p;
+  float gix = 0.f, giy = 0.f;
+  auto put = [&](int j, int cell, long long* gaddr, float v) {
+    const unsigned long long q = (unsigned long long)__double2ll_rn((double)v * scale);
+    if (cell >= 0) atomicAdd(&win[j][cell], q);
+    else atomicAdd(reinterpret_cast<unsigned long long*>(gaddr), q);
+  };
+  for (int c0 = blockIdx.y; c0 < C; c0 += G * WCH) {   // (workgroup-uniform trip count: barriers inside)
+#pragma unroll
+    for (int j = 0; j < WCH; ++j) {
+      const int c = c0 + j * G;
+      if (c < C && act) {
+        const float g = go[(size_t)c * plane];
+        const float* xc = xb + (size_t)c * plane;
+        long long* gc = gb + (size_t)c * plane;
+        const float vnw = xc[onw], vne = xc[one], vsw = xc[osw], vse = xc[ose];
+        if (bnw) {
+          put(j, cnw, gc + onw, nw * g);
+          gix -= vnw * ey * g;
+          giy -= vnw * ex * g;
+        }
+        if (bne) {
+          put(j, cne, gc + one, ne * g);
+          gix += vne * ey * g;
+          giy -= vne * t.wx1 * g;
+        }
+        if (bsw) {
+          put(j, csw, gc + osw, sw * g);
+          gix -= vsw * t.wy1 * g;
+          giy += vsw * ex * g;
+        }
+        if (bse) {
+          put(j, cse, gc + ose, se * g);
+          gix += vse * t.wy1 * g;
+          giy += vse * t.wx1 * g;
+        }
+      }
+    }
+    __syncthreads();
+    // flush (and clear for the next pass): one global atomic per non-zero texel, rows of the window = runs of texels
+    for (int e = tid; e < WCH * WWIN * WWIN; e += 256) {
+      const int j = e / (WWIN * WWIN), cell = e - j * (WWIN * WWIN);
+      const unsigned long long v = win[j][cell];
+      if (v != 0ull) {
+        win[j][cell] = 0ull;
+        const int yy = wy0 + cell / WWIN, xx = wx0 + cell % WWIN;   // (a non-zero cell was hit by a valid tap: inside the image)
+        atomicAdd(reinterpret_cast<unsigned long long*>(gb + (size_t)(c0 + j * G) * plane + (size_t)yy * W + xx), v);
+      }
+    }
+    __syncthreads();
+  }
+  if (inside) {
+    gf[p] = act ? 2.0f * ((0.5f * (float)W * gix) / (float)max(W - 1, 1)) : 0.f;
+    gf[plane + p] = act ? 2.0f * ((0.5f * (float)H * giy) / (float)max(H - 1, 1)) : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void pwc_warp_finish_kernel(const long long* __restrict__ gxi,
                                                               const float* __restrict__ gfpart,
                                                               const float* __restrict__ bmax, int nblk,
@@ -339,9 +451,18 @@ extern "C" int pcfa_pwc_warp_bwd_det(const float* x, const float* flo, const flo
   const int nblk = (int)min((nx + 255) / 256, (long long)WARP_BMAX);
   pcfa_launch(zero_ll_max_kernel, dim3(nblk), dim3(256), 0, s, gxi, grad_out, bmax, nx);
   PCFA_LAUNCH_CHECK();
-  dim3 grid(pcfa_cdiv(plane, 256), G, B);
-  pcfa_launch(pwc_warp_bwd_det_kernel, grid, dim3(256), 0, s, x, flo, grad_out, gxi, gfpart, (const float*)bmax, nblk, C,
-              H, W, mask_threshold, flow_scale);
+  // PCFA_WARP_SCATTER=global: one global atomic per tap (the r03 kernel; dev A/B, read once)
+  static const bool lds_window = !(getenv("PCFA_WARP_SCATTER") && getenv("PCFA_WARP_SCATTER")[0] == 'g');
+  if (lds_window && plane >= 1024) {   // (tiny planes: the window's clear / flush passes cost more than they save)
+    const int tiles_x = pcfa_cdiv(W, WT), tiles_y = pcfa_cdiv(H, WT);
+    dim3 grid((unsigned)(tiles_x * tiles_y), G, B);
+    pcfa_launch(pwc_warp_bwd_det_lds_kernel, grid, dim3(256), 0, s, x, flo, grad_out, gxi, gfpart, (const float*)bmax, nblk,
+                C, H, W, mask_threshold, flow_scale, tiles_x);
+  } else {
+    dim3 grid(pcfa_cdiv(plane, 256), G, B);
+    pcfa_launch(pwc_warp_bwd_det_kernel, grid, dim3(256), 0, s, x, flo, grad_out, gxi, gfpart, (const float*)bmax, nblk, C,
+                H, W, mask_threshold, flow_scale);
+  }
   PCFA_LAUNCH_CHECK();
   pcfa_launch(pwc_warp_finish_kernel, dim3((int)min((nx + nf + 255) / 256, 4096LL)), dim3(256), 0, s,
               (const long long*)gxi, (const float*)gfpart, (const float*)bmax, nblk, grad_x, grad_flo, nx, nf, G, flow_scale);

@@ -764,6 +764,45 @@ def test_pwc_warp_vs_oracle(oracle_ops, shape, scale):
     assert max_abs(hip_ops.pwc_warp(xg.detach(), fg.detach(), flow_scale=0.625), ws) <= 2e-6 * float(x.detach().abs().max())
 
 
+def test_pwc_warp_scatter_through_lds_window_moves_no_bit():
+    """The deterministic warp backward scatters through a per-workgroup LDS window (r04: 123 -> 28 us on the 32 x 96 x 320
+    level); PCFA_WARP_SCATTER=global is the r03 form, one global atomic per tap.  Both add the same fixed-point integers,
+    so the gradients must be IDENTICAL -- smooth, textured and tearing flows (taps outside the window take the global
+    path), ragged sizes, batch 2.  The switch is read once per process: the other form runs in a child."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from pcfa_amd import hip_ops
+def chk(t): return int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
+out = []
+for shape, scale in (((1, 32, 96, 320), 6.0), ((2, 24, 40, 72), 3.0), ((1, 7, 33, 70), 40.0), ((1, 16, 50, 35), 1.0)):
+    g = torch.Generator().manual_seed(shape[1])
+    B, C, H, W = shape
+    x = torch.randn(*shape, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(*shape, generator=g).cuda()
+    for kind in range(3):
+        base = torch.nn.functional.interpolate(scale * torch.randn(B, 2, max(H // 8, 1), max(W // 8, 1), generator=g),
+                                               size=(H, W), mode="bilinear", align_corners=False)
+        f = (base, base + 0.3 * torch.randn(B, 2, H, W, generator=g), scale * torch.randn(B, 2, H, W, generator=g))[kind]
+        flo = f.contiguous().cuda().requires_grad_(True)
+        gx, gf = torch.autograd.grad(hip_ops.pwc_warp(x, flo, flow_scale=1.25), (x, flo), go)
+        out.append((chk(gx), chk(gf), float(gx.abs().max())))
+print("CHK", out)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for env in ({}, {"PCFA_WARP_SCATTER": "global"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("CHK ")]
+        assert r.returncode == 0 and line, r.stderr[-2000:]
+        res.append(line[-1])
+    assert res[0] == res[1]
+    assert "0.0)" not in res[0]    # (the gradients are not all zero)
+
+
 # --------------------------------------------------------------------------- flow-prediction convolutions
 @pytest.mark.parametrize("shape,n", [((1, 256, 55, 128), 2), ((2, 37, 9, 13), 2), ((1, 1026, 14, 32), 2),
                                      ((1, 5, 3, 70), 1), ((2, 16, 17, 5), 3), ((1, 64, 24, 40), 4),
