@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""pwc_warp deterministic backward with and without the in-register combination of neighbouring lanes' taps
+"""pwc_warp deterministic backward: run once per scatter form (PCFA_WARP_SCATTER=global: one atomic per tap; default: the LDS
+window) or per variant library -- originally with and without the in-register combination of neighbouring lanes' taps
 (-DPCFA_WARP_COMBINE=0 variant: tools/dev/build_variant.sh warp0 warp_ops.hip -DPCFA_WARP_COMBINE=0, selected with
 PCFA_HIP_LIB): device time per call at the four KITTI-size levels (smooth, PWC-like and noisy flow) and an exact checksum
 of both gradients -- the two builds must print the same checksums (integer addends: the combination moves no bit).
