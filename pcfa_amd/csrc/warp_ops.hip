@@ -453,7 +453,7 @@ extern "C" int pcfa_pwc_warp_bwd_det(const float* x, const float* flo, const flo
   PCFA_LAUNCH_CHECK();
   // PCFA_WARP_SCATTER=global: one global atomic per tap (the r03 kernel; dev A/B, read once)
   static const bool lds_window = !(getenv("PCFA_WARP_SCATTER") && getenv("PCFA_WARP_SCATTER")[0] == 'g');
-  if (lds_window && plane >= 1024) {   // (tiny planes: the window's clear / flush passes cost more than they save)
+  if (lds_window && plane >= 256) {   // (tiny planes: the window's clear / flush passes cost more than they save)
     const int tiles_x = pcfa_cdiv(W, WT), tiles_y = pcfa_cdiv(H, WT);
     dim3 grid((unsigned)(tiles_x * tiles_y), G, B);
     pcfa_launch(pwc_warp_bwd_det_lds_kernel, grid, dim3(256), 0, s, x, flo, grad_out, gxi, gfpart, (const float*)bmax, nblk,
