@@ -477,7 +477,9 @@ PCFA_API int pcfa_conv3x3_masked_fwd(const float* x, const float* packed, const 
  * F(2x2,3x3).  Where one launch would leave CUs idle (RAFT's 55 x 128 maps: 56-112
  * workgroups) the input channels are split over several workgroups that write partial outputs into `workspace`
  * (pcfa_conv3x3_workspace_bytes, caller-owned, 16-B aligned, may be NULL when that returns 0) and a streaming kernel
- * adds them in index order: deterministic, no atomics. */
+ * adds them in index order: deterministic, no atomics.  Small maps of one or two images (PWC-Net's 6 x 20 .. 24 x 80
+ * levels: 3-48 workgroups that would walk 16-79 channel chunks one after the other) run F(2x2,3x3) with the input
+ * channels sliced over workgroups the same way (partial outputs in `workspace`, the same finish pass). */
 PCFA_API int pcfa_conv3x3_algo(int B, int K, int N, int H, int W);   /* 23 or 43: the transform pcfa_conv3x3_run picks */
 PCFA_API size_t pcfa_conv3x3_workspace_bytes(int B, int K, int N, int H, int W);
 /* mask (act = 0 only; same shape as out) is the OUTPUT of the (Leaky)ReLU layer that produced the tensor this data
@@ -570,6 +572,8 @@ PCFA_API int pcfa_pwc_warp_bwd(const float* x, const float* flo, const float* gr
  * order in which the atomics land does not matter) and the flow gradient's channel groups are summed in index order;
  * grid_sampler_2d_backward (and pcfa_pwc_warp_bwd) add fp32 values in whatever order the hardware serves them, which
  * made two 20-step PWC-Net attacks on the same pair end 3 % apart (profiles/r03_schedule_parity_pwcnet_20steps.json).
+ * The scatter goes through a per-workgroup LDS window (16 x 16 pixel tiles, 32 x 32 texels, 64-bit LDS adds) that is
+ * flushed with one global atomic per non-zero texel; taps outside the window use global atomics directly.
  * The fixed point is scaled per call to max|grad_out| (40 bits below its leading power of two, room for 2^22 addends
  * of maximal size).  workspace >= pcfa_pwc_warp_bwd_det_workspace_bytes(), 8-B aligned.  {clear + max, scatter, finish} */
 PCFA_API size_t pcfa_pwc_warp_bwd_det_workspace_bytes(int B, int C, int H, int W);
