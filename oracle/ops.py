@@ -8,7 +8,10 @@ by the real reference (tests/golden/make_golden.py -> tests/golden/*.npz) and,
 for the cost volume, against the reference's own C++ build (oracle/_ref).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
-import this package; nothing under pcfa_amd/ does.
+import this package (plus the parity checkers the tests invoke as child
+processes: tools/schedule_parity.py, tools/parity_matrix.py,
+tools/trajectory_closure_parity.py -- always as the thing compared AGAINST);
+nothing under pcfa_amd/ does.
 
 Every function cites the reference lines it follows (paths relative to the
 reference root).
