@@ -213,6 +213,10 @@ def null_launch_device_us(reps=50):
     return sum(d) / len(d) if d else None
 
 
+TRAFFIC_SOURCE = ("profiles/lookup_traffic.json: rocprofv3 --pmc passes collected offline (tools/pmc_traffic.sh), "
+                  "a committed constant -- NOT measured by this run")
+
+
 def lookup_traffic(kernel="corr_lookup_fwd"):
     """HBM bytes per launch of the lookup kernel from rocprofv3 PMC counters (collected offline by
     tools/pmc_traffic.sh with the guide's gfx950 corrections, committed under profiles/); None if absent."""
@@ -513,29 +517,121 @@ def calibration(dev):
             "peaks_used": {"mfma_f32_tflops": MFMA_F32_PEAK_TFLOPS, "hbm_GBs": HBM_PEAK_GBS}}
 
 
+SCHEDULE_PARITY_FILE = "profiles/r04_schedule_parity_matrix.json"
+
+
 def schedule_parity_record():
-    """The committed end-of-attack parity matrix (tools/parity_matrix.py -> profiles/r04_schedule_parity_matrix.json):
-    pairs inside the tolerance per config, for the reader of the bench line (bench.py times synthetic pair `rank`)."""
-    path = os.path.join(REPO, "profiles", "r04_schedule_parity_matrix.json")
+    """POINTER to the committed end-of-attack parity matrix (tools/parity_matrix.py): file name + pairs inside the
+    tolerance per config.  Nothing of it is measured by this run (bench.py times synthetic pair `rank`)."""
     try:
-        m = json.load(open(path))
+        m = json.load(open(os.path.join(REPO, SCHEDULE_PARITY_FILE)))
     except (OSError, ValueError):
         return None
-    rec = {"file": "profiles/r04_schedule_parity_matrix.json", "rule": m.get("rule")}
+    rec = {"file": SCHEDULE_PARITY_FILE, "source": "committed file, not measured by this run"}
     for cfg in m.get("configs", []):
-        key = "%s_%dsteps" % (cfg["net"].lower(), cfg["steps"])
-        rec[key] = {"pairs_ok": cfg["pairs_ok"], "pairs_total": cfg["pairs_total"],
-                    "pairs_ok_per_metric": cfg.get("pairs_ok_per_metric"),
-                    "bench_pair_0_inside": next((r.get("inside_all") for r in cfg["pairs"] if r["pair"] == 0), None)}
-        dist = (cfg.get("distribution") or {}).get("aee_adv_tgt_min")
-        if dist:   # the same legs as distributions over the pairs: [mean, std] of AEE(adv, target) at the best iterate
-            rec[key]["aee_adv_tgt_min_mean_std"] = {leg: [round(v["mean"], 4), round(v["std"], 4)] for leg, v in dist.items()}
-            ad = cfg["abs_difference_over_pairs"]["aee_adv_tgt_min"]
-            rec[key]["abs_difference_median_max"] = {k: [round(v["median"], 4), round(v["max"], 4)] for k, v in ad.items()}
-            rec[key]["closure_at_the_split_gpu_vs_port16"] = cfg.get("closure_at_the_split_gpu_vs_port16")
+        rec["%s_%dsteps" % (cfg["net"].lower(), cfg["steps"])] = [cfg["pairs_ok"], cfg["pairs_total"]]
         if cfg["net"] == "RAFT" and cfg["steps"] == 20:
             rec["pairs_ok"], rec["pairs_total"] = cfg["pairs_ok"], cfg["pairs_total"]
     return rec
+
+
+# --------------------------------------------------------------------------------------------------------------
+# CPU baseline (+ the CPU side of the parity record)
+# --------------------------------------------------------------------------------------------------------------
+LINE_BUDGET = 6000   # bytes: the driver parses the ONE stdout line; r04's 22 KB line came back `parsed: null`
+DETAIL_FILE = "bench_detail.json"
+
+
+def _sig(x, sig=6):
+    """Floats to `sig` significant digits, recursively (the line is for reading; the detail file keeps full precision)."""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if k in d and d[k] is not None} if isinstance(d, dict) else d
+
+
+def compact_line(out):
+    """The ONE JSON line the driver parses: the contract's keys + `roofline` + `cpu_baseline` + the short form of each
+    leg.  Everything else of `out` (kernel rows, families, optimiser, notes, set-up times) lives in DETAIL_FILE.
+    Optional keys are dropped in DROP_ORDER until the line fits LINE_BUDGET."""
+    roof_keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "mean_launch_us",
+                 "launches_timed", "bytes_per_launch", "flop_per_launch", "hbm_frac")
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "per_rank_ms_per_step",
+                       "higher_is_better", "scaling", "dtype", "data", "rehearsal", "n_ranks"))
+    line["vs_baseline"] = out.get("vs_baseline")
+    line["config"] = _pick(out.get("config", {}), ("workload", "weights", "closure_evals_per_step", "parallelism",
+                                                   "closure_launch"))
+    for k in ("closure_evals_per_sec", "final"):
+        if k in out:
+            line[k] = out[k]
+    if "roofline" in out:
+        r = dict(out["roofline"])
+        if isinstance(r.get("hbm_view"), dict):
+            r["hbm_frac"] = r["hbm_view"].get("frac_of_8TBs")
+        line["roofline"] = _pick(r, roof_keys)
+        line["roofline"].setdefault("traffic", None)
+    if "roofline_unfused_lookup" in out:
+        line["roofline_unfused_lookup"] = _pick(out["roofline_unfused_lookup"], roof_keys)
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "cpu", "sample"))
+    par = ("loss_rel", "grad_rel_l2", "flow_aee", "flow_max_abs")
+    if "parity_vs_cpu_port" in out:
+        line["parity_vs_cpu_port"] = _pick(out["parity_vs_cpu_port"], par)
+    if "calibration" in out:
+        line["calibration"] = _pick(out["calibration"], ("mfma_f32_tflops", "copy_GBs", "error"))
+    if "schedule_parity" in out:
+        line["schedule_parity"] = _pick(out["schedule_parity"], ("file", "source", "pairs_ok", "pairs_total"))
+    for leg in ("pwcnet", "gma"):
+        if leg in out:
+            src = out[leg]
+            rec = _pick(src, ("value", "unit", "ms_per_step", "steps", "warmup", "final", "error"))
+            if isinstance(src.get("parity_vs_cpu_port"), dict):
+                rec["parity"] = _pick(src["parity_vs_cpu_port"], par)
+            rows = [r for r in src.get("kernels", []) if " level " not in r.get("kernel", "")][:2]
+            if rows:
+                rec["kernels"] = [_pick(r, ("kernel", "bound", "achieved", "unit", "frac", "traffic", "mean_launch_us"))
+                                  for r in rows]
+            line[leg] = rec
+    if "pairs_in_flight" in out:
+        line["pairs_in_flight"] = _pick(out["pairs_in_flight"], ("pairs", "value", "unit", "ratio_to_one_pair",
+                                                                "bit_identical_to_solo", "error"))
+    if "shared_forward_schedule" in out:
+        line["shared_forward_schedule"] = _pick(out["shared_forward_schedule"], ("value", "ms_per_step", "error"))
+    if "universal" in out:
+        line["universal"] = _pick(out["universal"], ("metric", "value", "unit", "ms_per_step", "steps", "global_batch",
+                                                     "pairs_per_gpu", "allreduces_per_closure", "allreduce_bytes",
+                                                     "closure_launch", "error"))
+    line["detail"] = DETAIL_FILE
+    # nested records to 6 significant digits; the contract's own top-level numbers keep full precision (the driver
+    # checks value against steps / ms_per_step)
+    line = {k: (v if isinstance(v, float) and v == v else _sig(v)) for k, v in line.items()}
+    DROP_ORDER = ("shared_forward_schedule", "calibration", "pairs_in_flight", "roofline_unfused_lookup", "gma",
+                  "pwcnet", "schedule_parity", "universal", "parity_vs_cpu_port")
+    for k in DROP_ORDER:
+        if len(json.dumps(line)) < LINE_BUDGET:
+            break
+        line.pop(k, None)
+    return line
+
+
+def emit(out, json_out):
+    """Write the full record next to bench.py (PCFA_BENCH_DETAIL overrides the path) and print the compact line."""
+    path = os.environ.get("PCFA_BENCH_DETAIL", os.path.join(REPO, DETAIL_FILE))
+    try:
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:
+        print("could not write %s: %r" % (path, e), file=sys.stderr)
+    text = json.dumps(compact_line(out))
+    assert len(text) < LINE_BUDGET and "\n" not in text, "bench line too long: %d bytes" % len(text)
+    print(text, file=json_out, flush=True)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -712,7 +808,7 @@ def rehearse_cpu(a, json_out):
                "final": {"aee_adv_tgt": last[0], "aee_adv_init": last[1], "l2_delta": last[2]}}
         if universal is not None:
             out["universal"] = universal
-        print(json.dumps(out), file=json_out, flush=True)
+        emit(out, json_out)
     sharding.shutdown()
 
 
@@ -767,7 +863,7 @@ def main():
                                           % (a.net, a.pairs_per_gpu, h, w), "weights": "random:1234",
                               "parallelism": "data parallel over the batch, %d rank(s)" % world},
                    "universal": rec}
-            print(json.dumps(out), file=json_out, flush=True)
+            emit(out, json_out)
         sharding.shutdown()
         return
 
@@ -905,7 +1001,8 @@ def main():
                 out["kernel_rows_cover"] = getattr(graph_replay_kernel_times, "coverage", None)
             unfused = {"kernel": "corr_lookup_fwd_kernel<4> (un-fused lookup, models/raft/corr.py:29-50)", "bound": "hbm",
                        "bytes_per_launch": nbytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "traffic": lookup_traffic("corr_lookup_fwd"), "event_bracket_overhead_us": event_overhead_us()}
+                       "traffic": lookup_traffic("corr_lookup_fwd"), "traffic_source": TRAFFIC_SOURCE,
+                       "event_bracket_overhead_us": event_overhead_us()}
             if traced and "corr_lookup_fwd" in traced:     # the closure runs the un-fused kernel (fusion off / n.a.)
                 us, n = traced["corr_lookup_fwd"]
                 unfused.update(mean_launch_us=us, launches_timed=n, timing=how_graph, eager_step_hip_event_us=eager_us)
@@ -924,7 +1021,7 @@ def main():
                 out["roofline"] = {
                     "kernel": "corr_lookup_convc1_fwd_kernel (correlation lookup fused with convc1 + bias + ReLU)",
                     "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": lookup_traffic("corr_lookup_convc1_fwd"),
+                    "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": lookup_traffic("corr_lookup_convc1_fwd"), "traffic_source": TRAFFIC_SOURCE,
                     "flop_per_launch": flop, "mean_launch_us": us, "launches_timed": n, "timing": how_graph,
                     "why_mfma": "2*256*324*Q flop over texels + coords + [256][Q] output + weights = %.0f flop/B, "
                                 "above the fp32-matrix ridge (157.3 TFLOP/s / 8 TB/s = 20 flop/B)" % (flop / fbytes),
@@ -969,7 +1066,7 @@ def main():
                 out["pwcnet"] = pwcnet_leg(a, dev, sharding)
             except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure of the extra leg
                 out["pwcnet"] = {"error": repr(e)}
-        print(json.dumps(out), file=json_out, flush=True)
+        emit(out, json_out)
     sharding.shutdown()
     return out
 

@@ -38,6 +38,55 @@ def test_bench_gpus2_without_torchrun_starts_two_ranks():
     assert u["allreduce_bytes"] == (2 * 3 * 64 * 64 + 1) * 4
 
 
+def _strict_json(text):
+    def bad(c):
+        raise ValueError("non-strict JSON constant %r" % c)
+    return json.loads(text, parse_constant=bad)       # NaN / Infinity are not JSON: the driver's parser may refuse them
+
+
+def test_bench_line_is_short_strict_json_and_detail_file_is_written(tmp_path):
+    """the driver could not parse r04's 22 KB line.  The line stays under 6000 bytes, is strict JSON
+    and names the file that holds everything else."""
+    import bench
+    env = _clean_env()
+    env["PCFA_BENCH_DETAIL"] = str(tmp_path / "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--rehearse-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    text = r.stdout.strip()
+    assert len(text) < bench.LINE_BUDGET and "\n" not in text
+    out = _strict_json(text)
+    assert out["detail"] == bench.DETAIL_FILE
+    detail = json.load(open(env["PCFA_BENCH_DETAIL"]))
+    assert detail["metric"] == out["metric"] and abs(detail["value"] - out["value"]) <= 1e-5 * detail["value"]
+
+
+def test_compact_line_keeps_the_contract_and_sheds_the_rest():
+    """The r04 record (22 KB, the one the driver lost) through compact_line: every contract key + roofline +
+    cpu_baseline survive, the bulky sections do not; an absurdly large record still fits by shedding optional legs."""
+    import bench
+    full = json.load(open(os.path.join(REPO, "profiles", "r04_bench_n1_driver_settings.json")))
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_BUDGET
+    _strict_json(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert abs(line["value"] - full["value"]) < 1e-5 * full["value"]
+    for k in ("kernel_families", "kernels", "lbfgs", "per_pair_setup_s", "kernels_eager_step_hip_events"):
+        assert k not in line
+    full["config"]["workload"] = full["config"]["workload"] + " x" * 1200       # pathological: optional legs are shed
+    full["pwcnet"]["final"] = {"k%d" % i: float(i) for i in range(300)}
+    shed = bench.compact_line(full)
+    assert len(json.dumps(shed)) < bench.LINE_BUDGET and "roofline" in shed and "cpu_baseline" in shed
+    nan = dict(full, value=float("nan"))
+    _strict_json(json.dumps(bench.compact_line(nan)))                            # NaN becomes null, never `NaN`
+
+
 def test_bench_gpus1_does_not_spawn():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
                         "--rehearse-cpu"], env=_clean_env(), capture_output=True, text=True, timeout=600)

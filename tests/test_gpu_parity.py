@@ -1675,6 +1675,40 @@ def test_bench_gpus2_spawns_two_ranks_on_one_gpu():
     assert u["allreduce_bytes"] == (2 * 3 * 128 * 160 + 1) * 4
 
 
+def test_bench_default_command_prints_one_short_strict_json_line(tmp_path):
+    """`python bench.py --gpus 1 --steps K --warmup W` (the driver's command, every leg on, at the
+    BASELINE size) prints ONE line under 6000 bytes of strict JSON that carries the contract's keys, `roofline` and
+    `cpu_baseline`; the full record goes to the detail file the line names."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import bench
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCFA_BENCH_DETAIL=str(tmp_path / "detail.json"))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--cpu-closures", "2"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < bench.LINE_BUDGET, len(lines[0])
+
+    def bad(c):
+        raise ValueError("non-strict JSON constant %r" % c)
+    out = json.loads(lines[0], parse_constant=bad)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["n_gpus"] == 1
+    assert abs(out["value"] - 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert 0 < out["roofline"]["frac"] < 1
+    assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert "error" not in out.get("pwcnet", {}) and "error" not in out.get("gma", {})
+    detail = json.load(open(env["PCFA_BENCH_DETAIL"]))
+    assert "kernel_families" in detail and "kernels" in detail and out["detail"] == bench.DETAIL_FILE
+
+
 @pytest.mark.parametrize("net,size", [("RAFT", (128, 160)), ("FlowNet2", (64, 128))])
 def test_graphed_closure_matches_eager(net, size):
     """The hipGraph replay of a closure reproduces the eager launch: same kernels in the same order; the loss
