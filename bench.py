@@ -213,8 +213,7 @@ def null_launch_device_us(reps=50):
     return sum(d) / len(d) if d else None
 
 
-TRAFFIC_SOURCE = ("profiles/lookup_traffic.json: rocprofv3 --pmc passes collected offline (tools/pmc_traffic.sh), "
-                  "a committed constant -- NOT measured by this run")
+TRAFFIC_SOURCE = "profiles/lookup_traffic.json (offline rocprofv3 --pmc passes; committed constant, not measured by this run)"
 
 
 def lookup_traffic(kernel="corr_lookup_fwd"):

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define PCFA_MAX_LEVELS 8
-#define PCFA_ABI_VERSION 1
+#define PCFA_ABI_VERSION 2
 
 /* f_type of the similarity term: helper_functions/losses.py:145-174 */
 #define PCFA_LOSS_AEE 0

@@ -8,7 +8,7 @@ import ctypes
 import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 LIB_PATH = os.environ.get("PCFA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
                                                           "libpcfa_hip.so")  # PCFA_HIP_LIB: A/B builds of the same ABI
 

@@ -94,15 +94,25 @@ class _PairGraphs:
             st._retire()
 
 
-MAX_CACHED_SHAPES = 2   # graph sets kept per model (LRU): each pins a closure graph pool + a 2 x 101 x n L-BFGS history
+def _max_cached_shapes(model):
+    """Graph sets kept per model (LRU), from the model's Config (default 4; KITTI under /8 padding alone has three padded
+    shapes).  Each set pins a closure graph pool + a 2 x 101 x n L-BFGS history (~1.1 GB at 440x1024)."""
+    return config.cfg(model).max_cached_shapes
 
 
-def _cache_put(cache, key, kept):
+def _log_eviction(what, key):
+    import logging as pylog
+    pylog.warning("pcfa_amd: %s cache full: dropping the graph set of %r -- the next pair of that shape pays warm-up + "
+                  "capture again (raise Config.max_cached_shapes / PCFA_MAX_CACHED_SHAPES if this repeats)", what, key)
+
+
+def _cache_put(cache, key, kept, cap):
     cache.pop(key, None)
     cache[key] = kept                      # dicts keep insertion order: the last entry is the most recently used
-    while len(cache) > MAX_CACHED_SHAPES:
+    while len(cache) > cap:
         old_key = next(iter(cache))
         old = cache.pop(old_key)
+        _log_eviction("pair-graph", old_key)
         old.retire_owner()                 # its PairAttack must not replay graphs whose buffers are about to go
         old.graphed = old.repredict = old.optimizer = None
 
@@ -163,7 +173,7 @@ class PairAttack:
             # PairAttack (if still alive) is retired first: its variables, target and optimiser state are this pair's now.
             kept.retire_owner()
             kept.owner = weakref.ref(self)
-            _cache_put(_graph_cache(model), self.graph_key, kept)   # most recently used
+            _cache_put(_graph_cache(model), self.graph_key, kept, _max_cached_shapes(model))   # most recently used
             with torch.no_grad():
                 kept.image1.copy_(image1)
                 kept.image2.copy_(image2)
@@ -318,7 +328,8 @@ class PairAttack:
             self.graphed = GraphedClosure(self.closure_body, self.params, grad_sink=sink() if sink else None)
             self.repredict = GraphedForward(self._repredict_body, self.device)
             if self.reuse_graphs and hasattr(self.optimizer, "reset"):
-                _cache_put(_graph_cache(self.model), self.graph_key, _PairGraphs(self))   # the next pair of this shape adopts them
+                _cache_put(_graph_cache(self.model), self.graph_key, _PairGraphs(self),
+                           _max_cached_shapes(self.model))   # the next pair of this shape adopts them
         except Exception as e:  # noqa: BLE001 -- the eager closure launches the same kernels in the same order
             import logging as pylog
             pylog.warning("hipGraph capture of the closure failed (%r): launching eagerly", e)
@@ -596,8 +607,10 @@ class UniversalAttack:
             st.image1.copy_(image1)
             st.image2.copy_(image2)
         self.states[key] = st                              # most recently used last
-        while len(self.states) > MAX_CACHED_SHAPES:        # every state pins a closure graph pool: keep the newest
-            self.states.pop(next(iter(self.states)))
+        while len(self.states) > _max_cached_shapes(self.model):   # every state pins a closure graph pool: keep the newest
+            old_key = next(iter(self.states))
+            self.states.pop(old_key)
+            _log_eviction("universal batch-state", old_key)
         self.st = st
         with torch.no_grad():
             self.flow_pred_init = self.predict(perturbed=False).detach().clone()

@@ -38,17 +38,21 @@ class Config:
                                          # straight into the dense-block buffer, one re-gridding copy between dilated layers
     # ---- attack loop (attack_PCFA.py) ----
     reuse_pair_graphs: bool = True       # pairs of one shape share static buffers + hipGraphs
+    max_cached_shapes: int = 4           # graph sets kept per model (LRU); KITTI under /8 padding has three padded shapes
 
     @classmethod
     def from_env(cls):
         return cls(fused_lookup=_env_bool("PCFA_FUSED_LOOKUP", True),
                    overlap_encoders=_env_bool("PCFA_OVERLAP_ENCODERS", False),
                    defer_relu=_env_bool("PCFA_DEFER_RELU", True),
-                   gma_gemm=os.environ.get("PCFA_GMA_GEMM", "lib"))
+                   gma_gemm=os.environ.get("PCFA_GMA_GEMM", "lib"),
+                   max_cached_shapes=int(os.environ.get("PCFA_MAX_CACHED_SHAPES", "4")))
 
     def __post_init__(self):
         if self.gma_gemm not in ("lib", "hip"):
             raise ValueError("Config.gma_gemm must be 'lib' or 'hip', got %r" % (self.gma_gemm,))
+        if self.max_cached_shapes < 1:
+            raise ValueError("Config.max_cached_shapes must be >= 1")
 
 
 DEFAULT = Config.from_env()

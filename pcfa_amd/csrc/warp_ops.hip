@@ -168,6 +168,11 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_kernel(const float* __restri
 // absolute scale -- AEE / npix-scaled gradients of 1e-9 included), and 2^22 addends of maximal size fit an int64.
 constexpr int WARP_FIX_BITS = 40;
 constexpr int WARP_BMAX = 4096;   // block maxima of |grad_out| (one per block of the clearing kernel)
+// A non-finite grad_out has no fixed-point image (fmaxf drops NaN, __double2ll_rn saturates): the call is flagged instead
+// -- the scatter kernels run with scale 0 (their sums are not used) and the finish kernel writes NaN into ALL of grad_x and
+// grad_flo, so that the optimiser sees the fault as it would after grid_sample's backward (which poisons only the taps of
+// the non-finite pixels: a superset here, never finite garbage).
+constexpr int WARP_NONFINITE = -(1 << 20);
 
 __device__ __forceinline__ float block_max_256(float m, float* red) {   // 256 threads, result on every thread
 #pragma unroll
@@ -184,7 +189,8 @@ __device__ __forceinline__ int warp_fix_shift(const float* __restrict__ bmax, in
   float m = 0.f;
   for (int i = threadIdx.x; i < nblk; i += 256) m = fmaxf(m, bmax[i]);
   m = block_max_256(m, red);
-  return (m > 0.f && m < 3.0e38f) ? WARP_FIX_BITS - ilogbf(m) : WARP_FIX_BITS;
+  if (!(m < 3.0e38f)) return WARP_NONFINITE;   // zero_ll_max_kernel stores +inf for a block that saw Inf / NaN (or > 3e38)
+  return m > 0.f ? WARP_FIX_BITS - ilogbf(m) : WARP_FIX_BITS;
 }
 
 __device__ __forceinline__ void fix_add(long long* p, float v, double scale) {
@@ -373,8 +379,15 @@ __global__ __launch_bounds__(256) void pwc_warp_finish_kernel(const long long* _
                                                               float* __restrict__ gx, float* __restrict__ gflo,
                                                               long long nx, long long nf, int G, float fs) {
   __shared__ float red[4];
-  const double inv = ldexp(1.0, -warp_fix_shift(bmax, nblk, red));
+  const int shift = warp_fix_shift(bmax, nblk, red);
   const long long step = (long long)gridDim.x * blockDim.x;
+  if (shift == WARP_NONFINITE) {
+    const float qnan = __int_as_float(0x7fc00000);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx + nf; i += step)
+      (i < nx ? gx[i] : gflo[i - nx]) = qnan;
+    return;
+  }
+  const double inv = ldexp(1.0, -shift);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx + nf; i += step) {
     if (i < nx) {
       gx[i] = (float)((double)gxi[i] * inv);
@@ -395,7 +408,8 @@ __global__ __launch_bounds__(256) void zero_ll_max_kernel(long long* __restrict_
   float m = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
     a[i] = 0;
-    m = fmaxf(m, fabsf(g[i]));
+    const float v = fabsf(g[i]);
+    m = (v <= 3.0e38f) ? fmaxf(m, v) : __int_as_float(0x7f800000);   // NaN fails the comparison too: +inf = the flag
   }
   m = block_max_256(m, red);
   if (threadIdx.x == 0) bmax[blockIdx.x] = m;

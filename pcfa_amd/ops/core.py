@@ -109,8 +109,25 @@ _WORK_TABLE = {   # entry point -> accounting of its positional arguments (the o
 }
 
 
+_spy = None
+
+
+def set_call_spy(spy):
+    """spy(name, args, invoke) sees EVERY entry-point call of every operator module while set (None: off) and decides
+    itself whether to run `invoke(name, *args)` -- the hook for tools (tools/dev/conv_shapes.py).  The operator modules bind
+    `_call` by name at import, so patching an attribute of this module or of the `hip_ops` table intercepts nothing."""
+    global _spy
+    _spy = spy
+
+
 def _call(name, *args):
     """Invoke C-ABI entry point `name` on torch's current stream and raise on a non-zero status."""
+    if _spy is not None:
+        return _spy(name, args, _invoke)
+    return _invoke(name, *args)
+
+
+def _invoke(name, *args):
     fn = getattr(_hip.load(), name)
     if _work is not None and name in _WORK_TABLE:
         _WORK_TABLE[name](args)

@@ -764,6 +764,26 @@ def test_pwc_warp_vs_oracle(oracle_ops, shape, scale):
     assert max_abs(hip_ops.pwc_warp(xg.detach(), fg.detach(), flow_scale=0.625), ws) <= 2e-6 * float(x.detach().abs().max())
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), -float("inf")])
+def test_pwc_warp_deterministic_backward_propagates_non_finite_gradients(bad):
+    """the fixed-point scatter has no image of Inf / NaN (fmaxf drops NaN, the int64 conversion saturates), so
+    a non-finite grad_out used to come back as FINITE garbage.  grid_sample's backward (PWCNet.py:193) lets the optimiser
+    see such a fault; the deterministic path now flags the call and returns NaN in both gradients (a superset of the
+    reference's poisoned taps), and a finite call right after it is unaffected."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 8, 40, 72, generator=g).to(DEV).requires_grad_(True)
+    flo = (2.0 * torch.randn(1, 2, 40, 72, generator=g)).to(DEV).requires_grad_(True)
+    go = torch.randn(1, 8, 40, 72, generator=g).to(DEV)
+    good = torch.autograd.grad(hip_ops.pwc_warp(x, flo, deterministic=True), (x, flo), go)
+    assert all(bool(torch.isfinite(t).all()) for t in good)
+    poisoned = go.clone()
+    poisoned[0, 3, 17, 29] = bad
+    gx, gf = torch.autograd.grad(hip_ops.pwc_warp(x, flo, deterministic=True), (x, flo), poisoned)
+    assert bool(torch.isnan(gx).all()) and bool(torch.isnan(gf).all())
+    again = torch.autograd.grad(hip_ops.pwc_warp(x, flo, deterministic=True), (x, flo), go)
+    assert torch.equal(again[0], good[0]) and torch.equal(again[1], good[1])
+
+
 def test_pwc_warp_scatter_through_lds_window_moves_no_bit():
     """The deterministic warp backward scatters through a per-workgroup LDS window (r04: 123 -> 28 us on the 32 x 96 x 320
     level); PCFA_WARP_SCATTER=global is the r03 form, one global atomic per tap.  Both add the same fixed-point integers,
@@ -1774,9 +1794,15 @@ def test_pair_graph_reuse_equals_fresh_capture():
     reused, n_kept = run(True)
     fresh, n_none = run(False)
     # the donor of an adopted graph set is retired (its variables / optimiser are the new pair's now), and
-    # the per-model cache is bounded (LRU of attack_PCFA.MAX_CACHED_SHAPES shapes)
+    # the per-model cache is bounded (LRU of Config.max_cached_shapes shapes; ADVICE r04: the cap is a Config field,
+    # default 4 -- set to 2 on this model's top module for the eviction check, restored below)
+    import dataclasses
+    from pcfa_amd import config as pcfa_config
     model = closure_util.load_model("RAFT", True, dev)
     model._pcfa_pair_graphs.clear()
+    cfg0 = pcfa_config.cfg(model)
+    assert cfg0.max_cached_shapes == 4
+    object.__setattr__(model, "_pcfa_config", dataclasses.replace(cfg0, max_cached_shapes=2))
     sts = []
     for seed, (h, w) in ((0, (128, 160)), (1, (128, 160)), (2, (136, 168)), (3, (144, 176))):
         i1, i2, _ = datasets.synthetic_pair(seed, h, w)
@@ -1786,9 +1812,10 @@ def test_pair_graph_reuse_equals_fresh_capture():
     with pytest.raises(RuntimeError, match="retired"):
         sts[0].step()
     assert sts[1].retired and not sts[2].retired and not sts[3].retired   # three shapes, two kept: the oldest is evicted
-    assert len(model._pcfa_pair_graphs) == attack_PCFA.MAX_CACHED_SHAPES == 2
+    assert len(model._pcfa_pair_graphs) == 2
     sts[3].step()
     model._pcfa_pair_graphs.clear()
+    object.__setattr__(model, "_pcfa_config", cfg0)
     assert [r[0] for r in reused] == [False, True, False, True] and n_kept == 2       # two shapes, two graph sets
     assert not any(r[0] for r in fresh) and n_none == 0
     for (_, la, fa, ca, ta), (_, lb, fb, cb, tb) in zip(reused, fresh):

@@ -264,3 +264,18 @@ def test_universal_artifacts_round_trip_through_evaluate(tmp_path):
     re8 = evaluate_PCFA.convert_perturbationsizes(padded64, img, "SpyNet", "RAFT")
     assert re8.shape == (1, 3, 64, 72) and torch.equal(re8[0, :, 2:62, 1:71], padded64[:, 2:62, 29:99])
     assert evaluate_PCFA.convert_perturbationsizes(delta, img, "RAFT", "GMA") is delta
+
+
+def test_call_spy_sees_calls_of_every_operator_module():
+    """tools patched `hip_ops._call`, which the operator modules (bound `from .core import _call`) never
+    look at.  `ops.core.set_call_spy` is the hook: every module's launches go through it while it is set."""
+    from pcfa_amd import hip_ops
+    from pcfa_amd.ops import attack_math, conv, corr, gru, pwc
+    seen = []
+    hip_ops.set_call_spy(lambda name, args, invoke: seen.append((name, args)))
+    try:
+        for i, mod in enumerate((attack_math, conv, corr, gru, pwc)):
+            mod._call("pcfa_entry_%d" % i, i)
+    finally:
+        hip_ops.set_call_spy(None)
+    assert [n for n, _ in seen] == ["pcfa_entry_%d" % i for i in range(5)] and seen[3][1] == (3,)

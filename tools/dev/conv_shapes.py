@@ -26,24 +26,23 @@ def main():
         st._closure_body()
     torch.cuda.synchronize()
     log = []
-    orig = hip_ops._call
-
-    def spy(name, *args):
+    def spy(name, args, invoke):
         if name not in WATCH:
-            return orig(name, *args)
+            return invoke(name, *args)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        orig(name, *args)
+        invoke(name, *args)
         e.record()
         log.append((name, tuple(a for a in args if isinstance(a, int) and not isinstance(a, bool) and abs(a) < 1 << 20), s, e))
 
-    hip_ops._call = spy
+    hip_ops.set_call_spy(spy)      # ops.core hook: the operator modules bind _call by name, patching the table does nothing
     try:
         st.optimizer.zero_grad()
         st._closure_body()
         torch.cuda.synchronize()
     finally:
-        hip_ops._call = orig
+        hip_ops.set_call_spy(None)
+    assert log, "the spy saw no launch: WATCH names no entry point of this network"
     acc = collections.OrderedDict()
     for name, ints, s, e in log:
         a = acc.setdefault((name, ints), [0, 0.0])
