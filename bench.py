@@ -71,6 +71,8 @@ def parse():
                     help="no GPU: rehearse launcher + collectives with the CPU port on a tiny workload (not a result)")
     ap.add_argument("--no-shared-forward-leg", action="store_true", help="skip the informational shared-forward leg")
     ap.add_argument("--no-pwcnet-leg", action="store_true", help="skip the PWC-Net (BASELINE config 4) leg")
+    ap.add_argument("--no-pairs-in-flight-leg", action="store_true", help="skip the two-pairs-per-GPU leg")
+    ap.add_argument("--no-gma-leg", action="store_true", help="skip the GMA (BASELINE config 3 network) leg")
     ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC convolutions")
     ap.add_argument("--no-graph", action="store_true", help="launch the closure eagerly instead of replaying "
                                                             "its hipGraph")
@@ -636,7 +638,7 @@ def emit(out, json_out):
 # --------------------------------------------------------------------------------------------------------------
 # CPU baseline (+ the CPU side of the parity record)
 # --------------------------------------------------------------------------------------------------------------
-def cpu_baseline(net, h, w, nclosures, threads=0, boxconstraint="change_of_variables", joint=False):
+def cpu_baseline(net, h, w, nclosures, threads=0, boxconstraint="change_of_variables", joint=False, target="zero"):
     """Time the CPU port (pcfa_amd host code + oracle operators) on a bounded sample of the workload.  Its warm-up
     closure is evaluated at the parity point, so the same leg yields the CPU side of `parity_vs_cpu_port`."""
     from oracle import ops as oracle_ops
@@ -644,7 +646,7 @@ def cpu_baseline(net, h, w, nclosures, threads=0, boxconstraint="change_of_varia
     cores = threads if threads > 0 else min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     with ops.override_for_testing(oracle_ops):
-        st = AttackStepper(net, h, w, torch.device("cpu"), seed=0, boxconstraint=boxconstraint, joint=joint)
+        st = AttackStepper(net, h, w, torch.device("cpu"), seed=0, boxconstraint=boxconstraint, joint=joint, target=target)
         t0 = time.perf_counter()
         with torch.no_grad():
             st.predict()
@@ -738,12 +740,45 @@ def universal_leg(net, h, w, dev, rank, world, pairs_per_gpu, warmup, steps, sha
             "setup_s": setup, "final": last}
 
 
+def pairs_in_flight_leg(net, h, w, dev, rank, model, one_pair_value, steps=4, warmup=1, pairs=2):
+    """Informational, NOT the headline (one pair per GPU stays `value`): `pairs` independent pairs attacked side by side on
+    this GPU -- one host thread + stream + graph set each (pcfa_amd.attack_PCFA.PairsInFlight) -- and then the last of them
+    again ALONE, from scratch, for the bit-identity check.  value = pair-steps/s of the concurrent run."""
+    from pcfa_amd import attack_PCFA
+    seeds = [rank + 500 + k for k in range(pairs)]
+    try:
+        flight = attack_PCFA.PairsInFlight(lambda k: AttackStepper(net, h, w, dev, seeds[k], use_graph=True, model=model),
+                                           pairs, dev)
+        if any(st.graphed is None for st in flight.attacks):
+            return {"error": "capture failed"}
+        flight.run(warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = flight.run(steps)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        a = flight.attacks[-1]
+        solo = AttackStepper(net, h, w, dev, seeds[-1], use_graph=True, model=model)   # lane 0, after lane 0's pair is done
+        for _ in range(warmup + steps):
+            solo_last = solo.step()
+        same = bool(torch.equal(a.delta1, solo.delta1) and torch.equal(a.delta2, solo.delta2)
+                    and torch.equal(a.flow_pred, solo.flow_pred) and tuple(last[-1]) == tuple(solo_last))
+        value = pairs * steps / elapsed
+        return {"pairs": pairs, "value": value, "unit": "pair-steps/s", "steps": steps, "warmup": warmup,
+                "ms_per_step_per_pair": 1e3 * elapsed / steps, "ratio_to_one_pair": value / one_pair_value,
+                "bit_identical_to_solo": same, "final_in_flight": [list(map(float, v)) for v in last],
+                "note": "pairs %s side by side, one thread + stream + hipGraph set per pair; the last pair re-run alone "
+                        "gives the same bits" % seeds}
+    except Exception as e:  # noqa: BLE001 -- an extra: the headline line must survive it
+        return {"error": repr(e)}
+
+
 def pwcnet_leg(a, dev, sharding):
     """BASELINE config 4 beside the headline: PWC-Net on one synthetic KITTI-sized pair (375x1242 -> 384x1280),
-    --joint_perturbation --boxconstraint=clipping, delta_bound 0.005, zero target: a few attack steps (the same
+    --joint_perturbation --boxconstraint=clipping, delta_bound 0.005, zero target: the config's 50 attack steps (the same
     PairAttack.step), the cost-volume / warp kernels' roofline rows from the graph replays, and one closure against
     the CPU port at the same point (PWCNet.py:45-58,166-206,227-330 through the HIP spatial-correlation sampler)."""
-    h, w, steps, warmup = 375, 1242, 3, 1
+    h, w, steps, warmup = 375, 1242, 50, 2   # config 4 is a 50-step attack
     st = AttackStepper("PWCNet", h, w, dev, seed=0, boxconstraint="clipping", joint=True)
     gpu_parity = None if a.no_cpu_baseline else parity_closure(st)
     st.enable_graph()
@@ -769,6 +804,33 @@ def pwcnet_leg(a, dev, sharding):
             rec["kernels_error"] = repr(e)
     if gpu_parity is not None:
         cpu, cpu_parity = cpu_baseline("PWCNet", h, w, 3, a.cpu_threads, boxconstraint="clipping", joint=True)
+        rec["cpu_baseline"] = cpu
+        rec["parity_vs_cpu_port"] = parity_record(gpu_parity, cpu_parity)
+    return rec
+
+
+def gma_leg(a, dev, sharding):
+    """BASELINE config 3's network beside the headline: GMA on one synthetic 436x1024 pair (one pair per GPU is config 3's
+    sharding), change of variables, delta_bound 0.005, neg_flow target (mu = 7.5e5): a few attack steps of the same
+    PairAttack.step and one closure against the CPU port at the same point (models/gma/network.py:72-129, gma.py:34-115)."""
+    h, w, steps, warmup = 436, 1024, 5, 1
+    st = AttackStepper("GMA", h, w, dev, seed=0, target="neg_flow")
+    gpu_parity = None if a.no_cpu_baseline else parity_closure(st)
+    st.enable_graph()
+    for _ in range(warmup):
+        st.step()
+    elapsed, closures, last = timed_steps(st, steps, sharding)
+    from pcfa_amd import config as pcfa_config
+    rec = {"metric": "attack_steps_per_sec", "value": steps / elapsed, "unit": "attack_steps/s", "steps": steps,
+           "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "closure_evals_per_step": closures / steps,
+           "closure_launch": "hipGraph replay" if st.graphed is not None else "eager",
+           "attention_products": pcfa_config.cfg(st.model).gma_gemm,
+           "config": {"workload": "GMA, 1 synthetic %dx%d pair (padded %dx%d), disjoint delta, change_of_variables, "
+                                  "delta_bound=0.005, neg_flow target, L-BFGS max_iter=10 (BASELINE config 3 per GPU)"
+                                  % (h, w, st.image1.shape[-2], st.image1.shape[-1])},
+           "final": {"aee_adv_tgt": last[0], "aee_adv_init": last[1], "l2_delta": last[2]}}
+    if gpu_parity is not None:
+        cpu, cpu_parity = cpu_baseline("GMA", h, w, 3, a.cpu_threads, target="neg_flow")
         rec["cpu_baseline"] = cpu
         rec["parity_vs_cpu_port"] = parity_record(gpu_parity, cpu_parity)
     return rec
@@ -1054,6 +1116,8 @@ def main():
         sp = schedule_parity_record()
         if sp is not None:
             out["schedule_parity"] = sp
+        if world == 1 and use_graph and a.net == "RAFT" and not a.no_pairs_in_flight_leg:
+            out["pairs_in_flight"] = pairs_in_flight_leg(a.net, h, w, dev, rank, st.model, out["value"])
         if world == 1 and use_graph and not a.no_shared_forward_leg:
             out["shared_forward_schedule"] = shared_forward_leg(a.net, h, w, dev, a.warmup, a.steps, sharding, st.model)
         if world == 1 and not a.no_cpu_baseline:
@@ -1065,6 +1129,11 @@ def main():
                 out["pwcnet"] = pwcnet_leg(a, dev, sharding)
             except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure of the extra leg
                 out["pwcnet"] = {"error": repr(e)}
+        if world == 1 and a.net == "RAFT" and not a.no_gma_leg:
+            try:
+                out["gma"] = gma_leg(a, dev, sharding)
+            except Exception as e:  # noqa: BLE001
+                out["gma"] = {"error": repr(e)}
         emit(out, json_out)
     sharding.shutdown()
     return out

@@ -32,13 +32,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # --------------------------------------------------------------------------- #
 # RAFT / GMA correlation volume + lookup
 # --------------------------------------------------------------------------- #
+def _f32_unless_f64(t):
+    """dtype of the reference's `.float()` casts: float32 -- except when the parity ARBITER (tools/parity_arbiter.py,
+    tools/trajectory_closure_parity.py) evaluates this port in float64 to judge which fp32 leg is closer to exact."""
+    return torch.float64 if t.dtype == torch.float64 else torch.float32
+
+
 def corr_volume(fmap1, fmap2):
     """models/raft/corr.py:52-60 -- all-pairs dot products scaled by 1/sqrt(dim)."""
     b, d, h, w = fmap1.shape
     a = fmap1.reshape(b, d, h * w).transpose(1, 2)
     vol = torch.matmul(a, fmap2.reshape(b, d, h * w))
     vol = vol.reshape(b, h, w, 1, h, w)
-    return vol / torch.sqrt(torch.tensor(d).float())
+    return vol / torch.sqrt(torch.tensor(d).to(_f32_unless_f64(vol)))
 
 
 def corr_pyramid(fmap1, fmap2, num_levels=4):
@@ -73,7 +79,7 @@ def corr_lookup(pyramid, coords, radius=4):
     n1 = 2 * r + 1
     pts = coords.permute(0, 2, 3, 1)
     b, h1, w1, _ = pts.shape
-    offs = torch.linspace(-r, r, n1)
+    offs = torch.linspace(-r, r, n1, dtype=_f32_unless_f64(pts))
     first, second = torch.meshgrid(offs, offs, indexing="ij")
     window = torch.stack([first, second], dim=-1).to(pts.device).view(1, n1, n1, 2)
     outs = []
@@ -81,7 +87,7 @@ def corr_lookup(pyramid, coords, radius=4):
         centre = pts.reshape(b * h1 * w1, 1, 1, 2) / 2 ** lvl
         taps = _sample_pixels(vol, centre + window)
         outs.append(taps.view(b, h1, w1, -1))
-    return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+    return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().to(_f32_unless_f64(coords))
 
 
 class CorrBlock:

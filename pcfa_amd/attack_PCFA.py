@@ -162,7 +162,7 @@ class PairAttack:
             use_graph = _graphs_enabled(device, args)
         share_forward = os.environ.get("PCFA_SHARED_FORWARD", "0") == "1"
         self.graph_key = (args.net, tuple(image1.shape), args.boxconstraint, bool(args.joint_perturbation), args.loss,
-                          float(optim_mu), float(args.delta_bound), float(eps_box), str(device))
+                          float(optim_mu), float(args.delta_bound), float(eps_box), str(device), ops.core.current_lane())
         kept = _graph_cache(model).get(self.graph_key) if (use_graph and reuse_graphs and not share_forward) else None
         self.graphed = self.repredict = None
         self.graphs_reused = kept is not None
@@ -458,6 +458,55 @@ def _output_folder(args, tag):
                               "u" if args.universal_perturbation else "-")
     folder = os.path.join(args.output_folder, kind, stamp + tag)
     return logging.create_subfolder(folder, "patches")
+
+
+class PairsInFlight:
+    """Several independent image pairs attacked SIDE BY SIDE on one GPU (attack_PCFA.py:668-670 loops over pairs one after
+    the other; the pairs share nothing but the frozen weights).
+
+    At one pair per GPU every launch of the 55 x 128 feature maps is 1-2 workgroups per CU and ends in a tail; a second
+    pair's launches fill the idle CUs.  Lane k = one host thread + one HIP stream + one set of static buffers, hipGraphs
+    and L-BFGS state (`ops.core.lane(k)` keys every shared scratch buffer and the per-model graph cache), so the lanes
+    never touch each other's memory and each pair's arithmetic is exactly the solo run's: results are bit-identical to
+    attacking the pairs one after the other (tests/test_gpu_parity.py::test_pairs_in_flight_bit_identical_to_solo).
+
+    make_attack(k) -> PairAttack is called in the caller's thread, one lane after the other (weight packs and graph
+    captures are built sequentially); `run(steps)` then drives every lane's `step()` from its own thread."""
+
+    def __init__(self, make_attack, n, device):
+        self.device = torch.device(device)
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(n)]
+        self.attacks = []
+        for k in range(n):
+            with ops.core.lane(k), torch.cuda.stream(self.streams[k]):
+                self.attacks.append(make_attack(k))
+            torch.cuda.synchronize(self.device)
+
+    def run(self, steps):
+        """`steps` attack steps on every lane, concurrently; returns each lane's last (aee_adv_tgt, aee_adv_pred, l2)."""
+        import threading
+        last, errors = [None] * len(self.attacks), []
+        start = threading.Barrier(len(self.attacks))
+
+        def drive(k):
+            try:
+                torch.cuda.set_device(self.device)       # the current device is per host thread
+                with ops.core.lane(k), torch.cuda.stream(self.streams[k]):
+                    start.wait()
+                    for _ in range(steps):
+                        last[k] = self.attacks[k].step()
+                    self.streams[k].synchronize()
+            except BaseException as e:  # noqa: BLE001 -- re-raised in the caller's thread
+                errors.append(e)
+                start.abort()
+        threads = [threading.Thread(target=drive, args=(k,), name="pcfa-lane-%d" % k) for k in range(len(self.attacks))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return last
 
 
 def attack_l2(args, data_loader=None, has_gt=None):

@@ -564,13 +564,18 @@ static int f23_kslices(int B, int K, int N, int H, int W) {
 // (tools/dev/bench_conv3x3.py, device time, F(2x2,3x3) -> F(4x4,3x3)): 256->192 at 55x128 58.6 -> 42.0 us (but see
 // below), 192->256 47.0 -> 42.0, 64->64 at 220x512 (batch 2) 124 -> 106, (batch 1) 64 -> 53.5; 128->256 / 256->126 at
 // 55x128 and 96->96 at 110x256 tie (34 us, 35 us, 68 us) and stay on F(2x2,3x3), whose rounding error is 6x smaller.
-// PCFA_CONV3X3_ALGO=f23|f43 overrides (read once; dev A/B only).
+// PCFA_CONV3X3_ALGO=f23|f43|f43big overrides (read once; A/B of tools/parity_arbiter.py and tools/dev): f43big = the policy
+// below without its small-map (< 100000 pixels) cases, i.e. F(4x4,3x3) only on the encoders' large maps and never inside
+// RAFT's / GMA's 12-iteration update loop.
 static bool use_f43(int B, int K, int N, int H, int W) {
   static const int forced = [] {
     const char* e = getenv("PCFA_CONV3X3_ALGO");
-    return e == nullptr ? 0 : (e[1] == '4' ? 43 : 23);
+    if (e == nullptr) return 0;
+    if (e[0] == 'f' && e[1] == '4' && e[3] == 'b') return 100;
+    return e[1] == '4' ? 43 : 23;
   }();
   if (!pcfa_f43_supported(B, K, N, H, W)) return false;
+  if (forced == 100) return (long long)H * W >= 100000 && H >= 24 && W >= 64 && K >= 16 && pcfa_f43_ksplit(B, K, N, H, W) <= 1;
   if (forced) return forced == 43;
   // Single images with many input channels (PWC-Net's dense decoder blocks, PWCNet.py:110-158: 117..629 -> 128..32 at
   // 96x320 .. 6x20): the F(2x2,3x3) kernel has no channel split, so a small map is a handful of workgroups each

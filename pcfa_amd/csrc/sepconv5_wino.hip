@@ -29,6 +29,13 @@
 #ifndef PCFA_SC5W_DBG
 #define PCFA_SC5W_DBG 0
 #endif
+// PCFA_SC5W_WLDS = 1: the U operands reach the waves through LDS.  The two pixel-half waves of a group multiply the same
+// 6 KB of U per chunk; instead of each fetching them from L2 into registers (48 KB per CU and chunk), every wave copies
+// half of them global -> LDS with three LDS-DMA instructions (global_load_lds_dwordx4: 1 KB each, no VGPR staging) two
+// chunks ahead, and reads its 24 operands of the NEXT chunk back with six ds_read_b128 under this chunk's MFMAs.
+#ifndef PCFA_SC5W_WLDS
+#define PCFA_SC5W_WLDS 1
+#endif
 #ifndef PCFA_SC5W_STORE_AT
 #define PCFA_SC5W_STORE_AT 1   // channel pair after whose MFMAs the next patch is written to LDS (4 = after the last: r04a)
 #endif
@@ -86,9 +93,11 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
   constexpr int GT = 128 * WN, WPG = 2 * WN;
   constexpr int PATCH = VERT ? VPATCH : HPATCH, NV = VERT ? VNV : HNV, NLOAD = (NV + GT - 1) / GT;
   constexpr int RN = 16 / KS;
+  constexpr int WBLK = STEPS * 64;   // floats of one 32-channel block's U operands per chunk (6 KB)
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / GT);
   float* smem = smem_all + grp * 2 * PATCH;
+  float* wlds = smem_all + KS * 2 * PATCH + grp * 2 * WN * WBLK;   // [slot][wn][WBLK] of this group (PCFA_SC5W_WLDS)
   const int tid = threadIdx.x % GT, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave inside the group
   const int wn = WN == 2 ? (wv & 1) : 0, wpx = WN == 2 ? (wv >> 1) : wv;
@@ -158,7 +167,28 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
       w[4 * sq + 3] = t.w;
     }
   };
-  load_w(grp, wa);
+  // chunk `chunk_global`'s U operands of this wave's channel block -> LDS slot `slot`: this wave's half (three 1-KB pieces)
+  auto dma_w = [&](int chunk_global, int slot) {
+    const float* src = pw + (long long)chunk_global * WBLK + (3 * wpx * 64 + lane) * 4;
+    float* dst = wlds + (slot * WN + wn) * WBLK + 3 * wpx * 256;   // wave-uniform: the DMA adds lane * 16 B itself
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 256),
+                                       (__attribute__((address_space(3))) void*)(dst + k * 256), 16, 0, 0);
+  };
+  auto read_w = [&](int slot, int sq, float (&w)[STEPS]) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(wlds + (slot * WN + wn) * WBLK + (sq * 64 + lane) * 4);
+    w[4 * sq] = t.x;
+    w[4 * sq + 1] = t.y;
+    w[4 * sq + 2] = t.z;
+    w[4 * sq + 3] = t.w;
+  };
+  if (PCFA_SC5W_WLDS) {
+    dma_w(grp, 0);
+    dma_w(KS * min(1, nchunk - 1) + grp, 1);
+  } else {
+    load_w(grp, wa);
+  }
 
   // ---- this lane's two output pixels and the rows of the accumulator tile its group finalises ----------------------
   const int mw = 32 * nb;                       // first output channel of the wave
@@ -219,6 +249,11 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
 
   store_patch(0, ra);
   __syncthreads();
+  if (PCFA_SC5W_WLDS) {   // (the barrier above waited for the two DMAs: an LDS-DMA counts on vmcnt)
+#pragma unroll
+    for (int sq = 0; sq < STEPS / 4; ++sq) read_w(0, sq, wa);
+    __syncthreads();      // every wave holds chunk 0's operands: slot 0 may be refilled
+  }
   load_patch(min(1, nchunk - 1), rb);
 
   // 1x5: pair j = 32 wpx + l31 of the tile -> patch columns 2 j + 2 .. 2 j + 7, channel 2 p + lh
@@ -233,6 +268,9 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
     if (PCFA_SC5W_DBG & 8) {
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) wnext[s] = wcur[s];
+    } else if (PCFA_SC5W_WLDS) {
+      // slot chunk & 1 held THIS chunk's operands: every wave copied them to registers before the last barrier
+      dma_w(KS * min(chunk + 2, nchunk - 1) + grp, chunk & 1);
     } else {
       load_w(KS * min(chunk + 1, nchunk - 1) + grp, wnext);
     }
@@ -272,6 +310,14 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
       acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 3], v3, acc[3], 0, 0, 0);
       acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 4], v4, acc[4], 0, 0, 0);
       acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[6 * p + 5], v5, acc[5], 0, 0, 0);
+      if (PCFA_SC5W_WLDS && !(PCFA_SC5W_DBG & 8)) {   // next chunk's operands (landed before the last barrier): 6 reads over 4 pairs
+        if (p < 2) {
+          read_w((chunk + 1) & 1, 2 * p, wnext);
+          read_w((chunk + 1) & 1, 2 * p + 1, wnext);
+        } else {
+          read_w((chunk + 1) & 1, p + 2, wnext);
+        }
+      }
       // the next chunk's patch goes to the other LDS buffer in the shadow of this chunk's MFMAs (nobody reads that buffer
       // since the previous barrier) instead of between the last MFMA and the barrier, where the slowest wave's wait for
       // its load stalled all eight
@@ -408,7 +454,8 @@ int wino_run(const Operand& in, const float* w, const OutSplit& out, int B, int 
              const GruEpi& epi) {
   constexpr int PATCH = VERT ? VPATCH : HPATCH, WPG = 2 * WN;
   constexpr int SRED = KS * WPG * 32 * 64;
-  constexpr int LDSF = 2 * KS * PATCH > SRED ? 2 * KS * PATCH : SRED;
+  constexpr int STAGE = 2 * KS * PATCH + (PCFA_SC5W_WLDS ? KS * 2 * WN * STEPS * 64 : 0);   // patches + U slots
+  constexpr int LDSF = STAGE > SRED ? STAGE : SRED;
   static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)sc5_wino_kernel<VERT, WN, KS, MODE>,

@@ -17,7 +17,7 @@ import torch.nn as nn
 from .. import ops
 from ..config import cfg
 from .raft import (BasicEncoder, BasicMotionEncoder, FlowHead, LookupRef, SepConvGRU, _mask_head, convex_upsample,
-                   coords_grid, mask_logits)
+                   _f32, coords_grid, mask_logits)
 
 
 class RelPosEmb(nn.Module):
@@ -190,7 +190,7 @@ class RAFTGMA(nn.Module):
         hdim, cdim = self.hidden_dim, self.context_dim
 
         fmap1, fmap2 = self.fnet(images12, split=image1.shape[0])
-        corr_fn = ops.get().CorrBlock(fmap1.float(), fmap2.float(), num_levels=4, radius=self.args.corr_radius,
+        corr_fn = ops.get().CorrBlock(_f32(fmap1), _f32(fmap2), num_levels=4, radius=self.args.corr_radius,
                                       bwd_windows=cfg(self).pyramid_bwd_windows)
 
         net, inp = torch.split(self.cnet(image1), [hdim, cdim], dim=1)
@@ -198,8 +198,8 @@ class RAFTGMA(nn.Module):
         attention = self.att(inp)
 
         N, _, H, W = image1.shape
-        coords0 = coords_grid(N, H // 8, W // 8, image1.device)
-        coords1 = coords_grid(N, H // 8, W // 8, image1.device)
+        coords0 = coords_grid(N, H // 8, W // 8, image1.device, _f32(image1).dtype)
+        coords1 = coords_grid(N, H // 8, W // 8, image1.device, _f32(image1).dtype)
         if flow_init is not None:
             coords1 = coords1 + flow_init
 

@@ -469,10 +469,16 @@ class BasicUpdateBlock(nn.Module):
         return net, mask, delta_flow
 
 
-def coords_grid(batch, ht, wd, device):
+def _f32(x):
+    """`.float()` of the reference -- except on fp64 tensors, which only the parity arbiter (the CPU port evaluated in
+    double precision, tools/parity_arbiter.py) feeds through this file."""
+    return x if x.dtype == torch.float64 else x.float()
+
+
+def coords_grid(batch, ht, wd, device, dtype=torch.float32):
     """[B,2,ht,wd] pixel grid, channel 0 = x, channel 1 = y (models/raft/utils/utils.py:74-77)."""
     ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
-    return torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1)
+    return torch.stack([xs, ys], dim=0).to(dtype)[None].repeat(batch, 1, 1, 1)
 
 
 def convex_upsample(flow, mask):
@@ -518,7 +524,7 @@ class RAFT(nn.Module):
             with torch.cuda.stream(side):
                 cnet_out = self.cnet(image1)
         fmap1, fmap2 = self.fnet(images12, split=image1.shape[0])
-        corr_fn = ops.get().CorrBlock(fmap1.float(), fmap2.float(), num_levels=self.args["corr_levels"],
+        corr_fn = ops.get().CorrBlock(_f32(fmap1), _f32(fmap2), num_levels=self.args["corr_levels"],
                                       radius=self.args["corr_radius"], bwd_windows=cfg(self).pyramid_bwd_windows)
         if side is not None:
             main.wait_stream(side)
@@ -529,8 +535,8 @@ class RAFT(nn.Module):
         net, inp = torch.tanh(net), torch.relu(inp)
 
         N, _, H, W = image1.shape
-        coords0 = coords_grid(N, H // 8, W // 8, image1.device)
-        coords1 = coords_grid(N, H // 8, W // 8, image1.device)
+        coords0 = coords_grid(N, H // 8, W // 8, image1.device, _f32(image1).dtype)
+        coords1 = coords_grid(N, H // 8, W // 8, image1.device, _f32(image1).dtype)
         if flow_init is not None:
             coords1 = coords1 + flow_init
 

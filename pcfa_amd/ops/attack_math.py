@@ -8,7 +8,7 @@ import torch
 
 from .. import _hip
 from . import core
-from .core import _call, _dev, _note_work, _pair, _ptr, _ptr_off, _stream
+from .core import _call, _dev, _note_work, _pair, _ptr, _ptr_off, _stream, current_lane
 
 
 # --------------------------------------------------------------------------- #
@@ -150,16 +150,17 @@ _WS = {}
 
 
 def _workspace(device):
-    """Reduction scratch of the loss / metric kernels (32 KB), one per (device, stream), allocated once.
+    """Reduction scratch of the loss / metric kernels (32 KB), one per (device, stream, lane), allocated once.
     While a hipGraph is being captured the capture stream reuses a buffer that was allocated OUTSIDE any capture
     (every capture in this package is preceded by eager warm-up calls on the same device), so no scratch comes from --
     and pins -- a graph's private memory pool; the kernels of one closure are stream-ordered on one stream at a time."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     capturing = torch.cuda.is_current_stream_capturing()
-    key = (idx, None if capturing else torch.cuda.current_stream().cuda_stream)
+    ln = current_lane()
+    key = (idx, None if capturing else torch.cuda.current_stream().cuda_stream, ln)
     ws = _WS.get(key)
     if ws is None and capturing:
-        ws = next((w for (d, s_), w in _WS.items() if d == idx and s_ is not None), None)
+        ws = next((w for (d, s_, l_), w in _WS.items() if d == idx and s_ is not None and l_ == ln), None)
     if ws is None:
         nbytes = _hip.load().pcfa_flow_loss_workspace_bytes()
         ws = torch.empty(nbytes // 4, device=device, dtype=torch.float32)

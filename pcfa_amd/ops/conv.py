@@ -9,7 +9,7 @@ import torch
 
 from .. import _hip
 from . import core
-from .core import _call, _dev, _note_work, _pair, _ptr, _ptr_off, _stream
+from .core import _call, _dev, _note_work, _pair, _ptr, _ptr_off, _stream, current_lane
 
 
 _sepconv_packs = {}  # id(weight) -> (weakref, version, fwd_packed, bwd_packed)
@@ -435,12 +435,12 @@ def side_stream(device):
 
 
 def _conv_workspace(device, nbytes):
-    """One scratch buffer per (device, stream), grown on demand OUTSIDE graph captures (every capture in this package
+    """One scratch buffer per (device, main | side stream, lane), grown on demand OUTSIDE graph captures (every capture in this package
     follows eager warm-up calls of the same shapes); convolutions are stream-ordered per stream, and two streams (the
     encoders running side by side, nets/raft.py) never share a buffer."""
     dev_idx = device.index if device.index is not None else torch.cuda.current_device()
     side = _SIDE_STREAMS.get(dev_idx)
-    idx = (dev_idx, side is not None and torch.cuda.current_stream(device) == side)
+    idx = (dev_idx, side is not None and torch.cuda.current_stream(device) == side, current_lane())
     ws = _CONV_WS.get(idx)
     if ws is None or ws.numel() * 4 < nbytes:
         if torch.cuda.is_current_stream_capturing():

@@ -1,10 +1,34 @@
 """Plumbing shared by every operator module: launches through the C-ABI on torch's current stream (no CPU fallback),
 the optional per-launch timers and the work recorder that bench.py's roofline rows read."""
+import contextlib
 import ctypes
+import threading
 
 import torch
 
 from .. import _hip
+
+# ---- lanes: several image pairs in flight on one GPU ---------------------------------------------------------------------
+# Every scratch buffer that is shared between launches (the convolutions' split-K partials, the loss kernels' reduction
+# scratch) assumes ONE stream-ordered sequence of launches.  Two attacks running side by side (attack_PCFA.PairsInFlight:
+# one host thread + one stream + one set of hipGraphs per pair) would race on them, so those buffers are keyed by the
+# caller's LANE as well: a small integer, thread-local, 0 unless `with lane(k):` says otherwise.  Graph sets are cached per
+# lane for the same reason (attack_PCFA.PairAttack.graph_key).
+_lane_state = threading.local()
+
+
+def current_lane():
+    return getattr(_lane_state, "k", 0)
+
+
+@contextlib.contextmanager
+def lane(k):
+    prev = current_lane()
+    _lane_state.k = int(k)
+    try:
+        yield
+    finally:
+        _lane_state.k = prev
 
 
 def _stream():

@@ -1610,6 +1610,37 @@ def test_schedule_parity_at_baseline_size_vs_cpu_port(pair):
     assert out["ok"] and r.returncode == 0, out["metrics"]
 
 
+def test_fp64_arbiter_rule_on_raft_pair6(tmp_path):
+    """RAFT pair 6 is the pair of the 20-step matrix whose GPU leg ends 0.69 AEE away from the CPU port
+    (profiles/r04_schedule_parity_matrix.json) while the port's two thread counts agree to 5e-5.  tools/parity_arbiter.py
+    evaluates GPU, port@16, port@8 and the port in FLOAT64 at the port's first four iterates (the legs' closure losses separate
+    at the third) and asserts  |g_gpu - g_64| <= max(1e-2 |g_64|, 3 |g_port - g_64|)  at every one of them.
+    Recorded r05 (profiles/r05/fp64_arbiter.json): gpu 4.3e-3 / port 3.8e-3 at x0; the first curvature pair has
+    |g0| / |y| = 170 and y.s = 2.8e-10 (GPU), 3.7e-10 (port), 6.3e-10 (fp64): no leg is on the other side of torch
+    LBFGS's 1e-10 gate, every fp32 leg -- the port included -- is 40-55 % away from the exact y.s, which sets the length of
+    the second move.  Also checked here: all legs on one side of the gate, and the fp32 port itself NOT closer than 10x to
+    fp64 than the GPU (i.e. the port's thread-count spread is not the yardstick, its distance from fp64 is)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "parity_arbiter.py"), "run", "--net", "RAFT", "--seed", "6",
+                        "--at-steps", "0", "--threads", "16", "--floor-threads", "8", "--out", str(tmp_path)],
+                       capture_output=True, text=True, timeout=2400, env=_rank_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.load(open(os.path.join(str(tmp_path), "raft_pair6_arbiter.json")))
+    assert rec["rule_ok_everywhere"] and len(rec["points"]) == 4
+    for p in rec["points"]:
+        v = p["grad_rel_l2_vs_fp64"]
+        assert v["gpu"] <= max(1e-2, 3 * v["port16"]), p
+        assert v["gpu"] <= 10 * max(v["port16"], 1e-6), p
+        assert abs(p["loss"]["gpu"] - p["loss"]["port_fp64"]) <= 2e-6 * abs(p["loss"]["port_fp64"]), p
+    assert rec["legs_on_one_side_of_the_gate"]
+    fp = rec["first_curvature_pair"]
+    assert fp["port_fp64"]["amplification_g0_over_y"] > 50          # the ill-conditioning the record documents
+
+
 @pytest.mark.parametrize("cfg", [("RAFT", "436x1024", []), ("PWCNet", "375x1242", ["--box", "clipping", "--joint"])],
                          ids=["raft", "pwcnet"])
 def test_trajectory_closure_parity_vs_cpu_port(cfg):
@@ -1693,6 +1724,34 @@ def test_bench_gpus2_spawns_two_ranks_on_one_gpu():
     u = out["universal"]
     assert u["global_batch"] == 2 and u["allreduces_per_closure"] == 1.0
     assert u["allreduce_bytes"] == (2 * 3 * 128 * 160 + 1) * 4
+
+
+def test_pairs_in_flight_bit_identical_to_solo():
+    """two PairAttacks side by side on one GPU (attack_PCFA.PairsInFlight: one thread + stream + graph
+    set + scratch lane per pair) must leave every pair with exactly the bits of a solo attack of that pair."""
+    import bench
+    from pcfa_amd import attack_PCFA
+    dev = torch.device(DEV)
+    model = closure_util.load_model("RAFT", True, dev)
+    if hasattr(model, "_pcfa_pair_graphs"):
+        model._pcfa_pair_graphs.clear()
+    seeds, steps = (11, 12), 2
+    flight = attack_PCFA.PairsInFlight(
+        lambda k: bench.AttackStepper("RAFT", 128, 160, dev, seeds[k], use_graph=True, model=model), 2, dev)
+    assert all(st.graphed is not None for st in flight.attacks)
+    assert flight.attacks[0].graph_key != flight.attacks[1].graph_key and not flight.attacks[0].retired   # one set per lane
+    last = flight.run(steps)
+    for k, seed in enumerate(seeds):
+        model._pcfa_pair_graphs.clear()
+        solo = bench.AttackStepper("RAFT", 128, 160, dev, seed, use_graph=True, model=model, )
+        for _ in range(steps):
+            solo_last = solo.step()
+        a = flight.attacks[k]
+        assert tuple(last[k]) == tuple(solo_last), (k, last[k], solo_last)
+        assert torch.equal(a.delta1, solo.delta1) and torch.equal(a.delta2, solo.delta2)
+        assert torch.equal(a.flow_pred, solo.flow_pred) and a.closures == solo.closures == 10 * steps
+        del solo
+    model._pcfa_pair_graphs.clear()
 
 
 def test_bench_default_command_prints_one_short_strict_json_line(tmp_path):
