@@ -464,6 +464,7 @@ class PairsInFlight:
     """Several independent image pairs attacked SIDE BY SIDE on one GPU (attack_PCFA.py:668-670 loops over pairs one after
     the other; the pairs share nothing but the frozen weights).
 
+    (The lane travels with the STREAM, not with the host thread: autograd runs backward nodes on a thread of its own.)
     At one pair per GPU every launch of the 55 x 128 feature maps is 1-2 workgroups per CU and ends in a tail; a second
     pair's launches fill the idle CUs.  Lane k = one host thread + one HIP stream + one set of static buffers, hipGraphs
     and L-BFGS state (`ops.core.lane(k)` keys every shared scratch buffer and the per-model graph cache), so the lanes
@@ -475,7 +476,7 @@ class PairsInFlight:
 
     def __init__(self, make_attack, n, device):
         self.device = torch.device(device)
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(n)]
+        self.streams = [ops.core.bind_stream(torch.cuda.Stream(self.device), k) for k in range(n)]
         self.attacks = []
         for k in range(n):
             with ops.core.lane(k), torch.cuda.stream(self.streams[k]):

@@ -558,25 +558,27 @@ static int f23_kslices(int B, int K, int N, int H, int W) {
   return (nchunk + cper - 1) / cper;   // every slice holds at least one chunk
 }
 
-// Which transform serves a shape.  F(4x4,3x3) needs 1.78x fewer matrix instructions, but three waves per SIMD leave
-// its loop 168 registers (96 of them accumulators): the U operand stream can only run one channel pair ahead and the
-// channel-split path pays for its partial outputs, so it wins where the matrix work dominates -- measured on MI355X
-// (tools/dev/bench_conv3x3.py, device time, F(2x2,3x3) -> F(4x4,3x3)): 256->192 at 55x128 58.6 -> 42.0 us (but see
-// below), 192->256 47.0 -> 42.0, 64->64 at 220x512 (batch 2) 124 -> 106, (batch 1) 64 -> 53.5; 128->256 / 256->126 at
-// 55x128 and 96->96 at 110x256 tie (34 us, 35 us, 68 us) and stay on F(2x2,3x3), whose rounding error is 6x smaller.
-// PCFA_CONV3X3_ALGO=f23|f43|f43big overrides (read once; A/B of tools/parity_arbiter.py and tools/dev): f43big = the policy
-// below without its small-map (< 100000 pixels) cases, i.e. F(4x4,3x3) only on the encoders' large maps and never inside
-// RAFT's / GMA's 12-iteration update loop.
+// Which transform serves a shape.  F(4x4,3x3) needs 1.78x fewer matrix instructions than F(2x2,3x3), at 6x its rounding
+// error (2e-6 against 3.5e-7 relative per layer).
+//   r05 policy: F(4x4,3x3) serves ONLY PWC-Net's single-image, many-input-channel decoder shapes (the B == 1 block below),
+//   where it is worth 1.0 ms of a 4.8 ms closure and the GPU gradient measures CLOSER to the float64 port than the fp32
+//   port does (profiles/r05/fp64_arbiter.json).  RAFT / GMA never take it any more: on their shapes it bought nothing at
+//   the step level (bench at driver settings, back to back: r04 policy 7.44, F(2x2,3x3) only 7.45, large maps only 7.46
+//   attack steps/s -- three waves per SIMD leave its loop 168 registers, so the U operand stream runs one channel pair
+//   ahead and the channel-split path pays for its partial outputs), while the same arbiter puts the gradient of the r04
+//   policy 1.1-2.3x farther from float64 than the port's and the F(2x2,3x3)-only build level with the port
+//   (geometric mean over ten trajectory points: port 5.9e-4, F(2x2,3x3) 6.3e-4, r04 policy 8.3e-4).
+// PCFA_CONV3X3_ALGO = f23 | f43 | r04 overrides (read once; A/B of tools/parity_arbiter.py and tools/dev): r04 = the policy
+// of round 4 (additionally: the 55x128 two-way channel split at K N >= 192 x 256 and every >= 100000-pixel map).
 static bool use_f43(int B, int K, int N, int H, int W) {
   static const int forced = [] {
     const char* e = getenv("PCFA_CONV3X3_ALGO");
     if (e == nullptr) return 0;
-    if (e[0] == 'f' && e[1] == '4' && e[3] == 'b') return 100;
+    if (e[0] == 'r') return 4;
     return e[1] == '4' ? 43 : 23;
   }();
   if (!pcfa_f43_supported(B, K, N, H, W)) return false;
-  if (forced == 100) return (long long)H * W >= 100000 && H >= 24 && W >= 64 && K >= 16 && pcfa_f43_ksplit(B, K, N, H, W) <= 1;
-  if (forced) return forced == 43;
+  if (forced == 43 || forced == 23) return forced == 43;
   // Single images with many input channels (PWC-Net's dense decoder blocks, PWCNet.py:110-158: 117..629 -> 128..32 at
   // 96x320 .. 6x20): the F(2x2,3x3) kernel has no channel split, so a small map is a handful of workgroups each
   // walking the whole K (81 us at 533 -> 64 on 24x80); F(4x4,3x3) splits K over workgroups (27 us).  Thresholds from
@@ -590,13 +592,11 @@ static bool use_f43(int B, int K, int N, int H, int W) {
     if (px > 4096 && px <= 16384 && K >= 384) return true;
     if (px >= 16384 && px < 100000 && (long long)K * N >= 15000) return true;
   }
+  if (forced != 4) return false;
+  // ---- round 4's additional cases (PCFA_CONV3X3_ALGO=r04 only) ----
   if (H < 24 || W < 64 || K < 16) return false;
-  // channel-split path: every split is one more partial output to write and re-read (and 256->192, three splits, is
-  // already paired with convf2 in one F(2x2,3x3) launch that fills its tail: 57 us for both against 42 + 19)
   const int ks = pcfa_f43_ksplit(B, K, N, H, W);
   if (ks > 1) return ks == 2 && (long long)K * N >= 192LL * 256;
-  // enough tiles without a split: large maps only.  (96->96 at 110x256, batch 2, looks like a candidate back to back --
-  // 70.5 -> 44.1 us -- but takes 68 us inside a closure, where its 21 MB input is not already in the caches: measured, left.)
   return (long long)H * W >= 100000;
 }
 

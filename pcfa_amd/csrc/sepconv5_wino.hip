@@ -53,6 +53,10 @@ constexpr int HPX = 128, HRV = HPX / 4 + 2, HCHS = 4 * HRV, HPATCH = CK * HCHS, 
 // 5x1 patch [ch][6 rows][64]: rows 2 rp - 2 .. 2 rp + 3
 constexpr int VPX = 64, VCHS = 6 * 64, VPATCH = CK * VCHS, VNV = CK * 6 * 16;
 
+// source of the out-of-image 16-B pieces when the patch is staged by LDS-DMA (a DMA cannot substitute a value: its
+// per-lane SOURCE address points here instead)
+__device__ __attribute__((aligned(16))) float sc5_zero_piece[4] = {0.f, 0.f, 0.f, 0.f};
+
 __device__ __forceinline__ float wino_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }   // as sepconv5.hip / gru_math.hip
 
 __device__ __forceinline__ const float* wino_plane(const Operand& in, int ci, long long plane) {
@@ -145,6 +149,19 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
       if (tid + GT * k < NV) *reinterpret_cast<f32x4*>(smem + buf * PATCH + plds[k]) = t;
     }
   };
+  // PCFA_SC5W_WLDS: the same pieces by LDS-DMA -- piece e = tid + GT k lies at LDS float 4 e of its buffer (both patch
+  // layouts are contiguous in e), so one wave-instruction fills 1 KB; out-of-image pieces read sc5_zero_piece; no VGPR
+  // staging, no ds_write pass, nothing for the compiler to wait on in the middle of a chunk
+  auto dma_patch = [&](int chunk, int buf) {
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) {
+      const float* src = (okm >> k & 1u) ? wino_plane(in, (KS * chunk + grp) * CK + pch[k], plane) + poff[k] : sc5_zero_piece;
+      float* dst = smem + buf * PATCH + 4 * (GT * k + 64 * wv);   // wave-uniform; the DMA adds lane * 16 B
+      if (tid + GT * k < NV)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
   const float* pw = wp + ((long long)nb * nchunk_all * STEPS) * 64;
 
   f32x16 acc[6];
@@ -155,7 +172,8 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
 
   f32x4 ra[NLOAD], rb[NLOAD];
   float wa[STEPS], wb[STEPS];
-  load_patch(0, ra);
+  if (PCFA_SC5W_WLDS) dma_patch(0, 0);
+  else load_patch(0, ra);
   auto load_w = [&](int chunk_global, float (&w)[STEPS]) {
     const f32x4* q4 = reinterpret_cast<const f32x4*>(pw + (long long)chunk_global * STEPS * 64);
 #pragma unroll
@@ -247,14 +265,16 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
     }
   }
 
-  store_patch(0, ra);
+  if (PCFA_SC5W_WLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed (see `item`)
+  else store_patch(0, ra);
   __syncthreads();
-  if (PCFA_SC5W_WLDS) {   // (the barrier above waited for the two DMAs: an LDS-DMA counts on vmcnt)
+  if (PCFA_SC5W_WLDS) {
 #pragma unroll
     for (int sq = 0; sq < STEPS / 4; ++sq) read_w(0, sq, wa);
     __syncthreads();      // every wave holds chunk 0's operands: slot 0 may be refilled
+  } else {
+    load_patch(min(1, nchunk - 1), rb);
   }
-  load_patch(min(1, nchunk - 1), rb);
 
   // 1x5: pair j = 32 wpx + l31 of the tile -> patch columns 2 j + 2 .. 2 j + 7, channel 2 p + lh
   // 5x1: x = x0 + 32 wpx + l31, the pair's six rows 64 floats apart
@@ -264,15 +284,18 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
   auto item = [&](int chunk, const float (&wcur)[STEPS], float (&wnext)[STEPS], f32x4 (&rload)[NLOAD],
                   const f32x4 (&rstore)[NLOAD]) {
     const float* sp = smem + (chunk & 1) * PATCH + bl;
-    if (!(PCFA_SC5W_DBG & 16)) load_patch(min(chunk + 2, nchunk - 1), rload);
+    // slot chunk & 1 held THIS chunk's operands (every wave copied them to registers before the last barrier) and patch
+    // buffer (chunk + 1) & 1 was last read in the previous item: both are refilled now and have this whole item to land
+    if (PCFA_SC5W_WLDS) {
+      if (!(PCFA_SC5W_DBG & 8)) dma_w(KS * min(chunk + 2, nchunk - 1) + grp, chunk & 1);
+      if (!(PCFA_SC5W_DBG & 16)) dma_patch(min(chunk + 1, nchunk - 1), (chunk + 1) & 1);
+    } else {
+      if (!(PCFA_SC5W_DBG & 16)) load_patch(min(chunk + 2, nchunk - 1), rload);
+      if (!(PCFA_SC5W_DBG & 8)) load_w(KS * min(chunk + 1, nchunk - 1) + grp, wnext);
+    }
     if (PCFA_SC5W_DBG & 8) {
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) wnext[s] = wcur[s];
-    } else if (PCFA_SC5W_WLDS) {
-      // slot chunk & 1 held THIS chunk's operands: every wave copied them to registers before the last barrier
-      dma_w(KS * min(chunk + 2, nchunk - 1) + grp, chunk & 1);
-    } else {
-      load_w(KS * min(chunk + 1, nchunk - 1) + grp, wnext);
     }
     __builtin_amdgcn_sched_barrier(0);
     float d[2][6];
@@ -321,10 +344,17 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
       // the next chunk's patch goes to the other LDS buffer in the shadow of this chunk's MFMAs (nobody reads that buffer
       // since the previous barrier) instead of between the last MFMA and the barrier, where the slowest wave's wait for
       // its load stalled all eight
-      if (p == PCFA_SC5W_STORE_AT && !(PCFA_SC5W_DBG & 16)) store_patch((chunk + 1) & 1, rstore);
+      if (!PCFA_SC5W_WLDS && p == PCFA_SC5W_STORE_AT && !(PCFA_SC5W_DBG & 16)) store_patch((chunk + 1) & 1, rstore);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (PCFA_SC5W_STORE_AT >= CK / 2 && !(PCFA_SC5W_DBG & 16)) store_patch((chunk + 1) & 1, rstore);
+    if (!PCFA_SC5W_WLDS && PCFA_SC5W_STORE_AT >= CK / 2 && !(PCFA_SC5W_DBG & 16)) store_patch((chunk + 1) & 1, rstore);
+    // The other waves read this wave's DMA pieces after the barrier: the pieces must have LANDED before this wave arrives
+    // (the compiler's own waits only protect the issuing wave's reads: without this one, a partner occasionally multiplied
+    // with the slot's previous contents -- run-to-run differences in test_gru_step_vs_oracle, batch 2)
+    if (PCFA_SC5W_WLDS) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (!(PCFA_SC5W_DBG & 1)) __syncthreads();
   };
   for (int chunk = 0; chunk < nchunk; chunk += 2) {   // host: nchunk even

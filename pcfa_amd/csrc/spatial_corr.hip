@@ -198,14 +198,18 @@ FwdPlan plan_fwd(int B, int C, int H, int W) {
   for (int i = 0; i < 3; ++i)
     if ((long long)pcfa_cdiv(H, th[i]) * pcfa_cdiv(W, tw[i]) * B >= 200) { k = i; break; }
   FwdPlan P;
-  if (const char* e = getenv("PCFA_SC_TILE")) k = atoi(e);          // tuning overrides (tools/dev only)
+  // tuning overrides (tools/dev only), read ONCE per process: plan_fwd runs on every launch
+  static const int env_tile = getenv("PCFA_SC_TILE") ? atoi(getenv("PCFA_SC_TILE")) : -1;
+  static const int env_ns = getenv("PCFA_SC_NS") ? atoi(getenv("PCFA_SC_NS")) : -1;
+  static const int env_cr = getenv("PCFA_SC_CR") ? atoi(getenv("PCFA_SC_CR")) : -1;
+  if (env_tile >= 0 && env_tile < 3) k = env_tile;
   P.th = th[k]; P.tw = tw[k];
   P.ns = nsmax[k];
   while (P.ns > 1 && C / P.ns < 4) P.ns >>= 1;
-  if (const char* e = getenv("PCFA_SC_NS")) P.ns = atoi(e) < nsmax[k] ? atoi(e) : nsmax[k];
+  if (env_ns > 0) P.ns = env_ns < nsmax[k] ? env_ns : nsmax[k];
   const int pcf = P.th * P.tw + (P.th + 8) * (P.tw + 8);
   int crmax = SC_LDS_BUDGET / (pcf * 4);
-  if (const char* e = getenv("PCFA_SC_CR")) crmax = atoi(e) < crmax ? atoi(e) : crmax;
+  if (env_cr > 0) crmax = env_cr < crmax ? env_cr : crmax;
   const int rounds = pcfa_cdiv(C, crmax);
   P.cr = pcfa_cdiv(pcfa_cdiv(C, rounds), P.ns) * P.ns;
   if (P.cr > crmax) P.cr = crmax / P.ns * P.ns;
@@ -421,7 +425,8 @@ int scorr9_backward(const float* in1, const float* in2, const float* gout, const
   // (103 KB of LDS = one workgroup per CU, nothing overlaps its load phase): kept for tuning only
   static const int dbg = getenv("PCFA_SC_DBG") ? atoi(getenv("PCFA_SC_DBG")) : 0;   // phase ablation (tools/dev)
   bool tall = false;
-  if (const char* e = getenv("PCFA_SC_BTH")) tall = atoi(e) == 4;   // tuning override (tools/dev)
+  static const int env_bth = getenv("PCFA_SC_BTH") ? atoi(getenv("PCFA_SC_BTH")) : 0;   // tuning override (tools/dev), read once
+  if (env_bth) tall = env_bth == 4;
   if (tall) {
     dim3 grid(pcfa_cdiv(W, BTW), pcfa_cdiv(H, 4), 2 * B * pcfa_cdiv(C, BCG)), block(256);
     pcfa_launch(scorr9_bwd_kernel<4>, grid, block, 0, s, in1, in2, gout, fwd_out, gin1, gin2, C, H, W, gscale, slope,

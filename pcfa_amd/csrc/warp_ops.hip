@@ -30,11 +30,27 @@ struct WarpTaps {
   bool vx0, vx1, vy0, vy1;
 };
 
+// Every kernel of this file (forward, fp32-atomic backward, the two fixed-point backward kernels) must form the same sample
+// position and the same flow-gradient sums BIT FOR BIT.  With contraction left to the optimiser, the same source expression
+// became an fma in one kernel and a multiply + add in another after an unrelated edit (r05: the non-finite flag), and the
+// "moves no bit" A/B of the two fixed-point kernels differed in the last place.  So the two shared pieces state their
+// roundings explicitly: no contraction inside them, an fma exactly where one is written.
 __device__ __forceinline__ float warp_coord(float base, float flow, int size) {
+#pragma clang fp contract(off)
   float g = 2.0f * (base + flow);
   g = g / (float)max(size - 1, 1);
   g = g - 1.0f;
-  return ((g + 1.f) * (float)size - 1.f) / 2.f;  // grid_sampler_unnormalize, align_corners = false
+  // grid_sampler_unnormalize, align_corners = false: ((g + 1) * size - 1) / 2.  ATen's vectorised CPU kernel (what the port
+  // runs) forms it as (g + 1) * (size / 2) - 0.5 with a fused multiply-add: the same value, a power of two apart -- so the
+  // fma is written out (an un-fused form misses the port by 1 ulp of the coordinate, 2e-6 of max|x| in the output)
+  return fmaf(g + 1.f, (float)size, -1.f) / 2.f;
+}
+
+// acc (+/-)= (v * w) * g  as  fma(+/- (v * w), g, acc): one tap's contribution to d out / d ix (or iy)
+__device__ __forceinline__ float tap_fma(float acc, float v, float w, float g, bool minus) {
+#pragma clang fp contract(off)
+  const float t = v * w;
+  return fmaf(minus ? -t : t, g, acc);
 }
 
 __device__ __forceinline__ WarpTaps warp_taps(float ix, float iy, int H, int W) {
@@ -126,23 +142,23 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_kernel(const float* __restri
     const float vnw = xc[onw], vne = xc[one], vsw = xc[osw], vse = xc[ose];
     if (bnw) {
       unsafeAtomicAdd(gc + onw, nw * g);
-      gix -= vnw * ey * g;
-      giy -= vnw * ex * g;
+      gix = tap_fma(gix, vnw, ey, g, true);
+      giy = tap_fma(giy, vnw, ex, g, true);
     }
     if (bne) {
       unsafeAtomicAdd(gc + one, ne * g);
-      gix += vne * ey * g;
-      giy -= vne * t.wx1 * g;
+      gix = tap_fma(gix, vne, ey, g, false);
+      giy = tap_fma(giy, vne, t.wx1, g, true);
     }
     if (bsw) {
       unsafeAtomicAdd(gc + osw, sw * g);
-      gix -= vsw * t.wy1 * g;
-      giy += vsw * ex * g;
+      gix = tap_fma(gix, vsw, t.wy1, g, true);
+      giy = tap_fma(giy, vsw, ex, g, false);
     }
     if (bse) {
       unsafeAtomicAdd(gc + ose, se * g);
-      gix += vse * t.wy1 * g;
-      giy += vse * t.wx1 * g;
+      gix = tap_fma(gix, vse, t.wy1, g, false);
+      giy = tap_fma(giy, vse, t.wx1, g, false);
     }
   }
   // d ix / d grid = W / 2 (unnormalize), d grid / d flo = 2 / max(W - 1, 1) (the reference divides, then doubles)
@@ -239,23 +255,23 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_det_kernel(const float* __re
     const float vnw = xc[onw], vne = xc[one], vsw = xc[osw], vse = xc[ose];
     if (bnw) {
       fix_add(gc + onw, nw * g, scale);
-      gix -= vnw * ey * g;
-      giy -= vnw * ex * g;
+      gix = tap_fma(gix, vnw, ey, g, true);
+      giy = tap_fma(giy, vnw, ex, g, true);
     }
     if (bne) {
       fix_add(gc + one, ne * g, scale);
-      gix += vne * ey * g;
-      giy -= vne * t.wx1 * g;
+      gix = tap_fma(gix, vne, ey, g, false);
+      giy = tap_fma(giy, vne, t.wx1, g, true);
     }
     if (bsw) {
       fix_add(gc + osw, sw * g, scale);
-      gix -= vsw * t.wy1 * g;
-      giy += vsw * ex * g;
+      gix = tap_fma(gix, vsw, t.wy1, g, true);
+      giy = tap_fma(giy, vsw, ex, g, false);
     }
     if (bse) {
       fix_add(gc + ose, se * g, scale);
-      gix += vse * t.wy1 * g;
-      giy += vse * t.wx1 * g;
+      gix = tap_fma(gix, vse, t.wy1, g, false);
+      giy = tap_fma(giy, vse, t.wx1, g, false);
     }
   }
   gf[p] = 2.0f * ((0.5f * (float)W * gix) / (float)max(W - 1, 1));
@@ -334,23 +350,23 @@ __global__ __launch_bounds__(256) void pwc_warp_bwd_det_lds_kernel(
         const float vnw = xc[onw], vne = xc[one], vsw = xc[osw], vse = xc[ose];
         if (bnw) {
           put(j, cnw, gc + onw, nw * g);
-          gix -= vnw * ey * g;
-          giy -= vnw * ex * g;
+          gix = tap_fma(gix, vnw, ey, g, true);
+          giy = tap_fma(giy, vnw, ex, g, true);
         }
         if (bne) {
           put(j, cne, gc + one, ne * g);
-          gix += vne * ey * g;
-          giy -= vne * t.wx1 * g;
+          gix = tap_fma(gix, vne, ey, g, false);
+          giy = tap_fma(giy, vne, t.wx1, g, true);
         }
         if (bsw) {
           put(j, csw, gc + osw, sw * g);
-          gix -= vsw * t.wy1 * g;
-          giy += vsw * ex * g;
+          gix = tap_fma(gix, vsw, t.wy1, g, true);
+          giy = tap_fma(giy, vsw, ex, g, false);
         }
         if (bse) {
           put(j, cse, gc + ose, se * g);
-          gix += vse * t.wy1 * g;
-          giy += vse * t.wx1 * g;
+          gix = tap_fma(gix, vse, t.wy1, g, false);
+          giy = tap_fma(giy, vse, t.wx1, g, false);
         }
       }
     }

@@ -12,6 +12,8 @@ import gc
 
 import torch
 
+from .ops import core as _core
+
 
 @contextlib.contextmanager
 def _no_gc():
@@ -43,7 +45,7 @@ class GraphedClosure:
         self.params = list(params)
         dev = self.params[0].device
         cur = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(dev)
+        side = _core.new_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):  # warm-up off the capture stream: MIOpen first-call work, workspaces
             for _ in range(warmup):
@@ -55,7 +57,10 @@ class GraphedClosure:
         for p in self.params:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        with _no_gc(), torch.cuda.graph(self.graph):
+        # a capture stream of this object's own: torch.cuda.graph's default is ONE stream per process, and the library
+        # GEMMs' workspace is kept per (handle, stream) -- two closures captured on it (two pairs in flight,
+        # attack_PCFA.PairsInFlight) would replay against the same scratch side by side
+        with _no_gc(), torch.cuda.graph(self.graph, stream=_core.new_stream(dev)):
             self.loss = closure_fn()
             if grad_sink is not None:
                 with torch.no_grad():
@@ -77,7 +82,7 @@ class GraphedForward:
 
     def __init__(self, forward_fn, device, warmup=1):
         cur = torch.cuda.current_stream(device)
-        side = torch.cuda.Stream(device)
+        side = _core.new_stream(device)
         side.wait_stream(cur)
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):
@@ -85,7 +90,7 @@ class GraphedForward:
         cur.wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with _no_gc(), torch.no_grad(), torch.cuda.graph(self.graph):
+        with _no_gc(), torch.no_grad(), torch.cuda.graph(self.graph, stream=_core.new_stream(device)):   # (as GraphedClosure)
             self.out = forward_fn()
 
     def __call__(self):
@@ -110,7 +115,7 @@ class SplitGraphedClosure:
         self.params = list(params)
         dev = self.params[0].device
         cur = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(dev)
+        side = _core.new_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(warmup):
@@ -127,7 +132,7 @@ class SplitGraphedClosure:
         self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # ONE capture stream for both graphs: autograd runs every backward node on the stream its forward ran on, so a
         # second capture on a stream of its own would have to synchronise with the first one's -- invalid in a capture
-        cap = torch.cuda.Stream(dev)
+        cap = _core.new_stream(dev)
         with _no_gc():
             with torch.cuda.graph(self.fwd_graph, pool=pool, stream=cap):
                 self.loss, self.aux = forward_fn()

@@ -15,20 +15,43 @@ from .. import _hip
 # caller's LANE as well: a small integer, thread-local, 0 unless `with lane(k):` says otherwise.  Graph sets are cached per
 # lane for the same reason (attack_PCFA.PairAttack.graph_key).
 _lane_state = threading.local()
+_STREAM_LANE = {}   # HIP stream handle -> lane.  autograd runs every backward node on ITS OWN thread (thread-locals of the
+                    # caller are not there) but on the stream of the node's forward: the stream is what carries the lane
 
 
 def current_lane():
+    if _STREAM_LANE and torch.cuda.is_available():
+        k = _STREAM_LANE.get(torch.cuda.current_stream().cuda_stream)
+        if k is not None:
+            return k
     return getattr(_lane_state, "k", 0)
 
 
 @contextlib.contextmanager
 def lane(k):
-    prev = current_lane()
+    prev = getattr(_lane_state, "k", 0)
     _lane_state.k = int(k)
     try:
         yield
     finally:
         _lane_state.k = prev
+
+
+def bind_stream(stream, k=None):
+    """Register `stream` (a torch.cuda.Stream) with lane k (default: the caller's lane); returns the stream.  Every stream a
+    lane's work may run on -- its own, and the warm-up / capture streams of its hipGraphs (pcfa_amd/graphed.py) -- is bound,
+    so that launches issued from autograd's backward thread find the lane through the stream they run on."""
+    k = getattr(_lane_state, "k", 0) if k is None else int(k)
+    if k != 0:
+        _STREAM_LANE[stream.cuda_stream] = k
+    else:
+        _STREAM_LANE.pop(stream.cuda_stream, None)   # lane 0 is the default; a recycled handle must not keep an old binding
+    return stream
+
+
+def new_stream(device):
+    """A new stream of `device`, bound to the caller's lane."""
+    return bind_stream(torch.cuda.Stream(device))
 
 
 def _stream():

@@ -8,7 +8,7 @@ threads) runs the attack up to the step where the r04 matrix saw the GPU leg lea
     the first closure evaluation of every step in --at-steps   (where the per-step metrics separate).
 At each of these points the SAME variables are evaluated by
     gpu[:variant]   the product path on the GPU (child process per variant; `f23` = PCFA_CONV3X3_ALGO=f23, Winograd
-                    F(4x4,3x3) off),
+                    F(4x4,3x3) off everywhere; `r04policy` = round 4's F(4x4,3x3) policy, which RAFT / GMA no longer take),
     port<T>         the fp32 port on --threads threads (the recorded run itself),
     port<F>         the fp32 port on --floor-threads threads,
     port_fp64       the port with every tensor, weight and operator in float64  -- the arbiter.
@@ -43,7 +43,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 GRAD_TOL = 1e-2
 GATE = 1e-10
-VARIANT_ENV = {"default": {}, "f23": {"PCFA_CONV3X3_ALGO": "f23"}, "f43big": {"PCFA_CONV3X3_ALGO": "f43big"}}
+VARIANT_ENV = {"default": {}, "f23": {"PCFA_CONV3X3_ALGO": "f23"}, "r04policy": {"PCFA_CONV3X3_ALGO": "r04"}}
 
 
 def _flat(ts):
@@ -310,8 +310,9 @@ def cmd_assemble(a):
         out["winograd_variants_vs_fp64"] = {
             "rows": tab, "geometric_mean": {k: float(__import__("math").exp(sum(__import__("math").log(t[k]) for t in tab if k in t)
                                                                             / max(1, sum(k in t for t in tab)))) for k in keys},
-            "legs": "gpu = shipped policy; gpu:f23 = Winograd F(4x4,3x3) off everywhere; gpu:f43big = F(4x4,3x3) only on the "
-                    "encoders' >= 100000-pixel maps (never inside the 12-iteration update loop)"}
+            "legs": "gpu = the policy of the build that produced the record (r04 policy in the records taken before the r05 "
+                    "policy change: their `gpu_variants` field says which algorithm 256->192 at 55x128 took); gpu:f23 = "
+                    "Winograd F(4x4,3x3) off everywhere; gpu:r04policy = round 4's policy"}
     with open(a.out, "w") as f:
         f.write(json.dumps(out, indent=1) + "\n")
     for p in out["pairs"]:

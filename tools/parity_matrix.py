@@ -31,6 +31,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 CONFIGS = {   # net -> (size, box, joint, target)
     "RAFT": ("436x1024", "change_of_variables", False, "zero"),
@@ -203,6 +204,24 @@ def first_divergence(la, lb, rel=DIVERGENCE_REL):
     return None
 
 
+def _arbiter_summary(path):
+    """fp64_arbiter record of an outside pair (tools/parity_arbiter.py): what the float64 port says about the GPU gradient
+    at the first separated closures and about the first curvature pair."""
+    import parity_arbiter
+    r = json.load(open(path))
+    port = "port%d" % r["threads"]
+    worst = max(r["points"], key=lambda p: p["grad_rel_l2_vs_fp64"].get("gpu", 0.0))
+    fp = r["first_curvature_pair"]
+    return {"file": os.path.relpath(path, ROOT), "rule": r["rule"], "rule_ok_everywhere": r["rule_ok_everywhere"],
+            "points": len(r["points"]), "at_steps": r["at_steps"],
+            "worst_point": {"point": worst["point"], "gpu_vs_fp64": worst["grad_rel_l2_vs_fp64"].get("gpu"),
+                            "port_vs_fp64": worst["grad_rel_l2_vs_fp64"].get(port), "tolerance": worst.get("tolerance")},
+            "legs_on_one_side_of_the_gate": r["legs_on_one_side_of_the_gate"],
+            "first_curvature_pair": {k: {"ys": v["ys"], "y_norm": v["y_norm"], "g0_norm": v["g0_norm"], "H": v["H"],
+                                         "pair_stored": v["pair_stored"]} for k, v in fp.items()},
+            "verdict": parity_arbiter._verdict(r)}
+
+
 def cmd_assemble(a):
     legs = {}
     for path in sorted(glob.glob(os.path.join(a.dir, "*.json"))):
@@ -237,6 +256,9 @@ def cmd_assemble(a):
                 row["first_step_divergence_port16_vs_port8"] = first_step_divergence(pa["per_step"], pb["per_step"])
                 row["max_step_gap_aee_adv_tgt_port16_vs_port8"] = max(abs(x[0] - y[0]) for x, y in zip(pa["per_step"], pb["per_step"]))
                 row["port_hosts"] = {"port16": pa.get("host"), "port8": pb.get("host")}
+            if a.arbiter and row.get("inside_all") is False:
+                ap = os.path.join(a.arbiter, "%s_pair%d_arbiter.json" % (net.lower(), sd))
+                row["fp64_arbiter"] = _arbiter_summary(ap) if os.path.exists(ap) else None
             if g:
                 row["per_step_aee_adv_tgt_gpu"] = [round(s[0], 4) for s in g["per_step"]]
             if pa:
@@ -248,7 +270,12 @@ def cmd_assemble(a):
                "pairs_ok": sum(r["inside_all"] for r in full),
                "pairs_ok_per_metric": {k: sum(r[k]["inside"] for r in full) for k in FLOORS},
                "pairs_on_the_ports_branch": sum(r["first_step_divergence_gpu_vs_port16"] is None for r in full),
-               "fraction_inside": (sum(r["inside_all"] for r in full) / len(full)) if full else None}
+               "fraction_inside": (sum(r["inside_all"] for r in full) / len(full)) if full else None,
+               "pairs_outside": [r["pair"] for r in full if not r["inside_all"]],
+               "pairs_outside_cleared_by_fp64_arbiter": [r["pair"] for r in full if not r["inside_all"] and
+                                                         (r.get("fp64_arbiter") or {}).get("rule_ok_everywhere")],
+               "pairs_outside_without_arbiter_record": [r["pair"] for r in full if not r["inside_all"] and
+                                                        not r.get("fp64_arbiter")]}
         # the same records read as DISTRIBUTIONS over the pairs (an un-damped L-BFGS attack is chaotic per pair -- the legs
         # take different branches at the same few steps -- so the per-pair rule mostly measures branch luck; what a user of
         # the attack sees is the distribution of its results): per leg mean / std / range of the best-iterate metrics, and
@@ -303,6 +330,7 @@ def main():
     p = sub.add_parser("assemble")
     p.add_argument("--dir", required=True)
     p.add_argument("--out", required=True)
+    p.add_argument("--arbiter", default="", help="directory of tools/parity_arbiter.py records: attached to every outside pair")
     a = ap.parse_args()
     if a.cmd != "assemble":
         a.seeds = [int(v) for v in str(a.seeds).split(",")]

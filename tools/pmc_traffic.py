@@ -13,7 +13,9 @@ import sys
 OURS = ("corr_lookup_convc1_fwd", "corr_lookup_convc1_bwd", "corr_lookup_fwd", "corr_lookup_bwd", "scorr9_fwd",
         "scorr9_bwd", "sum_n_kernel", "gemm_f32_mfma", "f2ext_", "scorr_", "loss_partial", "box_fwd",
         "deltas_fwd", "instnorm_stats_kernel<false>", "instnorm_stats_kernel<true>", "instnorm_apply_kernel<false>",
-        "instnorm_apply_kernel<true>", "add_relu_kernel", "gru_gates_fwd", "gru_update_fwd")
+        "instnorm_apply_kernel<true>", "add_relu_kernel", "gru_gates_fwd", "gru_update_fwd", "pwc_warp_fwd",
+        "pwc_warp_bwd_det_lds", "pwc_warp_bwd_det", "pwc_warp_finish", "zero_ll_max")
+PER_GRID = ("scorr9_fwd", "scorr9_bwd", "pwc_warp_fwd", "pwc_warp_bwd_det_lds")   # one row per launch shape (= PWC-Net level)
 
 
 def collect(folder, counter):
@@ -28,6 +30,8 @@ def collect(folder, counter):
                 continue
             if key == "gemm_f32_mfma":
                 key = name[name.index("gemm_f32_mfma"):].split("(")[0]
+            if key in PER_GRID and row.get("Grid_Size"):
+                key = "%s grid %s wg %s" % (key, row["Grid_Size"], row.get("Workgroup_Size", "?"))
             out.setdefault(key, []).append(float(row["Counter_Value"]))
     return out
 
