@@ -476,6 +476,8 @@ class PairsInFlight:
 
     def __init__(self, make_attack, n, device):
         self.device = torch.device(device)
+        if self.device.index is None:      # "cuda": the caller's current device (a new host thread starts on device 0)
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.streams = [ops.core.bind_stream(torch.cuda.Stream(self.device), k) for k in range(n)]
         self.attacks = []
         for k in range(n):

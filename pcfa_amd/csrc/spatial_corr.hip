@@ -38,6 +38,27 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SC_LDS_BUDGET = 144 * 1024;  // bytes of dynamic LDS a forward workgroup may stage into
 
+// XCD-aware workgroup -> tile map.  Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its
+// own L2: with the plain (x, y) grid the tiles that share a halo (4 of the 12 x 40 staged in2 rows / columns belong to the
+// neighbours) sat on different XCDs, so every L2 fetched its own copy -- rocprofv3 counted 30.1 MB of L2 misses per launch for
+// the 7.9 MB of level-2 inputs (forward) and 137.6 MB for the backward's 25.7 MB (profiles/r05/pwc_traffic_before_xcd_map.json).
+// Here XCD k owns the contiguous band of tiles [k * chunk, (k + 1) * chunk) (row-major: x neighbours adjacent, rows stacked),
+// the launch is a 1-D grid of 8 * chunk * nz workgroups, and a workgroup whose tile falls past the end leaves at once.
+struct XcdTile {
+  int tile, z;
+  bool live;
+};
+__device__ __forceinline__ XcdTile xcd_tile(int ntiles, int nz) {
+  const int chunk = (ntiles + 7) >> 3;
+  const int lin = blockIdx.x, k = lin & 7, r = lin >> 3;   // r-th workgroup of XCD k
+  XcdTile t;
+  t.z = r % nz;                                           // z fastest: the workgroups of one tile (gradient side, channel
+  t.tile = k * chunk + r / nz;                            // group) follow each other on one XCD and share its taps
+  t.live = t.tile < ntiles;
+  return t;
+}
+inline unsigned xcd_grid(int ntiles, int nz) { return 8u * (unsigned)((ntiles + 7) / 8) * (unsigned)nz; }
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
@@ -45,7 +66,8 @@ template <int TH, int TW>
 __global__ __launch_bounds__(576) void scorr9_fwd_kernel(const float* __restrict__ in1,
                                                          const float* __restrict__ in2,
                                                          float* __restrict__ out, int C, int H, int W, int NS,
-                                                         int CR, float scale, float slope, int dbg) {
+                                                         int CR, float scale, float slope, int dbg, int tiles_x,
+                                                         int ntiles, int B) {
   constexpr int PS = 9, R = 4;
   constexpr int QW = TW / 4;                 // pixel quads per tile row
   constexpr int HW2 = TW + 2 * R, HH2 = TH + 2 * R;
@@ -56,8 +78,10 @@ __global__ __launch_bounds__(576) void scorr9_fwd_kernel(const float* __restrict
   constexpr int TPS = QW * TH * PS;          // threads per channel slice
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
-  const int b = blockIdx.z;
-  const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const XcdTile xt = xcd_tile(ntiles, B);
+  if (!xt.live) return;   // (whole workgroup, before any barrier)
+  const int b = xt.z;
+  const int y0 = (xt.tile / tiles_x) * TH, x0 = (xt.tile % tiles_x) * TW;
   const int tid = threadIdx.x, NT = blockDim.x;
   const size_t plane = (size_t)H * W;
   const float* p1 = in1 + (size_t)b * C * plane;
@@ -230,10 +254,11 @@ int launch_fwd(const FwdPlan& P, const float* in1, const float* in2, float* out,
     granted = P.lds;
   }
   const int tps = (TW / 4) * TH * 9;
-  dim3 grid(pcfa_cdiv(W, TW), pcfa_cdiv(H, TH), B), block(tps * P.ns);
+  const int tiles_x = pcfa_cdiv(W, TW), ntiles = tiles_x * pcfa_cdiv(H, TH);
+  dim3 grid(xcd_grid(ntiles, B)), block(tps * P.ns);
   static const int dbg = getenv("PCFA_SC_DBG") ? atoi(getenv("PCFA_SC_DBG")) : 0;   // phase ablation (tools/dev)
   pcfa_launch(scorr9_fwd_kernel<TH, TW>, grid, block, P.lds, s, in1, in2, out, C, H, W, P.ns, P.cr, scale, slope,
-              dbg);
+              dbg, tiles_x, ntiles, B);
   return PCFA_OK;
 }
 
@@ -258,7 +283,8 @@ __global__ __launch_bounds__(256) void scorr9_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ gout,
                                                          const float* __restrict__ fwd_out,
                                                          float* __restrict__ gin1, float* __restrict__ gin2,
-                                                         int C, int H, int W, float gscale, float slope, int dbg) {
+                                                         int C, int H, int W, float gscale, float slope, int dbg,
+                                                         int tiles_x, int ntiles, int nz) {
   constexpr int PS = 9, R = 4;
   constexpr int QW = BTW / 4, HW2 = BTW + 2 * R, HH2 = BTH + 2 * R;
   constexpr int NT = 256;
@@ -269,10 +295,12 @@ __global__ __launch_bounds__(256) void scorr9_bwd_kernel(const float* __restrict
   __shared__ __attribute__((aligned(16))) float Xs[BCG][HH2][HW2];
 
   const int ngroups = (C + BCG - 1) / BCG;
-  int z = blockIdx.z;
+  const XcdTile xt = xcd_tile(ntiles, nz);
+  if (!xt.live) return;   // (whole workgroup, before any barrier)
+  int z = xt.z;
   const int which = z & 1; z >>= 1;               // 0: gradient w.r.t. in1, 1: w.r.t. in2
   const int b = z / ngroups, c0 = (z - b * ngroups) * BCG;
-  const int y0 = blockIdx.y * BTH, x0 = blockIdx.x * BTW;
+  const int y0 = (xt.tile / tiles_x) * BTH, x0 = (xt.tile % tiles_x) * BTW;
   const int tid = threadIdx.x;
   const size_t plane = (size_t)H * W;
   const float* X = (which ? in1 : in2) + (size_t)b * C * plane;
@@ -427,14 +455,15 @@ int scorr9_backward(const float* in1, const float* in2, const float* gout, const
   bool tall = false;
   static const int env_bth = getenv("PCFA_SC_BTH") ? atoi(getenv("PCFA_SC_BTH")) : 0;   // tuning override (tools/dev), read once
   if (env_bth) tall = env_bth == 4;
+  const int tiles_x = pcfa_cdiv(W, BTW), nz = 2 * B * pcfa_cdiv(C, BCG);
   if (tall) {
-    dim3 grid(pcfa_cdiv(W, BTW), pcfa_cdiv(H, 4), 2 * B * pcfa_cdiv(C, BCG)), block(256);
-    pcfa_launch(scorr9_bwd_kernel<4>, grid, block, 0, s, in1, in2, gout, fwd_out, gin1, gin2, C, H, W, gscale, slope,
-                dbg);
+    const int ntiles = tiles_x * pcfa_cdiv(H, 4);
+    pcfa_launch(scorr9_bwd_kernel<4>, dim3(xcd_grid(ntiles, nz)), dim3(256), 0, s, in1, in2, gout, fwd_out, gin1, gin2, C, H,
+                W, gscale, slope, dbg, tiles_x, ntiles, nz);
   } else {
-    dim3 grid(pcfa_cdiv(W, BTW), pcfa_cdiv(H, 2), 2 * B * pcfa_cdiv(C, BCG)), block(256);
-    pcfa_launch(scorr9_bwd_kernel<2>, grid, block, 0, s, in1, in2, gout, fwd_out, gin1, gin2, C, H, W, gscale, slope,
-                dbg);
+    const int ntiles = tiles_x * pcfa_cdiv(H, 2);
+    pcfa_launch(scorr9_bwd_kernel<2>, dim3(xcd_grid(ntiles, nz)), dim3(256), 0, s, in1, in2, gout, fwd_out, gin1, gin2, C, H,
+                W, gscale, slope, dbg, tiles_x, ntiles, nz);
   }
   return PCFA_OK;
 }

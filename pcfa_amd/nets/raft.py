@@ -348,7 +348,7 @@ class SepConvGRU(nn.Module):
                            ("zr2", (self.convz2, self.convr2)), ("q2", (self.convq2,))):
             w_dyn, w_const, b = self._split(tag, convs)
             # the same (1,5)/(5,1) kernel as the per-iteration gate convolutions, here on the context features alone:
-            # 230 us against 340 us in the library for the four of them (forward + data gradient, tools/dev/ctx_conv_probe.py)
+            # 230 us against 340 us in the library for the four of them (forward + data gradient, r03 probe)
             ctx[tag] = (w_dyn, ops.get().sepconv5(inp, None, w_const) + b.view(1, -1, 1, 1))
         return ctx
 

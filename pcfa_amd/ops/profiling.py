@@ -88,7 +88,7 @@ class DispatchTimer:
             # timing-only events: without hipEventDisableSystemFence the dispatch they ride on ends with a
             # SYSTEM-scope release (write-back of every dirty L2 line, also those of earlier kernels), which a
             # plain or graph-replayed launch does not pay -- rocprofv3 shows the same kernel 1.7 us longer with
-            # default events attached (tools/dev/lookup_trace_split.py)
+            # default events attached (an r01 trace-splitting probe)
             err = self.hip.hipEventCreateWithFlags(ctypes.byref(e), self.EVENT_FLAGS)
             if err != 0:
                 raise RuntimeError("hipEventCreateWithFlags failed: %d" % err)

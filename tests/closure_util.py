@@ -107,7 +107,7 @@ def check_universal_against_golden(res, g, rel_l2):
     max(1, |ref|)) and at 3e-2 relative L2 for the final perturbations: 44 L-BFGS closures amplify last-bit noise
     chaotically -- the reference moves 0.4-0.6 % between two thread counts, and identical GPU runs land 0.4-2.4 % from
     the reference from run to run (MIOpen's backward convolutions accumulate with atomics; measured with
-    tools/dev/univ_probe.py)."""
+    an r03 probe, removed in r05)."""
     import numpy as np
     assert abs(res["batches"][0]["aee_pred-tgt"] - g["aee_pred-tgt_t8"][0]) < 1e-3   # unattacked: deterministic
     assert abs(res["batches"][1]["aee_pred-tgt"] - g["aee_pred-tgt_t8"][1]) < 1e-3

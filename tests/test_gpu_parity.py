@@ -1108,8 +1108,9 @@ def test_conv3x3_winograd_vs_oracle(oracle_ops, shape, relu):
     elif "PCFA_CONV3X3_ALGO" not in os.environ:
         # ((1, 565, 128, 24, 80) and (1, 196, 196, 6, 20) went from the channel-split F(4x4,3x3) path to F(2x2,3x3) with K
         # sliced over workgroups in r04; PCFA_CONV3X3_ALGO=f43 still runs them through F(4x4,3x3))
-        assert f43 == (shape in ((1, 192, 256, 55, 128), (2, 64, 64, 220, 512), (1, 245, 128, 96, 320),
-                                 (1, 501, 64, 48, 160)))
+        # r05: F(4x4,3x3) serves PWC-Net's decoder shapes only -- RAFT / GMA shapes ((1, 192, 256, 55, 128),
+        # (2, 64, 64, 220, 512)) left it: no speed at the step level, 1.1-2.3x farther from fp64 (csrc/conv3x3.hip use_f43)
+        assert f43 == (shape in ((1, 245, 128, 96, 320), (1, 501, 64, 48, 160)))
     tol = 1.5e-5 if f43 else 5e-6
     gen = torch.Generator().manual_seed(3 + Cin + W)
     x = torch.randn(B, Cin, H, W, generator=gen)
@@ -1594,7 +1595,7 @@ def test_schedule_parity_at_baseline_size_vs_cpu_port(pair):
     gradient itself (3e-3 between any two convolution back ends, the CPU port's included).  A pair that sits on that
     threshold runs the fixed-step optimiser's period-3 overshoot cycle one closure apart on the two sides (r03: pair 0 with
     the then-new conv_s2; r04 matrix: pair 6 on the GPU, pair 3 between the port's own two legs); pairs 0 and 1 are on the
-    port's branch with this build (tools/dev/first_pair_probe.py prints the numbers, DESIGN.md section 4 has them)."""
+    port's branch with this build (tools/parity_arbiter.py records the numbers per leg: profiles/r05/fp64_arbiter.json)."""
     import json
     import os
     import subprocess
@@ -1822,7 +1823,7 @@ def test_pair_graph_reuse_equals_fresh_capture():
     instead of warming up and capturing again.  Every pair must come out as from a fresh capture.  Compared on the
     unattacked flow (bit-level: forward only) and on the loss of the first six closure evaluations (1e-5 relative; 3e-2 on overshooting steps):
     this 128x160 random-weight problem bifurcates around the tenth evaluation under last-bit noise (identical fresh
-    runs end 2 % to 180 % apart, tools/dev/firstrun_probe.py), so later iterates say nothing about the mechanism."""
+    runs end 2 % to 180 % apart: an r03 probe), so later iterates say nothing about the mechanism."""
     from pcfa_amd import attack_PCFA
     from pcfa_amd.helper_functions import datasets
     dev = torch.device(DEV)

@@ -30,8 +30,9 @@ def collect(folder, counter):
                 continue
             if key == "gemm_f32_mfma":
                 key = name[name.index("gemm_f32_mfma"):].split("(")[0]
-            if key in PER_GRID and row.get("Grid_Size"):
-                key = "%s grid %s wg %s" % (key, row["Grid_Size"], row.get("Workgroup_Size", "?"))
+            if key in PER_GRID and row.get("Grid_Size"):   # template arguments + launch shape name the PWC-Net level
+                targs = name[name.index(key) + len(key):].split("(")[0].replace("_kernel", "")
+                key = "%s%s grid %s wg %s" % (key, targs, row["Grid_Size"], row.get("Workgroup_Size", "?"))
             out.setdefault(key, []).append(float(row["Counter_Value"]))
     return out
 

@@ -12,7 +12,6 @@ cd $R
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 python tools/summarize_rocprof.py $f 45 > gpurun_out/${TAG}_bench_kernel_stats.txt
 t=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
-python tools/dev/lookup_trace_split.py $t > gpurun_out/${TAG}_lookup_split.txt
 python tools/closure_profile.py report $t 40 > gpurun_out/${TAG}_closure_profile.txt
 rm -f $t
 cat gpurun_out/${TAG}_lookup_split.txt
