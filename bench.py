@@ -294,6 +294,24 @@ def kernel_table(timings, hf, wf, hp, wp, dim=256, levels=4, radius=4):
 
 
 PWC_LEVEL_CHANNELS = {2: 32, 3: 64, 4: 96, 5: 128, 6: 196}  # models/PWCNet/PWCNet.py:76-93
+PWC_TRAFFIC_FILE = "profiles/r05/pwc_traffic_after_xcd_map.json"
+
+
+def pwc_traffic():
+    """HBM-side bytes per launch of the cost-volume kernels per level, from the committed rocprofv3 --pmc passes
+    (tools/pmc_traffic_pwc.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): {"spatial_corr_fwd": {2: bytes, ...}, ...}.
+    One key per launch shape; a kernel's shapes in descending traffic are levels 2, 3, 4, 5, 6.  A constant, not measured by the
+    run (the rows say so)."""
+    try:
+        t = json.load(open(os.path.join(REPO, PWC_TRAFFIC_FILE)))
+    except (OSError, ValueError):
+        return {}
+    out = {}
+    for label, frag in (("spatial_corr_fwd", "scorr9_fwd"), ("spatial_corr_bwd", "scorr9_bwd")):
+        rows = sorted((v["traffic_bytes"] for k, v in t.items() if k.startswith(frag)), reverse=True)
+        if len(rows) == 5:
+            out[label] = dict(zip((2, 3, 4, 5, 6), rows))
+    return out
 
 
 def pwc_kernel_table(timings, hp, wp):
@@ -306,13 +324,19 @@ def pwc_kernel_table(timings, hp, wp):
         fwd += (2 * c + 81) * px * 4
         bwd += (81 + 2 * c + 2 * c) * px * 4
     rows = []
+    traffic = pwc_traffic()
+    src = PWC_TRAFFIC_FILE + " (offline rocprofv3 --pmc passes; committed constant, not measured by this run)"
     if "spatial_corr_fwd" in timings:
         us, n = timings["spatial_corr_fwd"]
         rows.append(_row("spatial_corr_fwd (5 levels)", "hbm", fwd, us * 5, n // 5, "per closure: 5 launches summed"))
+        if "spatial_corr_fwd" in traffic:
+            rows[-1].update(traffic=sum(traffic["spatial_corr_fwd"].values()), traffic_source=src)
     if "spatial_corr_bwd" in timings:
         us, n = timings["spatial_corr_bwd"]
         rows.append(_row("spatial_corr_bwd (5 levels, both gradients per launch)", "hbm", bwd, us * 5, n // 5,
                          "per closure: 5 launches summed"))
+        if "spatial_corr_bwd" in traffic:
+            rows[-1].update(traffic=sum(traffic["spatial_corr_bwd"].values()), traffic_source=src)
     # per level: the forward runs levels 6, 5, 4, 3, 2 in this order in every forward pass, the backward
     # 2, 3, 4, 5, 6 -- the position of a launch in the traced sequence names its level
     seqs = getattr(graph_replay_kernel_times, "sequences", {})
@@ -330,6 +354,8 @@ def pwc_kernel_table(timings, hp, wp):
             if null_us is not None and us < 2.5 * null_us:
                 note += "; floor-bound: a launch that does nothing takes %.1f us here" % null_us
             rows.append(_row("%s level %d" % (label, lvl), "hbm", nbytes, us, len(d), note))
+            if lvl in traffic.get(label, {}):
+                rows[-1].update(traffic=traffic[label][lvl], traffic_source=src)
     if "pwc_warp_fwd" in timings:
         us, n = timings["pwc_warp_fwd"]
         w = sum((2 * PWC_LEVEL_CHANNELS[l] + 2) * (hp >> l) * (wp >> l) * 4 for l in (2, 3, 4, 5))
@@ -518,7 +544,7 @@ def calibration(dev):
             "peaks_used": {"mfma_f32_tflops": MFMA_F32_PEAK_TFLOPS, "hbm_GBs": HBM_PEAK_GBS}}
 
 
-SCHEDULE_PARITY_FILE = "profiles/r04_schedule_parity_matrix.json"
+SCHEDULE_PARITY_FILE = "profiles/r05/schedule_parity_matrix.json"
 
 
 def schedule_parity_record():
@@ -531,6 +557,9 @@ def schedule_parity_record():
     rec = {"file": SCHEDULE_PARITY_FILE, "source": "committed file, not measured by this run"}
     for cfg in m.get("configs", []):
         rec["%s_%dsteps" % (cfg["net"].lower(), cfg["steps"])] = [cfg["pairs_ok"], cfg["pairs_total"]]
+        if cfg.get("pairs_outside"):   # every outside pair carries an fp64_arbiter record (tools/parity_arbiter.py)
+            rec.setdefault("outside_cleared_by_fp64_arbiter", {})["%s_%dsteps" % (cfg["net"].lower(), cfg["steps"])] = [
+                len(cfg.get("pairs_outside_cleared_by_fp64_arbiter", [])), len(cfg["pairs_outside"])]
         if cfg["net"] == "RAFT" and cfg["steps"] == 20:
             rec["pairs_ok"], rec["pairs_total"] = cfg["pairs_ok"], cfg["pairs_total"]
     return rec

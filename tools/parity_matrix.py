@@ -292,6 +292,11 @@ def cmd_assemble(a):
                                                       "gpu_vs_port8": stats([abs(r[key]["gpu"] - r[key]["port8"]) for r in full]),
                                                       "port16_vs_port8": stats([abs(r[key]["port16"] - r[key]["port8"]) for r in full])}
                                                 for key in FLOORS}
+            ad = cfg["abs_difference_over_pairs"]["aee_adv_tgt_min"]
+            # one number for "is GPU-vs-port any different from port-vs-port?": the ratio of the median per-pair |differences|
+            # (a chaotic attack -- PWC-Net: no two legs share a branch for 20 steps -- makes the per-pair rule a lottery)
+            cfg["median_abs_difference_gpu_vs_port16_over_port16_vs_port8"] = (
+                ad["gpu_vs_port16"]["median"] / ad["port16_vs_port8"]["median"] if ad["port16_vs_port8"]["median"] > 0 else None)
             cfg["first_split_step"] = {"gpu_vs_port16": [(r["first_step_divergence_gpu_vs_port16"] or {}).get("step") for r in full],
                                        "port16_vs_port8": [(r.get("first_step_divergence_port16_vs_port8") or {}).get("step") for r in full]}
             cl = [r["closure_delta_at_port_iterate"] for r in full if "closure_delta_at_port_iterate" in r]
