@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box: rocprofv3 kernel stats of the default bench command -> gpurun_out/<tag>_bench_kernel_stats.txt,
-# plus the split of the lookup-forward durations (graph replays vs the eager measurement step).
+# plus the per-closure kernel mix of the graph replays.
 export TMPDIR=/tmp
 export PCFA_BENCH_NO_TRACER=1
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -14,5 +14,4 @@ python tools/summarize_rocprof.py $f 45 > gpurun_out/${TAG}_bench_kernel_stats.t
 t=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
 python tools/closure_profile.py report $t 40 > gpurun_out/${TAG}_closure_profile.txt
 rm -f $t
-cat gpurun_out/${TAG}_lookup_split.txt
 head -12 gpurun_out/${TAG}_closure_profile.txt | cut -c1-140
