@@ -112,7 +112,9 @@ struct Second {
                 // AFTER the addend (the dense-block backward: the producer's LeakyReLU backward once its gradient is complete)
   int ksl;      // K slices over workgroups (blockIdx.z = image * ksl + slice): slice s convolves chunks [s cper, (s+1) cper)
   int cper;     // and writes its raw sums to out[(s * images + image)] -- a partial output for f43_finish_kernel (small
-};              // maps: a handful of workgroups walking the whole K is a latency chain of ~1 us per chunk)
+                // maps: a handful of workgroups walking the whole K is a latency chain of ~1 us per chunk)
+  PcfaXcdMap xcd;   // a != 0: 1-D grid, XCD k owns a sub-rectangle of (tile block, channel block) (common.hpp)
+};
 
 // KS = 2: in-workgroup split-K for launches of at most one workgroup per CU (e.g. conv 256 -> 126 at 55x128: 224
 // workgroups, one wave per SIMD, 37 us for 17 us of MFMA work).  Two groups of four waves run the same pipeline on
@@ -146,9 +148,10 @@ __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(K
   const int tid = KS == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);
   const int lane = tid & 63, wave = (tid >> 6) & 3, mt = tid >> 8;  // wave: xi group, mt: tile group
   const int l31 = lane & 31, lh = lane >> 5;
-  const int by = blockIdx.x / blocks_x, bx = blockIdx.x - by * blocks_x;
+  int tileblk = blockIdx.x, nby = blockIdx.y;
+  if (second.xcd.a != 0 && !pcfa_xcd_item(second.xcd, (int)blockIdx.x, tileblk, nby)) return;   // (dead: whole workgroup)
+  const int by = tileblk / blocks_x, bx = tileblk - by * blocks_x;
   const int y0 = by * (2 * TR), x0 = bx * (2 * TC);  // first output pixel of the block
-  int nby = blockIdx.y;
   if (nby >= second.nb0) {   // workgroup-uniform: this workgroup belongs to the second problem
     nby -= second.nb0;
     x = second.x;
@@ -669,11 +672,24 @@ static int conv3x3_launch(const float* x, const float* packed, const float* bias
     grid.z = (unsigned)(B * ksl);
     if (grid.z > 65535) return PCFA_ERR_UNSUPPORTED;
   }
-  Second second{x2, packed2, bias2, out2, K2, N2, (int)grid.y, mask_n, ksl, cper};
+  Second second{x2, packed2, bias2, out2, K2, N2, (int)grid.y, mask_n, ksl, cper, PcfaXcdMap{0, 0, 0, 0}};
   if (x2 != nullptr) {
     if (mt == 2) return PCFA_ERR_UNSUPPORTED;
     grid.y += (unsigned)((N2 + CB - 1) / CB * CB / 32);
     if (grid.y > 65535) return PCFA_ERR_UNSUPPORTED;
+  }
+  // XCD-aware placement (common.hpp): x = tile blocks (the input planes follow them), y = channel blocks (the U slices
+  // follow them).  Measured (tools/bench_conv3x3.py, on / off): 64 -> 64 at 220x512 117.9 / 124.4 us (batch 2), 61.3 / 63.1
+  // (batch 1); neutral within 1-2 % on the 110x256 and 55x128 maps -- so only grids of >= 1024 workgroups take it.
+  // PCFA_XCD_MAP=0: plain 2-D grid (A/B).
+  const long long nwg = (long long)grid.x * grid.y * grid.z;   // (live workgroups: the XCD map below pads the grid)
+  static const bool xcd_on = !(getenv("PCFA_XCD_MAP") && atoi(getenv("PCFA_XCD_MAP")) == 0);
+  if (xcd_on && mt == 1 && (long long)grid.x * grid.y >= 1024) {
+    second.xcd = pcfa_xcd_pick((int)grid.x, (int)grid.y, 4.0 * K * H * W, 4.0 * 16 * K * 32 * grid.y);
+    if (second.xcd.a != 0) {
+      grid.x = pcfa_xcd_grid(second.xcd);
+      grid.y = 1;
+    }
   }
 #define PCFA_C3_ARGS grid, block, 0, s, x, packed, bias, mask, addend, out, K, N, Npad, H, W, blocks_x, slope, second
 #define PCFA_C3_LAUNCH(MT_, KF_, NR_)                                                              \
@@ -685,7 +701,6 @@ static int conv3x3_launch(const float* x, const float* packed, const float* bias
   const bool kfull = K % KC == 0;
   // at most one workgroup per CU: split K inside the workgroup (8 waves, two per SIMD)
   static const int ks_env = getenv("PCFA_CONV3X3_KS") ? atoi(getenv("PCFA_CONV3X3_KS")) : 0;   // tuning override (1 / 2)
-  const long long nwg = (long long)grid.x * grid.y * grid.z;
   if (ksl == 1 && mt == 1 && x2 == nullptr && K % (2 * KC) == 0 && (ks_env ? ks_env == 2 : nwg <= 256)) {
     block.x = 512;
     if (act == 1) pcfa_launch(conv3x3_winograd_kernel<1, 32, 1, true, 2, 2>, PCFA_C3_ARGS);

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(128 * WN * KS) void sc5_wino_kernel(Operand in, con
   const int tid = threadIdx.x % GT, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave inside the group
   const int wn = WN == 2 ? (wv & 1) : 0, wpx = WN == 2 ? (wv >> 1) : wv;
+  // (an XCD-aware tile map -- common.hpp, as in conv3x3.hip -- was measured neutral here: 306.7 vs 305.7 us per GRU update)
   const int ty = blockIdx.x / tiles_x, x0 = (blockIdx.x - ty * tiles_x) * (VERT ? VPX : HPX);   // ty: row (1x5) / row pair (5x1)
   const int nb = blockIdx.y * WN + wn;
   const long long plane = (long long)H * W;
