@@ -632,6 +632,9 @@ def compact_line(out):
     if "pairs_in_flight" in out:
         line["pairs_in_flight"] = _pick(out["pairs_in_flight"], ("pairs", "value", "unit", "ratio_to_one_pair",
                                                                 "bit_identical_to_solo", "error"))
+    if "unfused_lookup_batch2" in out and "B2" in out["unfused_lookup_batch2"]:
+        line["unfused_lookup_batch2"] = {k: _pick(v, ("mean_launch_us", "frac")) for k, v in out["unfused_lookup_batch2"].items()
+                                         if k in ("B1", "B2")}
     if "shared_forward_schedule" in out:
         line["shared_forward_schedule"] = _pick(out["shared_forward_schedule"], ("value", "ms_per_step", "error"))
     if "universal" in out:
@@ -642,7 +645,7 @@ def compact_line(out):
     # nested records to 6 significant digits; the contract's own top-level numbers keep full precision (the driver
     # checks value against steps / ms_per_step)
     line = {k: (v if isinstance(v, float) and v == v else _sig(v)) for k, v in line.items()}
-    DROP_ORDER = ("shared_forward_schedule", "calibration", "pairs_in_flight", "roofline_unfused_lookup", "gma",
+    DROP_ORDER = ("unfused_lookup_batch2", "shared_forward_schedule", "calibration", "pairs_in_flight", "roofline_unfused_lookup", "gma",
                   "pwcnet", "schedule_parity", "universal", "parity_vs_cpu_port")
     for k in DROP_ORDER:
         if len(json.dumps(line)) < LINE_BUDGET:
@@ -767,6 +770,41 @@ def universal_leg(net, h, w, dev, rank, world, pairs_per_gpu, warmup, steps, sha
             "closure_evals_per_step": closures / steps, "allreduces_per_closure": cols / max(closures, 1),
             "allreduce_bytes": flat, "closure_launch": "hipGraph replay" if ua.graphed else "eager",
             "setup_s": setup, "final": last}
+
+
+def lookup_b2_row(dev, hf, wf, levels=4, radius=4, reps=30):
+    """The un-fused lookup kernel on a batch of TWO pairs' queries in one launch (at B = 1 the 20.44 MB of a
+    launch are a 7 us latency chain; does twice the work per launch reach the 0.40 target?).  Random feature maps, random
+    sub-pixel coordinates inside the map, device timestamps of `reps` launches."""
+    from torch.autograd import DeviceType
+    from torch.profiler import ProfilerActivity, profile
+    from pcfa_amd import hip_ops
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    for B in (1, 2):
+        f1 = torch.randn(B, 256, hf, wf, generator=g).to(dev)
+        f2 = torch.randn(B, 256, hf, wf, generator=g).to(dev)
+        base = torch.stack(torch.meshgrid(torch.arange(wf), torch.arange(hf), indexing="xy"), 0).float()[None].repeat(B, 1, 1, 1)
+        coords = (base + 3.0 * torch.randn(B, 2, hf, wf, generator=g)).to(dev)
+        with torch.no_grad():
+            blk = hip_ops.CorrBlock(f1, f2, num_levels=levels, radius=radius)
+            for _ in range(3):
+                blk(coords)
+            torch.cuda.synchronize()
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                for _ in range(reps):
+                    blk(coords)
+                torch.cuda.synchronize()
+        d = [e.time_range.elapsed_us() for e in prof.events()
+             if e.device_type == DeviceType.CUDA and "corr_lookup_fwd_kernel" in e.name]
+        us = sum(d) / len(d)
+        nbytes = B * lookup_algorithmic_bytes(hf, wf, levels, radius)
+        out["B%d" % B] = {"bytes_per_launch": nbytes, "mean_launch_us": us, "launches_timed": len(d),
+                          "achieved": nbytes / (us * 1e-6) / 1e9, "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        del blk, f1, f2
+    out["note"] = ("corr_lookup_fwd_kernel<4> back to back on random maps / coordinates (L2- / MALL-warm: flatters the kernel "
+                   "against the in-closure figure of roofline_unfused_lookup), one launch for B pairs' queries; peak 8 TB/s")
+    return out
 
 
 def pairs_in_flight_leg(net, h, w, dev, rank, model, one_pair_value, steps=4, warmup=1, pairs=2):
@@ -1145,6 +1183,11 @@ def main():
         sp = schedule_parity_record()
         if sp is not None:
             out["schedule_parity"] = sp
+        if world == 1 and corr_net:
+            try:
+                out["unfused_lookup_batch2"] = lookup_b2_row(dev, hp // 8, wp // 8)
+            except Exception as e:  # noqa: BLE001 -- informational
+                out["unfused_lookup_batch2"] = {"error": repr(e)}
         if world == 1 and use_graph and a.net == "RAFT" and not a.no_pairs_in_flight_leg:
             out["pairs_in_flight"] = pairs_in_flight_leg(a.net, h, w, dev, rank, st.model, out["value"])
         if world == 1 and use_graph and not a.no_shared_forward_leg:
