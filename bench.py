@@ -387,6 +387,8 @@ TRACED = {  # kernel-name fragment -> label
     "sc5_wino_kernel": "sepconv5_winograd", "sepconv5_kernel": "sepconv5_direct",
     "instnorm_stats_kernel<false>": "instnorm_fwd", "instnorm_apply_kernel<false>": "instnorm_fwd",
     "instnorm_stats_kernel<true>": "instnorm_bwd", "instnorm_apply_kernel<true>": "instnorm_bwd",
+    "instnorm_plane_kernel<256, 7, false>": "instnorm_fwd", "instnorm_plane_kernel<1024, 7, false>": "instnorm_fwd",
+    "instnorm_plane_kernel<256, 7, true>": "instnorm_bwd", "instnorm_plane_kernel<1024, 7, true>": "instnorm_bwd",
     "conv3x3_fewout_fwd": "conv3x3_fewout_fwd", "conv3x3_fewout_bwd_kernel": "conv3x3_fewout_bwd",
     "leaky_relu_bwd_kernel": "leaky_relu_bwd", "relu_bwd2_kernel": "relu_bwd2", "relu_bwd_kernel": "relu_bwd",
     "add_relu_kernel": "add_relu_fwd", "conv_fewin_packed_fwd_kernel": "conv_fewin_fwd",
@@ -468,8 +470,9 @@ FAMILY_NOTES = {
                                 "(segments x 128-wide blocks, read back from the kernel's own segment table), direct = the "
                                 "dense product the reference's autograd runs",
     "corr_pyramid_gemm_df2ext": "as corr_pyramid_gemm_dfmap1 (K = hull of the query rows that reach the block's tile rows)",
-    "instnorm_fwd": "statistics + apply launches together; algorithmic bytes = x in + y out",
-    "instnorm_bwd": "statistics + apply launches together; algorithmic bytes = x + grad_out in + grad_x out",
+    "instnorm_fwd": "one launch per call on the 55x128 / 110x256 stages (plane in registers), statistics + apply launches on "
+                    "220x512; algorithmic bytes = x in + y out",
+    "instnorm_bwd": "as instnorm_fwd; algorithmic bytes = x + grad_out in + grad_x out",
     "conv3x3_fewout_fwd": "flow-prediction convolutions (2 output channels): the input once + the output",
     "conv3x3_fewout_bwd": "their data gradient: grad_out + the streamed grad_x",
     "conv_fewin_fwd": "relu(convf1(flow)): 7x7 on two input channels as an im2col-in-LDS MFMA GEMM (3.6 MB out: launch-bound)",

@@ -111,4 +111,7 @@ class DispatchTimer:
             if n:
                 out[name] = (1e3 * tot / n, n)
         self.pairs = {}
+        # a pair whose kernel never launched (an entry point that took a shorter path: the one-launch instance norm) makes
+        # hipEventElapsedTime fail, and HIP keeps that as its sticky "last error": the next launch check would report it
+        self.hip.hipGetLastError()
         return out
