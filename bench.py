@@ -383,7 +383,10 @@ TRACED = {  # kernel-name fragment -> label
     "conv_s2_fwd_kernel<(anonymous namespace)::S2Cfg<3, 3": "conv_s2_block_entry_fwd",
     "conv_s2_bwd_kernel": "conv_s2_block_entry_bwd", "conv_s2_stem_bwd_kernel": "conv_s2_stem_bwd",
     # the kernels that own the step: family rows from hip_ops' work recorder (family_rows below)
-    "conv3x3_winograd_kernel": "conv3x3_winograd", "conv3x3_f43_kernel": "conv3x3_f43", "f43_finish_kernel": "conv3x3_f43",
+    "conv3x3_winograd_kernel": "conv3x3_winograd", "conv3x3_f43_kernel": "conv3x3_f43",
+    # the split-K finish launch is booked under the family whose partial sums it adds (template argument FAMILY)
+    "f43_finish_kernel<0, 23>": "conv3x3_winograd", "f43_finish_kernel<1, 23>": "conv3x3_winograd",
+    "f43_finish_kernel<2, 23>": "conv3x3_winograd", "f43_finish_kernel": "conv3x3_f43",
     "sc5_wino_kernel": "sepconv5_winograd", "sepconv5_kernel": "sepconv5_direct",
     "instnorm_stats_kernel<false>": "instnorm_fwd", "instnorm_apply_kernel<false>": "instnorm_fwd",
     "instnorm_stats_kernel<true>": "instnorm_bwd", "instnorm_apply_kernel<true>": "instnorm_bwd",

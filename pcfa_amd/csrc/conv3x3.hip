@@ -634,7 +634,8 @@ extern "C" int pcfa_conv3x3_run(const float* x, const float* packed, const float
     const int rc = conv3x3_launch(x, packed, nullptr, nullptr, part, B, K, N, H, W, 0, 0.f, stream, nullptr, nullptr,
                                   nullptr, nullptr, 0, 0, nullptr, 0, ksl);
     if (rc != PCFA_OK) return rc;
-    return pcfa_f43_finish(part, bias, mask, addend, out, ksl, B, N, H, W, act, slope, mask_channels, (hipStream_t)stream);
+    return pcfa_f43_finish(part, bias, mask, addend, out, ksl, B, N, H, W, act, slope, mask_channels, (hipStream_t)stream,
+                           23);
   }
   return conv3x3_launch(x, packed, bias, mask, out, B, K, N, H, W, act, slope, stream, nullptr, nullptr, nullptr,
                         nullptr, 0, 0, addend, mask_channels);

@@ -396,7 +396,9 @@ __global__ __launch_bounds__(NTG * NGT) void conv3x3_f43_kernel(
 }
 
 // out = act(sum_ks partial[ks] + bias) [* (mask > 0)] [+ addend], partials added in index order.
-template <int ACT>
+// FAMILY only names the instance (43: partials of this file's kernel, 23: of conv3x3.hip's K-sliced F(2x2,3x3) kernel), so
+// that a kernel trace books the finish launch under the family whose work it completes (bench.py TRACED).
+template <int ACT, int FAMILY>
 __global__ __launch_bounds__(256) void f43_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                          const float* __restrict__ mask,
                                                          const float* __restrict__ addend, float* __restrict__ out,
@@ -517,15 +519,19 @@ int pcfa_f43_run(const float* x, const float* packed, const float* bias, const f
 // The finish pass alone: out = epilogue(sum of `ksplit` partial outputs [ksplit][B][N][H][W], in index order).  Also
 // serves conv3x3.hip's F(2x2,3x3) kernel when it slices K over workgroups.  H * W % 4 == 0.
 int pcfa_f43_finish(const float* part, const float* bias, const float* mask, const float* addend, float* out, int ksplit,
-                    int B, int N, int H, int W, int act, float slope, int mask_n, hipStream_t s) {
+                    int B, int N, int H, int W, int act, float slope, int mask_n, hipStream_t s, int family) {
   if (((long long)H * W) % 4 != 0 || !aligned16(part) || !aligned16(out) || (mask && !aligned16(mask)) ||
       (addend && !aligned16(addend)))
     return PCFA_ERR_UNSUPPORTED;
   const long long total4 = (long long)B * N * H * W / 4, plane4 = (long long)H * W / 4;
   const dim3 fg((unsigned)min((total4 + 255) / 256, 2048LL)), fb(256);
-#define PCFA_F43_FINISH(A_) \
-  pcfa_launch(f43_finish_kernel<A_>, fg, fb, 0, s, part, bias, mask, addend, out, ksplit, total4, plane4, N, slope, mask_n)
-  if (act == 1) PCFA_F43_FINISH(1); else if (act == 2) PCFA_F43_FINISH(2); else PCFA_F43_FINISH(0);
+#define PCFA_F43_FINISH(A_, F_) \
+  pcfa_launch(f43_finish_kernel<A_, F_>, fg, fb, 0, s, part, bias, mask, addend, out, ksplit, total4, plane4, N, slope, mask_n)
+  if (family == 23) {
+    if (act == 1) PCFA_F43_FINISH(1, 23); else if (act == 2) PCFA_F43_FINISH(2, 23); else PCFA_F43_FINISH(0, 23);
+  } else {
+    if (act == 1) PCFA_F43_FINISH(1, 43); else if (act == 2) PCFA_F43_FINISH(2, 43); else PCFA_F43_FINISH(0, 43);
+  }
 #undef PCFA_F43_FINISH
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;

@@ -12,4 +12,4 @@ int pcfa_f43_run(const float* x, const float* packed, const float* bias, const f
                  float* out, int B, int K, int N, int H, int W, int act, float slope, int mask_n, void* workspace,
                  size_t workspace_bytes, hipStream_t s);
 int pcfa_f43_finish(const float* part, const float* bias, const float* mask, const float* addend, float* out, int ksplit,
-                    int B, int N, int H, int W, int act, float slope, int mask_n, hipStream_t s);
+                    int B, int N, int H, int W, int act, float slope, int mask_n, hipStream_t s, int family = 43);
