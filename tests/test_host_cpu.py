@@ -279,3 +279,38 @@ def test_call_spy_sees_calls_of_every_operator_module():
     finally:
         hip_ops.set_call_spy(None)
     assert [n for n, _ in seen] == ["pcfa_entry_%d" % i for i in range(5)] and seen[3][1] == (3,)
+
+
+def test_lanes_are_thread_local_without_a_gpu_and_nest():
+    """ops.core.lane(k): the scratch-buffer lane of attack_PCFA.PairsInFlight.  On the host it is a thread-local that nests
+    and is restored on exit; a stream binding (bind_stream) overrides it only for streams that were bound (GPU test:
+    test_pairs_in_flight_bit_identical_to_solo)."""
+    import threading
+    from pcfa_amd import ops
+    assert ops.core.current_lane() == 0
+    seen = {}
+
+    def worker(k):
+        with ops.core.lane(k):
+            with ops.core.lane(k + 10):
+                seen[(k, "inner")] = ops.core.current_lane()
+            seen[(k, "outer")] = ops.core.current_lane()
+        seen[(k, "after")] = ops.core.current_lane()
+    ts = [threading.Thread(target=worker, args=(k,)) for k in (1, 2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert seen == {(1, "inner"): 11, (1, "outer"): 1, (1, "after"): 0, (2, "inner"): 12, (2, "outer"): 2, (2, "after"): 0}
+    assert ops.core.current_lane() == 0
+
+
+def test_config_rejects_bad_values_and_reads_the_cache_cap():
+    import dataclasses
+    import pytest
+    from pcfa_amd import config
+    assert config.DEFAULT.max_cached_shapes >= 1
+    with pytest.raises(ValueError):
+        dataclasses.replace(config.DEFAULT, max_cached_shapes=0)
+    with pytest.raises(ValueError):
+        dataclasses.replace(config.DEFAULT, gma_gemm="cublas")
