@@ -307,13 +307,19 @@ __global__ __launch_bounds__(256 * MT * KS) __attribute__((amdgpu_waves_per_eu(K
         C3_STAMP(0);
         // the patch of chunk c+1 was requested one iteration ago and goes to the LDS buffer chunk c-1 used (free since
         // the last barrier); the raw slot j is free again once its patch is in LDS, the U slot j after the last MFMA
+        // The U slot that is refilled here is the one chunk c - 1 multiplied with (it gets chunk c - 1 + NRING), NOT this
+        // chunk's: a load whose destination registers are the B operands of MFMAs that are still queued on the matrix pipe
+        // waits for them -- with three waves per SIMD sharing the pipe the four U loads in front of the barrier took 853 of
+        // a chunk's 5645 cycles to ISSUE at 220x512 (r05 stamps); one channel pair into the next chunk those MFMAs are done.
         mfma_chunk(cur, ring_u[j],
-                   [&] { store_chunk(gc0(c + 1), nxt, ring_raw[(j + 1) % NRING]); },  // (past the end: never read)
+                   [&] {
+                     store_chunk(gc0(c + 1), nxt, ring_raw[(j + 1) % NRING]);   // (past the end: never read)
+                     load_u(min(gc0(c - 1 + NRING), lastc), ring_u[(j + NRING - 1) % NRING]);
+                   },
                    [&] { load_raw(min(gc0(c + NRING), lastc), ring_raw[j]); });
         __builtin_amdgcn_sched_barrier(0);
         C3_STAMP(1);
         C3_STAMP(2);
-        load_u(min(gc0(c + NRING), lastc), ring_u[j]);
         C3_STAMP(3);
         __syncthreads();  // patch c+1 visible; everyone done with the patch of chunk c
         C3_STAMP(4);
