@@ -314,3 +314,34 @@ def test_config_rejects_bad_values_and_reads_the_cache_cap():
         dataclasses.replace(config.DEFAULT, max_cached_shapes=0)
     with pytest.raises(ValueError):
         dataclasses.replace(config.DEFAULT, gma_gemm="cublas")
+
+
+def test_committed_parity_records_are_consistent(tmp_path):
+    """The r05 end-of-attack matrix and its fp64-arbiter records (profiles/r05/): every pair outside the schedule rule
+    carries an arbiter record whose rule passed at every point; the RAFT config (BASELINE config 2, the bench workload) has all
+    eight pairs inside; re-assembling the arbiter records reproduces the committed summary's counts."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = json.load(open(os.path.join(repo, "profiles", "r05", "schedule_parity_matrix.json")))
+    by = {(c["net"], c["steps"]): c for c in m["configs"]}
+    assert by[("RAFT", 20)]["pairs_ok"] == by[("RAFT", 20)]["pairs_total"] == 8
+    assert by[("GMA", 20)]["pairs_total"] == 8
+    for c in m["configs"]:
+        assert sorted(c["pairs_outside"]) == sorted(c["pairs_outside_cleared_by_fp64_arbiter"]), (c["net"], c["steps"])
+        assert c["pairs_outside_without_arbiter_record"] == []
+        for r in c["pairs"]:
+            if r.get("inside_all") is False:
+                fa = r["fp64_arbiter"]
+                assert fa["rule_ok_everywhere"] and fa["worst_point"]["gpu_vs_fp64"] <= fa["worst_point"]["tolerance"]
+        # GPU-vs-port no larger than port-vs-port, read as distributions
+        assert c["median_abs_difference_gpu_vs_port16_over_port16_vs_port8"] <= 1.0
+    out = tmp_path / "arb.json"
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "parity_arbiter.py"), "assemble", "--dir",
+                        os.path.join(repo, "profiles", "r05", "arbiter"), "--out", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = json.load(open(out)), json.load(open(os.path.join(repo, "profiles", "r05", "fp64_arbiter.json")))
+    assert a["pairs_total"] == a["pairs_rule_ok"] and a["pairs_total"] >= 15
+    assert b["pairs_rule_ok"] == b["pairs_total"]
