@@ -529,12 +529,40 @@ def attack_l2(args, data_loader=None, has_gt=None):
     model = _load_model(args, device, variable_change=cov)
 
     local = []
+    nflight = max(1, int(getattr(args, "pairs_in_flight", 1)))
+    if nflight > 1 and torch.device(device).type != "cuda":
+        raise ValueError("--pairs_in_flight needs a GPU (lanes are HIP streams)")
+    pending = []   # (batch, image1, image2, flow) of this rank, attacked `nflight` at a time
+
+    def attack_group(group):
+        if len(group) == 1 or nflight == 1:
+            for batch, image1, image2, flow in group:
+                res = pcfa_attack(model, image1, image2, flow, batch, distortion_folder, EPS_BOX, device, has_gt, optim_mu,
+                                  args)
+                local.append((batch,) + tuple(float('nan') if v is None else float(v) for v in res))
+            return
+        # the pairs of a dataset are independent (attack_PCFA.py:668-670): lane k = stream + graph set + scratch of its own,
+        # every pair's result bit-identical to attacking it alone (PairsInFlight)
+        flight = PairsInFlight(lambda k: PairAttack(model, group[k][1], group[k][2], group[k][3], group[k][0], EPS_BOX, device,
+                                                    has_gt, optim_mu, args), len(group), device)
+        if args.steps > 0:
+            flight.run(args.steps)
+        for (batch, _, _, _), st in zip(group, flight.attacks):
+            if args.steps == 0:
+                st.aee_gt = st.aee_gt if has_gt else None
+            if distortion_folder is not None and _should_save(batch, args):
+                st.save(distortion_folder)
+            local.append((batch,) + tuple(float('nan') if v is None else float(v) for v in st.result()))
+
     for batch, (image1, image2, flow, _) in enumerate(data_loader):
         if batch % world != rank:
             continue
-        res = pcfa_attack(model, image1, image2, flow, batch, distortion_folder, EPS_BOX, device, has_gt, optim_mu,
-                          args)
-        local.append((batch,) + tuple(float('nan') if v is None else float(v) for v in res))
+        pending.append((batch, image1, image2, flow))
+        if len(pending) == nflight:
+            attack_group(pending)
+            pending = []
+    if pending:
+        attack_group(pending)
 
     rows = sharding.gather_rows(local, width=13, device=device)
     if rank != 0:

@@ -1442,6 +1442,32 @@ def _cli_args(**kw):
     return Namespace(**base)
 
 
+@pytest.mark.parametrize("net,joint,box", [("RAFT", False, "change_of_variables"), ("PWCNet", True, "clipping")])
+def test_attack_l2_pairs_in_flight_equals_sequential(net, joint, box, tmp_path):
+    """`--pairs_in_flight 2` (the per-pair driver could not use the idle quarter of the chip): attack_l2
+    attacks the dataset's pairs two at a time on one GPU.  Averages AND the saved per-pair artefacts must equal the sequential
+    run bit for bit (three pairs: one full group and a remainder of one)."""
+    import glob
+    import os
+    from pcfa_amd import attack_PCFA
+    size = "128x160" if net == "RAFT" else "64x96"
+    outs = []
+    for nflight in (1, 2):
+        folder = str(tmp_path / ("flight%d" % nflight))
+        a = _cli_args(net=net, joint_perturbation=joint, boxconstraint=box, synthetic_size=size, synthetic_pairs=3, steps=2,
+                      no_save=False, output_folder=folder, pairs_in_flight=nflight)
+        res = attack_PCFA.attack_l2(a)
+        files = sorted(glob.glob(os.path.join(folder, "**", "*.npy"), recursive=True))
+        outs.append((res, {os.path.basename(f): np.load(f) for f in files}))
+    (r1, f1), (r2, f2) = outs
+    assert r1["pairs"] == r2["pairs"] == 3
+    for k in r1:
+        assert r1[k] == r2[k] or (np.isnan(r1[k]) and np.isnan(r2[k])), (k, r1[k], r2[k])
+    assert f1 and sorted(f1) == sorted(f2)
+    for name in f1:
+        assert np.array_equal(f1[name], f2[name]), name
+
+
 @pytest.mark.parametrize("net,joint,box", [("SpyNet", False, "change_of_variables"), ("PWCNet", True, "clipping"),
                                            ("RAFT", False, "clipping"), ("FlowNet2", False, "change_of_variables")])
 def test_attack_l2_end_to_end_on_gpu_vs_cpu_port(oracle_ops, net, joint, box):
