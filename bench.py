@@ -571,6 +571,41 @@ def schedule_parity_record():
     return rec
 
 
+class ExtraLegGuard:
+    """N > 1 only.  The headline figure is complete before the extra (universal) leg starts; that leg is the first place a
+    collective sits on the data path, so a rank that fails in it alone would leave the others waiting inside RCCL for ever
+    and the job would print nothing.  The guard gives the leg (and the shutdown after it) a deadline: when it passes, rank 0
+    prints the line it already has, with the reason in place of the leg's record, and every rank leaves with status 0."""
+
+    def __init__(self, seconds, publish, leave=None):
+        import threading
+        self._lock = threading.Lock()
+        self._published = False
+        self._publish = publish
+        self._leave = leave if leave is not None else (lambda: os._exit(0))
+        self.seconds = seconds
+        self._timer = threading.Timer(seconds, self._expired)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def publish(self, record):
+        """Print the line once (first caller wins); True if this call printed it."""
+        with self._lock:
+            if self._published:
+                return False
+            self._published = True
+        self._publish(record)
+        return True
+
+    def _expired(self):
+        self.publish({"error": "no result %.0f s after the headline measurement: the leg (or the shutdown after it) did not "
+                               "return on every rank; the headline figure above is unaffected" % self.seconds})
+        self._leave()
+
+    def cancel(self):
+        self._timer.cancel()
+
+
 # --------------------------------------------------------------------------------------------------------------
 # CPU baseline (+ the CPU side of the parity record)
 # --------------------------------------------------------------------------------------------------------------
@@ -1079,14 +1114,6 @@ def main():
         except Exception as e:  # noqa: BLE001 -- informational
             second_pair = {"error": repr(e)}
 
-    universal = None
-    if world > 1 and not a.no_universal_leg:
-        try:
-            universal = universal_leg(a.net, h, w, dev, rank, world, 1, 1, 2, sharding, cdev, model=st.model,
-                                      use_graph=use_graph)
-        except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure of the extra leg
-            universal = {"error": repr(e)}
-
     out = None
     if rank == 0:
         hp, wp = st.image1.shape[-2:]
@@ -1110,8 +1137,6 @@ def main():
                                          "the same shape reuse buffers + graphs (second_pair_same_shape)"},
             "final": {"aee_adv_tgt": last[0], "aee_adv_init": last[1], "l2_delta": last[2]},
         }
-        if universal is not None:
-            out["universal"] = universal
         lb = lbfgs_record(traced, st, lbfgs_history)
         if lb is not None:
             out["lbfgs"] = lb
@@ -1212,6 +1237,34 @@ def main():
                 out["gma"] = gma_leg(a, dev, sharding)
             except Exception as e:  # noqa: BLE001
                 out["gma"] = {"error": repr(e)}
+    if world > 1 and not a.no_universal_leg:
+        # last, and under a deadline: see ExtraLegGuard
+        def publish(record):
+            if rank == 0:
+                out["universal"] = record
+                emit(out, json_out)
+
+        guard = ExtraLegGuard(float(os.environ.get("PCFA_BENCH_EXTRA_LEG_DEADLINE_S", "240")), publish)
+        try:
+            universal = universal_leg(a.net, h, w, dev, rank, world, 1, 1, 2, sharding, cdev, model=st.model,
+                                      use_graph=use_graph)
+        except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure of the extra leg
+            universal = {"error": repr(e)}
+        guard.publish(universal)
+        # leave together: a rank that left alone (its leg raised) would make the launcher end the others before the
+        # deadline lets rank 0 print.  The store is the rendezvous' own TCP store, not a collective.
+        try:
+            from datetime import timedelta
+            store = torch.distributed.distributed_c10d._get_default_store()
+            store.set("pcfa_bench_leg_%d" % rank, "error" if "error" in universal else "ok")
+            store.wait(["pcfa_bench_leg_%d" % r for r in range(world)], timedelta(seconds=guard.seconds + 60.0))
+            sharding.shutdown()
+        except Exception as e:  # noqa: BLE001 -- the line is out; the guard ends this rank at the deadline
+            print("rank %d: leaving through the deadline: %r" % (rank, e), file=sys.stderr)
+            time.sleep(guard.seconds + 60.0)
+        guard.cancel()
+        return out
+    if rank == 0:
         emit(out, json_out)
     sharding.shutdown()
     return out

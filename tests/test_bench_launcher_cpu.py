@@ -129,3 +129,24 @@ def test_spawn_ranks_refuses_inside_a_rank(monkeypatch):
     assert launch.inside_rank()
     with pytest.raises(RuntimeError):
         launch.spawn_ranks(["x.py"], 2)
+
+
+def test_extra_leg_guard_prints_once_whichever_side_is_first():
+    """bench.ExtraLegGuard: at N > 1 the universal leg runs last and under a deadline, so that a rank stuck in a collective
+    cannot keep the headline line from being printed.  Whoever comes first -- the leg or the deadline -- publishes, once."""
+    import threading
+    import time
+    import bench
+    got, left = [], threading.Event()
+    g = bench.ExtraLegGuard(30.0, got.append, leave=left.set)
+    assert g.publish({"value": 1.0}) is True and g.publish({"value": 2.0}) is False
+    g.cancel()
+    assert got == [{"value": 1.0}] and not left.is_set()
+
+    got2, left2 = [], threading.Event()
+    g2 = bench.ExtraLegGuard(0.05, got2.append, leave=left2.set)
+    assert left2.wait(5.0)                        # the deadline passed: published the reason, then asked to leave
+    assert len(got2) == 1 and "error" in got2[0] and "headline" in got2[0]["error"]
+    assert g2.publish({"value": 3.0}) is False    # a leg that returns late does not print a second line
+    time.sleep(0.01)
+    assert len(got2) == 1

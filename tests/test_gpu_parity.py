@@ -1754,6 +1754,27 @@ def test_bench_gpus2_spawns_two_ranks_on_one_gpu():
     assert u["allreduce_bytes"] == (2 * 3 * 128 * 160 + 1) * 4
 
 
+def test_bench_gpus2_headline_survives_an_extra_leg_that_does_not_return():
+    """The universal leg runs last and under a deadline (bench.ExtraLegGuard).  With the deadline set to zero the guard
+    fires while the leg is still running on both ranks: rank 0 must print the headline line it already has, with the
+    reason in the leg's place, and the job must end with status 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = _rank_env()
+    env.update(PCFA_BENCH_BACKEND="gloo", PCFA_BENCH_SHARE_GPU="1", PCFA_BENCH_EXTRA_LEG_DEADLINE_S="0")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--size", "128x160"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and len(out["per_rank_ms_per_step"]) == 2
+    assert "error" in out["universal"] and "headline" in out["universal"]["error"]
+
+
 def test_pairs_in_flight_bit_identical_to_solo():
     """two PairAttacks side by side on one GPU (attack_PCFA.PairsInFlight: one thread + stream + graph
     set + scratch lane per pair) must leave every pair with exactly the bits of a solo attack of that pair."""
