@@ -1729,6 +1729,28 @@ def test_universal_cosim_two_ranks_on_gpu_equals_single_process(tmp_path):
     assert rel < 1e-2, rel
 
 
+def test_rccl_single_rank_collectives_run_on_gpu(tmp_path):
+    """RCCL needs one GPU per rank and this box has one, so the multi-rank tests run over gloo.  What CAN run here: every
+    collective pcfa_amd.sharding issues, through backend "nccl" with a communicator of one rank -- library load, communicator
+    set-up, all-reduce (fp32 SUM, fp64 SUM / MAX) and all-gather (fp64, int64) on device buffers, the universal closure's
+    FlatReducer on a side stream.  With one rank every reduction is the identity."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_two_rank_gpu.py")
+    out = str(tmp_path / "rccl1.json")
+    r = subprocess.run([sys.executable, script, "rccl1", out], env=_rank_env(), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.load(open(out))
+    assert rec["backend"] == "nccl"
+    assert rec["max"] == 3.25 and rec["all"] == [1.5] and rec["means"] == [2.0, -4.0]
+    assert rec["rows"] == [[1.0, 2.0], [3.0, 4.0]]
+    assert rec["loss"] == 7.5 and rec["grads_equal"] and rec["collectives"] == 1
+    assert rec["batch_sums_world"] == 1 and rec["sums"] == [1.0, 2.0, 3.0]
+
+
 def test_bench_gpus2_spawns_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` with no torchrun environment (the driver's command shape) must start two rank
     processes.  On this one-GPU box the ranks share the device and use gloo (PCFA_BENCH_SHARE_GPU / _BACKEND exist for
