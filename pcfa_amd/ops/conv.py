@@ -421,16 +421,22 @@ _CONV_WS = {}   # device index -> scratch of pcfa_conv3x3_run (split-K partial o
 _CONV_WS_RETIRED = []   # superseded (smaller) scratch buffers: kept alive for the graphs that captured their address
 
 
-_SIDE_STREAMS = {}
+_SIDE_STREAMS = {}          # (device index, lane) -> the lane's second stream
+_SIDE_HANDLES = set()       # their HIP handles
 
 
 def side_stream(device):
-    """The second stream of `device` on which nets/raft.py runs the context encoder beside the feature encoder (one per
-    device, created on first use); scratch buffers are kept per (device, main | side)."""
+    """The second stream on which nets/raft.py runs the context encoder beside the feature encoder: one per (device, lane),
+    created on first use and bound to its lane (core.bind_stream) -- autograd runs the encoder's backward nodes on a thread
+    of its own, where only the stream says whose scratch buffers a launch may use.  (r05: one stream per DEVICE made the
+    context encoder's backward of every lane take lane 0's K-slice scratch; two pairs in flight at a small map size raced
+    on it -- tests/test_gpu_parity.py::test_pairs_in_flight_bit_identical_to_solo caught it in the full-suite order.)"""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    s = _SIDE_STREAMS.get(idx)
+    k = current_lane()
+    s = _SIDE_STREAMS.get((idx, k))
     if s is None:
-        s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device)
+        s = _SIDE_STREAMS[(idx, k)] = core.bind_stream(torch.cuda.Stream(device), k)
+        _SIDE_HANDLES.add(s.cuda_stream)
     return s
 
 
@@ -439,8 +445,7 @@ def _conv_workspace(device, nbytes):
     follows eager warm-up calls of the same shapes); convolutions are stream-ordered per stream, and two streams (the
     encoders running side by side, nets/raft.py) never share a buffer."""
     dev_idx = device.index if device.index is not None else torch.cuda.current_device()
-    side = _SIDE_STREAMS.get(dev_idx)
-    idx = (dev_idx, side is not None and torch.cuda.current_stream(device) == side, current_lane())
+    idx = (dev_idx, torch.cuda.current_stream(device).cuda_stream in _SIDE_HANDLES, current_lane())
     ws = _CONV_WS.get(idx)
     if ws is None or ws.numel() * 4 < nbytes:
         if torch.cuda.is_current_stream_capturing():

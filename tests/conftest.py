@@ -16,6 +16,16 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
+    # PCFA_TEST_RANGE="a:b[,keep-substring]": collection indices a <= i < b plus every test whose name holds the substring,
+    # in file order -- for bisecting an order-dependent failure (tools/dev)
+    rng = os.environ.get("PCFA_TEST_RANGE")
+    if rng:
+        span, _, keep = rng.partition(",")
+        a, b = (int(v) for v in span.split(":"))
+        gpu_items = [it for it in items if "gpu" in it.keywords]     # (indices count the -m gpu tests only)
+        chosen = [it for i, it in enumerate(gpu_items) if a <= i < b or (keep and keep in it.name)]
+        config.hook.pytest_deselected(items=[it for it in items if it not in chosen])
+        items[:] = chosen
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible")

@@ -1797,6 +1797,40 @@ def test_bench_gpus2_headline_survives_an_extra_leg_that_does_not_return():
     assert "error" in out["universal"] and "headline" in out["universal"]["error"]
 
 
+def test_lanes_never_share_conv_scratch_in_forward_or_backward():
+    """Two pairs in flight may only share the frozen weights.  At a small map size the 3x3 convolutions slice K over
+    workgroups and keep their partial sums in a scratch buffer per (device, main | side stream, lane).  With
+    Config.overlap_encoders (opt-in) the context encoder runs on a side stream, and autograd runs its backward nodes on a
+    thread of its own, where only the STREAM says which lane a launch belongs to: the side stream is therefore one per
+    (device, lane) and bound to its lane (r05; one per device before, so that lane 1's context-encoder backward took lane
+    0's scratch).  One eager closure per lane with every scratch pointer recorded: main + side scratch in both lanes, and
+    the lanes' sets disjoint."""
+    import dataclasses
+    import bench
+    from pcfa_amd import config as pcfa_config
+    from pcfa_amd import ops
+    dev = torch.device(DEV)
+    model = bench.load_model("RAFT", dev, True, dataclasses.replace(pcfa_config.DEFAULT, overlap_encoders=True))
+    used = {0: set(), 1: set()}
+    streams = [ops.core.bind_stream(torch.cuda.Stream(dev), k) for k in (0, 1)]
+    for k in (0, 1):
+        def spy(name, args, invoke, k=k):
+            if name == "pcfa_conv3x3_run" and args[14].value:
+                used[k].add(int(args[14].value))
+            return invoke(name, *args)
+        with ops.core.lane(k), torch.cuda.stream(streams[k]):
+            st = bench.AttackStepper("RAFT", 128, 160, dev, 20 + k, use_graph=False, model=model)
+            ops.core.set_call_spy(spy)
+            try:
+                st.optimizer.zero_grad()
+                st.closure_body()
+                torch.cuda.synchronize()
+            finally:
+                ops.core.set_call_spy(None)
+    assert len(used[0]) == 2 and len(used[1]) == 2, used      # main-stream and side-stream scratch, both lanes
+    assert not (used[0] & used[1]), used
+
+
 def test_pairs_in_flight_bit_identical_to_solo():
     """two PairAttacks side by side on one GPU (attack_PCFA.PairsInFlight: one thread + stream + graph
     set + scratch lane per pair) must leave every pair with exactly the bits of a solo attack of that pair."""
