@@ -62,6 +62,15 @@ PCFA_API int pcfa_timing_arm(void* start_event, void* stop_event, int nth);
 /* Launches an empty kernel on `stream`: lets a caller calibrate the fixed cost of bracketing one launch with
  * HIP events (bench.py reports it next to the per-launch timings). */
 PCFA_API int pcfa_null_launch(void* stream);
+/* Test aid: fills the LDS of every CU with `pattern` (2048 workgroups that each own a CU's 160 KB for a moment).  LDS is
+ * not cleared between workgroups, so a kernel that reads LDS it never wrote sees whatever the previous tenant left: its
+ * own earlier workgroups when it runs alone (run-to-run identical), another pair's kernels with two pairs in flight.
+ * tests/test_gpu_parity.py launches this before every kernel of a closure with two different patterns and demands
+ * identical bits (no entry point of the attack path calls it). */
+PCFA_API int pcfa_poison_lds(unsigned pattern, void* stream);
+/* Its control: n workgroups each store one word of an LDS array they never wrote into out[0..n) -- after pcfa_poison_lds
+ * they must report the pattern. */
+PCFA_API int pcfa_peek_lds(unsigned* out, int n, void* stream);
 /* Calibration of the two roofs on the box the benchmark runs on (bench.py `calibration`; nothing in the attack path
  * calls them).  pcfa_calib_mfma_f32: `blocks` workgroups of four waves each issue `iters` x 4 independent
  * v_mfma_f32_32x32x2_f32 from registers (no memory, no LDS); returns the flop issued (< 0 on error) -- divide by the

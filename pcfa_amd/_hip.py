@@ -6,7 +6,7 @@ raises when handed a non-GPU tensor.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_uint, c_void_p, POINTER
 
 ABI_VERSION = 2
 LIB_PATH = os.environ.get("PCFA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
@@ -27,6 +27,8 @@ SIGNATURES = {
     "pcfa_abi_version": (c_int, []),
     "pcfa_timing_arm": (c_int, [_P, _P, c_int]),
     "pcfa_null_launch": (c_int, [_P]),
+    "pcfa_poison_lds": (c_int, [c_uint, _P]),
+    "pcfa_peek_lds": (c_int, [_P, c_int, _P]),
     "pcfa_calib_mfma_f32": (c_longlong, [_P, c_int, c_int, _P]),
     "pcfa_calib_copy": (c_int, [_P, _P, c_longlong, _P]),
     "pcfa_status_string": (c_char_p, [c_int]),

@@ -309,6 +309,25 @@ inline View4 mkview(const long long s[4]) { return View4{s[0], s[1], s[2], s[3]}
 
 __global__ void null_kernel() {}
 
+// Fills the workgroup's whole LDS allocation with `pattern` and lingers a little, so that the grid spreads over every CU.
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern, int nwords) {
+  extern __shared__ unsigned lds_words[];
+  for (int i = threadIdx.x; i < nwords; i += 256) lds_words[i] = pattern;
+  __syncthreads();
+  for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(32);
+  // (a read the compiler cannot drop, so the stores above are kept)
+  if (lds_words[(threadIdx.x * 97) % nwords] != pattern) __builtin_trap();
+}
+
+// The control of poison_lds_kernel: every workgroup reports word `blockIdx.x` of an LDS array it never wrote.
+__global__ __launch_bounds__(64) void peek_lds_kernel(unsigned* __restrict__ out, int nwords) {
+  extern __shared__ unsigned lds_words[];
+  if (threadIdx.x == 0) {
+    // (volatile: an uninitialised read the optimiser may not fold away)
+    out[blockIdx.x] = reinterpret_cast<volatile unsigned*>(lds_words)[(blockIdx.x * 61) % nwords];
+  }
+}
+
 }  // namespace
 
 extern "C" int pcfa_abi_version(void) { return PCFA_ABI_VERSION; }
@@ -388,6 +407,23 @@ extern "C" int pcfa_calib_copy(const float* src, float* dst, long long n_floats,
 
 extern "C" int pcfa_null_launch(void* stream) {
   pcfa_launch(null_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_poison_lds(unsigned pattern, void* stream) {
+  constexpr int BYTES = 160 * 1024;   // the whole LDS of a CU: one workgroup per CU at a time, 8 rounds of 256
+  static const hipError_t attr =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+  if (attr != hipSuccess) return PCFA_ERR_UNSUPPORTED;
+  pcfa_launch(poison_lds_kernel, dim3(2048), dim3(256), BYTES, (hipStream_t)stream, pattern, BYTES / 4);
+  PCFA_LAUNCH_CHECK();
+  return PCFA_OK;
+}
+
+extern "C" int pcfa_peek_lds(unsigned* out, int n, void* stream) {
+  if (!out || n < 1 || n > 65535) return PCFA_ERR_INVALID_ARG;
+  pcfa_launch(peek_lds_kernel, dim3((unsigned)n), dim3(64), 32 * 1024, (hipStream_t)stream, out, 32 * 1024 / 4);
   PCFA_LAUNCH_CHECK();
   return PCFA_OK;
 }

@@ -1797,6 +1797,63 @@ def test_bench_gpus2_headline_survives_an_extra_leg_that_does_not_return():
     assert "error" in out["universal"] and "headline" in out["universal"]["error"]
 
 
+def test_poison_lds_reaches_the_next_kernel():
+    """The control of the test below: after pcfa_poison_lds(pattern) a kernel that reads LDS it never wrote must see the
+    pattern, on (nearly) every CU -- otherwise that test proves nothing."""
+    from pcfa_amd import _hip
+    lib = _hip.load()
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = torch.zeros(4096, dtype=torch.int32, device=DEV)
+    for pattern in (0x7fc00000, 0x3f800000):
+        _hip.check(lib.pcfa_poison_lds(pattern, s), "pcfa_poison_lds")
+        _hip.check(lib.pcfa_peek_lds(ctypes.c_void_p(out.data_ptr()), out.numel(), s), "pcfa_peek_lds")
+        torch.cuda.synchronize()
+        hit = float((out == pattern).float().mean())
+        assert hit > 0.95, (hex(pattern), hit)
+
+
+@pytest.mark.parametrize("net,size,joint,box", [("RAFT", (128, 160), False, "change_of_variables"),
+                                                ("RAFT", (436, 1024), False, "change_of_variables"),
+                                                ("GMA", (128, 160), False, "change_of_variables"),
+                                                ("PWCNet", (64, 96), True, "clipping"),
+                                                ("PWCNet", (375, 1242), True, "clipping")])
+def test_kernels_do_not_read_lds_they_never_wrote(net, size, joint, box):
+    """LDS is not cleared between workgroups.  A kernel that reads LDS it never wrote gets its own earlier workgroups'
+    leftovers when it runs alone -- identical from run to run, and plausible enough to stay inside a tolerance -- but
+    another pair's kernels' leftovers with two pairs in flight: the kind of defect only a bit-identity test under
+    concurrency would ever see, and then only sometimes.  Here pcfa_poison_lds fills every CU's LDS before EVERY entry-point
+    call of one eager closure, once with quiet NaNs, once with zeros, once with 1.0: loss and gradients must come out
+    finite and bit-identical.  Small sizes make every kernel run its partial-tile paths, BASELINE sizes the full ones."""
+    import bench
+    from pcfa_amd import _hip, ops
+    dev = torch.device(DEV)
+    lib = _hip.load()
+    st = bench.AttackStepper(net, size[0], size[1], dev, 5, boxconstraint=box, joint=joint, use_graph=False)
+    st.optimizer.zero_grad()
+    st.closure_body()                      # weight packs, scratch growth
+    torch.cuda.synchronize()
+    results = []
+    for pattern in (0x7fc00000, 0x00000000, 0x3f800000):
+        def spy(name, args, invoke, pattern=pattern):
+            _hip.check(lib.pcfa_poison_lds(pattern, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "pcfa_poison_lds")
+            return invoke(name, *args)
+        st.optimizer.zero_grad()
+        ops.core.set_call_spy(spy)
+        try:
+            loss = st.closure_body()
+            torch.cuda.synchronize()
+        finally:
+            ops.core.set_call_spy(None)
+        grads = [p.grad.detach().clone() for p in st.optimizer._params]
+        assert bool(torch.isfinite(loss.detach()).all()) and all(bool(torch.isfinite(g).all()) for g in grads), hex(pattern)
+        results.append((loss.detach().clone(), grads))
+    for loss, grads in results[1:]:
+        assert torch.equal(loss, results[0][0])
+        for a, b in zip(grads, results[0][1]):
+            assert torch.equal(a, b), float((a - b).abs().max())
+
+
 def test_lanes_never_share_conv_scratch_in_forward_or_backward():
     """Two pairs in flight may only share the frozen weights.  At a small map size the 3x3 convolutions slice K over
     workgroups and keep their partial sums in a scratch buffer per (device, main | side stream, lane).  With

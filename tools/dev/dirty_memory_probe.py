@@ -2,7 +2,7 @@
 """Do results depend on what the allocator's recycled blocks held?  Poison the caching allocator (blocks of many sizes
 filled with POISON, then freed: later torch.empty calls get them back), then run a solo attack and the same pair in a
 two-lane flight and compare with a reference run made BEFORE the poisoning.
-usage: dirty_memory_probe.py [nan|rand|stale]"""
+usage: dirty_memory_probe.py [nan|rand|stale|vramnan|vramrand]"""
 import os
 import sys
 
@@ -27,7 +27,34 @@ def solo(seed):
     return tuple(last), st.delta1.clone(), st.flow_pred.clone()
 
 
+def poison_vram():
+    """Fill (nearly) all free VRAM with the pattern and hand it BACK TO THE DRIVER (empty_cache): what hipMalloc returns
+    afterwards -- the segments of a hipGraph's private pool, for one -- holds the pattern unless the driver scrubs."""
+    torch.cuda.synchronize()
+    free, _ = torch.cuda.mem_get_info(dev)
+    blocks, chunk = [], 4 << 30
+    n = int(free * 0.92) // chunk
+    for _ in range(n):
+        t = torch.empty(chunk // 4, device=dev)
+        if mode.endswith("nan"):
+            t.fill_(float("nan"))
+        else:
+            t.normal_(0.0, 3.0)
+        blocks.append(t)
+    torch.cuda.synchronize()
+    print("poisoned %d GiB of VRAM" % (n * 4), flush=True)
+    del blocks
+    torch.cuda.empty_cache()
+    probe = torch.empty(1 << 28, device=dev)   # 1 GiB straight from the driver: does it come back dirty?
+    print("fresh 1 GiB block: %.1f %% of its words are non-zero" % (100.0 * float((probe.view(torch.int32) != 0).float().mean())),
+          flush=True)
+    del probe
+    torch.cuda.empty_cache()
+
+
 def poison():
+    if mode.startswith("vram"):
+        return poison_vram()
     torch.cuda.synchronize()
     blocks = []
     g = torch.Generator(device=dev).manual_seed(1)
