@@ -1916,6 +1916,31 @@ def test_pairs_in_flight_bit_identical_to_solo():
     model._pcfa_pair_graphs.clear()
 
 
+def test_pairs_in_flight_with_overlapped_encoders_bit_identical_to_solo():
+    """The same with Config.overlap_encoders (opt-in): every lane's context encoder runs on that lane's own side stream, a
+    parallel branch of its captured graphs."""
+    import dataclasses
+    import bench
+    from pcfa_amd import attack_PCFA
+    from pcfa_amd import config as pcfa_config
+    dev = torch.device(DEV)
+    model = bench.load_model("RAFT", dev, True, dataclasses.replace(pcfa_config.DEFAULT, overlap_encoders=True))
+    seeds = (21, 22)
+    flight = attack_PCFA.PairsInFlight(
+        lambda k: bench.AttackStepper("RAFT", 128, 160, dev, seeds[k], use_graph=True, model=model), 2, dev)
+    assert all(st.graphed is not None for st in flight.attacks)
+    last = flight.run(1)
+    for k, seed in enumerate(seeds):
+        model._pcfa_pair_graphs.clear()
+        solo = bench.AttackStepper("RAFT", 128, 160, dev, seed, use_graph=True, model=model)
+        solo_last = solo.step()
+        a = flight.attacks[k]
+        assert tuple(last[k]) == tuple(solo_last), (k, last[k], solo_last)
+        assert torch.equal(a.delta1, solo.delta1) and torch.equal(a.delta2, solo.delta2)
+        del solo
+    model._pcfa_pair_graphs.clear()
+
+
 def test_bench_default_command_prints_one_short_strict_json_line(tmp_path):
     """`python bench.py --gpus 1 --steps K --warmup W` (the driver's command, every leg on, at the
     BASELINE size) prints ONE line under 6000 bytes of strict JSON that carries the contract's keys, `roofline` and
