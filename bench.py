@@ -488,6 +488,7 @@ def family_rows(traced, work):
     cores actually issue (direct-form flop / the Winograd saving; executed segments for the windowed pyramid products)
     against the fp32 matrix peak, next to the direct-form equivalent."""
     rows = []
+    pmc = family_traffic()
     for fam, (direct, issued, calls) in sorted(work.items()):
         if fam not in traced:
             continue
@@ -507,7 +508,31 @@ def family_rows(traced, work):
                      "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                      "direct_equivalent_tflops": round(direct / (tot_us * 1e-6) / 1e12, 2), "note": FAMILY_NOTES.get(fam)})
+        if fam in pmc:      # HBM / Infinity-Cache side traffic per launch from the committed PMC passes (not this run)
+            rows[-1].update(traffic=pmc[fam], traffic_source=FAMILY_TRAFFIC_FILE + " (offline rocprofv3 --pmc passes over "
+                            "one eager attack step; mean per launch over the family's launch shapes; committed constant)")
     return rows
+
+
+FAMILY_TRAFFIC_FILE = "profiles/r05/raft_step_traffic.json"
+FAMILY_TRAFFIC_KERNELS = {"conv3x3_winograd": "conv3x3_winograd_kernel", "sepconv5_winograd": "sc5_wino_kernel"}
+
+
+def family_traffic():
+    """family -> mean PMC traffic bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_traffic.py) over the launch
+    shapes of the family's kernel in tools/pmc_traffic_raft.sh's record; {} without the file."""
+    try:
+        with open(os.path.join(REPO, FAMILY_TRAFFIC_FILE)) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    out = {}
+    for fam, kern in FAMILY_TRAFFIC_KERNELS.items():
+        rows = [v for k, v in rec.items() if k.startswith(kern)]
+        n = sum(v["launches"] for v in rows)
+        if n:
+            out[fam] = sum(v["traffic_bytes"] * v["launches"] for v in rows) / n
+    return out
 
 
 def calibration(dev):

@@ -14,8 +14,11 @@ OURS = ("corr_lookup_convc1_fwd", "corr_lookup_convc1_bwd", "corr_lookup_fwd", "
         "scorr9_bwd", "sum_n_kernel", "gemm_f32_mfma", "f2ext_", "scorr_", "loss_partial", "box_fwd",
         "deltas_fwd", "instnorm_stats_kernel<false>", "instnorm_stats_kernel<true>", "instnorm_apply_kernel<false>",
         "instnorm_apply_kernel<true>", "add_relu_kernel", "gru_gates_fwd", "gru_update_fwd", "pwc_warp_fwd",
-        "pwc_warp_bwd_det_lds", "pwc_warp_bwd_det", "pwc_warp_finish", "zero_ll_max")
-PER_GRID = ("scorr9_fwd", "scorr9_bwd", "pwc_warp_fwd", "pwc_warp_bwd_det_lds")   # one row per launch shape (= PWC-Net level)
+        "pwc_warp_bwd_det_lds", "pwc_warp_bwd_det", "pwc_warp_finish", "zero_ll_max", "conv3x3_winograd_kernel",
+        "sc5_wino_kernel", "corr_pyramid_pool_gemm", "instnorm_plane_kernel", "gram_pass_kernel", "gram_direction_kernel",
+        "conv_s2_fwd_kernel", "conv_s2_bwd_kernel")
+PER_GRID = ("scorr9_fwd", "scorr9_bwd", "pwc_warp_fwd", "pwc_warp_bwd_det_lds", "conv3x3_winograd_kernel", "sc5_wino_kernel",
+            "instnorm_plane_kernel", "conv_s2_fwd_kernel", "conv_s2_bwd_kernel")   # one row per launch shape (= PWC-Net level)
 
 
 def collect(folder, counter):
