@@ -30,6 +30,15 @@ def _no_gc():
             gc.enable()
 
 
+def _release(stream):
+    """A dying graph object hands its capture stream back (ops.core.release_stream); nothing at interpreter shutdown."""
+    try:
+        if stream is not None:
+            _core.release_stream(stream)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 class GraphedClosure:
     """closure_fn() must (re)compute the loss from `params` and call .backward() on it, returning the loss.
 
@@ -54,13 +63,15 @@ class GraphedClosure:
                 closure_fn()
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
+        _core.release_stream(side)
         for p in self.params:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
         # a capture stream of this object's own: torch.cuda.graph's default is ONE stream per process, and the library
         # GEMMs' workspace is kept per (handle, stream) -- two closures captured on it (two pairs in flight,
-        # attack_PCFA.PairsInFlight) would replay against the same scratch side by side
-        with _no_gc(), torch.cuda.graph(self.graph, stream=_core.new_stream(dev)):
+        # attack_PCFA.PairsInFlight) would replay against the same scratch side by side.  Kept until the graph dies.
+        self._capture_stream = _core.new_stream(dev)
+        with _no_gc(), torch.cuda.graph(self.graph, stream=self._capture_stream):
             self.loss = closure_fn()
             if grad_sink is not None:
                 with torch.no_grad():
@@ -76,6 +87,9 @@ class GraphedClosure:
         self.replays += 1
         return self.loss
 
+    def __del__(self):
+        _release(getattr(self, "_capture_stream", None))
+
 
 class GraphedForward:
     """Capture of a no-grad forward (the re-prediction after every L-BFGS step)."""
@@ -89,13 +103,18 @@ class GraphedForward:
                 forward_fn()
         cur.wait_stream(side)
         torch.cuda.synchronize(device)
+        _core.release_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with _no_gc(), torch.no_grad(), torch.cuda.graph(self.graph, stream=_core.new_stream(device)):   # (as GraphedClosure)
+        self._capture_stream = _core.new_stream(device)   # (as GraphedClosure)
+        with _no_gc(), torch.no_grad(), torch.cuda.graph(self.graph, stream=self._capture_stream):
             self.out = forward_fn()
 
     def __call__(self):
         self.graph.replay()
         return self.out
+
+    def __del__(self):
+        _release(getattr(self, "_capture_stream", None))
 
 
 class SplitGraphedClosure:
@@ -126,13 +145,14 @@ class SplitGraphedClosure:
                 del loss
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
+        _core.release_stream(side)
         for p in self.params:
             p.grad = None
         pool = torch.cuda.graph_pool_handle()
         self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # ONE capture stream for both graphs: autograd runs every backward node on the stream its forward ran on, so a
         # second capture on a stream of its own would have to synchronise with the first one's -- invalid in a capture
-        cap = _core.new_stream(dev)
+        cap = self._capture_stream = _core.new_stream(dev)
         with _no_gc():
             with torch.cuda.graph(self.fwd_graph, pool=pool, stream=cap):
                 self.loss, self.aux = forward_fn()
@@ -150,6 +170,9 @@ class SplitGraphedClosure:
         self.fresh = True
         self._versions = [p._version for p in self.params]
         return self.loss_value, self.aux
+
+    def __del__(self):
+        _release(getattr(self, "_capture_stream", None))
 
     def invalidate(self):
         self.fresh = False

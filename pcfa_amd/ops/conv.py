@@ -435,7 +435,7 @@ def side_stream(device):
     k = current_lane()
     s = _SIDE_STREAMS.get((idx, k))
     if s is None:
-        s = _SIDE_STREAMS[(idx, k)] = core.bind_stream(torch.cuda.Stream(device), k)
+        s = _SIDE_STREAMS[(idx, k)] = core.own_stream(device, k)
         _SIDE_HANDLES.add(s.cuda_stream)
     return s
 

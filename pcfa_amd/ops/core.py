@@ -49,9 +49,68 @@ def bind_stream(stream, k=None):
     return stream
 
 
+_hiprt = None
+_FREE_STREAMS = {}   # device index -> HIP stream handles of own_stream() objects that have died (reused before new ones are made)
+
+
+def _hip_runtime():
+    global _hiprt
+    if _hiprt is None:
+        rt = ctypes.CDLL("libamdhip64.so")
+        rt.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        rt.hipStreamCreateWithFlags.restype = ctypes.c_int
+        _hiprt = rt
+    return _hiprt
+
+
+def release_stream(stream):
+    """Hand an own_stream() back: its handle loses its lane binding and waits on the free list for the next owner.  Called
+    by the OWNER when it is done with the stream (graphed.* after the warm-up / when the graph dies, PairsInFlight when it
+    dies) -- explicitly, because torch's stream objects cannot carry a weak reference (a weakref.finalize on an
+    ExternalStream crashed the interpreter's final collection in _PyWeakref_ClearRef, r05)."""
+    try:
+        handle = stream.cuda_stream
+        idx = stream.device.index
+    except Exception:  # noqa: BLE001 -- interpreter shutdown
+        return
+    if handle in _OWN_HANDLES.get(idx, ()) and handle not in _FREE_STREAMS.setdefault(idx, []):
+        _STREAM_LANE.pop(handle, None)
+        _FREE_STREAMS[idx].append(handle)
+
+
+_OWN_HANDLES = {}    # device index -> every handle own_stream() ever created (they are never destroyed)
+
+
+def own_stream(device, k=None):
+    """A stream NO OTHER live owner shares, bound to lane k (default: the caller's lane).
+
+    `torch.cuda.Stream()` does not create a stream: it hands out one of 32 pooled HIP streams per device, round-robin, so
+    the 33rd object IS the first one again while that may still be in use.  Lanes tell their work apart by the stream
+    (`_STREAM_LANE`, the scratch keys of ops.conv / ops.attack_math), so an aliased handle puts two lanes on one set of
+    scratch buffers: with Config.overlap_encoders (a persistent side stream per lane) every flight after the pool's first
+    wrap-around came out wrong (tools/dev/flight_repeat.py, r05), and seven pairs in flight would alias even without it.
+    Here the stream is created through the HIP runtime (non-blocking, as the pool's are) and wrapped as an ExternalStream;
+    `release_stream` puts its handle on a free list for the next owner instead of destroying it (a hipStreamDestroy could
+    land inside another thread's graph capture)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    free = _FREE_STREAMS.setdefault(idx, [])
+    if free:
+        handle = free.pop()
+    else:
+        h = ctypes.c_void_p()
+        with torch.cuda.device(idx):
+            err = _hip_runtime().hipStreamCreateWithFlags(ctypes.byref(h), 1)   # hipStreamNonBlocking
+        if err != 0 or not h.value:
+            raise RuntimeError("hipStreamCreateWithFlags failed: %d" % err)
+        handle = h.value
+        _OWN_HANDLES.setdefault(idx, set()).add(handle)
+    return bind_stream(torch.cuda.ExternalStream(handle, device=torch.device("cuda", idx)), k)
+
+
 def new_stream(device):
-    """A new stream of `device`, bound to the caller's lane."""
-    return bind_stream(torch.cuda.Stream(device))
+    """A new stream of `device` that is nobody else's (own_stream), bound to the caller's lane."""
+    return own_stream(device)
 
 
 def _stream():

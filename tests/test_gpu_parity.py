@@ -9,6 +9,7 @@ Tolerances (fp32 everywhere; stated per test):
   * reductions (loss): 1e-6 relative;  gradients through GEMMs: 1e-5 relative L2.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -20,6 +21,13 @@ from tests.util import load_golden, max_abs, rel_l2, t
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+
+# The two cases that are ~80-100 s of CPU-port work each and whose subject other tests and committed records also cover
+# (pair 1 of the 3-step schedule parity: pair 0 here + the 20-step matrix profiles/r05/schedule_parity_matrix.json;
+# FlowNet2 driver end to end against the 162 M-weight CPU port: its closure / operator / graph tests) run with
+# PCFA_LONG_TESTS=1 only, so that the default `-m gpu` suite stays under ~8 minutes on a loaded box.
+LONG_ONLY = pytest.mark.skipif(os.environ.get("PCFA_LONG_TESTS") != "1",
+                               reason="long CPU-port comparison: set PCFA_LONG_TESTS=1 (see the comment at the top)")
 
 
 def _grid(B, H, W):
@@ -1469,7 +1477,8 @@ def test_attack_l2_pairs_in_flight_equals_sequential(net, joint, box, tmp_path):
 
 
 @pytest.mark.parametrize("net,joint,box", [("SpyNet", False, "change_of_variables"), ("PWCNet", True, "clipping"),
-                                           ("RAFT", False, "clipping"), ("FlowNet2", False, "change_of_variables")])
+                                           ("RAFT", False, "clipping"),
+                                           pytest.param("FlowNet2", False, "change_of_variables", marks=LONG_ONLY)])
 def test_attack_l2_end_to_end_on_gpu_vs_cpu_port(oracle_ops, net, joint, box):
     """The whole driver (dataset -> model -> pcfa_attack per pair -> averages) on the GPU vs the same host code with
     the oracle operators on CPU: 2 pairs x 1 step (10 closures; longer runs amplify fp32 noise chaotically --
@@ -1607,7 +1616,7 @@ def test_universal_closure_at_baseline_size_two_pairs_vs_cpu_port(oracle_ops):
         assert rel_l2(b, a) < 1e-5, rel_l2(b, a)
 
 
-@pytest.mark.parametrize("pair", [0, 1])
+@pytest.mark.parametrize("pair", [0, pytest.param(1, marks=LONG_ONLY)])
 def test_schedule_parity_at_baseline_size_vs_cpu_port(pair):
     """The whole schedule at 436x1024 (BASELINE config 2): best-iterate AEE(adv, target), AEE(adv, init) and ||delta|| of
     a PCFA attack on the GPU against the CPU port, inside 3x the port's own spread between two thread counts
@@ -1854,6 +1863,36 @@ def test_kernels_do_not_read_lds_they_never_wrote(net, size, joint, box):
             assert torch.equal(a, b), float((a - b).abs().max())
 
 
+def test_lane_streams_are_nobodys_else():
+    """torch.cuda.Stream() hands out 32 pooled HIP streams round-robin: the 33rd object is the first one again.  Lanes tell
+    their work apart by the stream handle, so every stream of a lane comes from ops.core.own_stream: no two LIVE objects
+    share a handle, a dead object's handle is reused, and the binding of a reused handle is the new owner's."""
+    from pcfa_amd import ops
+    dev = torch.device(DEV)
+    pooled = [torch.cuda.Stream(dev).cuda_stream for _ in range(40)]
+    assert len(set(pooled)) < 40                                   # the reason own_stream exists
+    live = [ops.core.own_stream(dev, k % 3) for k in range(80)]
+    handles = [s.cuda_stream for s in live]
+    assert len(set(handles)) == 80 and not (set(handles) & set(pooled))
+    for k, s in enumerate(live):
+        with torch.cuda.stream(s):
+            assert ops.core.current_lane() == k % 3
+    x = torch.ones(1 << 16, device=dev)
+    with torch.cuda.stream(live[5]):                               # an ordinary stream: work runs and synchronises on it
+        y = (x * 3).sum()
+    live[5].synchronize()
+    assert float(y) == 3.0 * (1 << 16)
+    gone = live[7].cuda_stream
+    ops.core.release_stream(live[7])                                # what an owner does when it is done (explicitly:
+    del live[7], s                                                  # torch's stream objects cannot carry a weak reference)
+    again = ops.core.own_stream(dev, 0)
+    assert again.cuda_stream == gone                                # reused, not leaked ...
+    with torch.cuda.stream(again):
+        assert ops.core.current_lane() == 0                         # ... and its old lane-1 binding is gone
+    for s in live + [again]:
+        ops.core.release_stream(s)
+
+
 def test_lanes_never_share_conv_scratch_in_forward_or_backward():
     """Two pairs in flight may only share the frozen weights.  At a small map size the 3x3 convolutions slice K over
     workgroups and keep their partial sums in a scratch buffer per (device, main | side stream, lane).  With
@@ -1869,7 +1908,7 @@ def test_lanes_never_share_conv_scratch_in_forward_or_backward():
     dev = torch.device(DEV)
     model = bench.load_model("RAFT", dev, True, dataclasses.replace(pcfa_config.DEFAULT, overlap_encoders=True))
     used = {0: set(), 1: set()}
-    streams = [ops.core.bind_stream(torch.cuda.Stream(dev), k) for k in (0, 1)]
+    streams = [ops.core.own_stream(dev, k) for k in (0, 1)]   # (released at the end of the test)
     for k in (0, 1):
         def spy(name, args, invoke, k=k):
             if name == "pcfa_conv3x3_run" and args[14].value:
@@ -1884,6 +1923,8 @@ def test_lanes_never_share_conv_scratch_in_forward_or_backward():
                 torch.cuda.synchronize()
             finally:
                 ops.core.set_call_spy(None)
+    for stream in streams:
+        ops.core.release_stream(stream)
     assert len(used[0]) == 2 and len(used[1]) == 2, used      # main-stream and side-stream scratch, both lanes
     assert not (used[0] & used[1]), used
 

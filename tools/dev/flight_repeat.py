@@ -29,6 +29,15 @@ refs = [solo(11), solo(12)]
 again = [solo(11), solo(12)]
 print("solo twice:", all(a[0] == b[0] and torch.equal(a[1], b[1]) for a, b in zip(refs, again)), flush=True)
 bad = 0
+if os.environ.get("FLIGHT_SOLO_ONLY") == "1":      # the same number of fresh captures, one pair at a time
+    for it in range(N):
+        for k, seed in enumerate((11, 12)):
+            got = solo(seed)
+            if not (got[0] == refs[k][0] and torch.equal(got[1], refs[k][1])):
+                bad += 1
+                print("solo run %d seed %d DIFFERENT: %r vs %r" % (it, seed, got[0], refs[k][0]), flush=True)
+    print("solo runs: %d x 2, differed: %d" % (N, bad), flush=True)
+    sys.exit(0)
 for it in range(N):
     model._pcfa_pair_graphs.clear()
     flight = attack_PCFA.PairsInFlight(lambda k: bench.AttackStepper("RAFT", H, W, dev, (11, 12)[k], use_graph=True, model=model), 2, dev)
