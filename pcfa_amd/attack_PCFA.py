@@ -478,19 +478,12 @@ class PairsInFlight:
         self.device = torch.device(device)
         if self.device.index is None:      # "cuda": the caller's current device (a new host thread starts on device 0)
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.streams = [ops.core.own_stream(self.device, k) for k in range(n)]   # (not torch.cuda.Stream(): a pool of 32)
+        self.streams = ops.core.lane_run_streams(self.device, n)   # (not torch.cuda.Stream(): a pool of 32 shared objects)
         self.attacks = []
         for k in range(n):
             with ops.core.lane(k), torch.cuda.stream(self.streams[k]):
                 self.attacks.append(make_attack(k))
             torch.cuda.synchronize(self.device)
-
-    def __del__(self):
-        try:
-            for s in self.streams:
-                ops.core.release_stream(s)
-        except Exception:  # noqa: BLE001 -- interpreter shutdown
-            pass
 
     def run(self, steps):
         """`steps` attack steps on every lane, concurrently; returns each lane's last (aee_adv_tgt, aee_adv_pred, l2)."""

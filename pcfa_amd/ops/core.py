@@ -94,6 +94,7 @@ def own_stream(device, k=None):
     land inside another thread's graph capture)."""
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    _run_pool(idx)      # (the lanes' run streams take their hardware queues first: lane_run_streams)
     free = _FREE_STREAMS.setdefault(idx, [])
     if free:
         handle = free.pop()
@@ -106,6 +107,47 @@ def own_stream(device, k=None):
         handle = h.value
         _OWN_HANDLES.setdefault(idx, set()).add(handle)
     return bind_stream(torch.cuda.ExternalStream(handle, device=torch.device("cuda", idx)), k)
+
+
+_LANE_RUN_STREAMS = {}   # device index -> torch's pooled streams in pool order; lane k's attack steps run on the k-th
+
+
+def _run_pool(idx):
+    """torch's pooled streams of device idx in pool order, the first eight touched (a null launch each) the moment the
+    package first needs ANY stream of its own -- before own_stream creates one -- so that they get their hardware queues
+    while nothing else competes for them."""
+    pool = _LANE_RUN_STREAMS.get(idx)
+    if pool is None:
+        pool, seen = [], set()
+        for _ in range(64):                       # two trips round torch's pool of 32: every member, in pool order
+            s = torch.cuda.Stream(torch.device("cuda", idx))
+            if s.cuda_stream not in seen:
+                seen.add(s.cuda_stream)
+                pool.append(s)
+        lib = _hip.load()
+        for s in pool[:8]:
+            _hip.check(lib.pcfa_null_launch(ctypes.c_void_p(s.cuda_stream)), "pcfa_null_launch")
+        _LANE_RUN_STREAMS[idx] = pool
+    return pool
+
+
+def lane_run_streams(device, n):
+    """The n streams on which n pairs in flight run their steps: persistent, one per (device, lane).
+
+    These are the only streams of the package whose kernels are meant to overlap with each other, and kernels of two
+    streams overlap only if the streams sit on different hardware queues (four per device by default).  The runtime picks
+    the queue when a stream is first used and keeps it.  Measured (tools/dev/flight_scaling.py, r05): run streams taken
+    from own_stream's free list put two lanes on one queue (the second pair gained 4 % instead of 30 %); streams created
+    fresh and touched back to back still left lanes 0 and 3 on one queue (9.68 pair-steps/s at four pairs); torch's 32
+    pooled streams, created together when the process first asks for one, spread over the queues in pool order (10.70).
+    So lane k runs on the k-th DISTINCT pooled stream -- drawn once, kept for the life of the process, and never aliased by
+    this package, whose other streams (graph warm-up / capture, the encoders' side streams) all come from own_stream."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    pool = _run_pool(idx)
+    if n > len(pool):
+        raise ValueError("%d pairs in flight: at most %d lanes per device" % (n, len(pool)))
+    return [bind_stream(pool[k], k) for k in range(n)]
 
 
 def new_stream(device):

@@ -1891,6 +1891,12 @@ def test_lane_streams_are_nobodys_else():
         assert ops.core.current_lane() == 0                         # ... and its old lane-1 binding is gone
     for s in live + [again]:
         ops.core.release_stream(s)
+    run = ops.core.lane_run_streams(dev, 4)                         # the lanes' run streams: persistent, distinct, bound
+    assert len({s.cuda_stream for s in run}) == 4 and not ({s.cuda_stream for s in run} & set(handles))
+    assert [s.cuda_stream for s in ops.core.lane_run_streams(dev, 2)] == [s.cuda_stream for s in run[:2]]
+    for k, s in enumerate(run):
+        with torch.cuda.stream(s):
+            assert ops.core.current_lane() == k
 
 
 def test_lanes_never_share_conv_scratch_in_forward_or_backward():
