@@ -12,7 +12,7 @@ from pcfa_amd import attack_PCFA  # noqa: E402
 
 dev = torch.device("cuda", 0)
 model = bench.load_model("RAFT", dev, True)
-for n in (1, 2, 3, 4):
+for n in tuple(int(v) for v in os.environ.get('FLIGHT_N', '1,2,3,4').split(',')):
     model._pcfa_pair_graphs.clear() if hasattr(model, "_pcfa_pair_graphs") else None
     f = attack_PCFA.PairsInFlight(lambda k: bench.AttackStepper("RAFT", 436, 1024, dev, 600 + k, use_graph=True, model=model), n, dev)
     f.run(1)
