@@ -484,6 +484,26 @@ class PairsInFlight:
             with ops.core.lane(k), torch.cuda.stream(self.streams[k]):
                 self.attacks.append(make_attack(k))
             torch.cuda.synchronize(self.device)
+            if k == 0 and n > 1:
+                self._refuse_shared_library_workspaces(self.attacks[0])
+
+    @staticmethod
+    def _refuse_shared_library_workspaces(attack):
+        """GMA's attention products run on rocBLAS by default (Config.gma_gemm = "lib").  Every graph of this
+        process is captured by ONE host thread, i.e. with one rocBLAS handle, and a handle owns ONE device workspace that
+        all its launches share in stream order -- replayed side by side, two lanes' products use it at the same time.
+        Observed (r05, tools/dev/flight_scaling.py GMA 436x1024, two lanes): the first step never returns.  The package's own
+        products take their split-K scratch from the caller, so the build with gma_gemm = "hip" is safe in flight."""
+        net = getattr(getattr(attack, "args", None), "net", None)
+        if net in ("SpyNet", "FlowNet2"):
+            # their closures keep library convolutions (SpyNet's 7x7 layers, FlowNet2's transposed convolutions): the same
+            # question, never validated -- refused rather than left to chance
+            raise ValueError("%s keeps library convolutions inside its captured closure: several pairs in flight are "
+                             "validated for RAFT, PWCNet and GMA (gma_gemm='hip') only" % net)
+        if net == "GMA" and config.cfg(attack.model).gma_gemm != "hip":
+            raise ValueError("GMA with Config.gma_gemm='lib' cannot run several pairs in flight (the lanes' captured rocBLAS "
+                             "products would share one handle's workspace): build the model with gma_gemm='hip' "
+                             "(PCFA_GMA_GEMM=hip) or use --pairs_in_flight 1")
 
     def run(self, steps):
         """`steps` attack steps on every lane, concurrently; returns each lane's last (aee_adv_tgt, aee_adv_pred, l2)."""

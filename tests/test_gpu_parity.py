@@ -1988,6 +1988,33 @@ def test_pairs_in_flight_with_overlapped_encoders_bit_identical_to_solo():
     model._pcfa_pair_graphs.clear()
 
 
+def test_pairs_in_flight_refuses_closures_with_shared_library_workspaces():
+    """GMA's attention products run on rocBLAS by default, and every graph of a process is captured with ONE rocBLAS handle,
+    whose device workspace all its launches share: two lanes replaying side by side hung in their first step (r05).  Such a
+    model is refused in flight; the build with the package's own products (gma_gemm='hip') runs, bit-identical to solo."""
+    import dataclasses
+    import bench
+    from pcfa_amd import attack_PCFA
+    from pcfa_amd import config as pcfa_config
+    dev = torch.device(DEV)
+    lib = bench.load_model("GMA", dev, True)
+    assert pcfa_config.cfg(lib).gma_gemm == "lib"
+    with pytest.raises(ValueError, match="gma_gemm='hip'"):
+        attack_PCFA.PairsInFlight(lambda k: bench.AttackStepper("GMA", 128, 160, dev, 31 + k, use_graph=True, model=lib), 2, dev)
+    del lib
+    hip = bench.load_model("GMA", dev, True, dataclasses.replace(pcfa_config.DEFAULT, gma_gemm="hip"))
+    flight = attack_PCFA.PairsInFlight(
+        lambda k: bench.AttackStepper("GMA", 128, 160, dev, 31 + k, use_graph=True, model=hip), 2, dev)
+    last = flight.run(1)
+    for k in (0, 1):
+        hip._pcfa_pair_graphs.clear()
+        solo = bench.AttackStepper("GMA", 128, 160, dev, 31 + k, use_graph=True, model=hip)
+        assert tuple(solo.step()) == tuple(last[k]), k
+        assert torch.equal(flight.attacks[k].delta1, solo.delta1)
+        del solo
+    hip._pcfa_pair_graphs.clear()
+
+
 def test_bench_default_command_prints_one_short_strict_json_line(tmp_path):
     """`python bench.py --gpus 1 --steps K --warmup W` (the driver's command, every leg on, at the
     BASELINE size) prints ONE line under 6000 bytes of strict JSON that carries the contract's keys, `roofline` and
