@@ -345,3 +345,23 @@ def test_committed_parity_records_are_consistent(tmp_path):
     a, b = json.load(open(out)), json.load(open(os.path.join(repo, "profiles", "r05", "fp64_arbiter.json")))
     assert a["pairs_total"] == a["pairs_rule_ok"] and a["pairs_total"] >= 15
     assert b["pairs_rule_ok"] == b["pairs_total"]
+
+
+def test_pairs_in_flight_refuses_library_closures_host_rule():
+    """The host rule behind attack_PCFA.PairsInFlight's refusal (the GPU test shows the hang it prevents): closures that keep
+    library kernels with per-handle workspaces -- GMA on rocBLAS products, SpyNet, FlowNet2 -- do not go in flight."""
+    import dataclasses
+    from types import SimpleNamespace
+    from pcfa_amd import attack_PCFA
+    from pcfa_amd import config as pcfa_config
+    rule = attack_PCFA.PairsInFlight._refuse_shared_library_workspaces
+    lib = SimpleNamespace(_pcfa_config=dataclasses.replace(pcfa_config.DEFAULT, gma_gemm="lib"))
+    hip = SimpleNamespace(_pcfa_config=dataclasses.replace(pcfa_config.DEFAULT, gma_gemm="hip"))
+    for net, model, ok in (("RAFT", lib, True), ("PWCNet", lib, True), ("GMA", hip, True), ("GMA", lib, False),
+                           ("SpyNet", hip, False), ("FlowNet2", hip, False)):
+        attack = SimpleNamespace(args=SimpleNamespace(net=net), model=model)
+        if ok:
+            rule(attack)
+        else:
+            with pytest.raises(ValueError, match="in flight"):
+                rule(attack)
