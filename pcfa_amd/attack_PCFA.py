@@ -532,6 +532,20 @@ class PairsInFlight:
         return last
 
 
+def _hardware_queues_for(nflight):
+    """Kernels of two lanes overlap only if their streams sit on different hardware queues, and the HIP runtime makes four
+    per device unless GPU_MAX_HW_QUEUES says otherwise when it initialises.  Up to three pairs in flight that is enough; the
+    fourth lane shares a queue (RAFT, four pairs: 9.65 pair-steps/s with 4 queues, 10.73 with 8;
+    profiles/r05/pairs_in_flight_scaling.txt).  So ask for 8 -- which only works before the process first touches the GPU."""
+    if nflight < 4 or "GPU_MAX_HW_QUEUES" in os.environ:
+        return
+    if torch.cuda.is_initialized():
+        print("--pairs_in_flight %d: the GPU runtime is already initialised with its default of 4 hardware queues; export "
+              "GPU_MAX_HW_QUEUES=8 before starting for the fourth lane to overlap" % nflight)
+        return
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
+
 def attack_l2(args, data_loader=None, has_gt=None):
     """PCFA on every pair of a dataset, one perturbation (pair) per image pair (attack_PCFA.py:570-701).
 
@@ -544,6 +558,7 @@ def attack_l2(args, data_loader=None, has_gt=None):
     distortion_folder = _output_folder(args, "_r%d" % rank if world > 1 else "")
     if data_loader is None:
         data_loader, has_gt = datasets.prepare_dataloader(args, batch_size=1, shuffle=False)
+    _hardware_queues_for(max(1, int(getattr(args, "pairs_in_flight", 1))))
     device = select_device()
     cov = args.boxconstraint in ['change_of_variables']
     model = _load_model(args, device, variable_change=cov)
