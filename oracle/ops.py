@@ -632,6 +632,11 @@ def add_relu(a, b, b_is_relu=False):
     return F.relu(a + b)
 
 
+def conv1x1(x, weight, bias=None):
+    """A 1x1 / stride-1 convolution (models/raft/extractor.py:146,186; update.py:118-121): the library's."""
+    return F.conv2d(x, weight, bias)
+
+
 def bias_relu(x, bias=None):
     """F.relu(conv(x)) with the convolution's bias split off (models/raft/update.py:12-16,91-101)."""
     return torch.relu(x + _cb(bias))

@@ -28,6 +28,8 @@ class Config:
     defer_relu: bool = True              # ReLU backward of single-consumer layers inside neighbouring kernels
     pyramid_bwd_windows: bool = True     # pyramid backward over the lookup windows only (False: dense products)
     gma_gemm: str = "lib"                # GMA attention products: "lib" (rocBLAS through torch.matmul) | "hip" (pcfa_gemm_f32)
+    conv1x1: str = "lib"                 # the encoders' output layer and the mask head's 1x1 layer: "lib" | "hip" (pcfa_gemm_f32:
+                                         # a RAFT closure then holds no library kernel at all)
     # ---- PWC-Net (nets/pwcnet.py) ----
     dilated_as_subgrids: tuple = (2, 4, 8, 16)   # dilations run as d*d plain 3x3 convolutions on sub-grids (() = library)
     deconv_fewout: bool = True           # deconv / upfeat layers and the x4 up-sampling on own deterministic kernels
@@ -46,11 +48,14 @@ class Config:
                    overlap_encoders=_env_bool("PCFA_OVERLAP_ENCODERS", False),
                    defer_relu=_env_bool("PCFA_DEFER_RELU", True),
                    gma_gemm=os.environ.get("PCFA_GMA_GEMM", "lib"),
+                   conv1x1=os.environ.get("PCFA_CONV1X1", "lib"),
                    max_cached_shapes=int(os.environ.get("PCFA_MAX_CACHED_SHAPES", "4")))
 
     def __post_init__(self):
         if self.gma_gemm not in ("lib", "hip"):
             raise ValueError("Config.gma_gemm must be 'lib' or 'hip', got %r" % (self.gma_gemm,))
+        if self.conv1x1 not in ("lib", "hip"):
+            raise ValueError("Config.conv1x1 must be 'lib' or 'hip', got %r" % (self.conv1x1,))
         if self.max_cached_shapes < 1:
             raise ValueError("Config.max_cached_shapes must be >= 1")
 

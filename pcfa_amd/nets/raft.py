@@ -225,7 +225,7 @@ class BasicEncoder(nn.Module):
             x = torch.cat(x, dim=0)
         x = _conv_norm(self.conv1, self.norm1, x, True, self._fold_cache, "1")
         x = self.layer3(self.layer2(self.layer1(x)))
-        x = self.conv2(x)
+        x = _conv1x1(self.conv2, x, cfg(self))
         if self.training and self.dropout is not None:
             x = self.dropout(x)
         if pair:
@@ -245,6 +245,19 @@ def _conv_nobias(conv, x):
 def _is_plain3x3(conv, min_out=16):
     return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
             and conv.groups == 1 and conv.padding_mode == "zeros" and conv.out_channels >= min_out)
+
+
+def _is_plain1x1(conv):
+    return (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.dilation == (1, 1)
+            and conv.groups == 1)
+
+
+def _conv1x1(conv, x, config):
+    """conv(x) for a 1x1 layer: the library's convolution, or -- Config.conv1x1 = "hip", frozen weights, GPU -- the package's
+    own product (ops.conv1x1)."""
+    if config.conv1x1 == "hip" and x.is_cuda and _is_plain1x1(conv) and _frozen_conv(conv):
+        return ops.get().conv1x1(x, conv.weight, conv.bias)
+    return conv(x)
 
 
 def _frozen_conv(conv):
@@ -444,7 +457,10 @@ def mask_logits(head, net, cache):
     if cache.get("key") != key:
         with torch.no_grad():
             cache["key"], cache["w"], cache["b"] = key, (.25 * c2.weight).contiguous(), (.25 * c2.bias).contiguous()
-    return c2._conv_forward(_conv_relu(c0, net), cache["w"], cache["b"])
+    y = _conv_relu(c0, net)
+    if cfg(head).conv1x1 == "hip" and y.is_cuda and _is_plain1x1(c2):
+        return ops.get().conv1x1(y, cache["w"], cache["b"])
+    return c2._conv_forward(y, cache["w"], cache["b"])
 
 
 class BasicUpdateBlock(nn.Module):

@@ -35,6 +35,55 @@ def _fewin_packed(weight):
     return hit[2]
 
 
+class _Conv1x1(torch.autograd.Function):
+    """y[b] = W x[b] (+ bias) for a FROZEN 1x1 / stride-1 convolution on the package's own fp32-MFMA product
+    (pcfa_gemm_f32): the feature / context encoders' output layer (models/raft/extractor.py:146,186) and the mask head's
+    second layer (update.py:118-121).  Opt-in (Config.conv1x1 = "hip"): the library runs these three products 20-30 %
+    faster, but a closure without any library kernel cannot meet a library workspace in another lane's graph
+    (attack_PCFA.PairsInFlight) and does not depend on which solution the library picks for a shape."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _dev(x, w)
+        if w.dim() != 4 or tuple(w.shape[2:]) != (1, 1) or x.dim() != 4 or x.shape[1] != w.shape[1]:
+            raise ValueError("conv1x1: weight %s does not fit input %s" % (tuple(w.shape), tuple(x.shape)))
+        if x.dtype != torch.float32 or w.dtype != torch.float32:
+            raise ValueError("conv1x1: float32 only")
+        x = x.contiguous()
+        B, K, H, W = x.shape
+        N, hw = w.shape[0], H * W
+        w2 = w.reshape(N, K).contiguous()
+        out = torch.empty((B, N, H, W), device=x.device, dtype=torch.float32)
+        # C[b][n][p] = sum_k W[n][k] X[b][k][p]: A = W stored [M][K] (shared by the batch: stride 0), B = X[b] stored [K][N]
+        _call("pcfa_gemm_f32", _ptr(w2), _ptr(x), _ptr(out), N, hw, K, K, hw, hw, 0, 1, B, 0, K * hw, N * hw, 1.0, 1,
+              _ptr(None), ctypes.c_size_t(0))
+        if b is not None:
+            out.add_(b.view(1, N, 1, 1))
+        ctx.save_for_backward(w2)
+        ctx.dims = (B, K, N, H, W)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise RuntimeError("conv1x1 is the frozen-weight path: no weight / bias gradient")
+        (w2,) = ctx.saved_tensors
+        B, K, N, H, W = ctx.dims
+        hw = H * W
+        g = g.contiguous()
+        gx = torch.empty((B, K, H, W), device=g.device, dtype=torch.float32)
+        # dX[b][k][p] = sum_n W[n][k] G[b][n][p]: A = W stored [K' = N][M' = K], B = G[b] stored [K' = N][N' = hw]
+        _call("pcfa_gemm_f32", _ptr(w2), _ptr(g), _ptr(gx), K, hw, N, K, hw, hw, 1, 1, B, 0, N * hw, K * hw, 1.0, 1,
+              _ptr(None), ctypes.c_size_t(0))
+        return gx, None, None
+
+
+def conv1x1(x, weight, bias=None):
+    """conv2d(x, weight[N,K,1,1], bias), stride 1, frozen weights, without a library kernel (see _Conv1x1)."""
+    return _Conv1x1.apply(x, weight, bias)
+
+
 def conv_fewin(x, weight, bias=None, relu=False):
     """act(conv2d(x, weight, bias, stride=1, padding=k//2)) for a frozen k x k weight with <= 4 input channels and an
     input that needs no gradient (convf1 of the motion encoder on the detached flow): one streaming launch with bias

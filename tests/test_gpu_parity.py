@@ -1988,6 +1988,72 @@ def test_pairs_in_flight_with_overlapped_encoders_bit_identical_to_solo():
     model._pcfa_pair_graphs.clear()
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 256, 55, 128), (1, 256, 576, 55, 128), (1, 96, 40, 7, 9), (3, 7, 5, 4, 4)])
+def test_conv1x1_vs_library(shape):
+    """ops.conv1x1 (Config.conv1x1 = "hip": the encoders' output layer and the mask head's 1x1 layer on pcfa_gemm_f32,
+    models/raft/extractor.py:146,186, update.py:118-121) against the library convolution in float64: forward and data
+    gradient, 2e-6 relative to the largest value (fp32 fma chains over K <= 256)."""
+    B, K, N, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, K, H, W, generator=g)
+    w = torch.randn(N, K, 1, 1, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    go = torch.randn(B, N, H, W, generator=g)
+    xd = x.to(DEV).requires_grad_(True)
+    y = hip_ops.conv1x1(xd, w.to(DEV), b.to(DEV))
+    y.backward(go.to(DEV))
+    x64 = x.double().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, w.double(), b.double())
+    y64.backward(go.double())
+    assert max_abs(y, y64.float()) <= 2e-6 * float(y64.abs().max())
+    assert max_abs(xd.grad, x64.grad.float()) <= 2e-6 * float(x64.grad.abs().max())
+    with pytest.raises(RuntimeError, match="frozen"):
+        wd = w.to(DEV).requires_grad_(True)
+        hip_ops.conv1x1(x.to(DEV), wd, None).sum().backward()
+
+
+def test_raft_closure_without_any_library_kernel():
+    """Config.conv1x1 = "hip": a RAFT closure then launches no library GEMM / convolution kernel at all (torch.profiler sees
+    no Tensile `Cijk_` and no MIOpen kernel), agrees with the default build's closure to fp32 noise, and two pairs in flight
+    still equal their solo runs bit for bit."""
+    import dataclasses
+    import bench
+    from torch.autograd import DeviceType
+    from torch.profiler import ProfilerActivity, profile
+    from pcfa_amd import attack_PCFA
+    from pcfa_amd import config as pcfa_config
+    dev = torch.device(DEV)
+    own = bench.load_model("RAFT", dev, True, dataclasses.replace(pcfa_config.DEFAULT, conv1x1="hip"))
+    lib = bench.load_model("RAFT", dev, True)
+    res = []
+    for model in (own, lib):
+        st = bench.AttackStepper("RAFT", 128, 160, dev, 3, use_graph=False, model=model)
+        st.optimizer.zero_grad()
+        st.closure_body()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            st.optimizer.zero_grad()
+            loss = st.closure_body()
+            torch.cuda.synchronize()
+        names = [e.name for e in prof.events() if e.device_type == DeviceType.CUDA]
+        res.append((float(loss), [p.grad.detach().clone() for p in st.optimizer._params],
+                    [n for n in names if n.startswith("Cijk_") or "miopen" in n.lower() or "MIOpen" in n]))
+    (l_own, g_own, k_own), (l_lib, g_lib, k_lib) = res
+    assert k_lib and not k_own, (k_own[:3], len(k_lib))
+    assert abs(l_own - l_lib) <= 1e-5 * abs(l_lib)
+    for a, b in zip(g_own, g_lib):
+        assert rel_l2(a, b) < 1e-3, rel_l2(a, b)
+    flight = attack_PCFA.PairsInFlight(
+        lambda k: bench.AttackStepper("RAFT", 128, 160, dev, 41 + k, use_graph=True, model=own), 2, dev)
+    last = flight.run(1)
+    for k in (0, 1):
+        own._pcfa_pair_graphs.clear()
+        solo = bench.AttackStepper("RAFT", 128, 160, dev, 41 + k, use_graph=True, model=own)
+        assert tuple(solo.step()) == tuple(last[k]), k
+        del solo
+    own._pcfa_pair_graphs.clear()
+
+
 def test_pairs_in_flight_refuses_closures_with_shared_library_workspaces():
     """GMA's attention products run on rocBLAS by default, and every graph of a process is captured with ONE rocBLAS handle,
     whose device workspace all its launches share: two lanes replaying side by side hung in their first step (r05).  Such a
