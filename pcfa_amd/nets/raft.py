@@ -16,7 +16,6 @@ Differences that do not change results:
     11, raft.py:131-142);
   * only the full-size model ("small": false in models/_config/raft_config.json).
 """
-import os
 
 import torch
 import torch.nn as nn

@@ -9,7 +9,7 @@ import torch
 
 from .. import _hip
 from . import core
-from .core import _call, _dev, _note_work, _pair, _ptr, _ptr_off, _stream, current_lane
+from .core import _call, _dev, _ptr, _ptr_off, current_lane
 
 
 _sepconv_packs = {}  # id(weight) -> (weakref, version, fwd_packed, bwd_packed)

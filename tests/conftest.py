@@ -1,7 +1,6 @@
 import os
 import sys
 
-import numpy as np
 import pytest
 import torch
 

@@ -5,7 +5,6 @@ import os
 import pathlib
 import sys
 import tempfile
-import traceback
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import test_gpu_parity as T  # noqa: E402
